@@ -1,0 +1,65 @@
+"""UNet configuration for the denoise hot path.
+
+Field names and the SDXL-base values follow the `unet/config.json` fields the reference reads
+through `unet.config` (reference: instructany2pix/ddim/pnp_pipeline.py:44-47,
+instructany2pix/diffusion/ip_adapter/ip_adapter.py:114,124-132) and SURVEY.md Appendix A.1.
+"""
+from dataclasses import dataclass, field, asdict
+from typing import List, Tuple
+
+
+@dataclass
+class UNetConfig:
+    in_channels: int = 4
+    out_channels: int = 4
+    sample_size: int = 128
+    block_out_channels: Tuple[int, ...] = (320, 640, 1280)
+    # per down block: number of transformer layers (0 = plain DownBlock2D / UpBlock2D)
+    transformer_layers_per_block: Tuple[int, ...] = (0, 2, 10)
+    # diffusers calls this attention_head_dim but for SDXL it holds HEAD COUNTS (head_dim is 64)
+    attention_head_dim: Tuple[int, ...] = (5, 10, 20)
+    layers_per_block: int = 2
+    cross_attention_dim: int = 2048
+    norm_num_groups: int = 32
+    norm_eps: float = 1e-5
+    addition_time_embed_dim: int = 256
+    projection_class_embeddings_input_dim: int = 2816
+    time_embed_dim: int = 1280           # block_out_channels[0] * 4
+    time_proj_dim: int = 320             # block_out_channels[0]
+    head_dim: int = 64
+
+    def __getitem__(self, k):            # diffusers FrozenDict-style access
+        return getattr(self, k)
+
+    def to_dict(self):
+        return asdict(self)
+
+    @property
+    def pooled_dim(self) -> int:
+        return self.projection_class_embeddings_input_dim - 6 * self.addition_time_embed_dim
+
+    def validate(self):
+        n = len(self.block_out_channels)
+        assert len(self.transformer_layers_per_block) == n and len(self.attention_head_dim) == n
+        for c, h, d in zip(self.block_out_channels, self.attention_head_dim, self.transformer_layers_per_block):
+            assert c % self.norm_num_groups == 0
+            assert c % 64 == 0, "channel counts must be multiples of 64 (MFMA K tile)"
+            if d > 0:
+                assert h * self.head_dim == c, "inner dim must equal channels"
+        assert self.cross_attention_dim % 64 == 0
+        assert self.time_embed_dim % 64 == 0 and self.projection_class_embeddings_input_dim % 64 == 0
+        return self
+
+
+def sdxl_base() -> UNetConfig:
+    return UNetConfig().validate()
+
+
+def tiny(depths=(0, 1, 2)) -> UNetConfig:
+    """Same topology at toy width: used by the parity tests so the CPU oracle finishes in seconds."""
+    return UNetConfig(
+        block_out_channels=(64, 128, 256), transformer_layers_per_block=tuple(depths),
+        attention_head_dim=(1, 2, 4), cross_attention_dim=128, sample_size=32,
+        addition_time_embed_dim=32, projection_class_embeddings_input_dim=6 * 32 + 64,
+        time_embed_dim=256, time_proj_dim=64,
+    ).validate()

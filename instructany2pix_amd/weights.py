@@ -1,0 +1,212 @@
+"""Parameter inventory (diffusers key layout) and synthetic weights for the denoise hot path.
+
+The UNet the reference drives is diffusers' `UNet2DConditionModel` loaded from the SDXL-base checkpoint
+(reference: instructany2pix/pipeline.py:101); its state-dict keys are the interchange format here
+(SURVEY.md Appendix A.7), so a real `unet/diffusion_pytorch_model.safetensors` drops in unchanged.
+The IP-Adapter file layout `{"image_proj": ..., "ip_adapter": {"<idx>.to_k_ip.weight": ...}}` follows
+reference instructany2pix/diffusion/ip_adapter/ip_adapter.py:155-169.
+
+There is no network on the build/bench machines, so benchmarks and tests use seeded synthetic weights
+of exactly these names and shapes (recipe: SURVEY.md §8d).
+"""
+from __future__ import annotations
+
+import zlib
+from collections import OrderedDict
+from typing import Dict, Iterator, List, Tuple
+
+import torch
+
+from .config import UNetConfig
+
+Spec = Tuple[str, Tuple[int, ...], str]  # (key, shape, kind)
+
+
+def _resnet(prefix: str, cin: int, cout: int, temb: int) -> List[Spec]:
+    s: List[Spec] = [
+        (f"{prefix}.norm1.weight", (cin,), "gamma"), (f"{prefix}.norm1.bias", (cin,), "beta"),
+        (f"{prefix}.conv1.weight", (cout, cin, 3, 3), "w"), (f"{prefix}.conv1.bias", (cout,), "b"),
+        (f"{prefix}.time_emb_proj.weight", (cout, temb), "w"), (f"{prefix}.time_emb_proj.bias", (cout,), "b"),
+        (f"{prefix}.norm2.weight", (cout,), "gamma"), (f"{prefix}.norm2.bias", (cout,), "beta"),
+        (f"{prefix}.conv2.weight", (cout, cout, 3, 3), "w_res"), (f"{prefix}.conv2.bias", (cout,), "b"),
+    ]
+    if cin != cout:
+        s += [(f"{prefix}.conv_shortcut.weight", (cout, cin, 1, 1), "w"), (f"{prefix}.conv_shortcut.bias", (cout,), "b")]
+    return s
+
+
+def _transformer(prefix: str, c: int, depth: int, ctx: int) -> List[Spec]:
+    s: List[Spec] = [
+        (f"{prefix}.norm.weight", (c,), "gamma"), (f"{prefix}.norm.bias", (c,), "beta"),
+        (f"{prefix}.proj_in.weight", (c, c), "w"), (f"{prefix}.proj_in.bias", (c,), "b"),
+    ]
+    for k in range(depth):
+        p = f"{prefix}.transformer_blocks.{k}"
+        s += [
+            (f"{p}.norm1.weight", (c,), "gamma"), (f"{p}.norm1.bias", (c,), "beta"),
+            (f"{p}.attn1.to_q.weight", (c, c), "w"), (f"{p}.attn1.to_k.weight", (c, c), "w"),
+            (f"{p}.attn1.to_v.weight", (c, c), "w"),
+            (f"{p}.attn1.to_out.0.weight", (c, c), "w_res"), (f"{p}.attn1.to_out.0.bias", (c,), "b"),
+            (f"{p}.norm2.weight", (c,), "gamma"), (f"{p}.norm2.bias", (c,), "beta"),
+            (f"{p}.attn2.to_q.weight", (c, c), "w"), (f"{p}.attn2.to_k.weight", (c, ctx), "w"),
+            (f"{p}.attn2.to_v.weight", (c, ctx), "w"),
+            (f"{p}.attn2.to_out.0.weight", (c, c), "w_res"), (f"{p}.attn2.to_out.0.bias", (c,), "b"),
+            (f"{p}.norm3.weight", (c,), "gamma"), (f"{p}.norm3.bias", (c,), "beta"),
+            (f"{p}.ff.net.0.proj.weight", (8 * c, c), "w"), (f"{p}.ff.net.0.proj.bias", (8 * c,), "b"),
+            (f"{p}.ff.net.2.weight", (c, 4 * c), "w_res"), (f"{p}.ff.net.2.bias", (c,), "b"),
+        ]
+    s += [(f"{prefix}.proj_out.weight", (c, c), "w_res"), (f"{prefix}.proj_out.bias", (c,), "b")]
+    return s
+
+
+def unet_param_specs(cfg: UNetConfig) -> List[Spec]:
+    """Every UNet parameter as (diffusers key, shape, init kind), in module-registration order."""
+    ch = list(cfg.block_out_channels)
+    depth = list(cfg.transformer_layers_per_block)
+    temb = cfg.time_embed_dim
+    ctx = cfg.cross_attention_dim
+    n = len(ch)
+    s: List[Spec] = [
+        ("conv_in.weight", (ch[0], cfg.in_channels, 3, 3), "w"), ("conv_in.bias", (ch[0],), "b"),
+        ("time_embedding.linear_1.weight", (temb, cfg.time_proj_dim), "w"), ("time_embedding.linear_1.bias", (temb,), "b"),
+        ("time_embedding.linear_2.weight", (temb, temb), "w"), ("time_embedding.linear_2.bias", (temb,), "b"),
+        ("add_embedding.linear_1.weight", (temb, cfg.projection_class_embeddings_input_dim), "w"),
+        ("add_embedding.linear_1.bias", (temb,), "b"),
+        ("add_embedding.linear_2.weight", (temb, temb), "w"), ("add_embedding.linear_2.bias", (temb,), "b"),
+    ]
+    # down path
+    cprev = ch[0]
+    skip_ch = [ch[0]]
+    for i in range(n):
+        for j in range(cfg.layers_per_block):
+            cin = cprev if j == 0 else ch[i]
+            s += _resnet(f"down_blocks.{i}.resnets.{j}", cin, ch[i], temb)
+            if depth[i] > 0:
+                s += _transformer(f"down_blocks.{i}.attentions.{j}", ch[i], depth[i], ctx)
+            skip_ch.append(ch[i])
+        cprev = ch[i]
+        if i != n - 1:
+            s += [(f"down_blocks.{i}.downsamplers.0.conv.weight", (ch[i], ch[i], 3, 3), "w"),
+                  (f"down_blocks.{i}.downsamplers.0.conv.bias", (ch[i],), "b")]
+            skip_ch.append(ch[i])
+    # mid
+    cm = ch[-1]
+    s += _resnet("mid_block.resnets.0", cm, cm, temb)
+    s += _transformer("mid_block.attentions.0", cm, depth[-1], ctx)
+    s += _resnet("mid_block.resnets.1", cm, cm, temb)
+    # up path
+    rch = list(reversed(ch))
+    rdepth = list(reversed(depth))
+    cprev = cm
+    for i in range(n):
+        cout = rch[i]
+        for j in range(cfg.layers_per_block + 1):
+            cskip = skip_ch.pop()
+            cin = (cprev if j == 0 else cout) + cskip
+            s += _resnet(f"up_blocks.{i}.resnets.{j}", cin, cout, temb)
+            if rdepth[i] > 0:
+                s += _transformer(f"up_blocks.{i}.attentions.{j}", cout, rdepth[i], ctx)
+        cprev = cout
+        if i != n - 1:
+            s += [(f"up_blocks.{i}.upsamplers.0.conv.weight", (cout, cout, 3, 3), "w"),
+                  (f"up_blocks.{i}.upsamplers.0.conv.bias", (cout,), "b")]
+    s += [("conv_norm_out.weight", (ch[0],), "gamma"), ("conv_norm_out.bias", (ch[0],), "beta"),
+          ("conv_out.weight", (cfg.out_channels, ch[0], 3, 3), "w_out"), ("conv_out.bias", (cfg.out_channels,), "b")]
+    return s
+
+
+def attn_processor_names(cfg: UNetConfig) -> List[str]:
+    """Keys of `unet.attn_processors` in diffusers' module-registration order: down_blocks, up_blocks,
+    mid_block. The position in this list is the `<idx>` of the IP-Adapter
+    checkpoint keys (reference ip_adapter.py:168-169 loads them through a ModuleList of the values)."""
+    depth = list(cfg.transformer_layers_per_block)
+    n = len(depth)
+    names: List[str] = []
+
+    def add(prefix, d):
+        for k in range(d):
+            names.append(f"{prefix}.transformer_blocks.{k}.attn1.processor")
+            names.append(f"{prefix}.transformer_blocks.{k}.attn2.processor")
+
+    for i in range(n):
+        for j in range(cfg.layers_per_block):
+            add(f"down_blocks.{i}.attentions.{j}", depth[i])
+    rdepth = list(reversed(depth))
+    for i in range(n):
+        for j in range(cfg.layers_per_block + 1):
+            add(f"up_blocks.{i}.attentions.{j}", rdepth[i])
+    add("mid_block.attentions.0", depth[-1])
+    return names
+
+
+def hidden_size_of(cfg: UNetConfig, name: str) -> int:
+    """Same rule the reference uses to size IP processors (ip_adapter.py:125-132)."""
+    if name.startswith("mid_block"):
+        return cfg.block_out_channels[-1]
+    if name.startswith("up_blocks"):
+        return list(reversed(cfg.block_out_channels))[int(name[len("up_blocks.")])]
+    return cfg.block_out_channels[int(name[len("down_blocks.")])]
+
+
+def ip_adapter_specs(cfg: UNetConfig, clip_embeddings_dim: int = 1024, num_tokens: int = 4) -> Dict[str, List[Spec]]:
+    ctx = cfg.cross_attention_dim
+    image_proj: List[Spec] = [
+        ("proj.weight", (num_tokens * ctx, clip_embeddings_dim), "w"), ("proj.bias", (num_tokens * ctx,), "b"),
+        ("norm.weight", (ctx,), "gamma"), ("norm.bias", (ctx,), "beta"),
+        ("raw_embed", (2, ctx), "b"),
+    ]
+    ip: List[Spec] = []
+    for idx, name in enumerate(attn_processor_names(cfg)):
+        if name.endswith("attn2.processor"):
+            c = hidden_size_of(cfg, name)
+            ip += [(f"{idx}.to_k_ip.weight", (c, ctx), "w"), (f"{idx}.to_v_ip.weight", (c, ctx), "w")]
+    return {"image_proj": image_proj, "ip_adapter": ip}
+
+
+def _fan_in(shape: Tuple[int, ...]) -> int:
+    f = 1
+    for d in shape[1:]:
+        f *= d
+    return max(f, 1)
+
+
+def _make(key: str, shape, kind: str, seed: int, device, dtype) -> torch.Tensor:
+    g = torch.Generator(device=device)
+    g.manual_seed((zlib.crc32(key.encode()) ^ (seed * 0x9E3779B1)) & 0x7FFFFFFF)
+    r = torch.randn(shape, generator=g, device=device, dtype=torch.float32)
+    if kind == "w":
+        r.mul_(_fan_in(shape) ** -0.5)
+    elif kind == "w_res":        # output layer of a residual branch
+        r.mul_(0.3 * _fan_in(shape) ** -0.5)
+    elif kind == "w_out":        # conv_out: input is ~N(0,1) after GroupNorm+SiLU (rms ~0.6)
+        r.mul_(1.6 * _fan_in(shape) ** -0.5)
+    elif kind == "b":
+        r.mul_(0.02)
+    elif kind == "gamma":
+        r.mul_(0.1).add_(1.0)
+    elif kind == "beta":
+        r.mul_(0.05)
+    else:
+        raise ValueError(kind)
+    return r.to(dtype)
+
+
+def synthetic_state_dict(specs: List[Spec], seed: int = 7, device="cpu", dtype=torch.float16) -> "OrderedDict[str, torch.Tensor]":
+    """Seeded synthetic parameters. Each tensor depends only on (key, seed), so any subset can be
+    regenerated independently and CPU/GPU processes agree when `device` is the same kind."""
+    return OrderedDict((k, _make(k, shp, kind, seed, device, dtype)) for k, shp, kind in specs)
+
+
+def iter_synthetic(specs: List[Spec], seed: int = 7, device="cpu", dtype=torch.float16) -> Iterator[Tuple[str, torch.Tensor]]:
+    for k, shp, kind in specs:
+        yield k, _make(k, shp, kind, seed, device, dtype)
+
+
+def param_count(specs: List[Spec]) -> int:
+    t = 0
+    for _, shp, _ in specs:
+        n = 1
+        for d in shp:
+            n *= d
+        t += n
+    return t

@@ -1,0 +1,283 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory FROM THE REFERENCE'S OWN FILES.
+
+Run only in the build container (needs /root/reference): `python tests/golden/gen_goldens.py`.
+The fixtures are data (inputs, weights, expected outputs as float32 arrays); no reference source travels.
+
+How reference code is reached without its un-installable imports (diffusers, imagebind, ...):
+  * torch-only files are imported after registering bare parent packages in sys.modules (so no
+    reference `__init__.py` runs): attention_processor.py, llm/model/vae/modules/{blocks,attention,util}.py;
+  * pure functions/classes inside files that import diffusers are compiled from their own AST node
+    (read from /root/reference at run time, never copied): `_backward_ddim`, `_get_add_time_ids`
+    (pnp_pipeline.py), `ImageProjModel` (ip_adapter.py), `polar_intrtpolate` (pipeline.py).
+
+Fixtures:
+  G1 attn_self.npz     AttnProcessor2_0 + AttnProcessor on a stand-in `attn`
+  G2 attn_ip.npz       IPAttnProcessor2_0 + IPAttnProcessor: 81-token ctx and the 77-token inversion quirk, 3 scales, attn_map
+  G3 image_proj.npz    ImageProjModel, modes global/local/both
+  G4 backward_ddim.npz _backward_ddim over the 20/25/50-step schedules
+  G5 schedule.npz      ldm make_beta_schedule / make_ddim_timesteps / make_ddim_sampling_parameters
+  G6 ldm_blocks.npz    ldm ResnetBlock, SpatialTransformer, timestep_embedding
+  G7 misc.npz          polar_intrtpolate, _get_add_time_ids
+  G8 unet_refprocs.npz tiny UNet (oracle module tree) with the REFERENCE processor classes installed
+"""
+import ast
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+
+def _stub_pkg(name, path):
+    m = types.ModuleType(name)
+    m.__path__ = [path]
+    sys.modules[name] = m
+
+
+def import_reference_modules():
+    base = os.path.join(REF, "instructany2pix")
+    _stub_pkg("instructany2pix", base)
+    for sub in ("diffusion", "diffusion/ip_adapter", "llm", "llm/model", "llm/model/vae", "llm/model/vae/modules", "ddim"):
+        _stub_pkg("instructany2pix." + sub.replace("/", "."), os.path.join(base, sub))
+    ap = importlib.import_module("instructany2pix.diffusion.ip_adapter.attention_processor")
+    blocks = importlib.import_module("instructany2pix.llm.model.vae.modules.blocks")
+    attention = importlib.import_module("instructany2pix.llm.model.vae.modules.attention")
+    util = importlib.import_module("instructany2pix.llm.model.vae.modules.util")
+    return ap, blocks, attention, util
+
+
+def ast_extract(relpath, names, glb):
+    """Compile selected top-level defs / class methods of a reference file from its AST."""
+    src = open(os.path.join(REF, relpath)).read()
+    tree = ast.parse(src)
+    out = {}
+    for node in ast.walk(tree):
+        if isinstance(node, (ast.FunctionDef, ast.ClassDef)) and node.name in names and node.name not in out:
+            mod = ast.Module(body=[node], type_ignores=[])
+            ns = dict(glb)
+            exec(compile(mod, relpath, "exec"), ns)
+            out[node.name] = ns[node.name]
+    missing = set(names) - set(out)
+    assert not missing, missing
+    return out
+
+
+class StandInAttn(torch.nn.Module):
+    """Minimal `attn` object for the processor protocol."""
+
+    def __init__(self, dim, ctx_dim, heads):
+        super().__init__()
+        self.heads = heads
+        self.scale = (dim // heads) ** -0.5
+        self.to_q = torch.nn.Linear(dim, dim, bias=False)
+        self.to_k = torch.nn.Linear(ctx_dim or dim, dim, bias=False)
+        self.to_v = torch.nn.Linear(ctx_dim or dim, dim, bias=False)
+        self.to_out = torch.nn.ModuleList([torch.nn.Linear(dim, dim), torch.nn.Dropout(0.0)])
+        self.spatial_norm = self.group_norm = self.norm_cross = None
+        self.residual_connection = False
+        self.rescale_output_factor = 1.0
+
+    def prepare_attention_mask(self, m, *a):
+        return m
+
+    def head_to_batch_dim(self, t):
+        b, n, c = t.shape
+        return t.reshape(b, n, self.heads, c // self.heads).permute(0, 2, 1, 3).reshape(b * self.heads, n, c // self.heads)
+
+    def batch_to_head_dim(self, t):
+        bh, n, d = t.shape
+        return t.reshape(bh // self.heads, self.heads, n, d).permute(0, 2, 1, 3).reshape(bh // self.heads, n, d * self.heads)
+
+    def get_attention_scores(self, q, k, mask=None):
+        return (torch.bmm(q, k.transpose(-1, -2)) * self.scale).softmax(dim=-1)
+
+
+def npf(t):
+    return t.detach().float().numpy()
+
+
+def main():
+    torch.manual_seed(1234)
+    torch.set_grad_enabled(False)
+    ap, blocks, attention, util = import_reference_modules()
+    g = torch.Generator().manual_seed(11)
+    rn = lambda *s: torch.randn(*s, generator=g)
+
+    # ---- G1 ------------------------------------------------------------------------------------
+    dim, heads, ctxd = 128, 2, 96
+    attn = StandInAttn(dim, None, heads)
+    for p in attn.parameters():
+        p.copy_(rn(*p.shape) * (0.09 if p.ndim == 2 else 0.02))
+    x = rn(2, 48, dim)
+    o2 = ap.AttnProcessor2_0()(attn, x)
+    o1 = ap.AttnProcessor()(attn, x)
+    np.savez(os.path.join(HERE, "attn_self.npz"), x=npf(x), heads=heads,
+             to_q=npf(attn.to_q.weight), to_k=npf(attn.to_k.weight), to_v=npf(attn.to_v.weight),
+             to_out_w=npf(attn.to_out[0].weight), to_out_b=npf(attn.to_out[0].bias),
+             out_2_0=npf(o2), out_bmm=npf(o1))
+    print("G1 max|2_0 - bmm| =", float((o1 - o2).abs().max()))
+
+    # ---- G2 ------------------------------------------------------------------------------------
+    attn = StandInAttn(dim, ctxd, heads)
+    for p in attn.parameters():
+        p.copy_(rn(*p.shape) * (0.09 if p.ndim == 2 else 0.02))
+    proc = ap.IPAttnProcessor2_0(dim, ctxd, scale=1.0, num_tokens=4)
+    proc_b = ap.IPAttnProcessor(dim, ctxd, scale=1.0, num_tokens=4)
+    for p in proc.parameters():
+        p.copy_(rn(*p.shape) * 0.1)
+    proc_b.load_state_dict(proc.state_dict())
+    x = rn(2, 48, dim)
+    d = dict(x=npf(x), heads=heads, to_q=npf(attn.to_q.weight), to_k=npf(attn.to_k.weight), to_v=npf(attn.to_v.weight),
+             to_out_w=npf(attn.to_out[0].weight), to_out_b=npf(attn.to_out[0].bias),
+             to_k_ip=npf(proc.to_k_ip.weight), to_v_ip=npf(proc.to_v_ip.weight))
+    for L in (81, 77):
+        ctx = rn(2, L, ctxd)
+        d[f"ctx{L}"] = npf(ctx)
+        for s in (0.0, 0.5, 1.0):
+            proc.scale = proc_b.scale = s
+            o = proc(attn, x, encoder_hidden_states=ctx)
+            ob = proc_b(attn, x, encoder_hidden_states=ctx)
+            d[f"out{L}_s{s}"] = npf(o)
+            d[f"outbmm{L}_s{s}"] = npf(ob)
+        d[f"attn_map{L}"] = npf(proc.attn_map)
+    np.savez(os.path.join(HERE, "attn_ip.npz"), **d)
+
+    # ---- G3 ------------------------------------------------------------------------------------
+    IPM = ast_extract("instructany2pix/diffusion/ip_adapter/ip_adapter.py", ["ImageProjModel"], {"torch": torch})["ImageProjModel"]
+    m = IPM(cross_attention_dim=64, clip_embeddings_dim=48, clip_extra_context_tokens=4)
+    for p in m.parameters():
+        p.copy_(rn(*p.shape) * 0.2)
+    emb = rn(2, 2, 48)
+    d = dict(emb=npf(emb), **{k.replace(".", "_"): npf(v) for k, v in m.state_dict().items()})
+    for mode in ("global", "local", "both"):
+        for sc in ((1.0, 1.0), (1.0, 0.5)):
+            d[f"out_{mode}_{sc[1]}"] = npf(m(emb.clone(), mode=mode, scales=list(sc)))
+    d["out_zero_global"] = npf(m(torch.zeros_like(emb), mode="global"))
+    np.savez(os.path.join(HERE, "image_proj.npz"), **d)
+
+    # ---- G4 / G7 -------------------------------------------------------------------------------
+    fns = ast_extract("instructany2pix/ddim/pnp_pipeline.py", ["_backward_ddim", "_get_add_time_ids"], {"torch": torch})
+    bd = fns["_backward_ddim"]
+    betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float32) ** 2
+    acp = torch.cumprod(1 - betas, 0)
+    xs = rn(1, 4, 8, 8)
+    es = rn(60, 1, 4, 8, 8)
+    d = dict(x0=npf(xs), eps=npf(es))
+    for n in (20, 25, 50):
+        ts = (np.arange(0, n) * (1000 // n)).round()[::-1].copy().astype(np.int64) + 1
+        lat = xs.clone()
+        prev = None
+        traj = []
+        for i, t in enumerate(reversed(ts.tolist())):
+            a_t = acp[t]
+            a_p = acp[prev] if prev is not None else acp[0]
+            prev = t
+            lat = bd(lat, a_t, a_p, es[i])
+            traj.append(npf(lat))
+        d[f"traj{n}"] = np.stack(traj)
+        d[f"timesteps{n}"] = ts
+    # fp16 tensor x fp32 0-dim coefficient, as in the live pipeline
+    d["half_step"] = npf(bd(xs.half(), acp[501], acp[481], es[0].half()))
+    np.savez(os.path.join(HERE, "backward_ddim.npz"), **d)
+
+    polar = ast_extract("instructany2pix/pipeline.py", ["polar_intrtpolate"], {"torch": torch})["polar_intrtpolate"]
+    a, b = rn(1, 4, 16, 16), rn(1, 4, 16, 16)
+    dm = dict(pa=npf(a), pb=npf(b), polar_07=npf(polar(None, a, b, 0.7)), polar_03=npf(polar(None, a, b, 0.3)),
+              polar_half=npf(polar(None, a.half(), b.half(), 0.7)))
+    fake = types.SimpleNamespace(
+        config=types.SimpleNamespace(requires_aesthetics_score=False),
+        unet=types.SimpleNamespace(config=types.SimpleNamespace(addition_time_embed_dim=256),
+                                   add_embedding=types.SimpleNamespace(linear_1=types.SimpleNamespace(in_features=2816))),
+        text_encoder_2=types.SimpleNamespace(config=types.SimpleNamespace(projection_dim=1280)))
+    ids, nids = fns["_get_add_time_ids"](fake, (1024, 1024), (0, 0), (1024, 1024), 6.0, 2.5, (1024, 1024), (0, 0), (1024, 1024), torch.float32)
+    dm["time_ids"] = npf(ids)
+    dm["neg_time_ids"] = npf(nids)
+    fake.unet.add_embedding.linear_1.in_features = 2560
+    try:
+        fns["_get_add_time_ids"](fake, (1024, 1024), (0, 0), (1024, 1024), 6.0, 2.5, (1024, 1024), (0, 0), (1024, 1024), torch.float32)
+        dm["bad_dim_raises"] = 0
+    except ValueError:
+        dm["bad_dim_raises"] = 1
+    np.savez(os.path.join(HERE, "misc.npz"), **dm)
+
+    # ---- G5 ------------------------------------------------------------------------------------
+    b64 = util.make_beta_schedule("linear", 1000, 0.00085, 0.012)
+    acp64 = np.cumprod(1 - b64)
+    d = dict(betas=b64, alphas_cumprod=acp64)
+    for n in (20, 25, 50):
+        ts = util.make_ddim_timesteps("uniform", n, 1000, verbose=False)
+        _, al, alp = util.make_ddim_sampling_parameters(acp64, ts, 0.0, verbose=False)
+        d[f"ts{n}"], d[f"alphas{n}"], d[f"alphas_prev{n}"] = ts, al, alp
+    np.savez(os.path.join(HERE, "schedule.npz"), **d)
+
+    # ---- G6 ------------------------------------------------------------------------------------
+    d = {}
+    rb = blocks.ResnetBlock(in_channels=64, out_channels=96, dropout=0.0, temb_channels=48)
+    for p in rb.parameters():
+        p.copy_(rn(*p.shape) * (0.06 if p.ndim > 1 else 0.3))
+    x, temb = rn(2, 64, 8, 8), rn(2, 48)
+    d.update({"rb_" + k.replace(".", "_"): npf(v) for k, v in rb.state_dict().items()})
+    d["rb_x"], d["rb_temb"], d["rb_out"] = npf(x), npf(temb), npf(rb(x, temb))
+    st = attention.SpatialTransformer(64, 1, 64, depth=2, context_dim=40)
+    for p in st.parameters():
+        p.copy_(rn(*p.shape) * (0.1 if p.ndim > 1 else 0.3))
+    x, ctx = rn(2, 64, 6, 6), rn(2, 9, 40)
+    d.update({"st_" + k.replace(".", "_"): npf(v) for k, v in st.state_dict().items()})
+    d["st_keys"] = np.array(list(st.state_dict().keys()))
+    d["st_x"], d["st_ctx"], d["st_out"] = npf(x), npf(ctx), npf(st(x, ctx))
+    tt = torch.tensor([1.0, 481.0, 981.0, 1024.0])
+    d["temb_t"], d["temb_320"], d["temb_256"] = npf(tt), npf(util.timestep_embedding(tt, 320)), npf(util.timestep_embedding(tt, 256))
+    np.savez(os.path.join(HERE, "ldm_blocks.npz"), **d)
+
+    # ---- G8: oracle module tree driven by the REFERENCE processor classes -----------------------------
+    import oracle
+    from instructany2pix_amd.config import tiny
+    from instructany2pix_amd.weights import unet_param_specs, ip_adapter_specs, synthetic_state_dict
+    cfg = tiny()
+    sd = synthetic_state_dict(unet_param_specs(cfg), seed=7)
+    ipsd = synthetic_state_dict(ip_adapter_specs(cfg, 64)["ip_adapter"], seed=7)
+    net = oracle.build_unet(cfg, sd)
+    procs = {}
+    for name in net.attn_processors.keys():            # reference ip_adapter.py:120-142, verbatim semantics
+        if name.endswith("attn1.processor"):
+            procs[name] = ap.AttnProcessor2_0()
+        else:
+            if name.startswith("mid_block"):
+                hs = cfg.block_out_channels[-1]
+            elif name.startswith("up_blocks"):
+                hs = list(reversed(cfg.block_out_channels))[int(name[len("up_blocks.")])]
+            else:
+                hs = cfg.block_out_channels[int(name[len("down_blocks.")])]
+            procs[name] = ap.IPAttnProcessor2_0(hidden_size=hs, cross_attention_dim=cfg.cross_attention_dim, scale=1.0, num_tokens=4)
+    net.set_attn_processor(procs)
+    torch.nn.ModuleList(net.attn_processors.values()).load_state_dict({k: v.float() for k, v in ipsd.items()})
+    gg = torch.Generator().manual_seed(5)
+    B = 2
+    x = torch.randn(B, 4, 16, 16, generator=gg)
+    te = torch.randn(B, cfg.pooled_dim, generator=gg)
+    tid = torch.tensor([[128.0, 128, 0, 0, 128, 128]] * B)
+    d = dict(x=npf(x), text_embeds=npf(te), time_ids=npf(tid))
+    for L in (81, 77):
+        ctx = torch.randn(B, L, cfg.cross_attention_dim, generator=gg)
+        d[f"ctx{L}"] = npf(ctx)
+        for t in (981, 1):
+            for s in (1.0, 0.5):
+                for p_ in procs.values():
+                    if hasattr(p_, "scale"):
+                        p_.scale = s
+                d[f"out_L{L}_t{t}_s{s}"] = npf(net(x, t, ctx, added_cond_kwargs=dict(text_embeds=te, time_ids=tid))[0])
+    np.savez(os.path.join(HERE, "unet_refprocs.npz"), **d)
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,166 @@
+"""The oracle pinned against the golden vectors generated from the reference's own files
+(tests/golden/gen_goldens.py). CPU only."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle.unet_ref import Attention, ResnetBlock2D, Transformer2DModel, sinusoid
+
+T = torch.from_numpy
+
+
+def _attn(d, ctx_dim):
+    dim = d["to_q"].shape[0]
+    a = Attention(dim, ctx_dim, int(d["heads"]), dim // int(d["heads"]))
+    a.to_q.weight.data = T(d["to_q"]); a.to_k.weight.data = T(d["to_k"]); a.to_v.weight.data = T(d["to_v"])
+    a.to_out[0].weight.data = T(d["to_out_w"]); a.to_out[0].bias.data = T(d["to_out_b"])
+    return a
+
+
+@torch.no_grad()
+def test_g1_self_attention_processor(golden):
+    d = golden("attn_self.npz")
+    a = _attn(d, None)
+    o = oracle.AttnProcessor2_0Ref()(a, T(d["x"]))
+    assert np.abs(o.numpy() - d["out_2_0"]).max() < 2e-6      # reference AttnProcessor2_0 :205-279
+    assert np.abs(o.numpy() - d["out_bmm"]).max() < 2e-6      # reference AttnProcessor (bmm twin) :19-79
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("L", [81, 77])
+def test_g2_ip_attention_processor(golden, L):
+    d = golden("attn_ip.npz")
+    a = _attn(d, d["to_k"].shape[1])
+    p = oracle.IPAttnProcessor2_0Ref(d["to_q"].shape[0], d["to_k"].shape[1], num_tokens=4)
+    p.to_k_ip.weight.data = T(d["to_k_ip"]); p.to_v_ip.weight.data = T(d["to_v_ip"])
+    for s in (0.0, 0.5, 1.0):
+        p.scale = s
+        o = p(a, T(d["x"]), encoder_hidden_states=T(d[f"ctx{L}"]))
+        assert np.abs(o.numpy() - d[f"out{L}_s{s}"]).max() < 2e-6       # IPAttnProcessor2_0 :310-412
+        assert np.abs(o.numpy() - d[f"outbmm{L}_s{s}"]).max() < 2e-6    # IPAttnProcessor :107-188
+    assert np.abs(p.attn_map.numpy() - d[f"attn_map{L}"]).max() < 1e-5    # side effect :390-391
+
+
+@torch.no_grad()
+def test_g3_image_proj(golden):
+    d = golden("image_proj.npz")
+    m = oracle.ImageProjModelRef(cross_attention_dim=64, clip_embeddings_dim=48, clip_extra_context_tokens=4)
+    m.proj.weight.data = T(d["proj_weight"]); m.proj.bias.data = T(d["proj_bias"])
+    m.norm.weight.data = T(d["norm_weight"]); m.norm.bias.data = T(d["norm_bias"]); m.raw_embed.data = T(d["raw_embed"])
+    emb = T(d["emb"])
+    for mode in ("global", "local", "both"):
+        for sl in (1.0, 0.5):
+            o = m(emb, mode, scales=(1.0, sl))
+            assert np.abs(o.numpy() - d[f"out_{mode}_{sl}"]).max() < 2e-6
+    assert np.abs(m(torch.zeros_like(emb), "global").numpy() - d["out_zero_global"]).max() < 2e-6
+    with pytest.raises(AssertionError):
+        m(emb, "bogus")
+
+
+def test_g4_backward_ddim_and_schedule(golden):
+    d = golden("backward_ddim.npz")
+    s = oracle.DDIMSchedulerRef()
+    for n in (20, 25, 50):
+        s.set_timesteps(n)
+        assert np.array_equal(s.timesteps.numpy(), d[f"timesteps{n}"])
+        lat = T(d["x0"]).clone()
+        prev = None
+        for i, t in enumerate(reversed(s.timesteps)):
+            a_p = s.alphas_cumprod[prev] if prev is not None else s.final_alpha_cumprod
+            lat = oracle.backward_ddim(lat, s.alphas_cumprod[t], a_p, T(d["eps"][i]))
+            prev = t
+            assert np.abs(lat.numpy() - d[f"traj{n}"][i]).max() <= 1e-6 * max(1.0, np.abs(d[f"traj{n}"][i]).max())
+    h = oracle.backward_ddim(T(d["x0"]).half(), s.alphas_cumprod[501], s.alphas_cumprod[481], T(d["eps"][0]).half())
+    assert h.dtype == torch.float16 and np.array_equal(h.float().numpy(), d["half_step"])
+
+
+def test_g4_step_inverts_backward_ddim():
+    """DDIM `step` (diffusers formula) and the reference's `_backward_ddim` are exact inverses for fixed eps."""
+    s = oracle.DDIMSchedulerRef()
+    s.set_timesteps(50)
+    g = torch.Generator().manual_seed(0)
+    x, e = torch.randn(1, 4, 8, 8, generator=g, dtype=torch.float64), torch.randn(1, 4, 8, 8, generator=g, dtype=torch.float64)
+    t = 501
+    a_t, a_p = s.alphas_cumprod[t].double(), s.alphas_cumprod[t - 20].double()
+    up = oracle.backward_ddim(x, a_t, a_p, e)
+    down = a_p ** 0.5 * (up - (1 - a_t) ** 0.5 * e) / a_t ** 0.5 + (1 - a_p) ** 0.5 * e
+    assert (down - x).abs().max() < 1e-12
+    # and the scheduler's own step agrees with that closed form
+    assert (s.step(e.float(), t, up.float()) - x.float()).abs().max() < 1e-5
+
+
+def test_g5_schedule_tables(golden):
+    d = golden("schedule.npz")
+    s = oracle.DDIMSchedulerRef()
+    assert np.abs(s.betas.numpy() - d["betas"]).max() < 1e-8
+    assert np.abs(s.alphas_cumprod.numpy() - d["alphas_cumprod"]).max() < 2e-6
+    for n in (20, 25, 50):
+        s.set_timesteps(n)
+        ts = s.timesteps.numpy()[::-1]                          # ldm lists ascending
+        assert np.array_equal(ts, d[f"ts{n}"])
+        a = s.alphas_cumprod.numpy()
+        assert np.abs(a[ts] - d[f"alphas{n}"]).max() < 2e-6
+        prev = [float(s.final_alpha_cumprod)] + [a[t - 1000 // n] for t in ts[1:]]
+        assert np.abs(np.array(prev) - d[f"alphas_prev{n}"]).max() < 2e-6
+
+
+@torch.no_grad()
+def test_g6_ldm_blocks(golden):
+    d = golden("ldm_blocks.npz")
+    assert np.abs(sinusoid(T(d["temb_t"]), 320).numpy() - d["temb_320"]).max() < 1e-6
+    assert np.abs(sinusoid(T(d["temb_t"]), 256).numpy() - d["temb_256"]).max() < 1e-6
+    rb = ResnetBlock2D(64, 96, 48, 32, 1e-6)                     # ldm Normalize eps 1e-6 (blocks.py:38-39)
+    ren = {"temb_proj": "time_emb_proj", "nin_shortcut": "conv_shortcut"}
+    sd = {}
+    for k in rb.state_dict():
+        src = k
+        for a, b in ren.items():
+            src = src.replace(b, a)
+        sd[k] = T(d["rb_" + src.replace(".", "_")])
+    rb.load_state_dict(sd)
+    o = rb(T(d["rb_x"]), T(d["rb_temb"]))
+    assert np.abs(o.numpy() - d["rb_out"]).max() < 2e-5
+    st = Transformer2DModel(64, 1, 64, 2, 40, 32)
+    sd = {}
+    for k in st.state_dict():
+        v = T(d["st_" + k.replace(".", "_")])
+        sd[k] = v.reshape(v.shape[0], v.shape[1]) if k in ("proj_in.weight", "proj_out.weight") else v   # conv1x1 == Linear
+    st.load_state_dict(sd)
+    o = st(T(d["st_x"]), T(d["st_ctx"]))
+    assert np.abs(o.numpy() - d["st_out"]).max() < 5e-5
+
+
+def test_g7_misc(golden):
+    d = golden("misc.npz")
+    a, b = T(d["pa"]), T(d["pb"])
+    assert np.abs(oracle.polar_interpolate(a, b, 0.7).numpy() - d["polar_07"]).max() < 1e-6
+    assert np.abs(oracle.polar_interpolate(a, b, 0.3).numpy() - d["polar_03"]).max() < 1e-6
+    assert np.array_equal(oracle.polar_interpolate(a.half(), b.half(), 0.7).float().numpy(), d["polar_half"])
+    ids = oracle.get_add_time_ids((1024, 1024), (0, 0), (1024, 1024), 256, 1280, 2816)
+    assert np.array_equal(ids.numpy(), d["time_ids"]) and np.array_equal(ids.numpy(), d["neg_time_ids"])
+    assert int(d["bad_dim_raises"]) == 1
+    with pytest.raises(ValueError):
+        oracle.get_add_time_ids((1024, 1024), (0, 0), (1024, 1024), 256, 1280, 2560)
+
+
+@torch.no_grad()
+def test_g8_unet_with_reference_processors(golden):
+    """Oracle UNet + oracle processors == oracle UNet tree + the REFERENCE processor classes."""
+    from instructany2pix_amd.config import tiny
+    from instructany2pix_amd.weights import unet_param_specs, ip_adapter_specs, synthetic_state_dict
+    d = golden("unet_refprocs.npz")
+    cfg = tiny()
+    sd = synthetic_state_dict(unet_param_specs(cfg), seed=7)
+    ipsd = synthetic_state_dict(ip_adapter_specs(cfg, 64)["ip_adapter"], seed=7)
+    net = oracle.build_unet(cfg, sd, ipsd)
+    added = dict(text_embeds=T(d["text_embeds"]), time_ids=T(d["time_ids"]))
+    for L in (81, 77):
+        for t in (981, 1):
+            for s in (1.0, 0.5):
+                for p in net.attn_processors.values():
+                    if hasattr(p, "scale"):
+                        p.scale = s
+                o = net(T(d["x"]), t, T(d[f"ctx{L}"]), added_cond_kwargs=added)[0]
+                ref = d[f"out_L{L}_t{t}_s{s}"]
+                assert np.abs(o.numpy() - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
