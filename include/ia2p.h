@@ -1,0 +1,129 @@
+/* ia2p.h -- C ABI of libia2p_hip.so: the MI355X (gfx950) denoise hot path of InstructAny2Pix.
+ *
+ * The reference (pure Python, no FFI of its own) reaches this path through three seams; each entry point
+ * below names the reference interface it stands in for (paths relative to the reference checkout):
+ *
+ *   UNet callable   unet(sample, t, encoder_hidden_states=, added_cond_kwargs={text_embeds,time_ids})[0]
+ *                   instructany2pix/ddim/pnp_pipeline.py:253-260, instructany2pix/ddim/sdxl_pipeline.py:832-839
+ *                   -> ia2p_unet_forward
+ *   operator plugin attn.processor(attn, hidden_states, encoder_hidden_states)
+ *                   instructany2pix/diffusion/ip_adapter/attention_processor.py:205-279 (AttnProcessor2_0),
+ *                   :310-412 (IPAttnProcessor2_0); installed by ip_adapter.py:120-142, scale set by :211-214
+ *                   -> ia2p_set_ip_adapter, ia2p_attention (+ ia2p_gemm for the projections)
+ *   sampler update  _backward_ddim pnp_pipeline.py:73-85; CFG combine sdxl_pipeline.py:842-844;
+ *                   DDIMScheduler.step (diffusers 0.26.3) called at sdxl_pipeline.py:851
+ *                   -> ia2p_ddim_step
+ *
+ * Conventions: plain pointers and sizes only (no torch types); every `const void*` / `void*` tensor argument
+ * is a DEVICE pointer to fp16 data unless stated otherwise; kernels are enqueued on the caller's HIP stream
+ * (`stream` is a hipStream_t passed as void*, NULL = default stream) with no hidden synchronisation;
+ * functions return IA2P_OK or an error code and never abort; ia2p_last_error() gives the message.
+ * A context is bound to the device that was current at ia2p_create and is not re-entrant.
+ * Activations inside the library are channels-last ([B*H*W, C]); the latent boundary is NCHW like the reference.
+ */
+#ifndef IA2P_H
+#define IA2P_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ia2p_ctx ia2p_ctx;
+
+typedef enum {
+  IA2P_OK = 0,
+  IA2P_ERR_INVALID = 1,   /* bad argument (null pointer, negative size, unknown enum) */
+  IA2P_ERR_SHAPE = 2,     /* shape / divisibility constraint violated */
+  IA2P_ERR_KEY = 3,       /* unknown or duplicate parameter key, or parameters missing at finalize */
+  IA2P_ERR_STATE = 4,     /* call order (weights not finalized, arena not bound, ...) */
+  IA2P_ERR_NOMEM = 5,     /* arena / workspace too small */
+  IA2P_ERR_HIP = 6,       /* HIP runtime error */
+  IA2P_ERR_ARCH = 7       /* current device is not gfx950 */
+} ia2p_status;
+
+#define IA2P_MAX_BLOCKS 4
+
+/* Mirrors the fields of diffusers' unet/config.json the reference reads (pnp_pipeline.py:44-47, ip_adapter.py:114,124-132). */
+typedef struct {
+  int in_channels, out_channels;
+  int n_blocks;
+  int block_out_channels[IA2P_MAX_BLOCKS];
+  int transformer_layers_per_block[IA2P_MAX_BLOCKS];   /* 0 = no attention in that block */
+  int num_heads[IA2P_MAX_BLOCKS];                      /* diffusers "attention_head_dim" (head counts for SDXL) */
+  int layers_per_block;
+  int cross_attention_dim;
+  int norm_num_groups;
+  float norm_eps;
+  int addition_time_embed_dim;
+  int projection_class_embeddings_input_dim;
+  int time_embed_dim;
+  int time_proj_dim;
+} ia2p_unet_config;
+
+/* ---- lifetime ---------------------------------------------------------------------------------------------- */
+ia2p_status ia2p_create(const ia2p_unet_config* cfg, ia2p_ctx** out);
+void ia2p_destroy(ia2p_ctx* ctx);
+const char* ia2p_last_error(ia2p_ctx* ctx);            /* ctx may be NULL: error of the failed ia2p_create */
+int ia2p_device_is_gfx950(void);
+
+/* ---- weights: one flat, position-deterministic arena (so ranks can RCCL-broadcast it as one buffer) ---------- */
+size_t ia2p_arena_bytes(ia2p_ctx* ctx);
+ia2p_status ia2p_bind_arena(ia2p_ctx* ctx, void* dev_arena, size_t bytes);   /* caller owns the memory */
+/* Load one parameter by its diffusers state-dict key (e.g. "down_blocks.1.attentions.0.transformer_blocks.0.attn1.to_q.weight")
+ * or IP-Adapter key ("ip_adapter.<idx>.to_k_ip.weight", idx = position in unet.attn_processors; ip_adapter.py:168-169).
+ * `dev_src` is fp16 in the checkpoint's own layout; it is re-laid-out into the arena on `stream`. */
+ia2p_status ia2p_load_tensor(ia2p_ctx* ctx, const char* key, const void* dev_src, const int64_t* shape, int ndim, void* stream);
+ia2p_status ia2p_finalize_weights(ia2p_ctx* ctx);      /* verifies every UNet parameter was loaded */
+ia2p_status ia2p_adopt_arena(ia2p_ctx* ctx);           /* arena was filled elsewhere (broadcast): mark as finalized */
+/* IP-Adapter plugin state: set_ip_adapter (ip_adapter.py:120-142) / set_scale (:211-214) / disable (:153-154). */
+ia2p_status ia2p_set_ip_adapter(ia2p_ctx* ctx, int enabled, int num_tokens, float scale);
+
+/* ---- the UNet callable ------------------------------------------------------------------------------------------- */
+size_t ia2p_workspace_bytes(ia2p_ctx* ctx, int B, int h, int w, int L);
+/* sample, out: [B, in/out_channels, h, w] NCHW; context: [B, L, cross_attention_dim]; text_embeds: [B, pooled];
+ * time_ids: [B, 6]. With the IP-Adapter enabled the last num_tokens rows of each context are the image tokens. */
+ia2p_status ia2p_unet_forward(ia2p_ctx* ctx, void* stream, const void* sample, float timestep, const void* context, int L,
+                              const void* text_embeds, const void* time_ids, void* out, int B, int h, int w,
+                              void* workspace, size_t workspace_bytes);
+
+/* ---- sampler update --------------------------------------------------------------------------------------------- */
+/* out = c_x * x + c_e * (eps_u + g * (eps_c - eps_u)); eps_c may be NULL (no guidance); out2 may be NULL. */
+ia2p_status ia2p_ddim_step(void* stream, const void* x, const void* eps_u, const void* eps_c, float g, float c_x, float c_e,
+                           void* out, void* out2, int64_t n);
+
+/* ---- per-operator entry points (unit tests, and hosts that keep their own module tree) ----------------------------- */
+ia2p_status ia2p_groupnorm_silu(void* stream, const void* x, void* y, const void* gamma, const void* beta, int B, int HW, int C,
+                                int groups, float eps, int silu, float* partial_ws /* >= B*64*groups*2 floats */);
+ia2p_status ia2p_layernorm(void* stream, const void* x, void* y, const void* gamma, const void* beta, int M, int C, float eps);
+/* C[M,N] = A[M,K] . W[N,K]^T + bias + residual ; geglu: W/bias packed by ia2p_pack_geglu, C is [M, N/2] */
+ia2p_status ia2p_gemm(void* stream, const void* A, const void* W, const void* bias, const void* residual, void* C,
+                      int M, int N, int K, int geglu);
+/* 3x3 conv, pad 1, over channels-last x[B,Hs,Ws,Cin] with W packed [Co][3][3][Cin] (ia2p_pack_conv3x3);
+ * stride 1|2; up=1 convolves the nearest-x2 upsampled x; rowvec [B,Co] (time embedding) and residual optional. */
+ia2p_status ia2p_conv3x3(void* stream, const void* x, const void* Wp, const void* bias, const void* rowvec, const void* residual,
+                         void* y, int B, int Hs, int Ws, int Cin, int Co, int stride, int up);
+ia2p_status ia2p_pack_conv3x3(void* stream, const void* w_oihw, void* w_packed, int Co, int Cin);
+ia2p_status ia2p_pack_geglu(void* stream, const void* src, void* dst, int rows, int rowlen);
+/* O[b,q,h*64:] = sum_s weight_s * softmax(Q K_s^T / 8) V_s over nseg <= 2 key segments (head_dim 64).
+ * Q rows have stride ldq, K_s/V_s rows stride ld_s; segment s has nkeys_s keys per batch. */
+ia2p_status ia2p_attention(void* stream, const void* Q, int ldq, void* O, int ldo, int B, int heads, int Nq, int nseg,
+                           const void* K0, const void* V0, int ld0, int nkeys0, float w0,
+                           const void* K1, const void* V1, int ld1, int nkeys1, float w1);
+ia2p_status ia2p_linear_small(void* stream, const void* X, const void* W, const void* bias, void* out, int M, int N, int K,
+                              int silu_in, int silu_out);
+
+void ia2p_debug_set_gemm_tile(int tile);   /* -1 auto, 0: 128x128, 1: 128x64, 2: 64x64 (tests / tuning) */
+
+/* ---- per-kernel-class timing (bench.py roofline leg): HIP events around each launch of the class ------------------- */
+typedef enum { IA2P_K_GEMM = 0, IA2P_K_CONV = 1, IA2P_K_ATTN = 2, IA2P_K_GNORM = 3, IA2P_K_LNORM = 4, IA2P_K_OTHER = 5, IA2P_K_COUNT = 6 } ia2p_kclass;
+ia2p_status ia2p_profile_enable(ia2p_ctx* ctx, int on);
+/* sums since enable: launches, milliseconds, algorithmic flops and bytes per class */
+ia2p_status ia2p_profile_read(ia2p_ctx* ctx, int kclass, int64_t* launches, double* ms, double* flops, double* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IA2P_H */

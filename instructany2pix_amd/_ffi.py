@@ -1,0 +1,128 @@
+"""ctypes binding of libia2p_hip.so (C ABI declared in include/ia2p.h).
+
+The product path has no CPU fallback: if the library is missing this module raises at import of the
+symbols, and every compute entry point needs device pointers on an MI355X.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libia2p_hip.so")
+
+IA2P_OK = 0
+_STATUS_NAMES = {1: "INVALID", 2: "SHAPE", 3: "KEY", 4: "STATE", 5: "NOMEM", 6: "HIP", 7: "ARCH"}
+K_GEMM, K_CONV, K_ATTN, K_GNORM, K_LNORM, K_OTHER = range(6)
+KCLASS_NAMES = ["gemm", "conv3x3", "attention", "groupnorm", "layernorm", "other"]
+MAX_BLOCKS = 4
+
+
+class UNetConfigC(C.Structure):
+    _fields_ = [
+        ("in_channels", C.c_int), ("out_channels", C.c_int), ("n_blocks", C.c_int),
+        ("block_out_channels", C.c_int * MAX_BLOCKS), ("transformer_layers_per_block", C.c_int * MAX_BLOCKS),
+        ("num_heads", C.c_int * MAX_BLOCKS), ("layers_per_block", C.c_int), ("cross_attention_dim", C.c_int),
+        ("norm_num_groups", C.c_int), ("norm_eps", C.c_float), ("addition_time_embed_dim", C.c_int),
+        ("projection_class_embeddings_input_dim", C.c_int), ("time_embed_dim", C.c_int), ("time_proj_dim", C.c_int),
+    ]
+
+
+# every symbol include/ia2p.h declares: name -> (restype, argtypes)
+_P, _I, _F, _SZ, _I64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_int64
+SIGNATURES = {
+    "ia2p_create": (_I, [C.POINTER(UNetConfigC), C.POINTER(_P)]),
+    "ia2p_destroy": (None, [_P]),
+    "ia2p_last_error": (C.c_char_p, [_P]),
+    "ia2p_device_is_gfx950": (_I, []),
+    "ia2p_arena_bytes": (_SZ, [_P]),
+    "ia2p_bind_arena": (_I, [_P, _P, _SZ]),
+    "ia2p_load_tensor": (_I, [_P, C.c_char_p, _P, C.POINTER(_I64), _I, _P]),
+    "ia2p_finalize_weights": (_I, [_P]),
+    "ia2p_adopt_arena": (_I, [_P]),
+    "ia2p_set_ip_adapter": (_I, [_P, _I, _I, _F]),
+    "ia2p_workspace_bytes": (_SZ, [_P, _I, _I, _I, _I]),
+    "ia2p_unet_forward": (_I, [_P, _P, _P, _F, _P, _I, _P, _P, _P, _I, _I, _I, _P, _SZ]),
+    "ia2p_ddim_step": (_I, [_P, _P, _P, _P, _F, _F, _F, _P, _P, _I64]),
+    "ia2p_groupnorm_silu": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
+    "ia2p_layernorm": (_I, [_P, _P, _P, _P, _P, _I, _I, _F]),
+    "ia2p_gemm": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I]),
+    "ia2p_conv3x3": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I]),
+    "ia2p_pack_conv3x3": (_I, [_P, _P, _P, _I, _I]),
+    "ia2p_pack_geglu": (_I, [_P, _P, _P, _I, _I]),
+    "ia2p_attention": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _F, _P, _P, _I, _I, _F]),
+    "ia2p_linear_small": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I]),
+    "ia2p_debug_set_gemm_tile": (None, [_I]),
+    "ia2p_profile_enable": (_I, [_P, _I]),
+    "ia2p_profile_read": (_I, [_P, _I, C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+}
+
+_lib = None
+
+
+class IA2PError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load the HIP library. Fails loudly when it has not been built (no fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise IA2PError(f"{LIB_PATH} is missing: build it with `python -m instructany2pix_amd.build` "
+                            f"(the denoise path has no non-HIP fallback)")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)           # AttributeError if the .so does not export a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(status: int, ctx=None):
+    """Map ia2p_status to the exception types the reference raises at the same conditions
+    (ValueError from check_inputs/_get_add_time_ids, reference pnp_pipeline.py:49-66)."""
+    if status == IA2P_OK:
+        return
+    msg = lib().ia2p_last_error(ctx)
+    msg = msg.decode() if msg else ""
+    text = f"ia2p {_STATUS_NAMES.get(status, status)}: {msg}"
+    if status in (1, 2):
+        raise ValueError(text)
+    if status == 3:
+        raise KeyError(text)
+    if status == 5:
+        raise MemoryError(text)
+    raise IA2PError(text)
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL). Tensors must be contiguous fp16 CUDA tensors."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "ia2p needs contiguous device tensors"
+    return C.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def make_config(cfg) -> UNetConfigC:
+    c = UNetConfigC()
+    c.in_channels, c.out_channels = cfg.in_channels, cfg.out_channels
+    c.n_blocks = len(cfg.block_out_channels)
+    if c.n_blocks > MAX_BLOCKS:
+        raise ValueError(f"at most {MAX_BLOCKS} resolution levels are supported")
+    for i in range(c.n_blocks):
+        c.block_out_channels[i] = cfg.block_out_channels[i]
+        c.transformer_layers_per_block[i] = cfg.transformer_layers_per_block[i]
+        c.num_heads[i] = cfg.attention_head_dim[i]
+    c.layers_per_block = cfg.layers_per_block
+    c.cross_attention_dim = cfg.cross_attention_dim
+    c.norm_num_groups, c.norm_eps = cfg.norm_num_groups, cfg.norm_eps
+    c.addition_time_embed_dim = cfg.addition_time_embed_dim
+    c.projection_class_embeddings_input_dim = cfg.projection_class_embeddings_input_dim
+    c.time_embed_dim, c.time_proj_dim = cfg.time_embed_dim, cfg.time_proj_dim
+    return c

@@ -1,0 +1,173 @@
+// Fused attention for gfx950, head_dim 64, fp16 in/out, fp32 softmax and accumulation.
+//
+// Replaces the F.scaled_dot_product_attention calls of the reference's operator plugins
+// (attention_processor.py:259 self-attention; :371 text cross-attention; :387 image-token cross-attention;
+// :397 `text_out + scale * ip_out`). A launch walks up to two KEY SEGMENTS, each with its OWN softmax, and
+// accumulates weight_s * softmax(Q K_s^T / 8) V_s -- exactly the decoupled cross-attention of the IP-Adapter
+// (two independent softmaxes, not one over 81 keys). Self-attention is one segment.
+//
+// Structure (cdna_hip_programming.md App. B, "Fused attention prefill"): 4 waves x 32 query rows per
+// workgroup; K/V tiles of 64 keys staged in LDS (K XOR-swizzled for ds_read_b128 row reads, V swizzled for
+// ds_read_b64_tr_b16 transposed reads); swapped QK^T (S^T = K.Q^T with v_mfma_f32_32x32x16_f16) so a lane
+// owns one query column: row max / sum are in-lane plus one cross-half shuffle; the S^T accumulator is
+// re-used directly as the B operand of O^T = V^T . P^T (accumulator-as-operand k-permutation, §3), so P never
+// touches LDS and the per-query rescale factors stay lane-local.
+#include "common.h"
+
+#define MASKED (-1.0e30f)
+
+__device__ __forceinline__ fp16x4 lds_tr16(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4f16((fp16x4 __attribute__((address_space(3)))*)p);
+}
+
+__global__ __launch_bounds__(256) void attention_f16_kernel(const AttnArgs p) {
+  __shared__ __attribute__((aligned(1024))) char smem[16384];  // K tile [64][64] fp16, V tile [64][64] fp16
+  char* sK = smem;
+  char* sV = smem + 8192;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z, hd = blockIdx.y;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int r31 = lane & 31, hh = lane >> 5;
+
+  // Q^T as the B operand of S^T = K . Q^T : lane holds Q[q0 + lane%32][16*s + 8*(lane/32) + 0..7]
+  h8 qf[4];
+  {
+    int q = q0 + r31;
+    if (q >= p.Nq) q = p.Nq - 1;  // clamp (rows past the end are computed and discarded)
+    const half_t* qp = p.Q + ((size_t)b * p.Nq + q) * p.ldq + hd * 64 + hh * 8;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *(const h8*)(qp + s * 16);
+  }
+
+  f16v otot[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) otot[d][r] = 0.f;
+
+  // staging role of this thread: 2 x 16-byte chunks of K and of V per tile
+  // chunk id c = tid + 256*u (u = 0,1): row = c / 8, position = c % 8
+  for (int sg = 0; sg < p.nseg; ++sg) {
+    const AttnSeg seg = p.seg[sg];
+    const half_t* Kb = seg.K + (size_t)b * seg.rows_per_batch * seg.ld + hd * 64;
+    const half_t* Vb = seg.V + (size_t)b * seg.rows_per_batch * seg.ld + hd * 64;
+    float mrun = MASKED, lrun = 0.f;
+    f16v o[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+
+    for (int k0 = 0; k0 < seg.nkeys; k0 += 64) {
+      __syncthreads();  // previous tile fully consumed
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int c = tid + 256 * u, row = c >> 3, pos = c & 7;
+        const int key = k0 + row;
+        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+        if (key < seg.nkeys) {
+          kv = *(const uint4*)(Kb + (size_t)key * seg.ld + pos * 8);
+          vv = *(const uint4*)(Vb + (size_t)key * seg.ld + pos * 8);
+        }
+        *(uint4*)(sK + row * 128 + ((pos ^ ((row >> 1) & 7)) << 4)) = kv;
+        *(uint4*)(sV + row * 128 + ((pos ^ (((row >> 1) & 1) << 2)) << 4)) = vv;
+      }
+      __syncthreads();
+
+      // ---- S^T[key][q] for the two 32-key halves of the tile
+      f16v st[2];
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[kh][r] = 0.f;
+        const int row = kh * 32 + r31;
+        const char* kp = sK + row * 128;
+        const int sw = (row >> 1) & 7;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const h8 kf = *(const h8*)(kp + (((2 * s + hh) ^ sw) << 4));
+          st[kh] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], st[kh], 0, 0, 0);
+        }
+      }
+      // st[kh][r] <-> key = k0 + 32kh + (r&3) + 8(r>>2) + 4*hh, query = q0 + lane%32
+      float mx = MASKED;
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = k0 + kh * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          const float v = key < seg.nkeys ? st[kh][r] * p.scale_log2e : MASKED;
+          st[kh][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mnew = fmaxf(mrun, mx);
+      const float alpha = exp2f(mrun - mnew);
+      mrun = mnew;
+      float psum = 0.f;
+      h8 pf[2][2];
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float e = exp2f(st[kh][r] - mnew);
+          psum += e;
+          pf[kh][r >> 3][r & 7] = (half_t)e;
+        }
+      lrun = lrun * alpha + psum;
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+
+      // ---- O^T[d][q] += V^T[d][key] . P^T[key][q]; k-step (kh,s2): slot (hh, j) <-> key 32kh + 16s2 + 8(j>>2) + 4hh + (j&3)
+      const int gi = (lane >> 4) & 1, li = lane & 15;
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int kb0 = kh * 32 + s2 * 16 + 4 * hh + (li >> 2);   // row this lane addresses for j<4
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            const int col = d * 32 + gi * 16 + 4 * (li & 3);          // first of 4 contiguous d this lane addresses
+            const int pos = col >> 3, sub = (col & 7) * 2;
+            const int r0 = kb0, r1 = kb0 + 8;
+            const fp16x4 lo = lds_tr16(sV + r0 * 128 + ((pos ^ (((r0 >> 1) & 1) << 2)) << 4) + sub);
+            const fp16x4 hi = lds_tr16(sV + r1 * 128 + ((pos ^ (((r1 >> 1) & 1) << 2)) << 4) + sub);
+            h8 vf;
+            vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
+            vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
+            o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kh][s2], o[d], 0, 0, 0);
+          }
+        }
+    }
+    const float l = lrun + __shfl_xor(lrun, 32, 64);
+    const float w = seg.weight / l;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) otot[d][r] += o[d][r] * w;
+  }
+
+  // ---- store: otot[d][r] <-> channel 32d + (r&3) + 8(r>>2) + 4hh of query q0 + lane%32
+  const int q = q0 + r31;
+  if (q < p.Nq) {
+    half_t* op = p.O + ((size_t)b * p.Nq + q) * p.ldo + hd * 64 + 4 * hh;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        h4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (half_t)otot[d][g * 4 + r];
+        *(h4*)(op + d * 32 + g * 8) = v;
+      }
+  }
+}
+
+hipError_t ia2p_launch_attention(const AttnArgs& a, hipStream_t s) {
+  dim3 grid((a.Nq + 127) / 128, a.heads, a.B);
+  hipLaunchKernelGGL(attention_f16_kernel, grid, dim3(256), 0, s, a);
+  return hipGetLastError();
+}

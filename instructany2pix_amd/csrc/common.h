@@ -1,0 +1,71 @@
+// Shared device/host helpers for the gfx950 (CDNA4) kernels of the denoise hot path.
+// Activations are fp16, channels-last: a feature map [B,C,H,W] of the reference lives in HBM as
+// [B*H*W, C] row-major ("tokens x channels"), so the transformer path needs no permutes and every
+// convolution is an implicit GEMM whose K axis (tap, channel) is contiguous in channels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 half_t;
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+#define IA2P_WAVE 64
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// ---- launch descriptors shared by kernels and the host executor --------------------------------------
+
+struct GemmArgs {
+  const half_t* A;       // activations (row source)
+  const half_t* W;       // weights [N, K] row-major (torch Linear layout; conv pre-packed [Co][ky][kx][Ci])
+  half_t* C;             // output [M, ldc]
+  const half_t* zero;    // >=16 B of zeros (out-of-range rows / conv padding read this)
+  int M, N, K;           // K % 64 == 0, N % 4 == 0
+  int lda, ldc;
+  // LINEAR row map: src_row = (m / rpb) * bstride + (m % rpb) + roff   (rpb == 0: identity)
+  int rpb, bstride, roff;
+  // CONV3x3 gather (implicit GEMM): m = (b, oy, ox); k = (ky, kx, ci)
+  int Hs, Ws;            // stored source height/width
+  int Ho, Wo;            // output height/width
+  int stride, up;        // conv stride (1|2); up=1 reads a nearest-x2 upsampled view of the source
+  int Cin;               // channels per tap (Cin % 64 == 0)
+  // epilogue
+  const half_t* bias;    // [N] (GEGLU: packed order) or null
+  const half_t* rowvec;  // per-batch vector added to every row of that batch (time embedding) or null
+  int rowvec_ld, rows_per_batch;
+  const half_t* residual;  // [M, ldr] or null (may alias C)
+  int ldr;
+  int geglu;             // 1: W/bias rows interleaved in 16-row (a,g) pairs; out[m, n/2] = a * gelu(g)
+  int m_fastest;         // tile order: 1 = consecutive blocks walk M (weights panel shared), 0 = walk N
+};
+
+struct AttnSeg {
+  const half_t* K;       // key rows:   K + ((b * rows_per_batch + r) * ld) + head*64
+  const half_t* V;
+  int nkeys, ld, rows_per_batch;
+  float weight;          // out += weight * softmax(QK^T) V   (IP-Adapter: text 1.0, image tokens `scale`)
+};
+
+struct AttnArgs {
+  const half_t* Q;       // Q + ((b * Nq + q) * ldq) + head*64
+  half_t* O;             // same indexing with ldo
+  int ldq, ldo, B, heads, Nq, nseg;
+  float scale_log2e;     // (1/sqrt(64)) * log2(e)
+  AttnSeg seg[2];
+};

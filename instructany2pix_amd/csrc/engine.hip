@@ -1,0 +1,818 @@
+// Host-side executor of one conditional-UNet evaluation + the C ABI (include/ia2p.h).
+//
+// The module wiring follows diffusers' UNet2DConditionModel with the SDXL-base config, i.e. the object the
+// reference calls at instructany2pix/ddim/pnp_pipeline.py:253-260 and ddim/sdxl_pipeline.py:832-839
+// (SURVEY.md §3.4, Appendix A). All launches of a forward are issued from here on the caller's stream: ~1.2k
+// launches per evaluation would be host-bound if driven op-by-op from Python.
+//
+// Memory: weights live in ONE flat fp16 arena whose layout depends only on the config (so data-parallel ranks
+// can receive it with a single RCCL broadcast); activations come from a caller-provided workspace managed by a
+// deterministic first-fit allocator (sized by a dry run of the same code path).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/ia2p.h"
+#include "common.h"
+
+// ---- kernel launchers (gemm.hip, attention.hip, norm.hip, misc.hip) ------------------------------------------
+hipError_t ia2p_launch_gemm(const GemmArgs& a, bool conv, hipStream_t s);
+hipError_t ia2p_launch_attention(const AttnArgs& a, hipStream_t s);
+int ia2p_gn_chunks(int B, int HW);
+hipError_t ia2p_launch_groupnorm(const half_t* x, int ldx, half_t* y, int ldy, const half_t* gamma, const half_t* beta,
+                                 float* partial, int B, int HW, int C, int G, float eps, int silu, hipStream_t s);
+hipError_t ia2p_launch_layernorm(const half_t* x, int ldx, half_t* y, int ldy, const half_t* gamma, const half_t* beta,
+                                 int M, int C, float eps, hipStream_t s);
+hipError_t ia2p_launch_embed(float t, const half_t* text_embeds, const half_t* time_ids, half_t* tsin, half_t* addin,
+                             int B, int Tp, int P, int Ad, int nids, hipStream_t s);
+hipError_t ia2p_launch_linear_small(const half_t* X, int ldx, const half_t* W, const half_t* bias, const half_t* addend, int ldadd,
+                                    half_t* out, int ldo, int M, int N, int K, int silu_in, int silu_out, hipStream_t s);
+hipError_t ia2p_launch_conv_in(const half_t* x, const half_t* w, const half_t* bias, half_t* y, int B, int Cin, int H, int W, int Co, hipStream_t s);
+hipError_t ia2p_launch_conv_out(const half_t* x, int ldx, const half_t* w, const half_t* bias, half_t* y, int B, int C, int H, int W, int Co, hipStream_t s);
+hipError_t ia2p_launch_concat(const half_t* a, int lda, int Ca, const half_t* b, int ldb, int Cb, half_t* y, long M, hipStream_t s);
+hipError_t ia2p_launch_ddim_step(const half_t* x, const half_t* eps_u, const half_t* eps_c, float g, float c_x, float c_e,
+                                 half_t* out, half_t* out2, long n, hipStream_t s);
+hipError_t ia2p_launch_pack_conv(const half_t* src, half_t* dst, int Co, int Ci, hipStream_t s);
+hipError_t ia2p_launch_pack_geglu(const half_t* src, half_t* dst, int rows, int rowlen, hipStream_t s);
+
+static thread_local std::string g_err;   // error of a failed ia2p_create / ctx-less entry point
+
+static const half_t* zero_page() {
+  static thread_local void* z[16] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (!z[dev]) {
+    if (hipMalloc(&z[dev], 256) != hipSuccess) return nullptr;
+    (void)hipMemset(z[dev], 0, 256);
+  }
+  return (const half_t*)z[dev];
+}
+
+enum PKind { PK_COPY = 0, PK_CONV = 1, PK_GEGLU_W = 2, PK_GEGLU_B = 3 };
+
+struct Param {
+  size_t off;       // element offset in the arena
+  size_t elems;
+  int kind;
+  int d0, d1;       // conv: Co, Ci ; geglu: rows, rowlen
+  bool loaded;
+  bool optional;    // IP-Adapter tensors
+};
+
+struct Resnet {
+  int cin, cout, temb_off;
+  bool shortcut;
+  size_t n1g, n1b, w1, b1, n2g, n2b, w2, b2, wsc, bsc;
+};
+struct TBlock {
+  size_t ln1g, ln1b, wqkv, wo1, bo1, ln2g, ln2b, wq2, wkv2, wkvip, wo2, bo2, ln3g, ln3b, wff1, bff1, wff2, bff2;
+};
+struct Transformer {
+  int c, heads;
+  size_t ng, nb, win, bin, wout, bout;
+  std::vector<TBlock> blocks;
+};
+struct Stage {            // one down/up block
+  std::vector<Resnet> res;
+  std::vector<Transformer> att;   // empty or same length as res
+  bool resample;
+  size_t rw, rb;
+  int rc;
+};
+
+struct Block { size_t off, size; bool free_; };
+
+struct Arena {            // deterministic first-fit allocator over [0, cap)
+  std::vector<Block> blocks;
+  size_t cap, high;
+  void reset(size_t c) { cap = c; high = 0; blocks.clear(); blocks.push_back({0, c, true}); }
+  size_t alloc(size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    for (size_t i = 0; i < blocks.size(); ++i)
+      if (blocks[i].free_ && blocks[i].size >= bytes) {
+        const size_t off = blocks[i].off;
+        if (blocks[i].size > bytes) {
+          Block rest{off + bytes, blocks[i].size - bytes, true};
+          blocks[i].size = bytes;
+          blocks.insert(blocks.begin() + i + 1, rest);
+        }
+        blocks[i].free_ = false;
+        if (off + bytes > high) high = off + bytes;
+        return off;
+      }
+    return (size_t)-1;
+  }
+  void release(size_t off) {
+    for (size_t i = 0; i < blocks.size(); ++i)
+      if (blocks[i].off == off && !blocks[i].free_) {
+        blocks[i].free_ = true;
+        if (i + 1 < blocks.size() && blocks[i + 1].free_) { blocks[i].size += blocks[i + 1].size; blocks.erase(blocks.begin() + i + 1); }
+        if (i > 0 && blocks[i - 1].free_) { blocks[i - 1].size += blocks[i].size; blocks.erase(blocks.begin() + i); }
+        return;
+      }
+  }
+};
+
+struct ProfRec { hipEvent_t e0, e1; int k; double flops, bytes; };
+
+struct ia2p_ctx {
+  ia2p_unet_config cfg;
+  std::string err;
+  std::unordered_map<std::string, Param> params;
+  size_t arena_elems = 0;
+  half_t* arena = nullptr;
+  bool finalized = false;
+  int ip_enabled = 0, ip_tokens = 4;
+  float ip_scale = 1.0f;
+  // plan
+  size_t conv_in_w, conv_in_b, te1w, te1b, te2w, te2b, ae1w, ae1b, ae2w, ae2b, tw_all, tb_all, ngo, nbo, conv_out_w, conv_out_b;
+  int temb_total = 0;
+  std::vector<Stage> down, up;
+  Resnet mid_r0, mid_r1;
+  Transformer mid_t;
+  int n_attn2 = 0;
+  // run state
+  Arena ws;
+  char* ws_base = nullptr;
+  bool dry = false;
+  hipStream_t stream = nullptr;
+  bool failed = false;
+  bool prof = false;
+  std::vector<ProfRec> recs;
+  std::vector<hipEvent_t> evpool;
+  double p_ms[IA2P_K_COUNT], p_fl[IA2P_K_COUNT], p_by[IA2P_K_COUNT];
+  int64_t p_n[IA2P_K_COUNT];
+};
+
+static ia2p_status fail(ia2p_ctx* c, ia2p_status st, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) { c->err = buf; c->failed = true; }
+  g_err = buf;
+  return st;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// plan: enumerate parameters in the diffusers key layout (same walk as instructany2pix_amd/weights.py)
+// ---------------------------------------------------------------------------------------------------------------------
+struct Planner {
+  ia2p_ctx* c;
+  size_t cur = 0;
+  size_t take(size_t elems) { size_t o = cur; cur += (elems + 127) & ~(size_t)127; return o; }
+  void reg(const std::string& key, size_t off, size_t elems, int kind = PK_COPY, int d0 = 0, int d1 = 0, bool optional = false) {
+    c->params[key] = Param{off, elems, kind, d0, d1, false, optional};
+  }
+  size_t vec(const std::string& key, int n) { size_t o = take(n); reg(key, o, n); return o; }
+  size_t mat(const std::string& key, int rows, int cols) { size_t o = take((size_t)rows * cols); reg(key, o, (size_t)rows * cols); return o; }
+  size_t conv3(const std::string& key, int co, int ci) { size_t o = take((size_t)co * ci * 9); reg(key, o, (size_t)co * ci * 9, PK_CONV, co, ci); return o; }
+
+  Resnet resnet(const std::string& p, int cin, int cout, int temb, size_t tw_all, size_t tb_all) {
+    Resnet r;
+    r.cin = cin; r.cout = cout; r.shortcut = cin != cout;
+    r.n1g = vec(p + ".norm1.weight", cin); r.n1b = vec(p + ".norm1.bias", cin);
+    r.w1 = conv3(p + ".conv1.weight", cout, cin); r.b1 = vec(p + ".conv1.bias", cout);
+    r.temb_off = c->temb_total;
+    reg(p + ".time_emb_proj.weight", tw_all + (size_t)r.temb_off * temb, (size_t)cout * temb);
+    reg(p + ".time_emb_proj.bias", tb_all + r.temb_off, cout);
+    c->temb_total += cout;
+    r.n2g = vec(p + ".norm2.weight", cout); r.n2b = vec(p + ".norm2.bias", cout);
+    r.w2 = conv3(p + ".conv2.weight", cout, cout); r.b2 = vec(p + ".conv2.bias", cout);
+    r.wsc = r.bsc = 0;
+    if (r.shortcut) { r.wsc = mat(p + ".conv_shortcut.weight", cout, cin); r.bsc = vec(p + ".conv_shortcut.bias", cout); }
+    return r;
+  }
+  Transformer transformer(const std::string& p, int ch, int heads, int depth, int ctx, std::vector<std::pair<std::string, size_t>>& ipslots) {
+    Transformer t;
+    t.c = ch; t.heads = heads;
+    t.ng = vec(p + ".norm.weight", ch); t.nb = vec(p + ".norm.bias", ch);
+    t.win = mat(p + ".proj_in.weight", ch, ch); t.bin = vec(p + ".proj_in.bias", ch);
+    for (int k = 0; k < depth; ++k) {
+      const std::string q = p + ".transformer_blocks." + std::to_string(k);
+      TBlock b;
+      b.ln1g = vec(q + ".norm1.weight", ch); b.ln1b = vec(q + ".norm1.bias", ch);
+      b.wqkv = take((size_t)3 * ch * ch);
+      reg(q + ".attn1.to_q.weight", b.wqkv, (size_t)ch * ch);
+      reg(q + ".attn1.to_k.weight", b.wqkv + (size_t)ch * ch, (size_t)ch * ch);
+      reg(q + ".attn1.to_v.weight", b.wqkv + (size_t)2 * ch * ch, (size_t)ch * ch);
+      b.wo1 = mat(q + ".attn1.to_out.0.weight", ch, ch); b.bo1 = vec(q + ".attn1.to_out.0.bias", ch);
+      b.ln2g = vec(q + ".norm2.weight", ch); b.ln2b = vec(q + ".norm2.bias", ch);
+      b.wq2 = mat(q + ".attn2.to_q.weight", ch, ch);
+      b.wkv2 = take((size_t)2 * ch * ctx);
+      reg(q + ".attn2.to_k.weight", b.wkv2, (size_t)ch * ctx);
+      reg(q + ".attn2.to_v.weight", b.wkv2 + (size_t)ch * ctx, (size_t)ch * ctx);
+      b.wkvip = take((size_t)2 * ch * ctx);
+      ipslots.push_back({q, b.wkvip});
+      b.wo2 = mat(q + ".attn2.to_out.0.weight", ch, ch); b.bo2 = vec(q + ".attn2.to_out.0.bias", ch);
+      b.ln3g = vec(q + ".norm3.weight", ch); b.ln3b = vec(q + ".norm3.bias", ch);
+      b.wff1 = take((size_t)8 * ch * ch); reg(q + ".ff.net.0.proj.weight", b.wff1, (size_t)8 * ch * ch, PK_GEGLU_W, 8 * ch, ch);
+      b.bff1 = take((size_t)8 * ch); reg(q + ".ff.net.0.proj.bias", b.bff1, (size_t)8 * ch, PK_GEGLU_B, 8 * ch, 1);
+      b.wff2 = mat(q + ".ff.net.2.weight", ch, 4 * ch); b.bff2 = vec(q + ".ff.net.2.bias", ch);
+      t.blocks.push_back(b);
+    }
+    t.wout = mat(p + ".proj_out.weight", ch, ch); t.bout = vec(p + ".proj_out.bias", ch);
+    return t;
+  }
+};
+
+static ia2p_status build_plan(ia2p_ctx* c) {
+  const ia2p_unet_config& g = c->cfg;
+  const int n = g.n_blocks;
+  if (n < 1 || n > IA2P_MAX_BLOCKS) return fail(c, IA2P_ERR_INVALID, "n_blocks %d out of range", n);
+  for (int i = 0; i < n; ++i) {
+    const int ch = g.block_out_channels[i];
+    if (ch % 64 || ch % g.norm_num_groups) return fail(c, IA2P_ERR_SHAPE, "block_out_channels[%d]=%d must be a multiple of 64 and of norm_num_groups", i, ch);
+    if (g.transformer_layers_per_block[i] > 0 && g.num_heads[i] * 64 != ch)
+      return fail(c, IA2P_ERR_SHAPE, "block %d: heads*64 must equal channels (head_dim is fixed to 64)", i);
+  }
+  if (g.cross_attention_dim % 64 || g.time_embed_dim % 8 || g.projection_class_embeddings_input_dim % 8 || g.time_proj_dim % 8 || g.time_proj_dim % 2 || g.addition_time_embed_dim % 2)
+    return fail(c, IA2P_ERR_SHAPE, "embedding / context dims violate the 8/64 divisibility rules");
+  if (g.in_channels * 9 > 64 || g.out_channels > 8) return fail(c, IA2P_ERR_SHAPE, "latent channels too large for the boundary convolutions");
+  const int pooled = g.projection_class_embeddings_input_dim - 6 * g.addition_time_embed_dim;
+  if (pooled <= 0) return fail(c, IA2P_ERR_SHAPE, "projection_class_embeddings_input_dim smaller than 6 time ids");
+
+  Planner P{c};
+  const int T = g.time_embed_dim, ctx = g.cross_attention_dim;
+  const int* ch = g.block_out_channels;
+  c->conv_in_w = P.take((size_t)ch[0] * g.in_channels * 9); P.reg("conv_in.weight", c->conv_in_w, (size_t)ch[0] * g.in_channels * 9);
+  c->conv_in_b = P.vec("conv_in.bias", ch[0]);
+  c->te1w = P.mat("time_embedding.linear_1.weight", T, g.time_proj_dim); c->te1b = P.vec("time_embedding.linear_1.bias", T);
+  c->te2w = P.mat("time_embedding.linear_2.weight", T, T); c->te2b = P.vec("time_embedding.linear_2.bias", T);
+  c->ae1w = P.mat("add_embedding.linear_1.weight", T, g.projection_class_embeddings_input_dim); c->ae1b = P.vec("add_embedding.linear_1.bias", T);
+  c->ae2w = P.mat("add_embedding.linear_2.weight", T, T); c->ae2b = P.vec("add_embedding.linear_2.bias", T);
+  // all time_emb_proj matrices stacked into one [sum Cout, T] projection
+  int nres = 0, tot = 0;
+  {
+    int skipn = 0;
+    for (int i = 0; i < n; ++i) { nres += g.layers_per_block; tot += g.layers_per_block * ch[i]; }
+    tot += 2 * ch[n - 1];
+    for (int i = 0; i < n; ++i) tot += (g.layers_per_block + 1) * ch[n - 1 - i];
+    (void)skipn; (void)nres;
+  }
+  c->tw_all = P.take((size_t)tot * T);
+  c->tb_all = P.take(tot);
+  c->temb_total = 0;
+
+  std::vector<std::pair<std::string, size_t>> ipslots_down, ipslots_up, ipslots_mid;
+  std::vector<int> skip_ch;
+  skip_ch.push_back(ch[0]);
+  int cprev = ch[0];
+  for (int i = 0; i < n; ++i) {
+    Stage st;
+    const std::string bp = "down_blocks." + std::to_string(i);
+    for (int j = 0; j < g.layers_per_block; ++j) {
+      st.res.push_back(P.resnet(bp + ".resnets." + std::to_string(j), j == 0 ? cprev : ch[i], ch[i], T, c->tw_all, c->tb_all));
+      if (g.transformer_layers_per_block[i] > 0)
+        st.att.push_back(P.transformer(bp + ".attentions." + std::to_string(j), ch[i], g.num_heads[i], g.transformer_layers_per_block[i], ctx, ipslots_down));
+      skip_ch.push_back(ch[i]);
+    }
+    cprev = ch[i];
+    st.resample = i != n - 1;
+    st.rc = ch[i];
+    if (st.resample) {
+      st.rw = P.conv3(bp + ".downsamplers.0.conv.weight", ch[i], ch[i]); st.rb = P.vec(bp + ".downsamplers.0.conv.bias", ch[i]);
+      skip_ch.push_back(ch[i]);
+    }
+    c->down.push_back(st);
+  }
+  const int cm = ch[n - 1];
+  c->mid_r0 = P.resnet("mid_block.resnets.0", cm, cm, T, c->tw_all, c->tb_all);
+  c->mid_t = P.transformer("mid_block.attentions.0", cm, g.num_heads[n - 1], g.transformer_layers_per_block[n - 1], ctx, ipslots_mid);
+  c->mid_r1 = P.resnet("mid_block.resnets.1", cm, cm, T, c->tw_all, c->tb_all);
+  cprev = cm;
+  for (int i = 0; i < n; ++i) {
+    Stage st;
+    const int co = ch[n - 1 - i];
+    const std::string bp = "up_blocks." + std::to_string(i);
+    for (int j = 0; j < g.layers_per_block + 1; ++j) {
+      const int cs = skip_ch.back(); skip_ch.pop_back();
+      st.res.push_back(P.resnet(bp + ".resnets." + std::to_string(j), (j == 0 ? cprev : co) + cs, co, T, c->tw_all, c->tb_all));
+      if (g.transformer_layers_per_block[n - 1 - i] > 0)
+        st.att.push_back(P.transformer(bp + ".attentions." + std::to_string(j), co, g.num_heads[n - 1 - i], g.transformer_layers_per_block[n - 1 - i], ctx, ipslots_up));
+    }
+    cprev = co;
+    st.resample = i != n - 1;
+    st.rc = co;
+    if (st.resample) { st.rw = P.conv3(bp + ".upsamplers.0.conv.weight", co, co); st.rb = P.vec(bp + ".upsamplers.0.conv.bias", co); }
+    c->up.push_back(st);
+  }
+  if (c->temb_total != tot) return fail(c, IA2P_ERR_STATE, "internal: time_emb_proj stacking mismatch %d != %d", c->temb_total, tot);
+  c->ngo = P.vec("conv_norm_out.weight", ch[0]); c->nbo = P.vec("conv_norm_out.bias", ch[0]);
+  c->conv_out_w = P.conv3("conv_out.weight", g.out_channels, ch[0]); c->conv_out_b = P.vec("conv_out.bias", g.out_channels);
+
+  // IP-Adapter keys: index = position in unet.attn_processors = down, up, mid (attn1 even, attn2 odd)
+  int idx = 0;
+  auto add_ip = [&](std::vector<std::pair<std::string, size_t>>& v) {
+    for (auto& s : v) {
+      const std::string& q = s.first;
+      // channel count from the attn2.to_q registration
+      const size_t cc = (size_t)std::llround(std::sqrt((double)c->params[q + ".attn2.to_q.weight"].elems));
+      const std::string k = "ip_adapter." + std::to_string(2 * idx + 1);
+      P.reg(k + ".to_k_ip.weight", s.second, cc * ctx, PK_COPY, 0, 0, true);
+      P.reg(k + ".to_v_ip.weight", s.second + cc * ctx, cc * ctx, PK_COPY, 0, 0, true);
+      ++idx;
+    }
+  };
+  add_ip(ipslots_down); add_ip(ipslots_up); add_ip(ipslots_mid);
+  c->n_attn2 = idx;
+  c->arena_elems = P.cur;
+  return IA2P_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// run helpers
+// ---------------------------------------------------------------------------------------------------------------------
+struct T2 { size_t off; half_t* p; };   // workspace tensor
+
+static T2 wsalloc(ia2p_ctx* c, size_t elems) {
+  const size_t off = c->ws.alloc(elems * sizeof(half_t));
+  if (off == (size_t)-1) { if (!c->failed) fail(c, IA2P_ERR_NOMEM, "workspace too small"); return T2{off, nullptr}; }
+  return T2{off, c->dry ? nullptr : (half_t*)(c->ws_base + off)};
+}
+static void wsfree(ia2p_ctx* c, T2 t) { if (t.off != (size_t)-1) c->ws.release(t.off); }
+
+static hipEvent_t get_event(ia2p_ctx* c) {
+  if (!c->evpool.empty()) { hipEvent_t e = c->evpool.back(); c->evpool.pop_back(); return e; }
+  hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+struct ProfScope {
+  ia2p_ctx* c; int k; double fl, by; hipEvent_t e0, e1; bool on;
+  ProfScope(ia2p_ctx* c_, int k_, double fl_, double by_) : c(c_), k(k_), fl(fl_), by(by_), on(c_ && c_->prof && !c_->dry) {
+    if (on) { e0 = get_event(c); e1 = get_event(c); (void)hipEventRecord(e0, c->stream); }
+  }
+  ~ProfScope() { if (on) { (void)hipEventRecord(e1, c->stream); c->recs.push_back(ProfRec{e0, e1, k, fl, by}); } }
+};
+#define CHECK_LAUNCH(c, expr, what)                                                             \
+  do { if (!(c)->dry && !(c)->failed) { hipError_t e_ = (expr); if (e_ != hipSuccess) fail((c), IA2P_ERR_HIP, "%s: %s", what, hipGetErrorString(e_)); } } while (0)
+
+static inline const half_t* W_(ia2p_ctx* c, size_t off) { return c->arena + off; }
+
+static void op_gemm(ia2p_ctx* c, const half_t* A, int lda, const half_t* W, const half_t* bias, const half_t* residual, int ldr,
+                    half_t* C, int ldc, int M, int N, int K, int geglu = 0, int rpb = 0, int bstride = 0, int roff = 0) {
+  GemmArgs a;
+  memset(&a, 0, sizeof a);
+  a.A = A; a.W = W; a.C = C; a.zero = zero_page(); a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldc = ldc;
+  a.rpb = rpb; a.bstride = bstride; a.roff = roff; a.bias = bias; a.residual = residual; a.ldr = ldr; a.geglu = geglu;
+  a.rows_per_batch = 1;
+  a.m_fastest = (long)M * K <= (long)N * K ? 1 : 0;
+  ProfScope ps(c, IA2P_K_GEMM, 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * (geglu ? N / 2 : N) + (residual ? (double)M * N : 0)));
+  CHECK_LAUNCH(c, ia2p_launch_gemm(a, false, c->stream), "gemm");
+}
+static void op_conv3(ia2p_ctx* c, const half_t* X, int B, int Hs, int Ws, int Cin, const half_t* W, const half_t* bias, int Co,
+                     int stride, int up, const half_t* rowvec, int rowvec_ld, const half_t* residual, half_t* Y) {
+  GemmArgs a;
+  memset(&a, 0, sizeof a);
+  const int Hv = Hs << up, Wv = Ws << up;
+  a.Ho = (Hv + 2 - 3) / stride + 1; a.Wo = (Wv + 2 - 3) / stride + 1;
+  a.A = X; a.W = W; a.C = Y; a.zero = zero_page(); a.M = B * a.Ho * a.Wo; a.N = Co; a.K = 9 * Cin; a.lda = Cin; a.ldc = Co;
+  a.Hs = Hs; a.Ws = Ws; a.stride = stride; a.up = up; a.Cin = Cin;
+  a.bias = bias; a.rowvec = rowvec; a.rowvec_ld = rowvec_ld; a.rows_per_batch = a.Ho * a.Wo; a.residual = residual; a.ldr = Co;
+  a.m_fastest = 0;
+  ProfScope ps(c, IA2P_K_CONV, 2.0 * a.M * (double)Co * a.K, 2.0 * ((double)B * Hs * Ws * Cin + (double)Co * a.K + (double)a.M * Co + (residual ? (double)a.M * Co : 0)));
+  CHECK_LAUNCH(c, ia2p_launch_gemm(a, true, c->stream), "conv3x3");
+}
+static void op_gn(ia2p_ctx* c, const half_t* x, half_t* y, size_t g, size_t b, int B, int HW, int C, float eps, int silu, float* partial) {
+  ProfScope ps(c, IA2P_K_GNORM, 8.0 * B * HW * C, 4.0 * B * HW * C);
+  CHECK_LAUNCH(c, ia2p_launch_groupnorm(x, C, y, C, W_(c, g), W_(c, b), partial, B, HW, C, c->cfg.norm_num_groups, eps, silu, c->stream), "groupnorm");
+}
+static void op_ln(ia2p_ctx* c, const half_t* x, half_t* y, size_t g, size_t b, int M, int C) {
+  ProfScope ps(c, IA2P_K_LNORM, 8.0 * M * C, 4.0 * M * C);
+  CHECK_LAUNCH(c, ia2p_launch_layernorm(x, C, y, C, W_(c, g), W_(c, b), M, C, 1e-5f, c->stream), "layernorm");
+}
+
+struct Fwd {
+  ia2p_ctx* c;
+  int B, h, w, L;
+  const half_t* ctxp;
+  T2 temb_all;
+  float* gn_partial;
+};
+
+static T2 run_resnet(Fwd& f, const Resnet& r, T2 x, int H, int Wd) {
+  ia2p_ctx* c = f.c;
+  const int HW = H * Wd, M = f.B * HW;
+  T2 n1 = wsalloc(c, (size_t)M * r.cin);
+  op_gn(c, x.p, n1.p, r.n1g, r.n1b, f.B, HW, r.cin, c->cfg.norm_eps, 1, f.gn_partial);
+  T2 hh = wsalloc(c, (size_t)M * r.cout);
+  op_conv3(c, n1.p, f.B, H, Wd, r.cin, W_(c, r.w1), W_(c, r.b1), r.cout, 1, 0, c->dry ? nullptr : f.temb_all.p + r.temb_off, c->temb_total, nullptr, hh.p);
+  wsfree(c, n1);
+  T2 n2 = wsalloc(c, (size_t)M * r.cout);
+  op_gn(c, hh.p, n2.p, r.n2g, r.n2b, f.B, HW, r.cout, c->cfg.norm_eps, 1, f.gn_partial);
+  wsfree(c, hh);
+  T2 xs{(size_t)-1, nullptr};
+  const half_t* resid = x.p;
+  if (r.shortcut) {
+    xs = wsalloc(c, (size_t)M * r.cout);
+    op_gemm(c, x.p, r.cin, W_(c, r.wsc), W_(c, r.bsc), nullptr, 0, xs.p, r.cout, M, r.cout, r.cin);
+    resid = xs.p;
+  }
+  T2 out = wsalloc(c, (size_t)M * r.cout);
+  op_conv3(c, n2.p, f.B, H, Wd, r.cout, W_(c, r.w2), W_(c, r.b2), r.cout, 1, 0, nullptr, 0, c->dry ? nullptr : resid, out.p);
+  wsfree(c, n2);
+  if (r.shortcut) wsfree(c, xs);
+  return out;
+}
+
+static void op_attn(ia2p_ctx* c, const AttnArgs& a) {
+  double keys = 0;
+  for (int s = 0; s < a.nseg; ++s) keys += a.seg[s].nkeys;
+  ProfScope ps(c, IA2P_K_ATTN, 4.0 * a.B * a.heads * (double)a.Nq * keys * 64, 2.0 * ((double)a.B * a.Nq * a.heads * 64 * 2 + 2.0 * a.B * keys * a.heads * 64));
+  CHECK_LAUNCH(c, ia2p_launch_attention(a, c->stream), "attention");
+}
+
+static T2 run_transformer(Fwd& f, const Transformer& t, T2 x, int H, int Wd) {
+  ia2p_ctx* c = f.c;
+  const int HW = H * Wd, M = f.B * HW, C = t.c;
+  const int ctxd = c->cfg.cross_attention_dim;
+  const int Lt = c->ip_enabled ? f.L - c->ip_tokens : f.L;
+  const int Li = c->ip_enabled ? c->ip_tokens : 0;
+  const float sl2e = 0.125f * 1.4426950408889634f;
+  T2 n = wsalloc(c, (size_t)M * C);
+  op_gn(c, x.p, n.p, t.ng, t.nb, f.B, HW, C, 1e-6f, 0, f.gn_partial);
+  T2 tk = wsalloc(c, (size_t)M * C);
+  op_gemm(c, n.p, C, W_(c, t.win), W_(c, t.bin), nullptr, 0, tk.p, C, M, C, C);
+  wsfree(c, n);
+  T2 ln = wsalloc(c, (size_t)M * C), qkv = wsalloc(c, (size_t)M * 3 * C), att = wsalloc(c, (size_t)M * C);
+  T2 kv = wsalloc(c, (size_t)f.B * Lt * 2 * C), kvip = wsalloc(c, (size_t)f.B * (Li ? Li : 1) * 2 * C), ff = wsalloc(c, (size_t)M * 4 * C);
+  for (const TBlock& b : t.blocks) {
+    // self-attention (AttnProcessor2_0, reference attention_processor.py:205-279)
+    op_ln(c, tk.p, ln.p, b.ln1g, b.ln1b, M, C);
+    op_gemm(c, ln.p, C, W_(c, b.wqkv), nullptr, nullptr, 0, qkv.p, 3 * C, M, 3 * C, C);
+    {
+      AttnArgs a;
+      memset(&a, 0, sizeof a);
+      a.Q = qkv.p; a.ldq = 3 * C; a.O = att.p; a.ldo = C; a.B = f.B; a.heads = t.heads; a.Nq = HW; a.nseg = 1; a.scale_log2e = sl2e;
+      a.seg[0].K = c->dry ? nullptr : qkv.p + C; a.seg[0].V = c->dry ? nullptr : qkv.p + 2 * C;
+      a.seg[0].nkeys = HW; a.seg[0].ld = 3 * C; a.seg[0].rows_per_batch = HW; a.seg[0].weight = 1.f;
+      op_attn(c, a);
+    }
+    op_gemm(c, att.p, C, W_(c, b.wo1), W_(c, b.bo1), tk.p, C, tk.p, C, M, C, C);
+    // cross-attention (IPAttnProcessor2_0 :310-412 when the adapter is installed, else AttnProcessor2_0)
+    op_ln(c, tk.p, ln.p, b.ln2g, b.ln2b, M, C);
+    op_gemm(c, ln.p, C, W_(c, b.wq2), nullptr, nullptr, 0, qkv.p, C, M, C, C);
+    op_gemm(c, f.ctxp, ctxd, W_(c, b.wkv2), nullptr, nullptr, 0, kv.p, 2 * C, f.B * Lt, 2 * C, ctxd, 0, Lt, f.L, 0);
+    if (Li) op_gemm(c, f.ctxp, ctxd, W_(c, b.wkvip), nullptr, nullptr, 0, kvip.p, 2 * C, f.B * Li, 2 * C, ctxd, 0, Li, f.L, Lt);
+    {
+      AttnArgs a;
+      memset(&a, 0, sizeof a);
+      a.Q = qkv.p; a.ldq = C; a.O = att.p; a.ldo = C; a.B = f.B; a.heads = t.heads; a.Nq = HW; a.nseg = Li ? 2 : 1; a.scale_log2e = sl2e;
+      a.seg[0].K = kv.p; a.seg[0].V = c->dry ? nullptr : kv.p + C; a.seg[0].nkeys = Lt; a.seg[0].ld = 2 * C; a.seg[0].rows_per_batch = Lt; a.seg[0].weight = 1.f;
+      a.seg[1].K = kvip.p; a.seg[1].V = c->dry ? nullptr : kvip.p + C; a.seg[1].nkeys = Li; a.seg[1].ld = 2 * C; a.seg[1].rows_per_batch = Li; a.seg[1].weight = c->ip_scale;
+      op_attn(c, a);
+    }
+    op_gemm(c, att.p, C, W_(c, b.wo2), W_(c, b.bo2), tk.p, C, tk.p, C, M, C, C);
+    // GEGLU feed-forward
+    op_ln(c, tk.p, ln.p, b.ln3g, b.ln3b, M, C);
+    op_gemm(c, ln.p, C, W_(c, b.wff1), W_(c, b.bff1), nullptr, 0, ff.p, 4 * C, M, 8 * C, C, 1);
+    op_gemm(c, ff.p, 4 * C, W_(c, b.wff2), W_(c, b.bff2), tk.p, C, tk.p, C, M, C, 4 * C);
+  }
+  wsfree(c, ln); wsfree(c, qkv); wsfree(c, att); wsfree(c, kv); wsfree(c, kvip); wsfree(c, ff);
+  T2 out = wsalloc(c, (size_t)M * C);
+  op_gemm(c, tk.p, C, W_(c, t.wout), W_(c, t.bout), x.p, C, out.p, C, M, C, C);
+  wsfree(c, tk);
+  return out;
+}
+
+static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep, const half_t* context, int L,
+                               const half_t* text_embeds, const half_t* time_ids, half_t* out, int B, int h, int w) {
+  const ia2p_unet_config& g = c->cfg;
+  const int n = g.n_blocks;
+  const int T = g.time_embed_dim, Tp = g.time_proj_dim, Ain = g.projection_class_embeddings_input_dim, Ad = g.addition_time_embed_dim;
+  const int pooled = Ain - 6 * Ad;
+  Fwd f{c, B, h, w, L, context, T2{(size_t)-1, nullptr}, nullptr};
+
+  // GroupNorm partial sums (fp32) live at the front of the workspace
+  T2 gnp = wsalloc(c, (size_t)B * 64 * g.norm_num_groups * 2 * 2);
+  f.gn_partial = (float*)gnp.p;
+  // ---- embeddings
+  T2 tsin = wsalloc(c, (size_t)B * Tp), addin = wsalloc(c, (size_t)B * Ain), e1 = wsalloc(c, (size_t)B * T), emb0 = wsalloc(c, (size_t)B * T);
+  T2 a1 = wsalloc(c, (size_t)B * T), emb = wsalloc(c, (size_t)B * T);
+  f.temb_all = wsalloc(c, (size_t)B * c->temb_total);
+  {
+    ProfScope ps(c, IA2P_K_OTHER, 0, 0);
+    CHECK_LAUNCH(c, ia2p_launch_embed(timestep, text_embeds, time_ids, tsin.p, addin.p, B, Tp, pooled, Ad, 6, c->stream), "embed");
+    CHECK_LAUNCH(c, ia2p_launch_linear_small(tsin.p, Tp, W_(c, c->te1w), W_(c, c->te1b), nullptr, 0, e1.p, T, B, T, Tp, 0, 1, c->stream), "time_embedding.linear_1");
+    CHECK_LAUNCH(c, ia2p_launch_linear_small(e1.p, T, W_(c, c->te2w), W_(c, c->te2b), nullptr, 0, emb0.p, T, B, T, T, 0, 0, c->stream), "time_embedding.linear_2");
+    CHECK_LAUNCH(c, ia2p_launch_linear_small(addin.p, Ain, W_(c, c->ae1w), W_(c, c->ae1b), nullptr, 0, a1.p, T, B, T, Ain, 0, 1, c->stream), "add_embedding.linear_1");
+    CHECK_LAUNCH(c, ia2p_launch_linear_small(a1.p, T, W_(c, c->ae2w), W_(c, c->ae2b), emb0.p, T, emb.p, T, B, T, T, 0, 0, c->stream), "add_embedding.linear_2");
+    CHECK_LAUNCH(c, ia2p_launch_linear_small(emb.p, T, W_(c, c->tw_all), W_(c, c->tb_all), nullptr, 0, f.temb_all.p, c->temb_total, B, c->temb_total, T, 1, 0, c->stream), "time_emb_proj (stacked)");
+  }
+  wsfree(c, tsin); wsfree(c, addin); wsfree(c, e1); wsfree(c, emb0); wsfree(c, a1); wsfree(c, emb);
+
+  // ---- down path
+  int H = h, Wd = w;
+  std::vector<T2> skips;
+  std::vector<int> skip_c;
+  T2 x = wsalloc(c, (size_t)B * H * Wd * g.block_out_channels[0]);
+  {
+    ProfScope ps(c, IA2P_K_OTHER, 0, 0);
+    CHECK_LAUNCH(c, ia2p_launch_conv_in(sample, W_(c, c->conv_in_w), W_(c, c->conv_in_b), x.p, B, g.in_channels, H, Wd, g.block_out_channels[0], c->stream), "conv_in");
+  }
+  skips.push_back(x); skip_c.push_back(g.block_out_channels[0]);
+  for (int i = 0; i < n; ++i) {
+    const Stage& st = c->down[i];
+    for (size_t j = 0; j < st.res.size(); ++j) {
+      T2 r = run_resnet(f, st.res[j], x, H, Wd);
+      if (!st.att.empty()) { T2 t = run_transformer(f, st.att[j], r, H, Wd); wsfree(c, r); r = t; }
+      x = r;
+      skips.push_back(x); skip_c.push_back(st.res[j].cout);
+    }
+    if (st.resample) {
+      const int Ho = (H - 1) / 2 + 1, Wo = (Wd - 1) / 2 + 1;
+      T2 d = wsalloc(c, (size_t)B * Ho * Wo * st.rc);
+      op_conv3(c, x.p, B, H, Wd, st.rc, W_(c, st.rw), W_(c, st.rb), st.rc, 2, 0, nullptr, 0, nullptr, d.p);
+      H = Ho; Wd = Wo; x = d;
+      skips.push_back(x); skip_c.push_back(st.rc);
+    }
+  }
+  // ---- mid
+  {
+    T2 r0 = run_resnet(f, c->mid_r0, x, H, Wd);          // x stays alive: it is the top skip
+    T2 t = run_transformer(f, c->mid_t, r0, H, Wd); wsfree(c, r0);
+    T2 r1 = run_resnet(f, c->mid_r1, t, H, Wd); wsfree(c, t);
+    x = r1;
+  }
+  // ---- up path
+  for (int i = 0; i < n; ++i) {
+    const Stage& st = c->up[i];
+    for (size_t j = 0; j < st.res.size(); ++j) {
+      T2 sk = skips.back(); skips.pop_back();
+      const int cs = skip_c.back(); skip_c.pop_back();
+      const int cx = st.res[j].cin - cs;
+      const long M = (long)B * H * Wd;
+      T2 cat = wsalloc(c, (size_t)M * st.res[j].cin);
+      {
+        ProfScope ps(c, IA2P_K_OTHER, 0, 4.0 * M * st.res[j].cin);
+        CHECK_LAUNCH(c, ia2p_launch_concat(x.p, cx, cx, sk.p, cs, cs, cat.p, M, c->stream), "concat");
+      }
+      wsfree(c, x); wsfree(c, sk);
+      T2 r = run_resnet(f, st.res[j], cat, H, Wd);
+      wsfree(c, cat);
+      if (!st.att.empty()) { T2 t = run_transformer(f, st.att[j], r, H, Wd); wsfree(c, r); r = t; }
+      x = r;
+    }
+    if (st.resample) {
+      T2 u = wsalloc(c, (size_t)B * (2 * H) * (2 * Wd) * st.rc);
+      op_conv3(c, x.p, B, H, Wd, st.rc, W_(c, st.rw), W_(c, st.rb), st.rc, 1, 1, nullptr, 0, nullptr, u.p);
+      wsfree(c, x);
+      H *= 2; Wd *= 2; x = u;
+    }
+  }
+  if (H != h || Wd != w) return fail(c, IA2P_ERR_SHAPE, "latent %dx%d does not survive the down/up path (needs divisibility by 2^%d)", h, w, n - 1);
+  // ---- out
+  const int c0 = g.block_out_channels[0];
+  T2 no = wsalloc(c, (size_t)B * H * Wd * c0);
+  op_gn(c, x.p, no.p, c->ngo, c->nbo, B, H * Wd, c0, g.norm_eps, 1, f.gn_partial);
+  wsfree(c, x);
+  {
+    ProfScope ps(c, IA2P_K_OTHER, 0, 0);
+    CHECK_LAUNCH(c, ia2p_launch_conv_out(no.p, c0, W_(c, c->conv_out_w), W_(c, c->conv_out_b), out, B, c0, H, Wd, g.out_channels, c->stream), "conv_out");
+  }
+  wsfree(c, no); wsfree(c, f.temb_all); wsfree(c, gnp);
+  return c->failed ? IA2P_ERR_HIP : IA2P_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" {
+
+int ia2p_device_is_gfx950(void) {
+  int dev = 0;
+  hipDeviceProp_t p;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
+  return strncmp(p.gcnArchName, "gfx950", 6) == 0;
+}
+
+ia2p_status ia2p_create(const ia2p_unet_config* cfg, ia2p_ctx** out) {
+  if (!cfg || !out) return fail(nullptr, IA2P_ERR_INVALID, "ia2p_create: null argument");
+  ia2p_ctx* c = new ia2p_ctx();
+  c->cfg = *cfg;
+  ia2p_status st = build_plan(c);
+  if (st != IA2P_OK) { g_err = c->err; delete c; *out = nullptr; return st; }
+  c->failed = false;
+  for (int k = 0; k < IA2P_K_COUNT; ++k) { c->p_ms[k] = c->p_fl[k] = c->p_by[k] = 0; c->p_n[k] = 0; }
+  *out = c;
+  return IA2P_OK;
+}
+
+void ia2p_destroy(ia2p_ctx* c) {
+  if (!c) return;
+  for (auto& r : c->recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+  for (auto e : c->evpool) (void)hipEventDestroy(e);
+  delete c;
+}
+
+const char* ia2p_last_error(ia2p_ctx* c) { return c ? c->err.c_str() : g_err.c_str(); }
+
+size_t ia2p_arena_bytes(ia2p_ctx* c) { return c ? c->arena_elems * sizeof(half_t) : 0; }
+
+ia2p_status ia2p_bind_arena(ia2p_ctx* c, void* dev, size_t bytes) {
+  if (!c || !dev) return fail(c, IA2P_ERR_INVALID, "bind_arena: null argument");
+  if (bytes < c->arena_elems * sizeof(half_t)) return fail(c, IA2P_ERR_NOMEM, "arena needs %zu bytes, got %zu", c->arena_elems * sizeof(half_t), bytes);
+  if (((uintptr_t)dev) & 255) return fail(c, IA2P_ERR_INVALID, "arena must be 256-byte aligned");
+  c->arena = (half_t*)dev;
+  c->finalized = false;
+  return IA2P_OK;
+}
+
+ia2p_status ia2p_load_tensor(ia2p_ctx* c, const char* key, const void* src, const int64_t* shape, int ndim, void* stream) {
+  if (!c || !key || !src || !shape) return fail(c, IA2P_ERR_INVALID, "load_tensor: null argument");
+  if (!c->arena) return fail(c, IA2P_ERR_STATE, "load_tensor before bind_arena");
+  auto it = c->params.find(key);
+  if (it == c->params.end()) return fail(c, IA2P_ERR_KEY, "unknown parameter key '%s'", key);
+  Param& p = it->second;
+  size_t n = 1;
+  for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
+  if (n != p.elems) return fail(c, IA2P_ERR_SHAPE, "parameter '%s': expected %zu elements, got %zu", key, p.elems, n);
+  hipStream_t s = (hipStream_t)stream;
+  half_t* dst = c->arena + p.off;
+  hipError_t e = hipSuccess;
+  switch (p.kind) {
+    case PK_COPY: e = hipMemcpyAsync(dst, src, n * sizeof(half_t), hipMemcpyDeviceToDevice, s); break;
+    case PK_CONV: e = ia2p_launch_pack_conv((const half_t*)src, dst, p.d0, p.d1, s); break;
+    case PK_GEGLU_W: case PK_GEGLU_B: e = ia2p_launch_pack_geglu((const half_t*)src, dst, p.d0, p.d1, s); break;
+  }
+  if (e != hipSuccess) return fail(c, IA2P_ERR_HIP, "load '%s': %s", key, hipGetErrorString(e));
+  p.loaded = true;
+  return IA2P_OK;
+}
+
+ia2p_status ia2p_finalize_weights(ia2p_ctx* c) {
+  if (!c) return IA2P_ERR_INVALID;
+  if (!c->arena) return fail(c, IA2P_ERR_STATE, "finalize before bind_arena");
+  int missing = 0;
+  std::string first;
+  for (auto& kv : c->params)
+    if (!kv.second.loaded && !kv.second.optional) { if (!missing) first = kv.first; ++missing; }
+  if (missing) return fail(c, IA2P_ERR_KEY, "%d UNet parameters not loaded (e.g. '%s')", missing, first.c_str());
+  c->finalized = true;
+  return IA2P_OK;
+}
+
+ia2p_status ia2p_adopt_arena(ia2p_ctx* c) {
+  if (!c || !c->arena) return fail(c, IA2P_ERR_STATE, "adopt_arena before bind_arena");
+  for (auto& kv : c->params) kv.second.loaded = true;
+  c->finalized = true;
+  return IA2P_OK;
+}
+
+ia2p_status ia2p_set_ip_adapter(ia2p_ctx* c, int enabled, int num_tokens, float scale) {
+  if (!c) return IA2P_ERR_INVALID;
+  if (enabled) {
+    if (num_tokens < 1 || num_tokens > 64) return fail(c, IA2P_ERR_INVALID, "num_tokens %d out of range", num_tokens);
+    for (auto& kv : c->params)
+      if (kv.second.optional && !kv.second.loaded) return fail(c, IA2P_ERR_KEY, "IP-Adapter enabled but '%s' was never loaded", kv.first.c_str());
+  }
+  c->ip_enabled = enabled ? 1 : 0; c->ip_tokens = num_tokens; c->ip_scale = scale;
+  return IA2P_OK;
+}
+
+static ia2p_status check_fwd_shape(ia2p_ctx* c, int B, int h, int w, int L) {
+  if (B < 1 || B > 16) return fail(c, IA2P_ERR_SHAPE, "batch %d outside 1..16 (embedding kernels hold <=16 rows)", B);
+  const int div = 1 << (c->cfg.n_blocks - 1);
+  if (h < div || w < div || h % div || w % div) return fail(c, IA2P_ERR_SHAPE, "latent %dx%d must be divisible by %d", h, w, div);
+  if (L < 1) return fail(c, IA2P_ERR_SHAPE, "context length %d", L);
+  if (c->ip_enabled && L <= c->ip_tokens) return fail(c, IA2P_ERR_SHAPE, "context length %d must exceed the %d image tokens", L, c->ip_tokens);
+  return IA2P_OK;
+}
+
+size_t ia2p_workspace_bytes(ia2p_ctx* c, int B, int h, int w, int L) {
+  if (!c || check_fwd_shape(c, B, h, w, L) != IA2P_OK) return 0;
+  c->dry = true; c->failed = false;
+  c->ws.reset((size_t)1 << 46);
+  c->ws_base = nullptr;
+  (void)run_forward(c, nullptr, 0.f, nullptr, L, nullptr, nullptr, nullptr, B, h, w);
+  c->dry = false;
+  return c->failed ? 0 : c->ws.high + 256;
+}
+
+ia2p_status ia2p_unet_forward(ia2p_ctx* c, void* stream, const void* sample, float timestep, const void* context, int L,
+                              const void* text_embeds, const void* time_ids, void* out, int B, int h, int w, void* ws, size_t ws_bytes) {
+  if (!c || !sample || !context || !text_embeds || !time_ids || !out || !ws) return fail(c, IA2P_ERR_INVALID, "unet_forward: null argument");
+  if (!c->finalized) return fail(c, IA2P_ERR_STATE, "unet_forward before weights were finalized");
+  ia2p_status st = check_fwd_shape(c, B, h, w, L);
+  if (st != IA2P_OK) return st;
+  if (!zero_page()) return fail(c, IA2P_ERR_HIP, "cannot allocate zero page");
+  const uintptr_t base = ((uintptr_t)ws + 255) & ~(uintptr_t)255;
+  const size_t usable = ws_bytes - (base - (uintptr_t)ws);
+  c->dry = false; c->failed = false; c->stream = (hipStream_t)stream;
+  c->ws.reset(usable);
+  c->ws_base = (char*)base;
+  st = run_forward(c, (const half_t*)sample, timestep, (const half_t*)context, L, (const half_t*)text_embeds, (const half_t*)time_ids, (half_t*)out, B, h, w);
+  if (c->failed && st == IA2P_OK) st = IA2P_ERR_HIP;
+  if (c->failed && c->err == "workspace too small") st = IA2P_ERR_NOMEM;
+  return st;
+}
+
+ia2p_status ia2p_ddim_step(void* stream, const void* x, const void* eu, const void* ec, float g, float c_x, float c_e, void* out, void* out2, int64_t n) {
+  if (!x || !eu || !out || n < 0) return fail(nullptr, IA2P_ERR_INVALID, "ddim_step: null argument");
+  hipError_t e = ia2p_launch_ddim_step((const half_t*)x, (const half_t*)eu, (const half_t*)ec, g, c_x, c_e, (half_t*)out, (half_t*)out2, (long)n, (hipStream_t)stream);
+  return e == hipSuccess ? IA2P_OK : fail(nullptr, IA2P_ERR_HIP, "ddim_step: %s", hipGetErrorString(e));
+}
+
+// ---- per-operator entry points ---------------------------------------------------------------------------------------
+#define RET_HIP(e, what) return (e) == hipSuccess ? IA2P_OK : fail(nullptr, IA2P_ERR_HIP, "%s: %s", what, hipGetErrorString(e))
+
+ia2p_status ia2p_groupnorm_silu(void* stream, const void* x, void* y, const void* gamma, const void* beta, int B, int HW, int C, int groups, float eps, int silu, float* partial) {
+  if (!x || !y || !gamma || !beta || !partial) return fail(nullptr, IA2P_ERR_INVALID, "groupnorm: null argument");
+  if (C % 8 || C % groups || groups > 256) return fail(nullptr, IA2P_ERR_SHAPE, "groupnorm: C=%d groups=%d", C, groups);
+  hipError_t e = ia2p_launch_groupnorm((const half_t*)x, C, (half_t*)y, C, (const half_t*)gamma, (const half_t*)beta, partial, B, HW, C, groups, eps, silu, (hipStream_t)stream);
+  RET_HIP(e, "groupnorm");
+}
+ia2p_status ia2p_layernorm(void* stream, const void* x, void* y, const void* gamma, const void* beta, int M, int C, float eps) {
+  if (!x || !y || !gamma || !beta) return fail(nullptr, IA2P_ERR_INVALID, "layernorm: null argument");
+  if (C % 8 || C > 2048) return fail(nullptr, IA2P_ERR_SHAPE, "layernorm: C=%d must be a multiple of 8 and <= 2048", C);
+  hipError_t e = ia2p_launch_layernorm((const half_t*)x, C, (half_t*)y, C, (const half_t*)gamma, (const half_t*)beta, M, C, eps, (hipStream_t)stream);
+  RET_HIP(e, "layernorm");
+}
+ia2p_status ia2p_gemm(void* stream, const void* A, const void* W, const void* bias, const void* residual, void* C, int M, int N, int K, int geglu) {
+  if (!A || !W || !C) return fail(nullptr, IA2P_ERR_INVALID, "gemm: null argument");
+  if (K % 64 || N % 4 || (geglu && (N % 32 || !bias))) return fail(nullptr, IA2P_ERR_SHAPE, "gemm: K=%d must be a multiple of 64, N=%d of 4 (GEGLU: 32, with bias)", K, N);
+  GemmArgs a;
+  memset(&a, 0, sizeof a);
+  const int No = geglu ? N / 2 : N;
+  a.A = (const half_t*)A; a.W = (const half_t*)W; a.C = (half_t*)C; a.zero = zero_page(); a.M = M; a.N = N; a.K = K; a.lda = K; a.ldc = No;
+  a.bias = (const half_t*)bias; a.residual = (const half_t*)residual; a.ldr = No; a.geglu = geglu; a.rows_per_batch = 1;
+  a.m_fastest = M <= N;
+  hipError_t e = ia2p_launch_gemm(a, false, (hipStream_t)stream);
+  RET_HIP(e, "gemm");
+}
+ia2p_status ia2p_conv3x3(void* stream, const void* x, const void* Wp, const void* bias, const void* rowvec, const void* residual, void* y,
+                         int B, int Hs, int Ws, int Cin, int Co, int stride, int up) {
+  if (!x || !Wp || !y) return fail(nullptr, IA2P_ERR_INVALID, "conv3x3: null argument");
+  if (Cin % 64 || Co % 4 || (stride != 1 && stride != 2) || (up != 0 && up != 1)) return fail(nullptr, IA2P_ERR_SHAPE, "conv3x3: Cin=%d (mult of 64) Co=%d (mult of 4) stride=%d up=%d", Cin, Co, stride, up);
+  GemmArgs a;
+  memset(&a, 0, sizeof a);
+  const int Hv = Hs << up, Wv = Ws << up;
+  a.Ho = (Hv - 1) / stride + 1; a.Wo = (Wv - 1) / stride + 1;
+  a.A = (const half_t*)x; a.W = (const half_t*)Wp; a.C = (half_t*)y; a.zero = zero_page(); a.M = B * a.Ho * a.Wo; a.N = Co; a.K = 9 * Cin; a.lda = Cin; a.ldc = Co;
+  a.Hs = Hs; a.Ws = Ws; a.stride = stride; a.up = up; a.Cin = Cin; a.bias = (const half_t*)bias;
+  a.rowvec = (const half_t*)rowvec; a.rowvec_ld = Co; a.rows_per_batch = a.Ho * a.Wo; a.residual = (const half_t*)residual; a.ldr = Co;
+  hipError_t e = ia2p_launch_gemm(a, true, (hipStream_t)stream);
+  RET_HIP(e, "conv3x3");
+}
+ia2p_status ia2p_pack_conv3x3(void* stream, const void* src, void* dst, int Co, int Cin) {
+  if (!src || !dst) return fail(nullptr, IA2P_ERR_INVALID, "pack_conv3x3: null argument");
+  hipError_t e = ia2p_launch_pack_conv((const half_t*)src, (half_t*)dst, Co, Cin, (hipStream_t)stream);
+  RET_HIP(e, "pack_conv3x3");
+}
+ia2p_status ia2p_pack_geglu(void* stream, const void* src, void* dst, int rows, int rowlen) {
+  if (!src || !dst || rows % 32) return fail(nullptr, IA2P_ERR_SHAPE, "pack_geglu: rows must be a multiple of 32");
+  hipError_t e = ia2p_launch_pack_geglu((const half_t*)src, (half_t*)dst, rows, rowlen, (hipStream_t)stream);
+  RET_HIP(e, "pack_geglu");
+}
+ia2p_status ia2p_attention(void* stream, const void* Q, int ldq, void* O, int ldo, int B, int heads, int Nq, int nseg,
+                           const void* K0, const void* V0, int ld0, int nkeys0, float w0, const void* K1, const void* V1, int ld1, int nkeys1, float w1) {
+  if (!Q || !O || !K0 || !V0 || nseg < 1 || nseg > 2 || (nseg == 2 && (!K1 || !V1))) return fail(nullptr, IA2P_ERR_INVALID, "attention: bad argument");
+  if (nkeys0 < 1 || (nseg == 2 && nkeys1 < 1) || ldq % 8 || ldo % 4 || ld0 % 8 || (nseg == 2 && ld1 % 8)) return fail(nullptr, IA2P_ERR_SHAPE, "attention: key counts must be >= 1 and strides multiples of 8");
+  AttnArgs a;
+  memset(&a, 0, sizeof a);
+  a.Q = (const half_t*)Q; a.ldq = ldq; a.O = (half_t*)O; a.ldo = ldo; a.B = B; a.heads = heads; a.Nq = Nq; a.nseg = nseg;
+  a.scale_log2e = 0.125f * 1.4426950408889634f;
+  a.seg[0] = AttnSeg{(const half_t*)K0, (const half_t*)V0, nkeys0, ld0, nkeys0, w0};
+  a.seg[1] = AttnSeg{(const half_t*)K1, (const half_t*)V1, nkeys1, ld1, nkeys1, w1};
+  hipError_t e = ia2p_launch_attention(a, (hipStream_t)stream);
+  RET_HIP(e, "attention");
+}
+ia2p_status ia2p_linear_small(void* stream, const void* X, const void* W, const void* bias, void* out, int M, int N, int K, int silu_in, int silu_out) {
+  if (!X || !W || !out) return fail(nullptr, IA2P_ERR_INVALID, "linear_small: null argument");
+  if (M > 16 || K % 8) return fail(nullptr, IA2P_ERR_SHAPE, "linear_small: M=%d (<=16) K=%d (mult of 8)", M, K);
+  hipError_t e = ia2p_launch_linear_small((const half_t*)X, K, (const half_t*)W, (const half_t*)bias, nullptr, 0, (half_t*)out, N, M, N, K, silu_in, silu_out, (hipStream_t)stream);
+  RET_HIP(e, "linear_small");
+}
+
+ia2p_status ia2p_profile_enable(ia2p_ctx* c, int on) {
+  if (!c) return IA2P_ERR_INVALID;
+  for (auto& r : c->recs) { c->evpool.push_back(r.e0); c->evpool.push_back(r.e1); }
+  c->recs.clear();
+  for (int k = 0; k < IA2P_K_COUNT; ++k) { c->p_ms[k] = c->p_fl[k] = c->p_by[k] = 0; c->p_n[k] = 0; }
+  c->prof = on != 0;
+  return IA2P_OK;
+}
+ia2p_status ia2p_profile_read(ia2p_ctx* c, int k, int64_t* launches, double* ms, double* flops, double* bytes) {
+  if (!c || k < 0 || k >= IA2P_K_COUNT) return IA2P_ERR_INVALID;
+  for (auto& r : c->recs) {     // fold finished records (synchronises on their stop events)
+    float t = 0.f;
+    (void)hipEventSynchronize(r.e1);
+    (void)hipEventElapsedTime(&t, r.e0, r.e1);
+    c->p_ms[r.k] += t; c->p_fl[r.k] += r.flops; c->p_by[r.k] += r.bytes; c->p_n[r.k] += 1;
+    c->evpool.push_back(r.e0); c->evpool.push_back(r.e1);
+  }
+  c->recs.clear();
+  if (launches) *launches = c->p_n[k];
+  if (ms) *ms = c->p_ms[k];
+  if (flops) *flops = c->p_fl[k];
+  if (bytes) *bytes = c->p_by[k];
+  return IA2P_OK;
+}
+
+}  // extern "C"

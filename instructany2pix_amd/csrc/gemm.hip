@@ -1,0 +1,218 @@
+// MFMA GEMM for gfx950: C[M,N] = epilogue(A[M,K] . W[N,K]^T), fp16 in, fp32 accumulate, fp16 out.
+//
+// One kernel serves every contraction on the denoise path (reference call sites: the nn.Linear calls of
+// attention_processor.py:239,246-247,267,344,358-359,379-380,400 and, inside the diffusers UNet, the
+// ResnetBlock2D / Downsample2D / Upsample2D 3x3 convolutions, 1x1 shortcuts, proj_in/out and the GEGLU
+// feed-forward -- SURVEY.md §2b):
+//   * LINEAR  : A rows read directly (optional affine row map, used to pick text / image-token rows of ctx)
+//   * CONV3x3 : implicit GEMM over channels-last activations; K = (ky,kx,ci); stride 1/2; optional
+//               nearest-x2 upsample folded into the gather; zero padding reads a zero page.
+// Structure (cdna_hip_programming.md §5): 256 threads = 4 waves (2x2), BK = 64, both operand tiles staged
+// global->LDS with 16-byte `global_load_lds` (per-lane SOURCE address makes the conv gather free), LDS
+// double buffered, XOR-swizzled 16-B chunks (chunk ^ ((row>>1)&7): conflict-free ds_read_b128 fragments),
+// v_mfma_f32_16x16x32_f16 with W as the first operand so each lane ends up holding 4 consecutive output
+// columns of one row (8-byte epilogue stores/loads along N).
+#include "common.h"
+
+#define GLDS16(gptr, ldsptr)                                                                         \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),            \
+                                   (__attribute__((address_space(3))) void*)(ldsptr), 16, 0, 0)
+
+template <int BM, int BN, bool CONV>
+__global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
+  constexpr int WM = BM / 2, WN = BN / 2;      // wave tile (waves arranged 2 x 2)
+  constexpr int MR = WM / 16, NR = WN / 16;
+  constexpr int A_PW = BM / 32, B_PW = BN / 32;  // 1-KiB (8 rows x 128 B) staging pieces per wave
+  constexpr int STAGE = (BM + BN) * 128;
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // ---- tile of this workgroup; blocks b, b+8, ... share an XCD (its L2): give each XCD a contiguous tile range
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  int bid = blockIdx.x;
+  {
+    const int nwg = tiles_m * tiles_n;
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7, i = bid >> 3;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+  }
+  int tm, tn;
+  if (p.m_fastest) { tn = bid / tiles_m; tm = bid - tn * tiles_m; }
+  else             { tm = bid / tiles_n; tn = bid - tm * tiles_n; }
+  const int bm0 = tm * BM, bn0 = tn * BN;
+
+  // ---- staging addresses. Piece `pi` covers tile rows pi*8 .. pi*8+7; lane -> (row pi*8 + lane/8, LDS chunk lane%8),
+  //      which must hold global chunk (lane%8) ^ swz(row), swz(row) = (row>>1)&7.
+  const int srow = lane >> 3;
+  const half_t* a_ptr[A_PW];
+  int a_inc[A_PW];
+  int a_y[A_PW], a_x[A_PW], a_pix[A_PW], a_ch[A_PW];
+#pragma unroll
+  for (int i = 0; i < A_PW; ++i) {
+    const int pi = wave * A_PW + i;
+    const int m = bm0 + pi * 8 + srow;
+    const int gch = (lane & 7) ^ (((pi & 1) << 2) | (srow >> 1));
+    if (!CONV) {
+      if (m < p.M) {
+        int src = m;
+        if (p.rpb) { const int b = m / p.rpb; src = b * p.bstride + (m - b * p.rpb) + p.roff; }
+        a_ptr[i] = p.A + (size_t)src * p.lda + gch * 8;
+        a_inc[i] = 64;
+      } else { a_ptr[i] = p.zero; a_inc[i] = 0; }
+    } else {
+      a_ch[i] = gch * 8;
+      if (m < p.M) {
+        const int hw = p.Ho * p.Wo;
+        const int b = m / hw, rem = m - b * hw;
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        a_y[i] = oy * p.stride - 1; a_x[i] = ox * p.stride - 1; a_pix[i] = b * p.Hs * p.Ws;
+      } else { a_y[i] = -(1 << 20); a_x[i] = 0; a_pix[i] = 0; }
+    }
+  }
+  const half_t* w_ptr[B_PW];
+  int w_inc[B_PW];
+#pragma unroll
+  for (int i = 0; i < B_PW; ++i) {
+    const int pi = wave * B_PW + i;
+    const int n = bn0 + pi * 8 + srow;
+    const int gch = (lane & 7) ^ (((pi & 1) << 2) | (srow >> 1));
+    if (n < p.N) { w_ptr[i] = p.W + (size_t)n * p.K + gch * 8; w_inc[i] = 64; }
+    else         { w_ptr[i] = p.zero; w_inc[i] = 0; }
+  }
+
+  const int Hv = p.Hs << p.up, Wv = p.Ws << p.up;
+  int tap = 0, ci0 = 0;  // conv: position of the k-tile being staged
+
+  auto stage = [&](int kt, int buf) {
+    char* sA = smem + buf * STAGE + wave * (A_PW * 1024);
+    char* sB = smem + buf * STAGE + BM * 128 + wave * (B_PW * 1024);
+    if (CONV) {
+      const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+      for (int i = 0; i < A_PW; ++i) {
+        const int iy = a_y[i] + ky, ix = a_x[i] + kx;
+        const bool ok = (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
+        const half_t* src = p.A + (size_t)(a_pix[i] + (iy >> p.up) * p.Ws + (ix >> p.up)) * p.lda + ci0 + a_ch[i];
+        GLDS16(ok ? src : p.zero, sA + i * 1024);
+      }
+      ci0 += 64;
+      if (ci0 >= p.Cin) { ci0 = 0; ++tap; }
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_PW; ++i) GLDS16(a_ptr[i] + (size_t)kt * a_inc[i], sA + i * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < B_PW; ++i) GLDS16(w_ptr[i] + (size_t)kt * w_inc[i], sB + i * 1024);
+  };
+
+  // ---- fragment read offsets (wave tile origin is a multiple of 16, so swz(row) = (lane>>1)&7)
+  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+  const int frow = lane & 15, fq = lane >> 4;
+  const int fswz = (lane >> 1) & 7;
+  const int a_off = (wm0 + frow) * 128, w_off = BM * 128 + (wn0 + frow) * 128;
+
+  f4 acc[MR][NR];
+#pragma unroll
+  for (int i = 0; i < MR; ++i)
+#pragma unroll
+    for (int j = 0; j < NR; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K >> 6;
+  stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
+    const char* base = smem + cur * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int coff = ((kk * 4 + fq) ^ fswz) << 4;
+      h8 af[MR], wf[NR];
+#pragma unroll
+      for (int i = 0; i < MR; ++i) af[i] = *(const h8*)(base + a_off + i * 2048 + coff);
+#pragma unroll
+      for (int j = 0; j < NR; ++j) wf[j] = *(const h8*)(base + w_off + j * 2048 + coff);
+#pragma unroll
+      for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue: acc[i][j][r] = C[m = bm0+wm0+16i+(lane&15)][n = bn0+wn0+16j+4*(lane>>4)+r]
+#pragma unroll
+  for (int i = 0; i < MR; ++i) {
+    const int m = bm0 + wm0 + i * 16 + frow;
+    if (m >= p.M) continue;
+    const half_t* rv = nullptr;
+    if (p.rowvec) rv = p.rowvec + (size_t)(m / p.rows_per_batch) * p.rowvec_ld;
+    if (!p.geglu) {
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        const int n = bn0 + wn0 + j * 16 + fq * 4;
+        if (n >= p.N) continue;
+        f4 v = acc[i][j];
+        if (p.bias) { const h4 b = *(const h4*)(p.bias + n); v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3]; }
+        if (rv) { const h4 b = *(const h4*)(rv + n); v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3]; }
+        if (p.residual) { const h4 b = *(const h4*)(p.residual + (size_t)m * p.ldr + n); v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3]; }
+        h4 o; o[0] = (half_t)v[0]; o[1] = (half_t)v[1]; o[2] = (half_t)v[2]; o[3] = (half_t)v[3];
+        *(h4*)(p.C + (size_t)m * p.ldc + n) = o;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NR; j += 2) {
+        const int n = bn0 + wn0 + j * 16 + fq * 4;     // packed row of the `a` half; gate rows sit 16 further
+        if (n >= p.N) continue;
+        const h4 ba = *(const h4*)(p.bias + n), bg = *(const h4*)(p.bias + n + 16);
+        h4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (half_t)((acc[i][j][r] + (float)ba[r]) * gelu_erf_f(acc[i][j + 1][r] + (float)bg[r]));
+        const int nout = ((bn0 + wn0 + j * 16) >> 1) + fq * 4;
+        *(h4*)(p.C + (size_t)m * p.ldc + nout) = o;
+      }
+    }
+  }
+}
+
+template <int BM, int BN, bool CONV>
+static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
+  constexpr int smem = 2 * (BM + BN) * 128;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_f16_kernel<BM, BN, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+  hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, CONV>), dim3(tiles), dim3(256), smem, s, a);
+  return hipGetLastError();
+}
+
+// tile choice: biggest tile that still yields enough workgroups for 256 CUs
+static int g_force_tile = -1;   // test/tuning hook (ia2p_debug_set_gemm_tile)
+extern "C" void ia2p_debug_set_gemm_tile(int t) { g_force_tile = t; }
+
+template <bool CONV>
+static hipError_t launch_any(const GemmArgs& a, hipStream_t s) {
+  auto tiles = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
+  int pick;
+  if (g_force_tile >= 0) pick = g_force_tile;
+  else if (tiles(128, 128) >= 384) pick = 0;
+  else if (tiles(128, 64) >= 256) pick = 1;
+  else pick = 2;
+  switch (pick) {
+    case 0: return launch_cfg<128, 128, CONV>(a, s);
+    case 1: return launch_cfg<128, 64, CONV>(a, s);
+    default: return launch_cfg<64, 64, CONV>(a, s);
+  }
+}
+
+hipError_t ia2p_launch_gemm(const GemmArgs& a, bool conv, hipStream_t s) {
+  return conv ? launch_any<true>(a, s) : launch_any<false>(a, s);
+}

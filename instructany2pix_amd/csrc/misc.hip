@@ -1,0 +1,249 @@
+// Small kernels of the denoise step on gfx950: timestep / micro-conditioning embeddings, skinny (M<=16)
+// linears for the embedding MLPs, the 4-channel latent convolutions at the NCHW boundary, channel concat,
+// the fused CFG + DDIM update, and the one-time weight re-layouts.
+#include "common.h"
+
+// ---- sinusoidal embeddings (diffusers Timesteps(flip_sin_to_cos=True, freq_shift=0)) ------------------
+// tsin[b, :]   = [cos(t f_i), sin(t f_i)], i < Tp/2
+// addin[b, :]  = [text_embeds[b, :P], sinusoid(time_ids[b,0]), ..., sinusoid(time_ids[b,5])]
+__global__ void embed_kernel(float t, const half_t* text_embeds, const half_t* time_ids, half_t* tsin, half_t* addin,
+                             int B, int Tp, int P, int Ad, int nids) {
+  const int b = blockIdx.x;
+  const int Ain = P + nids * Ad;
+  for (int i = threadIdx.x; i < Tp; i += blockDim.x) {
+    const int half_ = Tp / 2, k = i % half_;
+    const float f = expf(-9.210340371976184f * (float)k / (float)half_);
+    const float a = t * f;
+    tsin[(size_t)b * Tp + i] = (half_t)(i < half_ ? cosf(a) : sinf(a));
+  }
+  for (int i = threadIdx.x; i < Ain; i += blockDim.x) {
+    half_t v;
+    if (i < P) v = text_embeds[(size_t)b * P + i];
+    else {
+      const int j = (i - P) / Ad, r = (i - P) % Ad, half_ = Ad / 2, k = r % half_;
+      const float id = (float)time_ids[(size_t)b * nids + j];
+      const float a = id * expf(-9.210340371976184f * (float)k / (float)half_);
+      v = (half_t)(r < half_ ? cosf(a) : sinf(a));
+    }
+    addin[(size_t)b * Ain + i] = v;
+  }
+}
+
+// ---- out[M<=16, N] = act_out( f_in(X)[M,K] . W[N,K]^T + bias + addend ), one wave per 4 output columns ---------------
+__global__ __launch_bounds__(256) void linear_small_kernel(const half_t* X, int ldx, const half_t* W, const half_t* bias,
+                                                           const half_t* addend, int ldadd, half_t* out, int ldo,
+                                                           int M, int N, int K, int silu_in, int silu_out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n0 = (blockIdx.x * 4 + wave) * 4;
+  if (n0 >= N) return;
+  float acc[4][16];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int m = 0; m < 16; ++m) acc[c][m] = 0.f;
+  const int nvec = K >> 3;
+  for (int v = lane; v < nvec; v += 64) {
+    float w[4][8];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int n = min(n0 + c, N - 1);
+      const h8 d = *(const h8*)(W + (size_t)n * K + v * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) w[c][e] = (float)d[e];
+    }
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      if (m < M) {
+        const h8 d = *(const h8*)(X + (size_t)m * ldx + v * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float x = (float)d[e];
+          if (silu_in) x = silu_f(x);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[c][m] += x * w[c][e];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      const float s = wave_sum(acc[c][m]);
+      if (lane == c * 16 + m && m < M && n0 + c < N) {
+        float v = s;
+        if (bias) v += (float)bias[n0 + c];
+        if (addend) v += (float)addend[(size_t)m * ldadd + n0 + c];
+        if (silu_out) v = silu_f(v);
+        out[(size_t)m * ldo + n0 + c] = (half_t)v;
+      }
+    }
+}
+
+// ---- conv_in: latent NCHW [B,Cin,H,W] -> channels-last [B*H*W, Co], 3x3 pad 1 (Cin*9 <= 64 taps) --------------------
+__global__ __launch_bounds__(256) void conv_in_kernel(const half_t* x, const half_t* w /*[Co][Cin][3][3]*/, const half_t* bias,
+                                                      half_t* y, int B, int Cin, int H, int W, int Co, int pix_per_block) {
+  extern __shared__ half_t wl[];   // [Cin*9][Co]
+  const int KT = Cin * 9;
+  for (int i = threadIdx.x; i < KT * Co; i += blockDim.x) {
+    const int co = i / KT, k = i - co * KT;
+    wl[k * Co + co] = w[i];
+  }
+  __syncthreads();
+  const int TX = Co >> 3, TY = blockDim.x / TX;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  if (ty >= TY) return;
+  const int npix = B * H * W;
+  const int p0 = blockIdx.x * pix_per_block;
+  float bs[8];
+  { const h8 d = *(const h8*)(bias + tx * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bs[e] = (float)d[e]; }
+  for (int pp = p0 + ty; pp < min(p0 + pix_per_block, npix); pp += TY) {
+    const int b = pp / (H * W), rem = pp - b * H * W, oy = rem / W, ox = rem - oy * W;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = bs[e];
+    for (int ci = 0; ci < Cin; ++ci)
+      for (int ky = 0; ky < 3; ++ky)
+        for (int kx = 0; kx < 3; ++kx) {
+          const int iy = oy + ky - 1, ix = ox + kx - 1;
+          if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) continue;
+          const float xv = (float)x[(((size_t)b * Cin + ci) * H + iy) * W + ix];
+          const h8 d = *(const h8*)(wl + (ci * 9 + ky * 3 + kx) * Co + tx * 8);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += xv * (float)d[e];
+        }
+    h8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)acc[e];
+    *(h8*)(y + (size_t)pp * Co + tx * 8) = o;
+  }
+}
+
+// ---- conv_out: channels-last [B*H*W, C] -> NCHW [B,Co<=8,H,W], 3x3 pad 1; one wave per output pixel ------------------
+__global__ __launch_bounds__(256) void conv_out_kernel(const half_t* x, int ldx, const half_t* w /*[Co][9][C]*/, const half_t* bias,
+                                                       half_t* y, int B, int C, int H, int W, int Co) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pp = blockIdx.x * 4 + wave;
+  if (pp >= B * H * W) return;
+  const int b = pp / (H * W), rem = pp - b * H * W, oy = rem / W, ox = rem - oy * W;
+  const int cv = C >> 3, nvec = 9 * cv;
+  float acc[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+  for (int v = lane; v < nvec; v += 64) {
+    const int tap = v / cv, c8 = v - tap * cv, ky = tap / 3, kx = tap - ky * 3;
+    const int iy = oy + ky - 1, ix = ox + kx - 1;
+    if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) continue;
+    const h8 d = *(const h8*)(x + ((size_t)(b * H + iy) * W + ix) * ldx + c8 * 8);
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      if (c < Co) {
+        const h8 wv = *(const h8*)(w + ((size_t)c * 9 + tap) * C + c8 * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[c] += (float)d[e] * (float)wv[e];
+      }
+  }
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+    if (c < Co) {
+      const float s = wave_sum(acc[c]);
+      if (lane == c) y[(((size_t)b * Co + c) * H + oy) * W + ox] = (half_t)(s + (float)bias[c]);
+    }
+}
+
+// ---- channel concat of two channels-last tensors (torch.cat([h, skip], dim=1) of the up path) --------------------------
+__global__ void concat_kernel(const half_t* a, int lda, int Ca, const half_t* b, int ldb, int Cb, half_t* y, long M) {
+  const int va = Ca >> 3, vb = Cb >> 3, vt = va + vb;
+  const long total = M * vt;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / vt;
+    const int v = (int)(i - m * vt);
+    const uint4 d = v < va ? *(const uint4*)(a + m * lda + v * 8) : *(const uint4*)(b + m * ldb + (v - va) * 8);
+    *(uint4*)(y + m * (long)(Ca + Cb) + v * 8) = d;
+  }
+}
+
+// ---- fused classifier-free guidance + DDIM update (fp32 math, one rounding) ------------------------------------------
+// eps = eps_u + g (eps_c - eps_u)          reference ddim/sdxl_pipeline.py:842-844
+// out = c_x * x + c_e * eps                 sampling: DDIMScheduler.step (eta 0); inversion: pnp_pipeline.py:73-85
+// out2 (optional) receives a second copy (the cat([latents]*2) input of the next CFG evaluation, :826)
+__global__ void ddim_step_kernel(const half_t* x, const half_t* eps_u, const half_t* eps_c, float g, float c_x, float c_e,
+                                 half_t* out, half_t* out2, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float e = (float)eps_u[i];
+    if (eps_c) e = e + g * ((float)eps_c[i] - e);
+    const half_t o = (half_t)(c_x * (float)x[i] + c_e * e);
+    out[i] = o;
+    if (out2) out2[i] = o;
+  }
+}
+
+// ---- one-time weight re-layouts -----------------------------------------------------------------------------------------
+// conv [Co][Ci][3][3] -> [Co][ky][kx][Ci] (implicit-GEMM K order)
+__global__ void pack_conv_kernel(const half_t* src, half_t* dst, int Co, int Ci) {
+  const long total = (long)Co * Ci * 9;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Ci);
+    const long t = i / Ci;
+    const int tap = (int)(t % 9), co = (int)(t / 9);
+    dst[i] = src[((long)co * Ci + ci) * 9 + tap];
+  }
+}
+// GEGLU pairing: packed row p (block t = p/32): p%32 < 16 -> value row 16t + p%32 ; else gate row half + 16t + p%32 - 16
+__global__ void pack_geglu_kernel(const half_t* src, half_t* dst, int rows, int rowlen) {
+  const long total = (long)rows * rowlen;
+  const int half_ = rows / 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int p = (int)(i / rowlen), k = (int)(i - (long)p * rowlen);
+    const int t = p >> 5, w = p & 31;
+    const int s = w < 16 ? 16 * t + w : half_ + 16 * t + (w - 16);
+    dst[i] = src[(long)s * rowlen + k];
+  }
+}
+
+// ---- host launchers -------------------------------------------------------------------------------------------------------
+static inline int grid_for(long n, int block) { long g = (n + block - 1) / block; return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
+
+hipError_t ia2p_launch_embed(float t, const half_t* text_embeds, const half_t* time_ids, half_t* tsin, half_t* addin,
+                             int B, int Tp, int P, int Ad, int nids, hipStream_t s) {
+  hipLaunchKernelGGL(embed_kernel, dim3(B), dim3(256), 0, s, t, text_embeds, time_ids, tsin, addin, B, Tp, P, Ad, nids);
+  return hipGetLastError();
+}
+hipError_t ia2p_launch_linear_small(const half_t* X, int ldx, const half_t* W, const half_t* bias, const half_t* addend, int ldadd,
+                                    half_t* out, int ldo, int M, int N, int K, int silu_in, int silu_out, hipStream_t s) {
+  if (M > 16 || K % 8) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(linear_small_kernel, dim3((N + 15) / 16), dim3(256), 0, s, X, ldx, W, bias, addend, ldadd, out, ldo, M, N, K, silu_in, silu_out);
+  return hipGetLastError();
+}
+hipError_t ia2p_launch_conv_in(const half_t* x, const half_t* w, const half_t* bias, half_t* y, int B, int Cin, int H, int W, int Co, hipStream_t s) {
+  if (Co % 8 || Co / 8 > 256) return hipErrorInvalidValue;
+  const int ppb = 64;
+  const size_t sm = (size_t)Cin * 9 * Co * sizeof(half_t);
+  hipLaunchKernelGGL(conv_in_kernel, dim3((B * H * W + ppb - 1) / ppb), dim3(256), sm, s, x, w, bias, y, B, Cin, H, W, Co, ppb);
+  return hipGetLastError();
+}
+hipError_t ia2p_launch_conv_out(const half_t* x, int ldx, const half_t* w, const half_t* bias, half_t* y, int B, int C, int H, int W, int Co, hipStream_t s) {
+  if (Co > 8 || C % 8) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(conv_out_kernel, dim3((B * H * W + 3) / 4), dim3(256), 0, s, x, ldx, w, bias, y, B, C, H, W, Co);
+  return hipGetLastError();
+}
+hipError_t ia2p_launch_concat(const half_t* a, int lda, int Ca, const half_t* b, int ldb, int Cb, half_t* y, long M, hipStream_t s) {
+  if (Ca % 8 || Cb % 8) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(concat_kernel, dim3(grid_for(M * ((Ca + Cb) / 8), 256)), dim3(256), 0, s, a, lda, Ca, b, ldb, Cb, y, M);
+  return hipGetLastError();
+}
+hipError_t ia2p_launch_ddim_step(const half_t* x, const half_t* eps_u, const half_t* eps_c, float g, float c_x, float c_e,
+                                 half_t* out, half_t* out2, long n, hipStream_t s) {
+  hipLaunchKernelGGL(ddim_step_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, x, eps_u, eps_c, g, c_x, c_e, out, out2, n);
+  return hipGetLastError();
+}
+hipError_t ia2p_launch_pack_conv(const half_t* src, half_t* dst, int Co, int Ci, hipStream_t s) {
+  hipLaunchKernelGGL(pack_conv_kernel, dim3(grid_for((long)Co * Ci * 9, 256)), dim3(256), 0, s, src, dst, Co, Ci);
+  return hipGetLastError();
+}
+hipError_t ia2p_launch_pack_geglu(const half_t* src, half_t* dst, int rows, int rowlen, hipStream_t s) {
+  hipLaunchKernelGGL(pack_geglu_kernel, dim3(grid_for((long)rows * rowlen, 256)), dim3(256), 0, s, src, dst, rows, rowlen);
+  return hipGetLastError();
+}

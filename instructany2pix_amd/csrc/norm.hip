@@ -1,0 +1,222 @@
+// GroupNorm(+SiLU) and LayerNorm for channels-last fp16 activations on gfx950. HBM-bound kernels:
+// 16-byte coalesced loads/stores, fp32 statistics, wavefront/LDS reductions.
+//
+// Replaces, inside the diffusers UNet the reference drives:
+//   ResnetBlock2D.norm1/norm2 + SiLU (eps 1e-5), Transformer2DModel.norm (eps 1e-6, no SiLU),
+//   conv_norm_out + SiLU, and BasicTransformerBlock.norm1/2/3 (LayerNorm eps 1e-5).
+//
+// GroupNorm over x[B, HW, C] (C contiguous), G groups of Cg = C/G channels:
+//   pass 1 (gn_stats): grid (chunks, B); a block owns `rows` pixels x all channels, every thread keeps a
+//          FIXED set of 8 (or 16) channels so per-channel sum / sum-of-squares live in registers; they are
+//          folded per group through LDS and written as one (sum, sumsq) pair per (b, chunk, group).
+//   pass 2 (gn_apply): same thread->channel map; each block folds the chunk partials of its batch in fp64,
+//          derives per-channel scale/shift once, then streams its rows: y = silu(x*scale + shift).
+// Algorithmic traffic: read x twice (second read normally served by L2 / Infinity Cache), write y once.
+#include "common.h"
+
+struct GNArgs {
+  const half_t* x; half_t* y;
+  const half_t* gamma; const half_t* beta;
+  float* partial;         // [B][chunks][G][2]
+  int B, HW, C, G, chunks, rows;   // rows = pixels per chunk (last chunk may be short)
+  int ldx, ldy;
+  float eps; int silu;
+};
+
+// thread map: TX = (C/8)/V threads across channels (V vectors of 8 channels each), TY = blockDim/TX rows in flight
+template <int V>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const GNArgs p) {
+  extern __shared__ float red[];   // [2][TY][C]
+  const int nvec = p.C >> 3, TX = nvec / V, TY = blockDim.x / TX;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  const int b = blockIdx.y, r0 = blockIdx.x * p.rows, r1 = min(r0 + p.rows, p.HW);
+  float s[V][8], ss[V][8];
+#pragma unroll
+  for (int v = 0; v < V; ++v)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[v][e] = 0.f; ss[v][e] = 0.f; }
+  if (ty < TY) {
+    for (int r = r0 + ty; r < r1; r += TY) {
+      const half_t* row = p.x + ((size_t)b * p.HW + r) * p.ldx;
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        const h8 d = *(const h8*)(row + (tx + v * TX) * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float f = (float)d[e]; s[v][e] += f; ss[v][e] += f * f; }
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = (tx + v * TX) * 8 + e;
+        red[ty * p.C + c] = s[v][e];
+        red[(TY + ty) * p.C + c] = ss[v][e];
+      }
+  }
+  __syncthreads();
+  // fold the TY row-slices per channel (column c is touched by one thread only), then per group
+  for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
+    float a = 0.f, q = 0.f;
+    for (int t = 0; t < TY; ++t) { a += red[t * p.C + c]; q += red[(TY + t) * p.C + c]; }
+    red[c] = a; red[TY * p.C + c] = q;
+  }
+  __syncthreads();
+  const int Cg = p.C / p.G;
+  if ((int)threadIdx.x < p.G) {
+    const int g = threadIdx.x;
+    float a = 0.f, q = 0.f;
+    for (int c = g * Cg; c < (g + 1) * Cg; ++c) { a += red[c]; q += red[TY * p.C + c]; }
+    float* out = p.partial + (((size_t)b * p.chunks + blockIdx.x) * p.G + g) * 2;
+    out[0] = a; out[1] = q;
+  }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const GNArgs p) {
+  extern __shared__ float stat[];   // [G][2] mean, rstd
+  const int nvec = p.C >> 3, TX = nvec / V, TY = blockDim.x / TX;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  const int b = blockIdx.y, r0 = blockIdx.x * p.rows, r1 = min(r0 + p.rows, p.HW);
+  const int Cg = p.C / p.G;
+  if ((int)threadIdx.x < p.G) {
+    const int g = threadIdx.x;
+    double a = 0.0, q = 0.0;
+    for (int c = 0; c < p.chunks; ++c) {
+      const float* in = p.partial + (((size_t)b * p.chunks + c) * p.G + g) * 2;
+      a += (double)in[0]; q += (double)in[1];
+    }
+    const double n = (double)p.HW * Cg;
+    const double mean = a / n;
+    double var = q / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stat[g * 2] = (float)mean;
+    stat[g * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
+  }
+  __syncthreads();
+  if (ty >= TY) return;
+  float sc[V][8], sh[V][8];
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    const int c0 = (tx + v * TX) * 8;
+    const h8 ga = *(const h8*)(p.gamma + c0), be = *(const h8*)(p.beta + c0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int g = (c0 + e) / Cg;
+      const float mean = stat[g * 2], rstd = stat[g * 2 + 1];
+      sc[v][e] = rstd * (float)ga[e];
+      sh[v][e] = (float)be[e] - mean * sc[v][e];
+    }
+  }
+  for (int r = r0 + ty; r < r1; r += TY) {
+    const half_t* row = p.x + ((size_t)b * p.HW + r) * p.ldx;
+    half_t* orow = p.y + ((size_t)b * p.HW + r) * p.ldy;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const int c0 = (tx + v * TX) * 8;
+      const h8 d = *(const h8*)(row + c0);
+      h8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float f = (float)d[e] * sc[v][e] + sh[v][e];
+        if (p.silu) f = silu_f(f);
+        o[e] = (half_t)f;
+      }
+      *(h8*)(orow + c0) = o;
+    }
+  }
+}
+
+// partial must hold B*chunks*G*2 floats. Returns the chunk count it used via *chunks_out when partial == null.
+int ia2p_gn_chunks(int B, int HW) {
+  int chunks = 1;
+  while (chunks < 64 && B * chunks < 512 && (HW / (chunks * 2)) >= 8) chunks *= 2;
+  return chunks;
+}
+
+hipError_t ia2p_launch_groupnorm(const half_t* x, int ldx, half_t* y, int ldy, const half_t* gamma, const half_t* beta,
+                                 float* partial, int B, int HW, int C, int G, float eps, int silu, hipStream_t s) {
+  GNArgs a;
+  a.x = x; a.y = y; a.gamma = gamma; a.beta = beta; a.partial = partial;
+  a.B = B; a.HW = HW; a.C = C; a.G = G; a.ldx = ldx; a.ldy = ldy; a.eps = eps; a.silu = silu;
+  a.chunks = ia2p_gn_chunks(B, HW);
+  a.rows = (HW + a.chunks - 1) / a.chunks;
+  a.chunks = (HW + a.rows - 1) / a.rows;
+  const int nvec = C / 8;
+  int V = 1;
+  while (nvec / V > 256 || nvec % V) ++V;
+  if (V > 2 || C % 8 || C % G) return hipErrorInvalidValue;
+  const int TX = nvec / V, TY = 256 / TX;
+  dim3 grid(a.chunks, B), block(256);
+  const size_t sm1 = (size_t)2 * TY * C * sizeof(float), sm2 = (size_t)G * 2 * sizeof(float);
+  if (sm1 > 65536) return hipErrorInvalidValue;
+  if (V == 1) {
+    hipLaunchKernelGGL(gn_stats_kernel<1>, grid, block, sm1, s, a);
+    hipLaunchKernelGGL(gn_apply_kernel<1>, grid, block, sm2, s, a);
+  } else {
+    hipLaunchKernelGGL(gn_stats_kernel<2>, grid, block, sm1, s, a);
+    hipLaunchKernelGGL(gn_apply_kernel<2>, grid, block, sm2, s, a);
+  }
+  return hipGetLastError();
+}
+
+// ---- LayerNorm over the last dim of x[M, C]: one wave per row, row held in registers (true two-pass stats)
+template <int NV>  // NV = ceil((C/8)/64) vectors of 8 per lane
+__global__ __launch_bounds__(256) void layernorm_kernel(const half_t* x, int ldx, half_t* y, int ldy, const half_t* gamma,
+                                                        const half_t* beta, int M, int C, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = blockIdx.x * 4 + wave;
+  if (m >= M) return;
+  const int nvec = C >> 3;
+  const half_t* row = x + (size_t)m * ldx;
+  float v[NV][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nvec) {
+      const h8 d = *(const h8*)(row + c * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v[i][e] = (float)d[e]; sum += v[i][e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+    }
+  }
+  const float mean = wave_sum(sum) / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if (lane + i * 64 < nvec) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; sq += d * d; }
+    }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+  half_t* orow = y + (size_t)m * ldy;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nvec) {
+      const h8 ga = *(const h8*)(gamma + c * 8), be = *(const h8*)(beta + c * 8);
+      h8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (half_t)((v[i][e] - mean) * rstd * (float)ga[e] + (float)be[e]);
+      *(h8*)(orow + c * 8) = o;
+    }
+  }
+}
+
+hipError_t ia2p_launch_layernorm(const half_t* x, int ldx, half_t* y, int ldy, const half_t* gamma, const half_t* beta,
+                                 int M, int C, float eps, hipStream_t s) {
+  if (C % 8) return hipErrorInvalidValue;
+  const int nv = (C / 8 + 63) / 64;
+  dim3 grid((M + 3) / 4), block(256);
+  switch (nv) {
+    case 1: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, ldx, y, ldy, gamma, beta, M, C, eps); break;
+    case 2: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x, ldx, y, ldy, gamma, beta, M, C, eps); break;
+    case 3: hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, s, x, ldx, y, ldy, gamma, beta, M, C, eps); break;
+    case 4: hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, s, x, ldx, y, ldy, gamma, beta, M, C, eps); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}

@@ -1,0 +1,86 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads, and exports every symbol
+include/ia2p.h declares; the plan/validation logic that needs no GPU behaves; the product package never
+imports the oracle."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from instructany2pix_amd import build, _ffi
+    build.build(verbose=False)
+    return _ffi.lib()
+
+
+def test_header_symbols_exported(lib):
+    from instructany2pix_amd import _ffi
+    hdr = open(os.path.join(ROOT, "include", "ia2p.h")).read()
+    declared = set(re.findall(r"\b(ia2p_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"ia2p_ctx"}
+    assert declared, "no declarations parsed"
+    assert declared == set(_ffi.SIGNATURES), declared ^ set(_ffi.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/ia2p.h but not exported"
+
+
+def test_create_plan_and_errors(lib):
+    from instructany2pix_amd import _ffi
+    from instructany2pix_amd.config import sdxl_base, tiny
+    from instructany2pix_amd.weights import unet_param_specs, ip_adapter_specs, param_count
+    for cfg in (sdxl_base(), tiny()):
+        ctx = C.c_void_p()
+        _ffi.check(lib.ia2p_create(C.byref(_ffi.make_config(cfg)), C.byref(ctx)))
+        ipn = param_count(ip_adapter_specs(cfg)["ip_adapter"])
+        n = param_count(unet_param_specs(cfg)) + ipn
+        arena = lib.ia2p_arena_bytes(ctx)
+        assert n * 2 <= arena < n * 2 * 1.02 + (1 << 20)      # fp16, small alignment padding only
+        # workspace sizing is a pure host dry run
+        assert lib.ia2p_workspace_bytes(ctx, 1, 16, 16, 77) > 0
+        assert lib.ia2p_workspace_bytes(ctx, 1, 15, 16, 77) == 0     # not divisible by 4
+        assert b"divisible" in lib.ia2p_last_error(ctx)
+        # state errors before an arena is bound
+        with pytest.raises(_ffi.IA2PError):
+            _ffi.check(lib.ia2p_finalize_weights(ctx), ctx)
+        lib.ia2p_destroy(ctx)
+    bad = tiny()
+    bad.block_out_channels = (60, 128, 256)
+    ctx = C.c_void_p()
+    with pytest.raises(ValueError):
+        _ffi.check(lib.ia2p_create(C.byref(_ffi.make_config(bad)), C.byref(ctx)))
+
+
+def test_workspace_scales_with_batch(lib):
+    from instructany2pix_amd import _ffi
+    from instructany2pix_amd.config import sdxl_base
+    ctx = C.c_void_p()
+    _ffi.check(lib.ia2p_create(C.byref(_ffi.make_config(sdxl_base())), C.byref(ctx)))
+    w1 = lib.ia2p_workspace_bytes(ctx, 1, 64, 64, 77)
+    w8 = lib.ia2p_workspace_bytes(ctx, 8, 64, 64, 81)
+    assert 0 < w1 < w8 < 4 << 30
+    lib.ia2p_destroy(ctx)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "instructany2pix_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{f} imports the oracle"
+    code = "import sys; import instructany2pix_amd; assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules)"
+    subprocess.run([sys.executable, "-c", code], check=True, cwd=ROOT)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from instructany2pix_amd import _ffi
+    monkeypatch.setattr(_ffi, "_lib", None)
+    monkeypatch.setattr(_ffi, "LIB_PATH", "/nonexistent/libia2p_hip.so")
+    with pytest.raises(_ffi.IA2PError):
+        _ffi.lib()
