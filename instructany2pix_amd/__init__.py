@@ -1,0 +1,27 @@
+"""MI355X-native denoise hot path of InstructAny2Pix (conditional SDXL UNet + DDIM loop).
+
+Importing this package touches no GPU and no native code; the HIP library (libia2p_hip.so, built by
+`python -m instructany2pix_amd.build`) is loaded on first use and there is no non-HIP fallback.
+"""
+from .config import UNetConfig, sdxl_base, tiny
+
+__all__ = ["UNetConfig", "sdxl_base", "tiny", "InstructAny2PixPipeline", "HipUNet2DConditionModel", "DDIMScheduler",
+           "SDXLDDIMPipeline", "StableDiffusionXLPipeline", "IPAdapterXL", "ImageProjModel"]
+
+
+def __getattr__(name):          # lazy: keep `import instructany2pix_amd` free of torch/ctypes work
+    if name == "InstructAny2PixPipeline":
+        from .pipeline import InstructAny2PixPipeline as v
+    elif name == "HipUNet2DConditionModel":
+        from .unet import HipUNet2DConditionModel as v
+    elif name == "DDIMScheduler":
+        from .scheduler import DDIMScheduler as v
+    elif name in ("SDXLDDIMPipeline", "StableDiffusionXLPipeline"):
+        from . import ddim
+        v = getattr(ddim, name)
+    elif name in ("IPAdapterXL", "ImageProjModel"):
+        from . import ip_adapter
+        v = getattr(ip_adapter, name)
+    else:
+        raise AttributeError(name)
+    return v

@@ -1,0 +1,189 @@
+"""HIP-backed conditional UNet with the call surface the reference uses on diffusers' UNet2DConditionModel.
+
+What callers in the reference touch, and where it lives here:
+  unet(sample, t, encoder_hidden_states=, cross_attention_kwargs=None, added_cond_kwargs={...}, return_dict=False)[0]
+        instructany2pix/ddim/pnp_pipeline.py:253-260; ddim/sdxl_pipeline.py:832-839          -> __call__
+  unet.config.{in_channels, addition_time_embed_dim, cross_attention_dim, block_out_channels, sample_size}
+        pnp_pipeline.py:44-47; diffusion/ip_adapter/ip_adapter.py:114,124-132                   -> .config
+  unet.add_embedding.linear_1.in_features       pnp_pipeline.py:47                            -> .add_embedding
+  unet.attn_processors / unet.set_attn_processor(...)   ip_adapter.py:123,142,154,168          -> same names
+All arithmetic runs in libia2p_hip.so (`ia2p_unet_forward`); this class owns the flat weight arena and the
+activation workspace as torch tensors (device memory plumbing only) and keeps no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+from types import SimpleNamespace
+from typing import Dict, Iterable, Optional, Tuple, Union
+
+import torch
+
+from . import _ffi
+from .attention_processor import AttnProcessor2_0, IPAttnProcessor2_0
+from .config import UNetConfig
+from .weights import attn_processor_names
+
+
+class HipUNet2DConditionModel:
+    dtype = torch.float16
+
+    def __init__(self, config: UNetConfig, device: Union[str, torch.device] = "cuda:0"):
+        config.validate()
+        self.config = config
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _ffi.IA2PError("HipUNet2DConditionModel runs only on an MI355X device (no CPU path exists)")
+        self._lib = _ffi.lib()
+        torch.cuda.set_device(self.device)
+        if not self._lib.ia2p_device_is_gfx950():
+            raise _ffi.IA2PError("libia2p_hip.so is compiled for gfx950 only")
+        self._ctx = C.c_void_p()
+        _ffi.check(self._lib.ia2p_create(C.byref(_ffi.make_config(config)), C.byref(self._ctx)))
+        nbytes = self._lib.ia2p_arena_bytes(self._ctx)
+        self.arena = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)     # the ONE flat weight buffer
+        _ffi.check(self._lib.ia2p_bind_arena(self._ctx, _ffi.ptr(self.arena), nbytes), self._ctx)
+        self._workspace: Optional[torch.Tensor] = None
+        self._ws_key = None
+        self._names = attn_processor_names(config)
+        self._procs: "OrderedDict[str, torch.nn.Module]" = OrderedDict((n, AttnProcessor2_0()) for n in self._names)
+        self._ip_sig = None
+        self.add_embedding = SimpleNamespace(linear_1=SimpleNamespace(in_features=config.projection_class_embeddings_input_dim))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_ctx", None):
+                self._lib.ia2p_destroy(self._ctx)
+                self._ctx = None
+        except Exception:
+            pass
+
+    # ---- torch.nn.Module look-alikes the pipelines call --------------------------------------------------------
+    def to(self, *a, **kw):
+        return self
+
+    def eval(self):
+        return self
+
+    # ---- weights --------------------------------------------------------------------------------------------------
+    def load_state_dict(self, state_dict: Union[Dict[str, torch.Tensor], Iterable[Tuple[str, torch.Tensor]]], strict: bool = True):
+        """Load parameters by diffusers key. Accepts a dict or an iterator of (key, tensor) so 5 GB of weights
+        never need to be resident twice."""
+        items = state_dict.items() if hasattr(state_dict, "items") else state_dict
+        torch.cuda.set_device(self.device)
+        for k, v in items:
+            self._load(k, v)
+        torch.cuda.synchronize(self.device)
+        if strict:
+            _ffi.check(self._lib.ia2p_finalize_weights(self._ctx), self._ctx)
+
+    def _load(self, key: str, v: torch.Tensor):
+        t = v.detach().to(device=self.device, dtype=torch.float16).contiguous()
+        shape = (C.c_int64 * t.ndim)(*t.shape)
+        _ffi.check(self._lib.ia2p_load_tensor(self._ctx, key.encode(), _ffi.ptr(t), shape, t.ndim, _ffi.current_stream()), self._ctx)
+        torch.cuda.current_stream().synchronize()      # `t` may be a temporary
+
+    def adopt_arena(self):
+        """Arena bytes were produced elsewhere (RCCL broadcast from rank 0): mark parameters present."""
+        _ffi.check(self._lib.ia2p_adopt_arena(self._ctx), self._ctx)
+
+    # ---- operator-plugin API (reference ip_adapter.py:120-154) ----------------------------------------------------
+    @property
+    def attn_processors(self) -> "OrderedDict[str, torch.nn.Module]":
+        return OrderedDict(self._procs)
+
+    def set_attn_processor(self, processor):
+        if isinstance(processor, dict):
+            if set(processor) != set(self._names):
+                raise ValueError(f"A dict of processors was passed, but the number of processors {len(processor)} does not match "
+                                 f"the number of attention layers: {len(self._names)}.")
+            self._procs = OrderedDict((n, processor[n]) for n in self._names)
+        else:
+            self._procs = OrderedDict((n, processor) for n in self._names)
+        self._ip_sig = None
+
+    def _sync_processors(self):
+        """Push the installed plugins into the HIP context when they changed (weights, scale or topology)."""
+        ips = [(n, p) for n, p in self._procs.items() if isinstance(p, IPAttnProcessor2_0)]
+        if not ips:
+            sig = ("off",)
+            if sig != self._ip_sig:
+                _ffi.check(self._lib.ia2p_set_ip_adapter(self._ctx, 0, 4, 1.0), self._ctx)
+                self._ip_sig = sig
+            return
+        bad = [n for n, p in ips if n.endswith("attn1.processor")]
+        if bad or len(ips) != len(self._names) // 2:
+            raise NotImplementedError("IP processors must sit on every attn2 and only there (reference ip_adapter.py:123-141)")
+        scales = {float(p.scale) for _, p in ips}
+        toks = {int(p.num_tokens) for _, p in ips}
+        if len(scales) != 1 or len(toks) != 1:
+            raise NotImplementedError("per-layer IP scales / token counts are not supported (the reference sets one value, ip_adapter.py:211-214)")
+        wsig = tuple((p.to_k_ip.weight.data_ptr(), p.to_k_ip.weight._version, p.to_v_ip.weight.data_ptr(), p.to_v_ip.weight._version) for _, p in ips)
+        sig = ("on", scales.pop(), toks.pop(), hash(wsig))
+        if sig == self._ip_sig:
+            return
+        if self._ip_sig is None or self._ip_sig[0] != "on" or self._ip_sig[3] != sig[3]:
+            for n, p in ips:
+                idx = self._names.index(n)
+                self._load(f"ip_adapter.{idx}.to_k_ip.weight", p.to_k_ip.weight)
+                self._load(f"ip_adapter.{idx}.to_v_ip.weight", p.to_v_ip.weight)
+        _ffi.check(self._lib.ia2p_set_ip_adapter(self._ctx, 1, sig[2], sig[1]), self._ctx)
+        self._ip_sig = sig
+
+    # ---- forward -----------------------------------------------------------------------------------------------------
+    def workspace_for(self, B: int, h: int, w: int, L: int) -> torch.Tensor:
+        key = (B, h, w, L, self._ip_sig[0] if self._ip_sig else None)
+        if self._ws_key != key:
+            n = self._lib.ia2p_workspace_bytes(self._ctx, B, h, w, L)
+            if n == 0:
+                _ffi.check(2, self._ctx)
+            if self._workspace is None or self._workspace.numel() < n:
+                self._workspace = torch.empty(n, dtype=torch.uint8, device=self.device)
+            self._ws_key = key
+        return self._workspace
+
+    def __call__(self, sample, timestep, encoder_hidden_states=None, cross_attention_kwargs=None, added_cond_kwargs=None,
+                 return_dict: bool = False, out: Optional[torch.Tensor] = None, **unused):
+        if encoder_hidden_states is None or added_cond_kwargs is None:
+            raise ValueError("encoder_hidden_states and added_cond_kwargs (text_embeds, time_ids) are required (text_time UNet)")
+        if "text_embeds" not in added_cond_kwargs or "time_ids" not in added_cond_kwargs:
+            raise ValueError("added_cond_kwargs must carry `text_embeds` and `time_ids`")      # diffusers raises ValueError here too
+        self._sync_processors()
+        B, c_in, h, w = sample.shape
+        if c_in != self.config.in_channels:
+            raise ValueError(f"sample has {c_in} channels, expected {self.config.in_channels}")
+        f16 = lambda t: t.to(device=self.device, dtype=torch.float16).contiguous()
+        sample, ctx = f16(sample), f16(encoder_hidden_states)
+        te, tid = f16(added_cond_kwargs["text_embeds"]), f16(added_cond_kwargs["time_ids"])
+        if ctx.shape[0] != B or ctx.shape[2] != self.config.cross_attention_dim:
+            raise ValueError(f"encoder_hidden_states must be [B, L, {self.config.cross_attention_dim}]")
+        if te.shape != (B, self.config.pooled_dim) or tid.shape != (B, 6):
+            raise ValueError(f"Model expects an added time embedding vector of length {self.config.projection_class_embeddings_input_dim}, "
+                             f"but a vector of {te.shape[-1] + 6 * self.config.addition_time_embed_dim} was created.")
+        L = ctx.shape[1]
+        ws = self.workspace_for(B, h, w, L)
+        if out is None:
+            out = torch.empty(B, self.config.out_channels, h, w, dtype=torch.float16, device=self.device)
+        t = float(timestep.item()) if torch.is_tensor(timestep) else float(timestep)
+        _ffi.check(self._lib.ia2p_unet_forward(self._ctx, _ffi.current_stream(), _ffi.ptr(sample), t, _ffi.ptr(ctx), L,
+                                               _ffi.ptr(te), _ffi.ptr(tid), _ffi.ptr(out), B, h, w, _ffi.ptr(ws), ws.numel()), self._ctx)
+        return (out,) if not return_dict else SimpleNamespace(sample=out)
+
+    # ---- per-kernel-class timing for the roofline leg of bench.py ------------------------------------------------
+    def profile(self, on: bool):
+        _ffi.check(self._lib.ia2p_profile_enable(self._ctx, int(on)), self._ctx)
+
+    def profile_read(self):
+        res = {}
+        for k, name in enumerate(_ffi.KCLASS_NAMES):
+            n, ms, fl, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
+            _ffi.check(self._lib.ia2p_profile_read(self._ctx, k, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)), self._ctx)
+            res[name] = dict(launches=n.value, ms=ms.value, flops=fl.value, bytes=by.value)
+        return res
+
+
+def build_unet(config: UNetConfig, state_dict=None, device="cuda:0") -> HipUNet2DConditionModel:
+    m = HipUNet2DConditionModel(config, device)
+    if state_dict is not None:
+        m.load_state_dict(state_dict)
+    return m
