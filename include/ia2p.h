@@ -117,11 +117,12 @@ ia2p_status ia2p_linear_small(void* stream, const void* X, const void* W, const 
 
 void ia2p_debug_set_gemm_tile(int tile);   /* -1 auto, 0: 128x128, 1: 128x64, 2: 64x64 (tests / tuning) */
 
-/* ---- per-kernel-class timing (bench.py roofline leg): HIP events around each launch of the class ------------------- */
-typedef enum { IA2P_K_GEMM = 0, IA2P_K_CONV = 1, IA2P_K_ATTN = 2, IA2P_K_GNORM = 3, IA2P_K_LNORM = 4, IA2P_K_OTHER = 5, IA2P_K_COUNT = 6 } ia2p_kclass;
-ia2p_status ia2p_profile_enable(ia2p_ctx* ctx, int on);
-/* sums since enable: launches, milliseconds, algorithmic flops and bytes per class */
-ia2p_status ia2p_profile_read(ia2p_ctx* ctx, int kclass, int64_t* launches, double* ms, double* flops, double* bytes);
+/* ---- per-kernel timing (bench.py roofline leg): HIP events on the launch stream around each launch ------------------
+ * Classes are device kernel names as rocprofv3 prints them (e.g. "gemm_f16_kernel<128, 64, false>"). */
+ia2p_status ia2p_profile_enable(ia2p_ctx* ctx, int on);   /* also clears the sums */
+int ia2p_profile_classes(void);
+/* sums since enable for class k: launches, milliseconds, algorithmic flops and bytes */
+ia2p_status ia2p_profile_read(ia2p_ctx* ctx, int k, char* name, int name_len, int64_t* launches, double* ms, double* flops, double* bytes);
 
 #ifdef __cplusplus
 }

@@ -13,8 +13,6 @@ LIB_PATH = os.path.join(_HERE, "libia2p_hip.so")
 
 IA2P_OK = 0
 _STATUS_NAMES = {1: "INVALID", 2: "SHAPE", 3: "KEY", 4: "STATE", 5: "NOMEM", 6: "HIP", 7: "ARCH"}
-K_GEMM, K_CONV, K_ATTN, K_GNORM, K_LNORM, K_OTHER = range(6)
-KCLASS_NAMES = ["gemm", "conv3x3", "attention", "groupnorm", "layernorm", "other"]
 MAX_BLOCKS = 4
 
 
@@ -54,7 +52,8 @@ SIGNATURES = {
     "ia2p_linear_small": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I]),
     "ia2p_debug_set_gemm_tile": (None, [_I]),
     "ia2p_profile_enable": (_I, [_P, _I]),
-    "ia2p_profile_read": (_I, [_P, _I, C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "ia2p_profile_classes": (_I, []),
+    "ia2p_profile_read": (_I, [_P, _I, C.c_char_p, _I, C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 
 _lib = None
@@ -71,6 +70,10 @@ def lib() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise IA2PError(f"{LIB_PATH} is missing: build it with `python -m instructany2pix_amd.build` "
                             f"(the denoise path has no non-HIP fallback)")
+        # torch bundles its own HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7). It MUST be in the
+        # process before this library is dlopen'ed so both bind to the SAME runtime instance; loaded the other way
+        # round, a second runtime comes up and one of the two sees "No HIP GPUs" (observed on the MI355X boxes).
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)           # AttributeError if the .so does not export a declared symbol

@@ -22,7 +22,7 @@
 #include "common.h"
 
 // ---- kernel launchers (gemm.hip, attention.hip, norm.hip, misc.hip) ------------------------------------------
-hipError_t ia2p_launch_gemm(const GemmArgs& a, bool conv, hipStream_t s);
+hipError_t ia2p_launch_gemm(const GemmArgs& a, bool conv, hipStream_t s, int* picked);
 hipError_t ia2p_launch_attention(const AttnArgs& a, hipStream_t s);
 int ia2p_gn_chunks(int B, int HW);
 hipError_t ia2p_launch_groupnorm(const half_t* x, int ldx, half_t* y, int ldy, const half_t* gamma, const half_t* beta,
@@ -120,6 +120,16 @@ struct Arena {            // deterministic first-fit allocator over [0, cap)
 };
 
 struct ProfRec { hipEvent_t e0, e1; int k; double flops, bytes; };
+// profile classes = device kernel names as rocprofv3 prints them (template arguments included)
+enum {
+  PK_GEMM_128x128 = 0, PK_GEMM_128x64, PK_GEMM_64x64, PK_CONV_128x128, PK_CONV_128x64, PK_CONV_64x64,
+  PK_ATTN, PK_GN, PK_LN, PK_EMBED, PK_CONV_IN, PK_CONV_OUT, PK_CONCAT, PK_NCLASS
+};
+static const char* const kProfNames[PK_NCLASS] = {
+  "gemm_f16_kernel<128, 128, false>", "gemm_f16_kernel<128, 64, false>", "gemm_f16_kernel<64, 64, false>",
+  "gemm_f16_kernel<128, 128, true>", "gemm_f16_kernel<128, 64, true>", "gemm_f16_kernel<64, 64, true>",
+  "attention_f16_kernel", "gn_stats_kernel+gn_apply_kernel", "layernorm_kernel", "embed_kernel+linear_small_kernel",
+  "conv_in_kernel", "conv_out_kernel", "concat_kernel"};
 
 struct ia2p_ctx {
   ia2p_unet_config cfg;
@@ -146,8 +156,8 @@ struct ia2p_ctx {
   bool prof = false;
   std::vector<ProfRec> recs;
   std::vector<hipEvent_t> evpool;
-  double p_ms[IA2P_K_COUNT], p_fl[IA2P_K_COUNT], p_by[IA2P_K_COUNT];
-  int64_t p_n[IA2P_K_COUNT];
+  double p_ms[PK_NCLASS], p_fl[PK_NCLASS], p_by[PK_NCLASS];
+  int64_t p_n[PK_NCLASS];
 };
 
 static ia2p_status fail(ia2p_ctx* c, ia2p_status st, const char* fmt, ...) {
@@ -349,6 +359,7 @@ struct ProfScope {
     if (on) { e0 = get_event(c); e1 = get_event(c); (void)hipEventRecord(e0, c->stream); }
   }
   ~ProfScope() { if (on) { (void)hipEventRecord(e1, c->stream); c->recs.push_back(ProfRec{e0, e1, k, fl, by}); } }
+  void set_class(int kk) { k = kk; }
 };
 #define CHECK_LAUNCH(c, expr, what)                                                             \
   do { if (!(c)->dry && !(c)->failed) { hipError_t e_ = (expr); if (e_ != hipSuccess) fail((c), IA2P_ERR_HIP, "%s: %s", what, hipGetErrorString(e_)); } } while (0)
@@ -363,8 +374,10 @@ static void op_gemm(ia2p_ctx* c, const half_t* A, int lda, const half_t* W, cons
   a.rpb = rpb; a.bstride = bstride; a.roff = roff; a.bias = bias; a.residual = residual; a.ldr = ldr; a.geglu = geglu;
   a.rows_per_batch = 1;
   a.m_fastest = (long)M * K <= (long)N * K ? 1 : 0;
-  ProfScope ps(c, IA2P_K_GEMM, 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * (geglu ? N / 2 : N) + (residual ? (double)M * N : 0)));
-  CHECK_LAUNCH(c, ia2p_launch_gemm(a, false, c->stream), "gemm");
+  ProfScope ps(c, PK_GEMM_128x128, 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * (geglu ? N / 2 : N) + (residual ? (double)M * N : 0)));
+  int pick = 0;
+  CHECK_LAUNCH(c, ia2p_launch_gemm(a, false, c->stream, &pick), "gemm");
+  ps.set_class(PK_GEMM_128x128 + pick);
 }
 static void op_conv3(ia2p_ctx* c, const half_t* X, int B, int Hs, int Ws, int Cin, const half_t* W, const half_t* bias, int Co,
                      int stride, int up, const half_t* rowvec, int rowvec_ld, const half_t* residual, half_t* Y) {
@@ -376,15 +389,17 @@ static void op_conv3(ia2p_ctx* c, const half_t* X, int B, int Hs, int Ws, int Ci
   a.Hs = Hs; a.Ws = Ws; a.stride = stride; a.up = up; a.Cin = Cin;
   a.bias = bias; a.rowvec = rowvec; a.rowvec_ld = rowvec_ld; a.rows_per_batch = a.Ho * a.Wo; a.residual = residual; a.ldr = Co;
   a.m_fastest = 0;
-  ProfScope ps(c, IA2P_K_CONV, 2.0 * a.M * (double)Co * a.K, 2.0 * ((double)B * Hs * Ws * Cin + (double)Co * a.K + (double)a.M * Co + (residual ? (double)a.M * Co : 0)));
-  CHECK_LAUNCH(c, ia2p_launch_gemm(a, true, c->stream), "conv3x3");
+  ProfScope ps(c, PK_CONV_128x128, 2.0 * a.M * (double)Co * a.K, 2.0 * ((double)B * Hs * Ws * Cin + (double)Co * a.K + (double)a.M * Co + (residual ? (double)a.M * Co : 0)));
+  int pick = 0;
+  CHECK_LAUNCH(c, ia2p_launch_gemm(a, true, c->stream, &pick), "conv3x3");
+  ps.set_class(PK_CONV_128x128 + pick);
 }
 static void op_gn(ia2p_ctx* c, const half_t* x, half_t* y, size_t g, size_t b, int B, int HW, int C, float eps, int silu, float* partial) {
-  ProfScope ps(c, IA2P_K_GNORM, 8.0 * B * HW * C, 4.0 * B * HW * C);
+  ProfScope ps(c, PK_GN, 8.0 * B * HW * C, 4.0 * B * HW * C);
   CHECK_LAUNCH(c, ia2p_launch_groupnorm(x, C, y, C, W_(c, g), W_(c, b), partial, B, HW, C, c->cfg.norm_num_groups, eps, silu, c->stream), "groupnorm");
 }
 static void op_ln(ia2p_ctx* c, const half_t* x, half_t* y, size_t g, size_t b, int M, int C) {
-  ProfScope ps(c, IA2P_K_LNORM, 8.0 * M * C, 4.0 * M * C);
+  ProfScope ps(c, PK_LN, 8.0 * M * C, 4.0 * M * C);
   CHECK_LAUNCH(c, ia2p_launch_layernorm(x, C, y, C, W_(c, g), W_(c, b), M, C, 1e-5f, c->stream), "layernorm");
 }
 
@@ -424,7 +439,7 @@ static T2 run_resnet(Fwd& f, const Resnet& r, T2 x, int H, int Wd) {
 static void op_attn(ia2p_ctx* c, const AttnArgs& a) {
   double keys = 0;
   for (int s = 0; s < a.nseg; ++s) keys += a.seg[s].nkeys;
-  ProfScope ps(c, IA2P_K_ATTN, 4.0 * a.B * a.heads * (double)a.Nq * keys * 64, 2.0 * ((double)a.B * a.Nq * a.heads * 64 * 2 + 2.0 * a.B * keys * a.heads * 64));
+  ProfScope ps(c, PK_ATTN, 4.0 * a.B * a.heads * (double)a.Nq * keys * 64, 2.0 * ((double)a.B * a.Nq * a.heads * 64 * 2 + 2.0 * a.B * keys * a.heads * 64));
   CHECK_LAUNCH(c, ia2p_launch_attention(a, c->stream), "attention");
 }
 
@@ -497,7 +512,7 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
   T2 a1 = wsalloc(c, (size_t)B * T), emb = wsalloc(c, (size_t)B * T);
   f.temb_all = wsalloc(c, (size_t)B * c->temb_total);
   {
-    ProfScope ps(c, IA2P_K_OTHER, 0, 0);
+    ProfScope ps(c, PK_EMBED, 0, 0);
     CHECK_LAUNCH(c, ia2p_launch_embed(timestep, text_embeds, time_ids, tsin.p, addin.p, B, Tp, pooled, Ad, 6, c->stream), "embed");
     CHECK_LAUNCH(c, ia2p_launch_linear_small(tsin.p, Tp, W_(c, c->te1w), W_(c, c->te1b), nullptr, 0, e1.p, T, B, T, Tp, 0, 1, c->stream), "time_embedding.linear_1");
     CHECK_LAUNCH(c, ia2p_launch_linear_small(e1.p, T, W_(c, c->te2w), W_(c, c->te2b), nullptr, 0, emb0.p, T, B, T, T, 0, 0, c->stream), "time_embedding.linear_2");
@@ -513,7 +528,7 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
   std::vector<int> skip_c;
   T2 x = wsalloc(c, (size_t)B * H * Wd * g.block_out_channels[0]);
   {
-    ProfScope ps(c, IA2P_K_OTHER, 0, 0);
+    ProfScope ps(c, PK_CONV_IN, 0, 0);
     CHECK_LAUNCH(c, ia2p_launch_conv_in(sample, W_(c, c->conv_in_w), W_(c, c->conv_in_b), x.p, B, g.in_channels, H, Wd, g.block_out_channels[0], c->stream), "conv_in");
   }
   skips.push_back(x); skip_c.push_back(g.block_out_channels[0]);
@@ -550,7 +565,7 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
       const long M = (long)B * H * Wd;
       T2 cat = wsalloc(c, (size_t)M * st.res[j].cin);
       {
-        ProfScope ps(c, IA2P_K_OTHER, 0, 4.0 * M * st.res[j].cin);
+        ProfScope ps(c, PK_CONCAT, 0, 4.0 * M * st.res[j].cin);
         CHECK_LAUNCH(c, ia2p_launch_concat(x.p, cx, cx, sk.p, cs, cs, cat.p, M, c->stream), "concat");
       }
       wsfree(c, x); wsfree(c, sk);
@@ -573,7 +588,7 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
   op_gn(c, x.p, no.p, c->ngo, c->nbo, B, H * Wd, c0, g.norm_eps, 1, f.gn_partial);
   wsfree(c, x);
   {
-    ProfScope ps(c, IA2P_K_OTHER, 0, 0);
+    ProfScope ps(c, PK_CONV_OUT, 0, 0);
     CHECK_LAUNCH(c, ia2p_launch_conv_out(no.p, c0, W_(c, c->conv_out_w), W_(c, c->conv_out_b), out, B, c0, H, Wd, g.out_channels, c->stream), "conv_out");
   }
   wsfree(c, no); wsfree(c, f.temb_all); wsfree(c, gnp);
@@ -599,7 +614,7 @@ ia2p_status ia2p_create(const ia2p_unet_config* cfg, ia2p_ctx** out) {
   ia2p_status st = build_plan(c);
   if (st != IA2P_OK) { g_err = c->err; delete c; *out = nullptr; return st; }
   c->failed = false;
-  for (int k = 0; k < IA2P_K_COUNT; ++k) { c->p_ms[k] = c->p_fl[k] = c->p_by[k] = 0; c->p_n[k] = 0; }
+  for (int k = 0; k < PK_NCLASS; ++k) { c->p_ms[k] = c->p_fl[k] = c->p_by[k] = 0; c->p_n[k] = 0; }
   *out = c;
   return IA2P_OK;
 }
@@ -743,7 +758,7 @@ ia2p_status ia2p_gemm(void* stream, const void* A, const void* W, const void* bi
   a.A = (const half_t*)A; a.W = (const half_t*)W; a.C = (half_t*)C; a.zero = zero_page(); a.M = M; a.N = N; a.K = K; a.lda = K; a.ldc = No;
   a.bias = (const half_t*)bias; a.residual = (const half_t*)residual; a.ldr = No; a.geglu = geglu; a.rows_per_batch = 1;
   a.m_fastest = M <= N;
-  hipError_t e = ia2p_launch_gemm(a, false, (hipStream_t)stream);
+  hipError_t e = ia2p_launch_gemm(a, false, (hipStream_t)stream, nullptr);
   RET_HIP(e, "gemm");
 }
 ia2p_status ia2p_conv3x3(void* stream, const void* x, const void* Wp, const void* bias, const void* rowvec, const void* residual, void* y,
@@ -757,7 +772,7 @@ ia2p_status ia2p_conv3x3(void* stream, const void* x, const void* Wp, const void
   a.A = (const half_t*)x; a.W = (const half_t*)Wp; a.C = (half_t*)y; a.zero = zero_page(); a.M = B * a.Ho * a.Wo; a.N = Co; a.K = 9 * Cin; a.lda = Cin; a.ldc = Co;
   a.Hs = Hs; a.Ws = Ws; a.stride = stride; a.up = up; a.Cin = Cin; a.bias = (const half_t*)bias;
   a.rowvec = (const half_t*)rowvec; a.rowvec_ld = Co; a.rows_per_batch = a.Ho * a.Wo; a.residual = (const half_t*)residual; a.ldr = Co;
-  hipError_t e = ia2p_launch_gemm(a, true, (hipStream_t)stream);
+  hipError_t e = ia2p_launch_gemm(a, true, (hipStream_t)stream, nullptr);
   RET_HIP(e, "conv3x3");
 }
 ia2p_status ia2p_pack_conv3x3(void* stream, const void* src, void* dst, int Co, int Cin) {
@@ -794,12 +809,13 @@ ia2p_status ia2p_profile_enable(ia2p_ctx* c, int on) {
   if (!c) return IA2P_ERR_INVALID;
   for (auto& r : c->recs) { c->evpool.push_back(r.e0); c->evpool.push_back(r.e1); }
   c->recs.clear();
-  for (int k = 0; k < IA2P_K_COUNT; ++k) { c->p_ms[k] = c->p_fl[k] = c->p_by[k] = 0; c->p_n[k] = 0; }
+  for (int k = 0; k < PK_NCLASS; ++k) { c->p_ms[k] = c->p_fl[k] = c->p_by[k] = 0; c->p_n[k] = 0; }
   c->prof = on != 0;
   return IA2P_OK;
 }
-ia2p_status ia2p_profile_read(ia2p_ctx* c, int k, int64_t* launches, double* ms, double* flops, double* bytes) {
-  if (!c || k < 0 || k >= IA2P_K_COUNT) return IA2P_ERR_INVALID;
+int ia2p_profile_classes(void) { return PK_NCLASS; }
+ia2p_status ia2p_profile_read(ia2p_ctx* c, int k, char* name, int name_len, int64_t* launches, double* ms, double* flops, double* bytes) {
+  if (!c || k < 0 || k >= PK_NCLASS) return IA2P_ERR_INVALID;
   for (auto& r : c->recs) {     // fold finished records (synchronises on their stop events)
     float t = 0.f;
     (void)hipEventSynchronize(r.e1);
@@ -808,6 +824,7 @@ ia2p_status ia2p_profile_read(ia2p_ctx* c, int k, int64_t* launches, double* ms,
     c->evpool.push_back(r.e0); c->evpool.push_back(r.e1);
   }
   c->recs.clear();
+  if (name && name_len > 0) { strncpy(name, kProfNames[k], name_len - 1); name[name_len - 1] = 0; }
   if (launches) *launches = c->p_n[k];
   if (ms) *ms = c->p_ms[k];
   if (flops) *flops = c->p_fl[k];

@@ -199,13 +199,14 @@ static int g_force_tile = -1;   // test/tuning hook (ia2p_debug_set_gemm_tile)
 extern "C" void ia2p_debug_set_gemm_tile(int t) { g_force_tile = t; }
 
 template <bool CONV>
-static hipError_t launch_any(const GemmArgs& a, hipStream_t s) {
+static hipError_t launch_any(const GemmArgs& a, hipStream_t s, int* picked) {
   auto tiles = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
   int pick;
   if (g_force_tile >= 0) pick = g_force_tile;
   else if (tiles(128, 128) >= 384) pick = 0;
   else if (tiles(128, 64) >= 256) pick = 1;
   else pick = 2;
+  if (picked) *picked = pick;
   switch (pick) {
     case 0: return launch_cfg<128, 128, CONV>(a, s);
     case 1: return launch_cfg<128, 64, CONV>(a, s);
@@ -213,6 +214,7 @@ static hipError_t launch_any(const GemmArgs& a, hipStream_t s) {
   }
 }
 
-hipError_t ia2p_launch_gemm(const GemmArgs& a, bool conv, hipStream_t s) {
-  return conv ? launch_any<true>(a, s) : launch_any<false>(a, s);
+// *picked (optional) receives the tile index: 0 = 128x128, 1 = 128x64, 2 = 64x64
+hipError_t ia2p_launch_gemm(const GemmArgs& a, bool conv, hipStream_t s, int* picked) {
+  return conv ? launch_any<true>(a, s, picked) : launch_any<false>(a, s, picked);
 }

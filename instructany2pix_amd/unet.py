@@ -118,17 +118,37 @@ class HipUNet2DConditionModel:
         toks = {int(p.num_tokens) for _, p in ips}
         if len(scales) != 1 or len(toks) != 1:
             raise NotImplementedError("per-layer IP scales / token counts are not supported (the reference sets one value, ip_adapter.py:211-214)")
-        wsig = tuple((p.to_k_ip.weight.data_ptr(), p.to_k_ip.weight._version, p.to_v_ip.weight.data_ptr(), p.to_v_ip.weight._version) for _, p in ips)
-        sig = ("on", scales.pop(), toks.pop(), hash(wsig))
+        if all(p.to_k_ip.weight.is_meta for _, p in ips):
+            wsig = "arena"           # descriptors only: weights were streamed straight into the arena (load_ip_adapter_weights)
+        else:
+            wsig = hash(tuple((p.to_k_ip.weight.data_ptr(), p.to_k_ip.weight._version, p.to_v_ip.weight.data_ptr(), p.to_v_ip.weight._version) for _, p in ips))
+        sig = ("on", scales.pop(), toks.pop(), wsig)
         if sig == self._ip_sig:
             return
-        if self._ip_sig is None or self._ip_sig[0] != "on" or self._ip_sig[3] != sig[3]:
+        if wsig != "arena" and (self._ip_sig is None or self._ip_sig[0] != "on" or self._ip_sig[3] != sig[3]):
             for n, p in ips:
                 idx = self._names.index(n)
                 self._load(f"ip_adapter.{idx}.to_k_ip.weight", p.to_k_ip.weight)
                 self._load(f"ip_adapter.{idx}.to_v_ip.weight", p.to_v_ip.weight)
         _ffi.check(self._lib.ia2p_set_ip_adapter(self._ctx, 1, sig[2], sig[1]), self._ctx)
         self._ip_sig = sig
+
+    def load_ip_adapter_weights(self, items, scale: float = 1.0, num_tokens: int = 4):
+        """Stream `{"<idx>.to_k_ip.weight": tensor, ...}` (the "ip_adapter" group of the checkpoint, reference
+        ip_adapter.py:165-169) straight into the arena and install storage-free IP processor descriptors: the
+        0.68 GB of adapter weights then exist once, in the arena, not twice."""
+        from .weights import hidden_size_of
+        it = items.items() if hasattr(items, "items") else items
+        for k, v in it:
+            self._load("ip_adapter." + k, v)
+        procs = {}
+        for n in self._names:
+            if n.endswith("attn1.processor"):
+                procs[n] = AttnProcessor2_0()
+            else:
+                with torch.device("meta"):
+                    procs[n] = IPAttnProcessor2_0(hidden_size_of(self.config, n), self.config.cross_attention_dim, scale=scale, num_tokens=num_tokens)
+        self.set_attn_processor(procs)
 
     # ---- forward -----------------------------------------------------------------------------------------------------
     def workspace_for(self, B: int, h: int, w: int, L: int) -> torch.Tensor:
@@ -174,11 +194,14 @@ class HipUNet2DConditionModel:
         _ffi.check(self._lib.ia2p_profile_enable(self._ctx, int(on)), self._ctx)
 
     def profile_read(self):
+        """{kernel name: dict(launches, ms, flops, bytes)} summed since profile(True)."""
         res = {}
-        for k, name in enumerate(_ffi.KCLASS_NAMES):
+        for k in range(self._lib.ia2p_profile_classes()):
+            name = C.create_string_buffer(96)
             n, ms, fl, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
-            _ffi.check(self._lib.ia2p_profile_read(self._ctx, k, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)), self._ctx)
-            res[name] = dict(launches=n.value, ms=ms.value, flops=fl.value, bytes=by.value)
+            _ffi.check(self._lib.ia2p_profile_read(self._ctx, k, name, 96, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)), self._ctx)
+            if n.value:
+                res[name.value.decode()] = dict(launches=n.value, ms=ms.value, flops=fl.value, bytes=by.value)
         return res
 
 

@@ -15,6 +15,29 @@ from .ddim_ref import (DDIMSchedulerRef, backward_ddim, cfg_combine, get_add_tim
                        ImageProjModelRef, invert_loop, sample_loop)
 
 
+def build_unet_fast(cfg, items, ip_items=None, ip_scale=1.0, num_tokens=4):
+    """Same as build_unet for multi-GB weights: modules are created on the meta device and the fp32 tensors
+    yielded by `items` / `ip_items` are ASSIGNED (no default init pass, no second copy)."""
+    import torch
+    with torch.device("meta"):
+        m = UNet2DConditionModelRef(cfg)
+    m.load_state_dict({k: v.float() for k, v in items}, strict=True, assign=True)
+    if ip_items is not None:
+        procs = {}
+        with torch.device("meta"):
+            for name in m.attn_processors.keys():
+                if name.endswith("attn1.processor"):
+                    procs[name] = AttnProcessor2_0Ref()
+                else:
+                    blk = name.split(".")
+                    ch = cfg.block_out_channels
+                    hs = ch[-1] if blk[0] == "mid_block" else (list(reversed(ch))[int(blk[1])] if blk[0] == "up_blocks" else ch[int(blk[1])])
+                    procs[name] = IPAttnProcessor2_0Ref(hs, cfg.cross_attention_dim, scale=ip_scale, num_tokens=num_tokens)
+        m.set_attn_processor(procs)
+        torch.nn.ModuleList(m.attn_processors.values()).load_state_dict({k: v.float() for k, v in ip_items}, assign=True)
+    return m.eval()
+
+
 def build_unet(cfg, state_dict, ip_state=None, ip_scale=1.0, num_tokens=4, dtype=None):
     """Oracle UNet with weights loaded by diffusers key; optionally installs the IP-Adapter plugins the way
     reference ip_adapter.py:120-142,168-169 does (self-attn -> AttnProcessor, cross-attn -> IPAttnProcessor,
