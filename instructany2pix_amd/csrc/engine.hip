@@ -72,6 +72,7 @@ struct Resnet {
 };
 struct TBlock {
   size_t ln1g, ln1b, wqkv, wo1, bo1, ln2g, ln2b, wq2, wkv2, wkvip, wo2, bo2, ln3g, ln3b, wff1, bff1, wff2, bff2;
+  int kv_col;   // column of this layer's [K | V] block in the batched context projection
 };
 struct Transformer {
   int c, heads;
@@ -143,6 +144,10 @@ struct ia2p_ctx {
   // plan
   size_t conv_in_w, conv_in_b, te1w, te1b, te2w, te2b, ae1w, ae1b, ae2w, ae2b, tw_all, tb_all, ngo, nbo, conv_out_w, conv_out_b;
   int temb_total = 0;
+  // context K/V projection weights of ALL cross-attention layers, stacked [kv_rows, ctx] (text) / (image tokens):
+  // the context is the same for every layer, so one GEMM per step projects it for all of them
+  size_t kv_text_base = 0, kv_ip_base = 0;
+  int kv_rows = 0;
   std::vector<Stage> down, up;
   Resnet mid_r0, mid_r1;
   Transformer mid_t;
@@ -177,6 +182,7 @@ static ia2p_status fail(ia2p_ctx* c, ia2p_status st, const char* fmt, ...) {
 struct Planner {
   ia2p_ctx* c;
   size_t cur = 0;
+  int kv_cursor = 0;
   size_t take(size_t elems) { size_t o = cur; cur += (elems + 127) & ~(size_t)127; return o; }
   void reg(const std::string& key, size_t off, size_t elems, int kind = PK_COPY, int d0 = 0, int d1 = 0, bool optional = false) {
     c->params[key] = Param{off, elems, kind, d0, d1, false, optional};
@@ -216,11 +222,13 @@ struct Planner {
       b.wo1 = mat(q + ".attn1.to_out.0.weight", ch, ch); b.bo1 = vec(q + ".attn1.to_out.0.bias", ch);
       b.ln2g = vec(q + ".norm2.weight", ch); b.ln2b = vec(q + ".norm2.bias", ch);
       b.wq2 = mat(q + ".attn2.to_q.weight", ch, ch);
-      b.wkv2 = take((size_t)2 * ch * ctx);
+      b.kv_col = kv_cursor;
+      b.wkv2 = c->kv_text_base + (size_t)kv_cursor * ctx;
       reg(q + ".attn2.to_k.weight", b.wkv2, (size_t)ch * ctx);
       reg(q + ".attn2.to_v.weight", b.wkv2 + (size_t)ch * ctx, (size_t)ch * ctx);
-      b.wkvip = take((size_t)2 * ch * ctx);
+      b.wkvip = c->kv_ip_base + (size_t)kv_cursor * ctx;
       ipslots.push_back({q, b.wkvip});
+      kv_cursor += 2 * ch;
       b.wo2 = mat(q + ".attn2.to_out.0.weight", ch, ch); b.bo2 = vec(q + ".attn2.to_out.0.bias", ch);
       b.ln3g = vec(q + ".norm3.weight", ch); b.ln3b = vec(q + ".norm3.bias", ch);
       b.wff1 = take((size_t)8 * ch * ch); reg(q + ".ff.net.0.proj.weight", b.wff1, (size_t)8 * ch * ch, PK_GEGLU_W, 8 * ch, ch);
@@ -270,6 +278,15 @@ static ia2p_status build_plan(ia2p_ctx* c) {
   c->tw_all = P.take((size_t)tot * T);
   c->tb_all = P.take(tot);
   c->temb_total = 0;
+  {
+    int rows = 0;
+    for (int i = 0; i < n; ++i) rows += g.layers_per_block * g.transformer_layers_per_block[i] * 2 * ch[i];          // down
+    rows += g.transformer_layers_per_block[n - 1] * 2 * ch[n - 1];                                                  // mid
+    for (int i = 0; i < n; ++i) rows += (g.layers_per_block + 1) * g.transformer_layers_per_block[n - 1 - i] * 2 * ch[n - 1 - i];   // up
+    c->kv_rows = rows;
+    c->kv_text_base = P.take((size_t)rows * ctx);
+    c->kv_ip_base = P.take((size_t)rows * ctx);
+  }
 
   std::vector<std::pair<std::string, size_t>> ipslots_down, ipslots_up, ipslots_mid;
   std::vector<int> skip_ch;
@@ -315,6 +332,7 @@ static ia2p_status build_plan(ia2p_ctx* c) {
     c->up.push_back(st);
   }
   if (c->temb_total != tot) return fail(c, IA2P_ERR_STATE, "internal: time_emb_proj stacking mismatch %d != %d", c->temb_total, tot);
+  if (P.kv_cursor != c->kv_rows) return fail(c, IA2P_ERR_STATE, "internal: context K/V stacking mismatch %d != %d", P.kv_cursor, c->kv_rows);
   c->ngo = P.vec("conv_norm_out.weight", ch[0]); c->nbo = P.vec("conv_norm_out.bias", ch[0]);
   c->conv_out_w = P.conv3("conv_out.weight", g.out_channels, ch[0]); c->conv_out_b = P.vec("conv_out.bias", g.out_channels);
 
@@ -409,6 +427,7 @@ struct Fwd {
   const half_t* ctxp;
   T2 temb_all;
   float* gn_partial;
+  T2 kv_text, kv_ip;   // [B*Lt, kv_rows], [B*Li, kv_rows]
 };
 
 static T2 run_resnet(Fwd& f, const Resnet& r, T2 x, int H, int Wd) {
@@ -456,7 +475,8 @@ static T2 run_transformer(Fwd& f, const Transformer& t, T2 x, int H, int Wd) {
   op_gemm(c, n.p, C, W_(c, t.win), W_(c, t.bin), nullptr, 0, tk.p, C, M, C, C);
   wsfree(c, n);
   T2 ln = wsalloc(c, (size_t)M * C), qkv = wsalloc(c, (size_t)M * 3 * C), att = wsalloc(c, (size_t)M * C);
-  T2 kv = wsalloc(c, (size_t)f.B * Lt * 2 * C), kvip = wsalloc(c, (size_t)f.B * (Li ? Li : 1) * 2 * C), ff = wsalloc(c, (size_t)M * 4 * C);
+  T2 ff = wsalloc(c, (size_t)M * 4 * C);
+  const int ldkv = c->kv_rows;
   for (const TBlock& b : t.blocks) {
     // self-attention (AttnProcessor2_0, reference attention_processor.py:205-279)
     op_ln(c, tk.p, ln.p, b.ln1g, b.ln1b, M, C);
@@ -473,14 +493,14 @@ static T2 run_transformer(Fwd& f, const Transformer& t, T2 x, int H, int Wd) {
     // cross-attention (IPAttnProcessor2_0 :310-412 when the adapter is installed, else AttnProcessor2_0)
     op_ln(c, tk.p, ln.p, b.ln2g, b.ln2b, M, C);
     op_gemm(c, ln.p, C, W_(c, b.wq2), nullptr, nullptr, 0, qkv.p, C, M, C, C);
-    op_gemm(c, f.ctxp, ctxd, W_(c, b.wkv2), nullptr, nullptr, 0, kv.p, 2 * C, f.B * Lt, 2 * C, ctxd, 0, Lt, f.L, 0);
-    if (Li) op_gemm(c, f.ctxp, ctxd, W_(c, b.wkvip), nullptr, nullptr, 0, kvip.p, 2 * C, f.B * Li, 2 * C, ctxd, 0, Li, f.L, Lt);
     {
       AttnArgs a;
       memset(&a, 0, sizeof a);
       a.Q = qkv.p; a.ldq = C; a.O = att.p; a.ldo = C; a.B = f.B; a.heads = t.heads; a.Nq = HW; a.nseg = Li ? 2 : 1; a.scale_log2e = sl2e;
-      a.seg[0].K = kv.p; a.seg[0].V = c->dry ? nullptr : kv.p + C; a.seg[0].nkeys = Lt; a.seg[0].ld = 2 * C; a.seg[0].rows_per_batch = Lt; a.seg[0].weight = 1.f;
-      a.seg[1].K = kvip.p; a.seg[1].V = c->dry ? nullptr : kvip.p + C; a.seg[1].nkeys = Li; a.seg[1].ld = 2 * C; a.seg[1].rows_per_batch = Li; a.seg[1].weight = c->ip_scale;
+      const half_t* kt = c->dry ? nullptr : f.kv_text.p + b.kv_col;
+      const half_t* ki = (c->dry || !Li) ? nullptr : f.kv_ip.p + b.kv_col;
+      a.seg[0].K = kt; a.seg[0].V = c->dry ? nullptr : kt + C; a.seg[0].nkeys = Lt; a.seg[0].ld = ldkv; a.seg[0].rows_per_batch = Lt; a.seg[0].weight = 1.f;
+      a.seg[1].K = ki; a.seg[1].V = ki ? ki + C : nullptr; a.seg[1].nkeys = Li; a.seg[1].ld = ldkv; a.seg[1].rows_per_batch = Li; a.seg[1].weight = c->ip_scale;
       op_attn(c, a);
     }
     op_gemm(c, att.p, C, W_(c, b.wo2), W_(c, b.bo2), tk.p, C, tk.p, C, M, C, C);
@@ -489,7 +509,8 @@ static T2 run_transformer(Fwd& f, const Transformer& t, T2 x, int H, int Wd) {
     op_gemm(c, ln.p, C, W_(c, b.wff1), W_(c, b.bff1), nullptr, 0, ff.p, 4 * C, M, 8 * C, C, 1);
     op_gemm(c, ff.p, 4 * C, W_(c, b.wff2), W_(c, b.bff2), tk.p, C, tk.p, C, M, C, 4 * C);
   }
-  wsfree(c, ln); wsfree(c, qkv); wsfree(c, att); wsfree(c, kv); wsfree(c, kvip); wsfree(c, ff);
+  wsfree(c, ln); wsfree(c, qkv); wsfree(c, att); wsfree(c, ff);
+  (void)ctxd;
   T2 out = wsalloc(c, (size_t)M * C);
   op_gemm(c, tk.p, C, W_(c, t.wout), W_(c, t.bout), x.p, C, out.p, C, M, C, C);
   wsfree(c, tk);
@@ -502,7 +523,7 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
   const int n = g.n_blocks;
   const int T = g.time_embed_dim, Tp = g.time_proj_dim, Ain = g.projection_class_embeddings_input_dim, Ad = g.addition_time_embed_dim;
   const int pooled = Ain - 6 * Ad;
-  Fwd f{c, B, h, w, L, context, T2{(size_t)-1, nullptr}, nullptr};
+  Fwd f{c, B, h, w, L, context, T2{(size_t)-1, nullptr}, nullptr, T2{(size_t)-1, nullptr}, T2{(size_t)-1, nullptr}};
 
   // GroupNorm partial sums (fp32) live at the front of the workspace
   T2 gnp = wsalloc(c, (size_t)B * 64 * g.norm_num_groups * 2 * 2);
@@ -521,6 +542,19 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
     CHECK_LAUNCH(c, ia2p_launch_linear_small(emb.p, T, W_(c, c->tw_all), W_(c, c->tb_all), nullptr, 0, f.temb_all.p, c->temb_total, B, c->temb_total, T, 1, 0, c->stream), "time_emb_proj (stacked)");
   }
   wsfree(c, tsin); wsfree(c, addin); wsfree(c, e1); wsfree(c, emb0); wsfree(c, a1); wsfree(c, emb);
+
+  // ---- context K/V for every cross-attention layer in one GEMM each (text rows / image-token rows of ctx);
+  //      per layer: reference attention_processor.py:358-359 (to_k/to_v) and :379-380 (to_k_ip/to_v_ip)
+  if (c->kv_rows > 0) {
+    const int ctxd = g.cross_attention_dim;
+    const int Lt = c->ip_enabled ? L - c->ip_tokens : L, Li = c->ip_enabled ? c->ip_tokens : 0;
+    f.kv_text = wsalloc(c, (size_t)B * Lt * c->kv_rows);
+    op_gemm(c, context, ctxd, W_(c, c->kv_text_base), nullptr, nullptr, 0, f.kv_text.p, c->kv_rows, B * Lt, c->kv_rows, ctxd, 0, Lt, L, 0);
+    if (Li) {
+      f.kv_ip = wsalloc(c, (size_t)B * Li * c->kv_rows);
+      op_gemm(c, context, ctxd, W_(c, c->kv_ip_base), nullptr, nullptr, 0, f.kv_ip.p, c->kv_rows, B * Li, c->kv_rows, ctxd, 0, Li, L, Lt);
+    }
+  }
 
   // ---- down path
   int H = h, Wd = w;
@@ -591,7 +625,7 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
     ProfScope ps(c, PK_CONV_OUT, 0, 0);
     CHECK_LAUNCH(c, ia2p_launch_conv_out(no.p, c0, W_(c, c->conv_out_w), W_(c, c->conv_out_b), out, B, c0, H, Wd, g.out_channels, c->stream), "conv_out");
   }
-  wsfree(c, no); wsfree(c, f.temb_all); wsfree(c, gnp);
+  wsfree(c, no); wsfree(c, f.temb_all); wsfree(c, gnp); wsfree(c, f.kv_text); wsfree(c, f.kv_ip);
   return c->failed ? IA2P_ERR_HIP : IA2P_OK;
 }
 

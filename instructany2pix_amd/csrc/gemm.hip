@@ -203,6 +203,7 @@ static hipError_t launch_any(const GemmArgs& a, hipStream_t s, int* picked) {
   auto tiles = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
   int pick;
   if (g_force_tile >= 0) pick = g_force_tile;
+  else if (a.M <= 64) pick = 2;
   else if (tiles(128, 128) >= 384) pick = 0;
   else if (tiles(128, 64) >= 256) pick = 1;
   else pick = 2;
