@@ -115,7 +115,7 @@ ia2p_status ia2p_attention(void* stream, const void* Q, int ldq, void* O, int ld
 ia2p_status ia2p_linear_small(void* stream, const void* X, const void* W, const void* bias, void* out, int M, int N, int K,
                               int silu_in, int silu_out);
 
-void ia2p_debug_set_gemm_tile(int tile);   /* -1 auto, 0: 128x128, 1: 128x64, 2: 64x64 (tests / tuning) */
+void ia2p_debug_set_gemm_tile(int variant);   /* -1 auto; else tile*2 + (stages-2), tile 0: 128x128, 1: 128x64, 2: 64x64, stages 2..3 (tests / tuning) */
 
 /* ---- per-kernel timing (bench.py roofline leg): HIP events on the launch stream around each launch ------------------
  * Classes are device kernel names as rocprofv3 prints them (e.g. "gemm_f16_kernel<128, 64, false>"). */

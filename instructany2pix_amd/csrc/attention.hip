@@ -7,7 +7,7 @@
 // (two independent softmaxes, not one over 81 keys). Self-attention is one segment.
 //
 // Structure (cdna_hip_programming.md App. B, "Fused attention prefill"): 4 waves x 32 query rows per
-// workgroup; K/V tiles of 64 keys staged in LDS (K XOR-swizzled for ds_read_b128 row reads, V swizzled for
+// workgroup; K/V staged in LDS 256 keys at a time and consumed in tiles of 64 (K XOR-swizzled for ds_read_b128 row reads, V swizzled for
 // ds_read_b64_tr_b16 transposed reads); swapped QK^T (S^T = K.Q^T with v_mfma_f32_32x32x16_f16) so a lane
 // owns one query column: row max / sum are in-lane plus one cross-half shuffle; the S^T accumulator is
 // re-used directly as the B operand of O^T = V^T . P^T (accumulator-as-operand k-permutation, §3), so P never
@@ -20,10 +20,34 @@ __device__ __forceinline__ fp16x4 lds_tr16(const char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4f16((fp16x4 __attribute__((address_space(3)))*)p);
 }
 
+// Stage NT key tiles (64 keys each) of K and V into their swizzled LDS images. All 4*NT loads of a thread are
+// issued before the first LDS write (clamped row index: never a per-lane branch around a load -- hipcc would
+// wait vmcnt(0) per element); padding rows are zeroed by select.
+template <int NT>
+__device__ __forceinline__ void stage_kv(const half_t* Kb, const half_t* Vb, int ld, int s0, int nsk, int tid, char* sK, char* sV) {
+  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+  u4 kreg[2 * NT], vreg[2 * NT];
+#pragma unroll
+  for (int u = 0; u < 2 * NT; ++u) {
+    const int c = tid + 256 * u, row = c >> 3, pos = c & 7;
+    const size_t off = (size_t)(s0 + min(row, nsk - 1)) * ld + pos * 8;
+    kreg[u] = *(const u4*)(Kb + off);
+    vreg[u] = *(const u4*)(Vb + off);
+  }
+#pragma unroll
+  for (int u = 0; u < 2 * NT; ++u) {
+    const int c = tid + 256 * u, row = c >> 3, pos = c & 7;
+    const unsigned keep = row < nsk ? 0xFFFFFFFFu : 0u;     // bit mask, not a pointer select (that went through scratch)
+    *(u4*)(sK + row * 128 + ((pos ^ ((row >> 1) & 7)) << 4)) = kreg[u] & keep;
+    *(u4*)(sV + row * 128 + ((pos ^ (((row >> 1) & 1) << 2)) << 4)) = vreg[u] & keep;
+  }
+}
+
 __global__ __launch_bounds__(256) void attention_f16_kernel(const AttnArgs p) {
-  __shared__ __attribute__((aligned(1024))) char smem[16384];  // K tile [64][64] fp16, V tile [64][64] fp16
+  // up to 4 key tiles (256 keys) of K and of V resident at once: one load phase + one barrier per 256 keys
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
   char* sK = smem;
-  char* sV = smem + 8192;
+  char* sV = smem + 32768;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.z, hd = blockIdx.y;
@@ -49,7 +73,7 @@ __global__ __launch_bounds__(256) void attention_f16_kernel(const AttnArgs p) {
   // staging role of this thread: 2 x 16-byte chunks of K and of V per tile
   // chunk id c = tid + 256*u (u = 0,1): row = c / 8, position = c % 8
   for (int sg = 0; sg < p.nseg; ++sg) {
-    const AttnSeg seg = p.seg[sg];
+    const AttnSeg seg = sg == 0 ? p.seg[0] : p.seg[1];   // (a runtime index into the by-value argument would push it to scratch)
     const half_t* Kb = seg.K + (size_t)b * seg.rows_per_batch * seg.ld + hd * 64;
     const half_t* Vb = seg.V + (size_t)b * seg.rows_per_batch * seg.ld + hd * 64;
     float mrun = MASKED, lrun = 0.f;
@@ -59,21 +83,21 @@ __global__ __launch_bounds__(256) void attention_f16_kernel(const AttnArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
 
-    for (int k0 = 0; k0 < seg.nkeys; k0 += 64) {
-      __syncthreads();  // previous tile fully consumed
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int c = tid + 256 * u, row = c >> 3, pos = c & 7;
-        const int key = k0 + row;
-        uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-        if (key < seg.nkeys) {
-          kv = *(const uint4*)(Kb + (size_t)key * seg.ld + pos * 8);
-          vv = *(const uint4*)(Vb + (size_t)key * seg.ld + pos * 8);
-        }
-        *(uint4*)(sK + row * 128 + ((pos ^ ((row >> 1) & 7)) << 4)) = kv;
-        *(uint4*)(sV + row * 128 + ((pos ^ (((row >> 1) & 1) << 2)) << 4)) = vv;
+    for (int s0 = 0; s0 < seg.nkeys; s0 += 256) {
+      const int nsk = min(256, seg.nkeys - s0);          // keys in this super-tile
+      const int ntile = (nsk + 63) >> 6;
+      __syncthreads();  // previous super-tile fully consumed
+      switch (ntile) {   // wave-uniform; each arm is fully unrolled so the staging registers never go to scratch
+        case 1: stage_kv<1>(Kb, Vb, seg.ld, s0, nsk, tid, sK, sV); break;
+        case 2: stage_kv<2>(Kb, Vb, seg.ld, s0, nsk, tid, sK, sV); break;
+        case 3: stage_kv<3>(Kb, Vb, seg.ld, s0, nsk, tid, sK, sV); break;
+        default: stage_kv<4>(Kb, Vb, seg.ld, s0, nsk, tid, sK, sV); break;
       }
       __syncthreads();
+      for (int tl = 0; tl < ntile; ++tl) {
+      const int k0 = s0 + tl * 64;
+      const char* sKt = sK + tl * 8192;
+      const char* sVt = sV + tl * 8192;
 
       // ---- S^T[key][q] for the two 32-key halves of the tile
       f16v st[2];
@@ -82,7 +106,7 @@ __global__ __launch_bounds__(256) void attention_f16_kernel(const AttnArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[kh][r] = 0.f;
         const int row = kh * 32 + r31;
-        const char* kp = sK + row * 128;
+        const char* kp = sKt + row * 128;
         const int sw = (row >> 1) & 7;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -133,14 +157,15 @@ __global__ __launch_bounds__(256) void attention_f16_kernel(const AttnArgs p) {
             const int col = d * 32 + gi * 16 + 4 * (li & 3);          // first of 4 contiguous d this lane addresses
             const int pos = col >> 3, sub = (col & 7) * 2;
             const int r0 = kb0, r1 = kb0 + 8;
-            const fp16x4 lo = lds_tr16(sV + r0 * 128 + ((pos ^ (((r0 >> 1) & 1) << 2)) << 4) + sub);
-            const fp16x4 hi = lds_tr16(sV + r1 * 128 + ((pos ^ (((r1 >> 1) & 1) << 2)) << 4) + sub);
+            const fp16x4 lo = lds_tr16(sVt + r0 * 128 + ((pos ^ (((r0 >> 1) & 1) << 2)) << 4) + sub);
+            const fp16x4 hi = lds_tr16(sVt + r1 * 128 + ((pos ^ (((r1 >> 1) & 1) << 2)) << 4) + sub);
             h8 vf;
             vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
             vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
             o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kh][s2], o[d], 0, 0, 0);
           }
         }
+      }   // tiles of the super-tile
     }
     const float l = lrun + __shfl_xor(lrun, 32, 64);
     const float w = seg.weight / l;
@@ -168,6 +193,12 @@ __global__ __launch_bounds__(256) void attention_f16_kernel(const AttnArgs p) {
 
 hipError_t ia2p_launch_attention(const AttnArgs& a, hipStream_t s) {
   dim3 grid((a.Nq + 127) / 128, a.heads, a.B);
-  hipLaunchKernelGGL(attention_f16_kernel, grid, dim3(256), 0, s, a);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)attention_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(attention_f16_kernel, grid, dim3(256), 65536, s, a);
   return hipGetLastError();
 }

@@ -122,15 +122,17 @@ struct Arena {            // deterministic first-fit allocator over [0, cap)
 
 struct ProfRec { hipEvent_t e0, e1; int k; double flops, bytes; };
 // profile classes = device kernel names as rocprofv3 prints them (template arguments included)
-enum {
-  PK_GEMM_128x128 = 0, PK_GEMM_128x64, PK_GEMM_64x64, PK_CONV_128x128, PK_CONV_128x64, PK_CONV_64x64,
-  PK_ATTN, PK_GN, PK_LN, PK_EMBED, PK_CONV_IN, PK_CONV_OUT, PK_CONCAT, PK_NCLASS
-};
-static const char* const kProfNames[PK_NCLASS] = {
-  "gemm_f16_kernel<128, 128, false>", "gemm_f16_kernel<128, 64, false>", "gemm_f16_kernel<64, 64, false>",
-  "gemm_f16_kernel<128, 128, true>", "gemm_f16_kernel<128, 64, true>", "gemm_f16_kernel<64, 64, true>",
-  "attention_f16_kernel", "gn_stats_kernel+gn_apply_kernel", "layernorm_kernel", "embed_kernel+linear_small_kernel",
-  "conv_in_kernel", "conv_out_kernel", "concat_kernel"};
+enum { PK_GEMM0 = 0, PK_CONV0 = 6, PK_ATTN = 12, PK_GN, PK_LN, PK_EMBED, PK_CONV_IN, PK_CONV_OUT, PK_CONCAT, PK_NCLASS };
+static const char* prof_name(int k) {
+  static char buf[PK_NCLASS][64];
+  static const char* const other[] = {"attention_f16_kernel", "gn_stats_kernel+gn_apply_kernel", "layernorm_kernel",
+                                      "embed_kernel+linear_small_kernel", "conv_in_kernel", "conv_out_kernel", "concat_kernel"};
+  if (k >= PK_ATTN) return other[k - PK_ATTN];
+  static const int bm[3] = {128, 128, 64}, bn[3] = {128, 64, 64};
+  const int v = k % 6;
+  snprintf(buf[k], sizeof buf[k], "gemm_f16_kernel<%d, %d, %d, %s>", bm[v / 2], bn[v / 2], v % 2 + 2, k >= PK_CONV0 ? "true" : "false");
+  return buf[k];
+}
 
 struct ia2p_ctx {
   ia2p_unet_config cfg;
@@ -392,10 +394,10 @@ static void op_gemm(ia2p_ctx* c, const half_t* A, int lda, const half_t* W, cons
   a.rpb = rpb; a.bstride = bstride; a.roff = roff; a.bias = bias; a.residual = residual; a.ldr = ldr; a.geglu = geglu;
   a.rows_per_batch = 1;
   a.m_fastest = (long)M * K <= (long)N * K ? 1 : 0;
-  ProfScope ps(c, PK_GEMM_128x128, 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * (geglu ? N / 2 : N) + (residual ? (double)M * N : 0)));
+  ProfScope ps(c, PK_GEMM0, 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * (geglu ? N / 2 : N) + (residual ? (double)M * N : 0)));
   int pick = 0;
   CHECK_LAUNCH(c, ia2p_launch_gemm(a, false, c->stream, &pick), "gemm");
-  ps.set_class(PK_GEMM_128x128 + pick);
+  ps.set_class(PK_GEMM0 + pick);
 }
 static void op_conv3(ia2p_ctx* c, const half_t* X, int B, int Hs, int Ws, int Cin, const half_t* W, const half_t* bias, int Co,
                      int stride, int up, const half_t* rowvec, int rowvec_ld, const half_t* residual, half_t* Y) {
@@ -407,10 +409,10 @@ static void op_conv3(ia2p_ctx* c, const half_t* X, int B, int Hs, int Ws, int Ci
   a.Hs = Hs; a.Ws = Ws; a.stride = stride; a.up = up; a.Cin = Cin;
   a.bias = bias; a.rowvec = rowvec; a.rowvec_ld = rowvec_ld; a.rows_per_batch = a.Ho * a.Wo; a.residual = residual; a.ldr = Co;
   a.m_fastest = 0;
-  ProfScope ps(c, PK_CONV_128x128, 2.0 * a.M * (double)Co * a.K, 2.0 * ((double)B * Hs * Ws * Cin + (double)Co * a.K + (double)a.M * Co + (residual ? (double)a.M * Co : 0)));
+  ProfScope ps(c, PK_CONV0, 2.0 * a.M * (double)Co * a.K, 2.0 * ((double)B * Hs * Ws * Cin + (double)Co * a.K + (double)a.M * Co + (residual ? (double)a.M * Co : 0)));
   int pick = 0;
   CHECK_LAUNCH(c, ia2p_launch_gemm(a, true, c->stream, &pick), "conv3x3");
-  ps.set_class(PK_CONV_128x128 + pick);
+  ps.set_class(PK_CONV0 + pick);
 }
 static void op_gn(ia2p_ctx* c, const half_t* x, half_t* y, size_t g, size_t b, int B, int HW, int C, float eps, int silu, float* partial) {
   ProfScope ps(c, PK_GN, 8.0 * B * HW * C, 4.0 * B * HW * C);
@@ -858,7 +860,7 @@ ia2p_status ia2p_profile_read(ia2p_ctx* c, int k, char* name, int name_len, int6
     c->evpool.push_back(r.e0); c->evpool.push_back(r.e1);
   }
   c->recs.clear();
-  if (name && name_len > 0) { strncpy(name, kProfNames[k], name_len - 1); name[name_len - 1] = 0; }
+  if (name && name_len > 0) { strncpy(name, prof_name(k), name_len - 1); name[name_len - 1] = 0; }
   if (launches) *launches = c->p_n[k];
   if (ms) *ms = c->p_ms[k];
   if (flops) *flops = c->p_fl[k];

@@ -18,7 +18,13 @@
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),            \
                                    (__attribute__((address_space(3))) void*)(ldsptr), 16, 0, 0)
 
-template <int BM, int BN, bool CONV>
+template <int N> __device__ __forceinline__ void wait_vm_barrier() {
+  // counted wait for this wave's LDS-DMA pieces + workgroup barrier, as ONE opaque statement: the "memory" clobber
+  // keeps the compiler from moving LDS reads / DMA issues across it
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, int NSTAGE, bool CONV>
 __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
   constexpr int WM = BM / 2, WN = BN / 2;      // wave tile (waves arranged 2 x 2)
   constexpr int MR = WM / 16, NR = WN / 16;
@@ -120,12 +126,19 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
     for (int j = 0; j < NR; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
 
   const int nk = p.K >> 6;
-  stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  constexpr int LPS = A_PW + B_PW;   // LDS-DMA pieces this wave issues per k-tile
+  // NSTAGE-deep LDS ring: tiles kt+1 .. kt+NSTAGE-2 stay in flight across the barrier of step kt (counted vmcnt,
+  // raw s_barrier -- cdna_hip_programming.md §5 "Pipelining across barriers"); ONE barrier per k-step.
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < nk) stage(s, s);
+  int cur = 0, nxt = NSTAGE - 1;      // ring slots: `cur` is consumed this step, `nxt` is refilled
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
+    const int ahead = nk - 1 - kt;    // tiles issued after tile kt that may remain in flight
+    if (NSTAGE >= 3 && ahead >= 1) wait_vm_barrier<LPS>();
+    else wait_vm_barrier<0>();
+    // every wave has passed the barrier => tile kt has landed for all, and slot `nxt` (read in step kt-1) is free
+    if (kt + NSTAGE - 1 < nk) stage(kt + NSTAGE - 1, nxt);
     const char* base = smem + cur * STAGE;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -141,8 +154,8 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
         for (int j = 0; j < NR; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], af[i], acc[i][j], 0, 0, 0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    cur = cur + 1 == NSTAGE ? 0 : cur + 1;
+    nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
   }
 
   // ---- epilogue: acc[i][j][r] = C[m = bm0+wm0+16i+(lane&15)][n = bn0+wn0+16j+4*(lane>>4)+r]
@@ -180,42 +193,53 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
   }
 }
 
-template <int BM, int BN, bool CONV>
+template <int BM, int BN, int NSTAGE, bool CONV>
 static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
-  constexpr int smem = 2 * (BM + BN) * 128;
+  constexpr int smem = NSTAGE * (BM + BN) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_f16_kernel<BM, BN, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_f16_kernel<BM, BN, NSTAGE, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-  hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, CONV>), dim3(tiles), dim3(256), smem, s, a);
+  hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, NSTAGE, CONV>), dim3(tiles), dim3(256), smem, s, a);
   return hipGetLastError();
 }
 
-// tile choice: biggest tile that still yields enough workgroups for 256 CUs
-static int g_force_tile = -1;   // test/tuning hook (ia2p_debug_set_gemm_tile)
-extern "C" void ia2p_debug_set_gemm_tile(int t) { g_force_tile = t; }
+// variant id = tile * 2 + (stages - 2); tile 0: 128x128, 1: 128x64, 2: 64x64; stages 2..3
+// Measured on MI355X (tools/gemm_bench.py): occupancy beats ring depth -- a third stage costs a resident block
+// (96 KiB LDS at 128x128) and loses 20-30 %, so 2 stages is the default; tile = largest that still gives every
+// CU >= 1.5-2 workgroups (the kernels run at ~13 TB/s of L2->LDS traffic, i.e. they are L2-bandwidth bound and
+// more co-resident blocks hide the per-k-step load latency).
+static int g_force_variant = -1;   // test/tuning hook (ia2p_debug_set_gemm_tile)
+extern "C" void ia2p_debug_set_gemm_tile(int v) { g_force_variant = v; }
 
 template <bool CONV>
 static hipError_t launch_any(const GemmArgs& a, hipStream_t s, int* picked) {
   auto tiles = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
-  int pick;
-  if (g_force_tile >= 0) pick = g_force_tile;
-  else if (a.M <= 64) pick = 2;
-  else if (tiles(128, 128) >= 384) pick = 0;
-  else if (tiles(128, 64) >= 256) pick = 1;
-  else pick = 2;
-  if (picked) *picked = pick;
-  switch (pick) {
-    case 0: return launch_cfg<128, 128, CONV>(a, s);
-    case 1: return launch_cfg<128, 64, CONV>(a, s);
-    default: return launch_cfg<64, 64, CONV>(a, s);
+  int v;
+  if (g_force_variant >= 0) v = g_force_variant;
+  else {
+    int tile;
+    if (a.M <= 64) tile = 2;
+    else if (tiles(128, 128) >= 384) tile = (a.N % 128 != 0 && a.N % 64 == 0) ? 1 : 0;   // N = 320: exact 5 x 64 columns
+    else if (tiles(128, 64) >= 512) tile = 1;
+    else tile = 2;
+    v = tile * 2;
+  }
+  if (picked) *picked = v;
+  switch (v) {
+    case 0: return launch_cfg<128, 128, 2, CONV>(a, s);
+    case 1: return launch_cfg<128, 128, 3, CONV>(a, s);
+    case 2: return launch_cfg<128, 64, 2, CONV>(a, s);
+    case 3: return launch_cfg<128, 64, 3, CONV>(a, s);
+    case 4: return launch_cfg<64, 64, 2, CONV>(a, s);
+    default: return launch_cfg<64, 64, 3, CONV>(a, s);
   }
 }
 
-// *picked (optional) receives the tile index: 0 = 128x128, 1 = 128x64, 2 = 64x64
+// *picked (optional) receives the variant id (see launch_any)
 hipError_t ia2p_launch_gemm(const GemmArgs& a, bool conv, hipStream_t s, int* picked) {
   return conv ? launch_any<true>(a, s, picked) : launch_any<false>(a, s, picked);
 }

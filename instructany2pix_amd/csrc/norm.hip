@@ -18,7 +18,8 @@ struct GNArgs {
   const half_t* x; half_t* y;
   const half_t* gamma; const half_t* beta;
   float* partial;         // [B][chunks][G][2]
-  int B, HW, C, G, chunks, rows;   // rows = pixels per chunk (last chunk may be short)
+  int B, HW, C, G, chunks, rows;   // rows = pixels per stats chunk (last chunk may be short)
+  int arows;                       // pixels per apply block (finer than the stats chunking)
   int ldx, ldy;
   float eps; int silu;
 };
@@ -36,14 +37,24 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GNArgs p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s[v][e] = 0.f; ss[v][e] = 0.f; }
   if (ty < TY) {
-    for (int r = r0 + ty; r < r1; r += TY) {
-      const half_t* row = p.x + ((size_t)b * p.HW + r) * p.ldx;
+    const half_t* base = p.x + (size_t)b * p.HW * p.ldx;
+    for (int r = r0 + ty; r < r1; r += 4 * TY) {       // 4 rows (4*V 16-byte loads) in flight per thread
+      h8 d[4][V];
 #pragma unroll
-      for (int v = 0; v < V; ++v) {
-        const h8 d = *(const h8*)(row + (tx + v * TX) * 8);
+      for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { const float f = (float)d[e]; s[v][e] += f; ss[v][e] += f * f; }
-      }
+        for (int v = 0; v < V; ++v) {
+          const int rr = min(r + u * TY, r1 - 1);
+          d[u][v] = *(const h8*)(base + (size_t)rr * p.ldx + (tx + v * TX) * 8);
+        }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (r + u * TY < r1) {
+#pragma unroll
+          for (int v = 0; v < V; ++v)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float f = (float)d[u][v][e]; s[v][e] += f; ss[v][e] += f * f; }
+        }
     }
 #pragma unroll
     for (int v = 0; v < V; ++v)
@@ -77,21 +88,30 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GNArgs p) {
   extern __shared__ float stat[];   // [G][2] mean, rstd
   const int nvec = p.C >> 3, TX = nvec / V, TY = blockDim.x / TX;
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
-  const int b = blockIdx.y, r0 = blockIdx.x * p.rows, r1 = min(r0 + p.rows, p.HW);
+  const int b = blockIdx.y, r0 = blockIdx.x * p.arows, r1 = min(r0 + p.arows, p.HW);
   const int Cg = p.C / p.G;
-  if ((int)threadIdx.x < p.G) {
-    const int g = threadIdx.x;
-    double a = 0.0, q = 0.0;
-    for (int c = 0; c < p.chunks; ++c) {
-      const float* in = p.partial + (((size_t)b * p.chunks + c) * p.G + g) * 2;
-      a += (double)in[0]; q += (double)in[1];
+  {   // fold the chunk partials of this batch: all threads, (group, chunk-slice) each, then across slices in fp64
+    double* fold = (double*)(stat + 2 * p.G);          // [nsl][G][2]
+    const int nsl = blockDim.x / p.G, g = threadIdx.x % p.G, sl = threadIdx.x / p.G;
+    if (sl < nsl) {
+      float a = 0.f, q = 0.f;
+      for (int c = sl; c < p.chunks; c += nsl) {
+        const float2 v = *(const float2*)(p.partial + (((size_t)b * p.chunks + c) * p.G + g) * 2);
+        a += v.x; q += v.y;
+      }
+      fold[(sl * p.G + g) * 2] = (double)a; fold[(sl * p.G + g) * 2 + 1] = (double)q;
     }
-    const double n = (double)p.HW * Cg;
-    const double mean = a / n;
-    double var = q / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    stat[g * 2] = (float)mean;
-    stat[g * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
+    __syncthreads();
+    if ((int)threadIdx.x < p.G) {
+      double a = 0.0, q = 0.0;
+      for (int t = 0; t < nsl; ++t) { a += fold[(t * p.G + g) * 2]; q += fold[(t * p.G + g) * 2 + 1]; }
+      const double n = (double)p.HW * Cg;
+      const double mean = a / n;
+      double var = q / n - mean * mean;
+      if (var < 0.0) var = 0.0;
+      stat[g * 2] = (float)mean;
+      stat[g * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
+    }
   }
   __syncthreads();
   if (ty >= TY) return;
@@ -108,22 +128,32 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GNArgs p) {
       sh[v][e] = (float)be[e] - mean * sc[v][e];
     }
   }
-  for (int r = r0 + ty; r < r1; r += TY) {
-    const half_t* row = p.x + ((size_t)b * p.HW + r) * p.ldx;
-    half_t* orow = p.y + ((size_t)b * p.HW + r) * p.ldy;
+  const half_t* base = p.x + (size_t)b * p.HW * p.ldx;
+  half_t* obase = p.y + (size_t)b * p.HW * p.ldy;
+  for (int r = r0 + ty; r < r1; r += 4 * TY) {         // 4 rows in flight per thread
+    h8 d[4][V];
 #pragma unroll
-    for (int v = 0; v < V; ++v) {
-      const int c0 = (tx + v * TX) * 8;
-      const h8 d = *(const h8*)(row + c0);
-      h8 o;
+    for (int u = 0; u < 4; ++u)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float f = (float)d[e] * sc[v][e] + sh[v][e];
-        if (p.silu) f = silu_f(f);
-        o[e] = (half_t)f;
+      for (int v = 0; v < V; ++v) {
+        const int rr = min(r + u * TY, r1 - 1);
+        d[u][v] = *(const h8*)(base + (size_t)rr * p.ldx + (tx + v * TX) * 8);
       }
-      *(h8*)(orow + c0) = o;
-    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (r + u * TY < r1) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          h8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float f = (float)d[u][v][e] * sc[v][e] + sh[v][e];
+            if (p.silu) f = silu_f(f);
+            o[e] = (half_t)f;
+          }
+          *(h8*)(obase + (size_t)(r + u * TY) * p.ldy + (tx + v * TX) * 8) = o;
+        }
+      }
   }
 }
 
@@ -147,15 +177,20 @@ hipError_t ia2p_launch_groupnorm(const half_t* x, int ldx, half_t* y, int ldy, c
   while (nvec / V > 256 || nvec % V) ++V;
   if (V > 2 || C % 8 || C % G) return hipErrorInvalidValue;
   const int TX = nvec / V, TY = 256 / TX;
-  dim3 grid(a.chunks, B), block(256);
-  const size_t sm1 = (size_t)2 * TY * C * sizeof(float), sm2 = (size_t)G * 2 * sizeof(float);
+  // apply pass: ~2k workgroups, each thread streaming >= 4 rows
+  int ablocks = 1;
+  while (B * ablocks < 2048 && HW / (ablocks * 2) >= 4 * TY) ablocks *= 2;
+  a.arows = (HW + ablocks - 1) / ablocks;
+  ablocks = (HW + a.arows - 1) / a.arows;
+  dim3 grid(a.chunks, B), agrid(ablocks, B), block(256);
+  const size_t sm1 = (size_t)2 * TY * C * sizeof(float), sm2 = (size_t)G * 2 * sizeof(float) + (size_t)(256 / G) * G * 2 * sizeof(double);
   if (sm1 > 65536) return hipErrorInvalidValue;
   if (V == 1) {
     hipLaunchKernelGGL(gn_stats_kernel<1>, grid, block, sm1, s, a);
-    hipLaunchKernelGGL(gn_apply_kernel<1>, grid, block, sm2, s, a);
+    hipLaunchKernelGGL(gn_apply_kernel<1>, agrid, block, sm2, s, a);
   } else {
     hipLaunchKernelGGL(gn_stats_kernel<2>, grid, block, sm1, s, a);
-    hipLaunchKernelGGL(gn_apply_kernel<2>, grid, block, sm2, s, a);
+    hipLaunchKernelGGL(gn_apply_kernel<2>, agrid, block, sm2, s, a);
   }
   return hipGetLastError();
 }
