@@ -53,6 +53,11 @@ struct GemmArgs {
   int ldr;
   int geglu;             // 1: W/bias rows interleaved in 16-row (a,g) pairs; out[m, n/2] = a * gelu(g)
   int m_fastest;         // tile order: 1 = consecutive blocks walk M (weights panel shared), 0 = walk N
+  // weight prefetch: extra workgroups (launched after the tiles) stream the NEXT contraction's weights once,
+  // sequentially, so they are in the Infinity Cache / L2 instead of HBM-cold when that kernel starts
+  const void* pf;        // or null
+  long pf_bytes;
+  int pf_blocks;
 };
 
 struct AttnSeg {

@@ -13,6 +13,8 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -160,6 +162,12 @@ struct ia2p_ctx {
   bool dry = false;
   hipStream_t stream = nullptr;
   bool failed = false;
+  // weight prefetch plan: weights of every GEMM/conv launch of a forward, in launch order
+  std::vector<std::pair<const half_t*, size_t>> wseq;
+  size_t widx = 0;
+  bool record = false;
+  int wseq_key = -1;
+  bool prefetch = true;
   bool prof = false;
   std::vector<ProfRec> recs;
   std::vector<hipEvent_t> evpool;
@@ -386,6 +394,16 @@ struct ProfScope {
 
 static inline const half_t* W_(ia2p_ctx* c, size_t off) { return c->arena + off; }
 
+static void set_prefetch(ia2p_ctx* c, GemmArgs& a, const half_t* W, size_t bytes) {
+  if (c->dry) { if (c->record) c->wseq.push_back({W, bytes}); return; }
+  if (!c->prefetch || c->widx + 1 >= c->wseq.size()) { ++c->widx; return; }
+  const auto& nx = c->wseq[c->widx + 1];
+  ++c->widx;
+  if (nx.second > ((size_t)96 << 20)) return;           // larger than the Infinity Cache can usefully hold
+  a.pf = nx.first; a.pf_bytes = (long)nx.second;
+  a.pf_blocks = (int)std::min<size_t>(128, (nx.second + 131071) / 131072);
+}
+
 static void op_gemm(ia2p_ctx* c, const half_t* A, int lda, const half_t* W, const half_t* bias, const half_t* residual, int ldr,
                     half_t* C, int ldc, int M, int N, int K, int geglu = 0, int rpb = 0, int bstride = 0, int roff = 0) {
   GemmArgs a;
@@ -394,6 +412,7 @@ static void op_gemm(ia2p_ctx* c, const half_t* A, int lda, const half_t* W, cons
   a.rpb = rpb; a.bstride = bstride; a.roff = roff; a.bias = bias; a.residual = residual; a.ldr = ldr; a.geglu = geglu;
   a.rows_per_batch = 1;
   a.m_fastest = (long)M * K <= (long)N * K ? 1 : 0;
+  set_prefetch(c, a, W, (size_t)N * K * sizeof(half_t));
   ProfScope ps(c, PK_GEMM0, 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * (geglu ? N / 2 : N) + (residual ? (double)M * N : 0)));
   int pick = 0;
   CHECK_LAUNCH(c, ia2p_launch_gemm(a, false, c->stream, &pick), "gemm");
@@ -409,6 +428,7 @@ static void op_conv3(ia2p_ctx* c, const half_t* X, int B, int Hs, int Ws, int Ci
   a.Hs = Hs; a.Ws = Ws; a.stride = stride; a.up = up; a.Cin = Cin;
   a.bias = bias; a.rowvec = rowvec; a.rowvec_ld = rowvec_ld; a.rows_per_batch = a.Ho * a.Wo; a.residual = residual; a.ldr = Co;
   a.m_fastest = 0;
+  set_prefetch(c, a, W, (size_t)Co * a.K * sizeof(half_t));
   ProfScope ps(c, PK_CONV0, 2.0 * a.M * (double)Co * a.K, 2.0 * ((double)B * Hs * Ws * Cin + (double)Co * a.K + (double)a.M * Co + (residual ? (double)a.M * Co : 0)));
   int pick = 0;
   CHECK_LAUNCH(c, ia2p_launch_gemm(a, true, c->stream, &pick), "conv3x3");
@@ -650,6 +670,7 @@ ia2p_status ia2p_create(const ia2p_unet_config* cfg, ia2p_ctx** out) {
   ia2p_status st = build_plan(c);
   if (st != IA2P_OK) { g_err = c->err; delete c; *out = nullptr; return st; }
   c->failed = false;
+  if (const char* e = getenv("IA2P_PREFETCH")) c->prefetch = atoi(e) != 0;
   for (int k = 0; k < PK_NCLASS; ++k) { c->p_ms[k] = c->p_fl[k] = c->p_by[k] = 0; c->p_n[k] = 0; }
   *out = c;
   return IA2P_OK;
@@ -755,6 +776,16 @@ ia2p_status ia2p_unet_forward(ia2p_ctx* c, void* stream, const void* sample, flo
   if (!zero_page()) return fail(c, IA2P_ERR_HIP, "cannot allocate zero page");
   const uintptr_t base = ((uintptr_t)ws + 255) & ~(uintptr_t)255;
   const size_t usable = ws_bytes - (base - (uintptr_t)ws);
+  const int key = c->ip_enabled ? 1 + c->ip_tokens : 0;
+  if (c->wseq_key != key) {          // (re)build the weight launch sequence with a dry pass of the same code path
+    c->wseq.clear();
+    c->dry = true; c->record = true; c->failed = false;
+    c->ws.reset((size_t)1 << 46); c->ws_base = nullptr;
+    (void)run_forward(c, nullptr, 0.f, nullptr, L, nullptr, nullptr, nullptr, B, h, w);
+    c->dry = false; c->record = false;
+    c->wseq_key = key;
+  }
+  c->widx = 0;
   c->dry = false; c->failed = false; c->stream = (hipStream_t)stream;
   c->ws.reset(usable);
   c->ws_base = (char*)base;

@@ -39,6 +39,21 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
   // ---- tile of this workgroup; blocks b, b+8, ... share an XCD (its L2): give each XCD a contiguous tile range
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   int bid = blockIdx.x;
+  if (bid >= tiles_m * tiles_n) {   // prefetch workgroup: touch its slice of the next kernel's weights and leave
+    const long per = ((p.pf_bytes + p.pf_blocks - 1) / p.pf_blocks + 4095) & ~4095L;
+    const long lo = (long)(bid - tiles_m * tiles_n) * per, hi = min(lo + per, p.pf_bytes & ~15L);
+    const char* src = (const char*)p.pf;
+    unsigned acc = 0;
+    for (long o = lo + tid * 16; o < hi; o += 4 * 4096) {
+      unsigned v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *(const unsigned*)(src + min(o + u * 4096, hi - 16));   // one dword per 16-B slot pulls the whole line
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc ^= v[u];
+    }
+    asm volatile("" ::"v"(acc));    // keep the loads alive
+    return;
+  }
   {
     const int nwg = tiles_m * tiles_n;
     const int q = nwg >> 3, r = nwg & 7, x = bid & 7, i = bid >> 3;
@@ -203,7 +218,8 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
     attr_set = true;
   }
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-  hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, NSTAGE, CONV>), dim3(tiles), dim3(256), smem, s, a);
+  const int extra = (a.pf && a.pf_bytes >= 4096) ? a.pf_blocks : 0;
+  hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, NSTAGE, CONV>), dim3(tiles + extra), dim3(256), smem, s, a);
   return hipGetLastError();
 }
 
