@@ -115,35 +115,44 @@ __global__ __launch_bounds__(256) void attention_f16_kernel(const AttnArgs p) {
         }
       }
       // st[kh][r] <-> key = k0 + 32kh + (r&3) + 8(r>>2) + 4*hh, query = q0 + lane%32
-      float mx = MASKED;
+      // softmax on RAW scores: max commutes with the positive scale, and exp2(c*s - c*m) is one FMA + one v_exp_f32
+      if (k0 + 64 > seg.nkeys) {        // only the last, partial tile of a segment needs masking (wave-uniform)
 #pragma unroll
-      for (int kh = 0; kh < 2; ++kh)
+        for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = k0 + kh * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          const float v = key < seg.nkeys ? st[kh][r] * p.scale_log2e : MASKED;
-          st[kh][r] = v;
-          mx = fmaxf(mx, v);
-        }
+          for (int r = 0; r < 16; ++r) {
+            const int key = k0 + kh * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (key >= seg.nkeys) st[kh][r] = MASKED;
+          }
+      }
+      float mx = st[0][0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[0][r]);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[1][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float mnew = fmaxf(mrun, mx);
-      const float alpha = exp2f(mrun - mnew);
-      mrun = mnew;
+      const float mc = mnew * p.scale_log2e;
       float psum = 0.f;
       h8 pf[2][2];
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float e = exp2f(st[kh][r] - mnew);
+          const float e = __builtin_amdgcn_exp2f(fmaf(st[kh][r], p.scale_log2e, -mc));
           psum += e;
           pf[kh][r >> 3][r & 7] = (half_t)e;
         }
-      lrun = lrun * alpha + psum;
+      if (__any(mnew != mrun)) {        // running max moved for some query of this wave: rescale (rare after the first tiles)
+        const float alpha = __builtin_amdgcn_exp2f((mrun - mnew) * p.scale_log2e);
+        lrun *= alpha;
 #pragma unroll
-      for (int d = 0; d < 2; ++d)
+        for (int d = 0; d < 2; ++d)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+          for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+        mrun = mnew;
+      }
+      lrun += psum;
 
       // ---- O^T[d][q] += V^T[d][key] . P^T[key][q]; k-step (kh,s2): slot (hh, j) <-> key 32kh + 16s2 + 8(j>>2) + 4hh + (j&3)
       const int gi = (lane >> 4) & 1, li = lane & 15;
