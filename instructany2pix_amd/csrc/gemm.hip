@@ -24,11 +24,13 @@ template <int N> __device__ __forceinline__ void wait_vm_barrier() {
   asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int NSTAGE, bool CONV>
-__global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
-  constexpr int WM = BM / 2, WN = BN / 2;      // wave tile (waves arranged 2 x 2)
+// BM x BN tile; WGM x 2 waves, each owning a (BM/WGM) x (BN/2) sub-tile
+template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2>
+__global__ __launch_bounds__(WGM * 128) void gemm_f16_kernel(const GemmArgs p) {
+  constexpr int NWAVE = WGM * 2;
+  constexpr int WM = BM / WGM, WN = BN / 2;      // wave tile (waves arranged WGM x 2)
   constexpr int MR = WM / 16, NR = WN / 16;
-  constexpr int A_PW = BM / 32, B_PW = BN / 32;  // 1-KiB (8 rows x 128 B) staging pieces per wave
+  constexpr int A_PW = BM / 8 / NWAVE, B_PW = BN / 8 / NWAVE;  // 1-KiB (8 rows x 128 B) staging pieces per wave
   constexpr int STAGE = (BM + BN) * 128;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
 
@@ -44,10 +46,11 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
     const long lo = (long)(bid - tiles_m * tiles_n) * per, hi = min(lo + per, p.pf_bytes & ~15L);
     const char* src = (const char*)p.pf;
     unsigned acc = 0;
-    for (long o = lo + tid * 16; o < hi; o += 4 * 4096) {
+    constexpr long SW = NWAVE * 64 * 16;   // bytes swept by the workgroup per pass
+    for (long o = lo + tid * 16; o < hi; o += 4 * SW) {
       unsigned v[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = *(const unsigned*)(src + min(o + u * 4096, hi - 16));   // one dword per 16-B slot pulls the whole line
+      for (int u = 0; u < 4; ++u) v[u] = *(const unsigned*)(src + min(o + u * SW, hi - 16));   // one dword per 16-B slot pulls the whole line
 #pragma unroll
       for (int u = 0; u < 4; ++u) acc ^= v[u];
     }
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
   };
 
   // ---- fragment read offsets (wave tile origin is a multiple of 16, so swz(row) = (lane>>1)&7)
-  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;   // wave / 2 in [0, WGM)
   const int frow = lane & 15, fq = lane >> 4;
   const int fswz = (lane >> 1) & 7;
   const int a_off = (wm0 + frow) * 128, w_off = BM * 128 + (wn0 + frow) * 128;
@@ -155,19 +158,41 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
     // every wave has passed the barrier => tile kt has landed for all, and slot `nxt` (read in step kt-1) is free
     if (kt + NSTAGE - 1 < nk) stage(kt + NSTAGE - 1, nxt);
     const char* base = smem + cur * STAGE;
+    if constexpr (MR * NR <= 16) {
+      // all fragment reads of the k-step are issued before the first MFMA
+      h8 af[2][MR], wf[2][NR];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int coff = ((kk * 4 + fq) ^ fswz) << 4;
-      h8 af[MR], wf[NR];
+      for (int kk = 0; kk < 2; ++kk) {
+        const int coff = ((kk * 4 + fq) ^ fswz) << 4;
 #pragma unroll
-      for (int i = 0; i < MR; ++i) af[i] = *(const h8*)(base + a_off + i * 2048 + coff);
+        for (int i = 0; i < MR; ++i) af[kk][i] = *(const h8*)(base + a_off + i * 2048 + coff);
 #pragma unroll
-      for (int j = 0; j < NR; ++j) wf[j] = *(const h8*)(base + w_off + j * 2048 + coff);
+        for (int j = 0; j < NR; ++j) wf[kk][j] = *(const h8*)(base + w_off + j * 2048 + coff);
+      }
+      __builtin_amdgcn_sched_barrier(0);   // keep hipcc from sinking the reads back between the MFMAs
 #pragma unroll
-      for (int i = 0; i < MR; ++i)
+      for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-        for (int j = 0; j < NR; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+          for (int j = 0; j < NR; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
+    } else {
+      // big wave tiles: registers go to accumulators, fragments are read per 32-deep half
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int coff = ((kk * 4 + fq) ^ fswz) << 4;
+        h8 af[MR], wf[NR];
+#pragma unroll
+        for (int i = 0; i < MR; ++i) af[i] = *(const h8*)(base + a_off + i * 2048 + coff);
+#pragma unroll
+        for (int j = 0; j < NR; ++j) wf[j] = *(const h8*)(base + w_off + j * 2048 + coff);
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+          for (int j = 0; j < NR; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], af[i], acc[i][j], 0, 0, 0);
+      }
     }
     cur = cur + 1 == NSTAGE ? 0 : cur + 1;
     nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
@@ -208,18 +233,18 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const GemmArgs p) {
   }
 }
 
-template <int BM, int BN, int NSTAGE, bool CONV>
+template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2>
 static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
   constexpr int smem = NSTAGE * (BM + BN) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_f16_kernel<BM, BN, NSTAGE, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_f16_kernel<BM, BN, NSTAGE, CONV, WGM>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   const int extra = (a.pf && a.pf_bytes >= 4096) ? a.pf_blocks : 0;
-  hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, NSTAGE, CONV>), dim3(tiles + extra), dim3(256), smem, s, a);
+  hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, NSTAGE, CONV, WGM>), dim3(tiles + extra), dim3(WGM * 128), smem, s, a);
   return hipGetLastError();
 }
 
@@ -243,6 +268,8 @@ static hipError_t launch_any(const GemmArgs& a, hipStream_t s, int* picked) {
     else if (tiles(128, 64) >= 512) tile = 1;
     else tile = 2;
     v = tile * 2;
+    // long-K, few-tile problems (ff.net.2: 2048 x 1280 x 5120): a 3-deep ring of 128x64 tiles still fits 2 blocks/CU
+    if (!CONV && tile == 2 && a.K >= 4096 && tiles(128, 64) >= 256) v = 3;
   }
   if (picked) *picked = v;
   switch (v) {
@@ -251,7 +278,9 @@ static hipError_t launch_any(const GemmArgs& a, hipStream_t s, int* picked) {
     case 2: return launch_cfg<128, 64, 2, CONV>(a, s);
     case 3: return launch_cfg<128, 64, 3, CONV>(a, s);
     case 4: return launch_cfg<64, 64, 2, CONV>(a, s);
-    default: return launch_cfg<64, 64, 3, CONV>(a, s);
+    case 5: return launch_cfg<64, 64, 3, CONV>(a, s);
+    case 6: return launch_cfg<256, 128, 2, CONV, 4>(a, s);     // 8 waves, 85 FLOP per L2 byte
+    default: return launch_cfg<256, 320, 2, CONV, 4>(a, s);    // 8 waves, one workgroup per CU, 142 FLOP per L2 byte
   }
 }
 
