@@ -16,6 +16,7 @@ Rank 0 prints ONE JSON line; besides the contract fields it carries
   "cpu_baseline": the CPU oracle (oracle/, torch fp32 on the host cores) timed on a bounded sample.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -180,8 +181,16 @@ def main():
         dom = max(table, key=lambda k: table[k]["ms"])
         d = table[dom]
         ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        traffic, traffic_src = None, None
+        pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+        if pmc:                     # HBM-side bytes per launch of this kernel, from separate rocprofv3 --pmc passes (tools/pmc_traffic.py)
+            k = json.load(open(pmc[-1]))["kernels"].get(dom)
+            if k:
+                traffic, traffic_src = k["traffic_bytes_per_launch"], os.path.basename(pmc[-1])
         res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
-                           "traffic": None, "launches_per_step": d["launches"] / nprof, "avg_launch_us": 1e3 * d["ms"] / d["launches"],
+                           "traffic": traffic, "traffic_unit": "bytes/launch (L2<->fabric, Infinity-Cache hits included)", "traffic_source": traffic_src,
+                           "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
+                           "launches_per_step": d["launches"] / nprof, "avg_launch_us": 1e3 * d["ms"] / d["launches"],
                            "flops_per_launch": d["flops"] / d["launches"], "share_of_step": d["ms"] / tot_ms}
         for k, v in sorted(table.items(), key=lambda kv: -kv[1]["ms"]):
             log(f"  {k:42s} {v['launches'] / nprof:7.1f} launches/step {v['ms'] / nprof:8.3f} ms/step "

@@ -268,8 +268,7 @@ static hipError_t launch_any(const GemmArgs& a, hipStream_t s, int* picked) {
     else if (tiles(128, 64) >= 512) tile = 1;
     else tile = 2;
     v = tile * 2;
-    // long-K, few-tile problems (ff.net.2: 2048 x 1280 x 5120): a 3-deep ring of 128x64 tiles still fits 2 blocks/CU
-    if (!CONV && tile == 2 && a.K >= 4096 && tiles(128, 64) >= 256) v = 3;
+    // (a 3-deep ring of 128x64 tiles for the long-K ff.net.2 measured 50 us in situ vs 46 us for 64x64 x2: not used)
   }
   if (picked) *picked = v;
   switch (v) {
