@@ -15,6 +15,8 @@ OUT = os.path.join(HERE, "libia2p_hip.so")
 SOURCES = ["gemm.hip", "attention.hip", "norm.hip", "misc.hip", "engine.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
+# attention: MFMA results feed VALU softmax directly; the VGPR form avoids ~250 v_accvgpr_read/write per key tile
+FILE_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _stamp():
@@ -23,7 +25,7 @@ def _stamp():
     for p in files:
         h.update(os.path.basename(p).encode())
         h.update(open(p, "rb").read())
-    h.update(" ".join(FLAGS).encode())
+    h.update((" ".join(FLAGS) + repr(sorted(FILE_FLAGS.items()))).encode())
     return h.hexdigest()
 
 
@@ -37,7 +39,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def cc(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [HIPCC, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [HIPCC, *FLAGS, *FILE_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")

@@ -43,6 +43,31 @@ __device__ __forceinline__ void stage_kv(const half_t* Kb, const half_t* Vb, int
   }
 }
 
+// Both key segments of a short-context cross-attention (e.g. 77 text + 4 image-token keys = 2 + 1 tiles) staged in ONE
+// load phase: tiles [0, nt0) hold segment 0, tiles [nt0, NT) segment 1.
+template <int NT>
+__device__ __forceinline__ void stage_kv2(const half_t* K0, const half_t* V0, int ld0, int n0, const half_t* K1, const half_t* V1,
+                                          int ld1, int n1, int nt0, int tid, char* sK, char* sV) {
+  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+  u4 kreg[2 * NT], vreg[2 * NT];
+#pragma unroll
+  for (int u = 0; u < 2 * NT; ++u) {
+    const bool s1 = (u >> 1) >= nt0;                       // wave-uniform
+    const int c = tid + 256 * u, row = (c >> 3) - (s1 ? nt0 * 64 : 0), pos = c & 7;
+    const size_t off = (size_t)min(row, (s1 ? n1 : n0) - 1) * (s1 ? ld1 : ld0) + pos * 8;
+    kreg[u] = *(const u4*)((s1 ? K1 : K0) + off);
+    vreg[u] = *(const u4*)((s1 ? V1 : V0) + off);
+  }
+#pragma unroll
+  for (int u = 0; u < 2 * NT; ++u) {
+    const bool s1 = (u >> 1) >= nt0;
+    const int c = tid + 256 * u, lrow = c >> 3, row = lrow - (s1 ? nt0 * 64 : 0), pos = c & 7;
+    const unsigned keep = row < (s1 ? n1 : n0) ? 0xFFFFFFFFu : 0u;
+    *(u4*)(sK + lrow * 128 + ((pos ^ ((lrow >> 1) & 7)) << 4)) = kreg[u] & keep;
+    *(u4*)(sV + lrow * 128 + ((pos ^ (((lrow >> 1) & 1) << 2)) << 4)) = vreg[u] & keep;
+  }
+}
+
 __global__ __launch_bounds__(256) void attention_f16_kernel(const AttnArgs p) {
   // up to 4 key tiles (256 keys) of K and of V resident at once: one load phase + one barrier per 256 keys
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -70,8 +95,21 @@ __global__ __launch_bounds__(256) void attention_f16_kernel(const AttnArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) otot[d][r] = 0.f;
 
-  // staging role of this thread: 2 x 16-byte chunks of K and of V per tile
-  // chunk id c = tid + 256*u (u = 0,1): row = c / 8, position = c % 8
+  // short two-segment contexts: everything resident after one load phase and one barrier
+  const int nt0 = (p.seg[0].nkeys + 63) >> 6, nt1 = p.nseg == 2 ? (p.seg[1].nkeys + 63) >> 6 : 0;
+  const bool resident = p.nseg == 2 && nt0 + nt1 <= 4;
+  if (resident) {
+    const half_t* K0 = p.seg[0].K + (size_t)b * p.seg[0].rows_per_batch * p.seg[0].ld + hd * 64;
+    const half_t* V0 = p.seg[0].V + (size_t)b * p.seg[0].rows_per_batch * p.seg[0].ld + hd * 64;
+    const half_t* K1 = p.seg[1].K + (size_t)b * p.seg[1].rows_per_batch * p.seg[1].ld + hd * 64;
+    const half_t* V1 = p.seg[1].V + (size_t)b * p.seg[1].rows_per_batch * p.seg[1].ld + hd * 64;
+    switch (nt0 + nt1) {
+      case 2: stage_kv2<2>(K0, V0, p.seg[0].ld, p.seg[0].nkeys, K1, V1, p.seg[1].ld, p.seg[1].nkeys, nt0, tid, sK, sV); break;
+      case 3: stage_kv2<3>(K0, V0, p.seg[0].ld, p.seg[0].nkeys, K1, V1, p.seg[1].ld, p.seg[1].nkeys, nt0, tid, sK, sV); break;
+      default: stage_kv2<4>(K0, V0, p.seg[0].ld, p.seg[0].nkeys, K1, V1, p.seg[1].ld, p.seg[1].nkeys, nt0, tid, sK, sV); break;
+    }
+    __syncthreads();
+  }
   for (int sg = 0; sg < p.nseg; ++sg) {
     const AttnSeg seg = sg == 0 ? p.seg[0] : p.seg[1];   // (a runtime index into the by-value argument would push it to scratch)
     const half_t* Kb = seg.K + (size_t)b * seg.rows_per_batch * seg.ld + hd * 64;
@@ -86,34 +124,62 @@ __global__ __launch_bounds__(256) void attention_f16_kernel(const AttnArgs p) {
     for (int s0 = 0; s0 < seg.nkeys; s0 += 256) {
       const int nsk = min(256, seg.nkeys - s0);          // keys in this super-tile
       const int ntile = (nsk + 63) >> 6;
-      __syncthreads();  // previous super-tile fully consumed
-      switch (ntile) {   // wave-uniform; each arm is fully unrolled so the staging registers never go to scratch
-        case 1: stage_kv<1>(Kb, Vb, seg.ld, s0, nsk, tid, sK, sV); break;
-        case 2: stage_kv<2>(Kb, Vb, seg.ld, s0, nsk, tid, sK, sV); break;
-        case 3: stage_kv<3>(Kb, Vb, seg.ld, s0, nsk, tid, sK, sV); break;
-        default: stage_kv<4>(Kb, Vb, seg.ld, s0, nsk, tid, sK, sV); break;
+      if (!resident) {
+        __syncthreads();  // previous super-tile fully consumed
+        switch (ntile) {   // wave-uniform; each arm is fully unrolled so the staging registers never go to scratch
+          case 1: stage_kv<1>(Kb, Vb, seg.ld, s0, nsk, tid, sK, sV); break;
+          case 2: stage_kv<2>(Kb, Vb, seg.ld, s0, nsk, tid, sK, sV); break;
+          case 3: stage_kv<3>(Kb, Vb, seg.ld, s0, nsk, tid, sK, sV); break;
+          default: stage_kv<4>(Kb, Vb, seg.ld, s0, nsk, tid, sK, sV); break;
+        }
+        __syncthreads();
       }
-      __syncthreads();
+      const int tbase = resident && sg == 1 ? nt0 : 0;
       for (int tl = 0; tl < ntile; ++tl) {
       const int k0 = s0 + tl * 64;
-      const char* sKt = sK + tl * 8192;
-      const char* sVt = sV + tl * 8192;
+      const char* sKt = sK + (tbase + tl) * 8192;
+      const char* sVt = sV + (tbase + tl) * 8192;
 
-      // ---- S^T[key][q] for the two 32-key halves of the tile
+      // ---- S^T[key][q] for the two 32-key halves of the tile. All LDS reads of a phase are issued ahead of its MFMAs
+      //      (with one wave per SIMD nothing else hides the ~130-cycle LDS latency in front of each MFMA).
+      h8 kf[2][4];
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh) {
+        const int row = kh * 32 + r31;
+        const char* kp = sKt + row * 128;
+        const int sw = (row >> 1) & 7;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) kf[kh][s] = *(const h8*)(kp + (((2 * s + hh) ^ sw) << 4));
+      }
+      __builtin_amdgcn_sched_barrier(0);
       f16v st[2];
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[kh][r] = 0.f;
-        const int row = kh * 32 + r31;
-        const char* kp = sKt + row * 128;
-        const int sw = (row >> 1) & 7;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const h8 kf = *(const h8*)(kp + (((2 * s + hh) ^ sw) << 4));
-          st[kh] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], st[kh], 0, 0, 0);
-        }
+        for (int s = 0; s < 4; ++s) st[kh] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kh][s], qf[s], st[kh], 0, 0, 0);
       }
+      // V^T fragments of the whole tile: issued now, their latency hides under the softmax arithmetic below
+      const int gi = (lane >> 4) & 1, li = lane & 15;
+      h8 vf[2][2][2];
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int kb0 = kh * 32 + s2 * 16 + 4 * hh + (li >> 2);   // row this lane addresses for j<4
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            const int col = d * 32 + gi * 16 + 4 * (li & 3);          // first of 4 contiguous d this lane addresses
+            const int pos = col >> 3, sub = (col & 7) * 2;
+            const int r0 = kb0, r1 = kb0 + 8;
+            const fp16x4 lo = lds_tr16(sVt + r0 * 128 + ((pos ^ (((r0 >> 1) & 1) << 2)) << 4) + sub);
+            const fp16x4 hi = lds_tr16(sVt + r1 * 128 + ((pos ^ (((r1 >> 1) & 1) << 2)) << 4) + sub);
+            vf[kh][s2][d][0] = lo[0]; vf[kh][s2][d][1] = lo[1]; vf[kh][s2][d][2] = lo[2]; vf[kh][s2][d][3] = lo[3];
+            vf[kh][s2][d][4] = hi[0]; vf[kh][s2][d][5] = hi[1]; vf[kh][s2][d][6] = hi[2]; vf[kh][s2][d][7] = hi[3];
+          }
+        }
+      __builtin_amdgcn_sched_barrier(0);
       // st[kh][r] <-> key = k0 + 32kh + (r&3) + 8(r>>2) + 4*hh, query = q0 + lane%32
       // softmax on RAW scores: max commutes with the positive scale, and exp2(c*s - c*m) is one FMA + one v_exp_f32
       if (k0 + 64 > seg.nkeys) {        // only the last, partial tile of a segment needs masking (wave-uniform)
@@ -155,25 +221,14 @@ __global__ __launch_bounds__(256) void attention_f16_kernel(const AttnArgs p) {
       lrun += psum;
 
       // ---- O^T[d][q] += V^T[d][key] . P^T[key][q]; k-step (kh,s2): slot (hh, j) <-> key 32kh + 16s2 + 8(j>>2) + 4hh + (j&3)
-      const int gi = (lane >> 4) & 1, li = lane & 15;
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          const int kb0 = kh * 32 + s2 * 16 + 4 * hh + (li >> 2);   // row this lane addresses for j<4
+        for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-          for (int d = 0; d < 2; ++d) {
-            const int col = d * 32 + gi * 16 + 4 * (li & 3);          // first of 4 contiguous d this lane addresses
-            const int pos = col >> 3, sub = (col & 7) * 2;
-            const int r0 = kb0, r1 = kb0 + 8;
-            const fp16x4 lo = lds_tr16(sVt + r0 * 128 + ((pos ^ (((r0 >> 1) & 1) << 2)) << 4) + sub);
-            const fp16x4 hi = lds_tr16(sVt + r1 * 128 + ((pos ^ (((r1 >> 1) & 1) << 2)) << 4) + sub);
-            h8 vf;
-            vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-            vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
-            o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kh][s2], o[d], 0, 0, 0);
-          }
-        }
+          for (int d = 0; d < 2; ++d)
+            o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[kh][s2][d], pf[kh][s2], o[d], 0, 0, 0);
       }   // tiles of the super-tile
     }
     const float l = lrun + __shfl_xor(lrun, 32, 64);
