@@ -124,15 +124,15 @@ struct Arena {            // deterministic first-fit allocator over [0, cap)
 
 struct ProfRec { hipEvent_t e0, e1; int k; double flops, bytes; };
 // profile classes = device kernel names as rocprofv3 prints them (template arguments included)
-enum { PK_GEMM0 = 0, PK_CONV0 = 6, PK_ATTN = 12, PK_GN, PK_LN, PK_EMBED, PK_CONV_IN, PK_CONV_OUT, PK_CONCAT, PK_NCLASS };
+enum { PK_GEMM0 = 0, PK_CONV0 = 8, PK_ATTN = 16, PK_GN, PK_LN, PK_EMBED, PK_CONV_IN, PK_CONV_OUT, PK_CONCAT, PK_NCLASS };
 static const char* prof_name(int k) {
   static char buf[PK_NCLASS][64];
   static const char* const other[] = {"attention_f16_kernel", "gn_stats_kernel+gn_apply_kernel", "layernorm_kernel",
                                       "embed_kernel+linear_small_kernel", "conv_in_kernel", "conv_out_kernel", "concat_kernel"};
   if (k >= PK_ATTN) return other[k - PK_ATTN];
-  static const int bm[3] = {128, 128, 64}, bn[3] = {128, 64, 64};
-  const int v = k % 6;
-  snprintf(buf[k], sizeof buf[k], "gemm_f16_kernel<%d, %d, %d, %s>", bm[v / 2], bn[v / 2], v % 2 + 2, k >= PK_CONV0 ? "true" : "false");
+  static const int bm[8] = {128, 128, 128, 128, 64, 64, 256, 256}, bn[8] = {128, 128, 64, 64, 64, 64, 128, 320}, st[8] = {2, 3, 2, 3, 2, 3, 2, 2};
+  const int v = k % 8;
+  snprintf(buf[k], sizeof buf[k], "gemm_f16_kernel<%d, %d, %d, %s>", bm[v], bn[v], st[v], k >= PK_CONV0 ? "true" : "false");
   return buf[k];
 }
 

@@ -14,6 +14,10 @@
 // columns of one row (8-byte epilogue stores/loads along N).
 #include "common.h"
 
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
 #define GLDS16(gptr, ldsptr)                                                                         \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),            \
                                    (__attribute__((address_space(3))) void*)(ldsptr), 16, 0, 0)
@@ -256,12 +260,34 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
 static int g_force_variant = -1;   // test/tuning hook (ia2p_debug_set_gemm_tile)
 extern "C" void ia2p_debug_set_gemm_tile(int v) { g_force_variant = v; }
 
+// tuning hook: IA2P_GEMM_RULES="MxNxK=variant;..." overrides the choice for exact shapes (in-situ A/B runs of bench.py)
+struct ShapeRule { int M, N, K, v; };
+static const std::vector<ShapeRule>& shape_rules() {
+  static std::vector<ShapeRule> rules = [] {
+    std::vector<ShapeRule> r;
+    if (const char* e = getenv("IA2P_GEMM_RULES")) {
+      const char* p = e;
+      while (*p) {
+        ShapeRule x;
+        int n = 0;
+        if (sscanf(p, "%dx%dx%d=%d%n", &x.M, &x.N, &x.K, &x.v, &n) == 4) { r.push_back(x); p += n; }
+        while (*p && *p != ';') ++p;
+        if (*p == ';') ++p;
+      }
+    }
+    return r;
+  }();
+  return rules;
+}
+
 template <bool CONV>
 static hipError_t launch_any(const GemmArgs& a, hipStream_t s, int* picked) {
   auto tiles = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
-  int v;
+  int v = -1;
+  for (const ShapeRule& r : shape_rules())
+    if (r.M == a.M && r.N == a.N && r.K == a.K) v = r.v;
   if (g_force_variant >= 0) v = g_force_variant;
-  else {
+  if (v < 0) {
     int tile;
     if (a.M <= 64) tile = 2;
     else if (tiles(128, 128) >= 384) tile = (a.N % 128 != 0 && a.N % 64 == 0) ? 1 : 0;   // N = 320: exact 5 x 64 columns
