@@ -110,7 +110,7 @@ def main():
     rank, world, local = D.init_distributed()
     if world != args.gpus:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}")
-    dev = torch.device(f"cuda:{local}")
+    dev = torch.device(f"cuda:{os.environ.get('IA2P_FORCE_DEVICE', local)}")     # (override: tests with several ranks on one GPU)
     torch.cuda.set_device(dev)
     cfg = sdxl_base()
     seed = 7

@@ -1,0 +1,46 @@
+"""Two ranks sharing ONE GPU (gloo transport): rank 0 loads weights, the flat arena is broadcast, rank 1 adopts it;
+both evaluate their own shard of a request batch and the gathered result must equal the single-process result
+bit for bit. Launched by tests/test_unet_gpu.py::test_two_ranks_broadcast_and_shard through torch.distributed.run."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["IA2P_DIST_BACKEND"] = "gloo"
+from instructany2pix_amd import dist as D
+from instructany2pix_amd.config import tiny
+from instructany2pix_amd.unet import HipUNet2DConditionModel
+from instructany2pix_amd.weights import unet_param_specs, ip_adapter_specs, synthetic_state_dict
+
+rank, world, _ = D.init_distributed()
+dev = torch.device("cuda:0")
+cfg = tiny()
+unet = HipUNet2DConditionModel(cfg, dev)
+ipsd = synthetic_state_dict(ip_adapter_specs(cfg, 64)["ip_adapter"], seed=7)
+if rank == 0:
+    unet.load_state_dict(synthetic_state_dict(unet_param_specs(cfg), seed=7))
+    unet.load_ip_adapter_weights(ipsd, scale=0.9, num_tokens=4)
+host = unet.arena.cpu()                      # gloo moves host memory; RCCL would broadcast unet.arena itself
+D.broadcast_flat(host, src=0, chunk_bytes=16 << 20)
+if rank != 0:
+    unet.arena.copy_(host)
+    unet.adopt_arena()
+    unet.load_ip_adapter_weights([], scale=0.9, num_tokens=4)
+g = torch.Generator().manual_seed(3)
+B = 4
+x = torch.randn(B, 4, 16, 16, generator=g).half().to(dev)
+ctx = torch.randn(B, 81, cfg.cross_attention_dim, generator=g).half().to(dev)
+te = torch.randn(B, cfg.pooled_dim, generator=g).half().to(dev)
+tid = torch.tensor([[128.0, 128, 0, 0, 128, 128]] * B).half().to(dev)
+lo, hi = D.shard_range(B, world, rank)
+out = unet(x[lo:hi].contiguous(), 401, encoder_hidden_states=ctx[lo:hi].contiguous(),
+           added_cond_kwargs=dict(text_embeds=te[lo:hi].contiguous(), time_ids=tid[lo:hi].contiguous()))[0]
+allo = D.gather_batches(out.cpu())
+if rank == 0:
+    full = unet(x, 401, encoder_hidden_states=ctx, added_cond_kwargs=dict(text_embeds=te, time_ids=tid))[0].cpu()
+    # per-request results do not depend on which rank (or which batch position) computed them
+    assert torch.equal(allo, full), float((allo.float() - full.float()).abs().max())
+    print("DIST_OK")
+D.barrier()
+torch.distributed.destroy_process_group()

@@ -224,3 +224,15 @@ def test_sdxl_base_full_size_forward_vs_oracle():
     with torch.no_grad():
         ref2 = ref_net(x.float(), 621, ctx[:, :77].float(), added_cond_kwargs=dict(text_embeds=te.float(), time_ids=tid.float()))[0]
     assert rel_l2(out2, ref2) < 5e-3, rel_l2(out2, ref2)
+
+
+def test_two_ranks_broadcast_and_shard():
+    """world_size 2 on one GPU: weight-arena broadcast, adopt on rank 1, batch sharding, bit-identical gather."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "tests", "dist_two_ranks_one_gpu.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=root)
+    assert r.returncode == 0 and "DIST_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
