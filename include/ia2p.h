@@ -101,6 +101,9 @@ ia2p_status ia2p_layernorm(void* stream, const void* x, void* y, const void* gam
 /* C[M,N] = A[M,K] . W[N,K]^T + bias + residual ; geglu: W/bias packed by ia2p_pack_geglu, C is [M, N/2] */
 ia2p_status ia2p_gemm(void* stream, const void* A, const void* W, const void* bias, const void* residual, void* C,
                       int M, int N, int K, int geglu);
+/* same with K split over `splitk` workgroups per tile; partial holds splitk*M*N floats (deterministic slab reduce) */
+ia2p_status ia2p_gemm_splitk(void* stream, const void* A, const void* W, const void* bias, const void* residual, void* C,
+                             int M, int N, int K, int splitk, float* partial);
 /* 3x3 conv, pad 1, over channels-last x[B,Hs,Ws,Cin] with W packed [Co][3][3][Cin] (ia2p_pack_conv3x3);
  * stride 1|2; up=1 convolves the nearest-x2 upsampled x; rowvec [B,Co] (time embedding) and residual optional. */
 ia2p_status ia2p_conv3x3(void* stream, const void* x, const void* Wp, const void* bias, const void* rowvec, const void* residual,
@@ -115,6 +118,7 @@ ia2p_status ia2p_attention(void* stream, const void* Q, int ldq, void* O, int ld
 ia2p_status ia2p_linear_small(void* stream, const void* X, const void* W, const void* bias, void* out, int M, int N, int K,
                               int silu_in, int silu_out);
 
+void ia2p_debug_set_gemm_splitk(int splitk);  /* -1 auto (tests / tuning; engine path only) */
 void ia2p_debug_set_gemm_tile(int variant);   /* -1 auto; else tile*2 + (stages-2), tile 0: 128x128, 1: 128x64, 2: 64x64, stages 2..3 (tests / tuning) */
 
 /* ---- per-kernel timing (bench.py roofline leg): HIP events on the launch stream around each launch ------------------

@@ -45,6 +45,8 @@ SIGNATURES = {
     "ia2p_groupnorm_silu": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
     "ia2p_layernorm": (_I, [_P, _P, _P, _P, _P, _I, _I, _F]),
     "ia2p_gemm": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I]),
+    "ia2p_gemm_splitk": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ia2p_debug_set_gemm_splitk": (None, [_I]),
     "ia2p_conv3x3": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I]),
     "ia2p_pack_conv3x3": (_I, [_P, _P, _P, _I, _I]),
     "ia2p_pack_geglu": (_I, [_P, _P, _P, _I, _I]),

@@ -58,7 +58,14 @@ struct GemmArgs {
   const void* pf;        // or null
   long pf_bytes;
   int pf_blocks;
+  // split-K: `splitk` workgroups per tile each own a contiguous K range and write fp32 slabs partial[s][M][N];
+  // splitk_reduce_kernel then sums them in slab order (deterministic) and applies the epilogue
+  int splitk;            // 0/1 = off
+  float* partial;
 };
+
+struct GemmPlan { int variant; int splitk; };
+GemmPlan ia2p_gemm_plan(int M, int N, int K, bool conv, bool geglu);
 
 struct AttnSeg {
   const half_t* K;       // key rows:   K + ((b * rows_per_batch + r) * ld) + head*64

@@ -130,7 +130,7 @@ static const char* prof_name(int k) {
   static const char* const other[] = {"attention_f16_kernel", "gn_stats_kernel+gn_apply_kernel", "layernorm_kernel",
                                       "embed_kernel+linear_small_kernel", "conv_in_kernel", "conv_out_kernel", "concat_kernel"};
   if (k >= PK_ATTN) return other[k - PK_ATTN];
-  static const int bm[8] = {128, 128, 128, 128, 64, 64, 256, 256}, bn[8] = {128, 128, 64, 64, 64, 64, 128, 320}, st[8] = {2, 3, 2, 3, 2, 3, 2, 2};
+  static const int bm[8] = {128, 128, 128, 128, 64, 64, 256, 256}, bn[8] = {128, 128, 64, 64, 64, 64, 128, 320}, st[8] = {2, 3, 2, 3, 2, 3, 3, 2};
   const int v = k % 8;
   snprintf(buf[k], sizeof buf[k], "gemm_f16_kernel<%d, %d, %d, %s>", bm[v], bn[v], st[v], k >= PK_CONV0 ? "true" : "false");
   return buf[k];
@@ -413,6 +413,10 @@ static void op_gemm(ia2p_ctx* c, const half_t* A, int lda, const half_t* W, cons
   a.rows_per_batch = 1;
   a.m_fastest = (long)M * K <= (long)N * K ? 1 : 0;
   set_prefetch(c, a, W, (size_t)N * K * sizeof(half_t));
+  const GemmPlan pl = ia2p_gemm_plan(M, N, K, false, geglu != 0);
+  T2 slab{(size_t)-1, nullptr};
+  if (pl.splitk > 1) { slab = wsalloc(c, (size_t)pl.splitk * M * N * 2); a.splitk = pl.splitk; a.partial = (float*)slab.p; }
+  struct Rel { ia2p_ctx* c; T2 t; ~Rel() { wsfree(c, t); } } rel{c, slab};
   ProfScope ps(c, PK_GEMM0, 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * (geglu ? N / 2 : N) + (residual ? (double)M * N : 0)));
   int pick = 0;
   CHECK_LAUNCH(c, ia2p_launch_gemm(a, false, c->stream, &pick), "gemm");
@@ -429,6 +433,10 @@ static void op_conv3(ia2p_ctx* c, const half_t* X, int B, int Hs, int Ws, int Ci
   a.bias = bias; a.rowvec = rowvec; a.rowvec_ld = rowvec_ld; a.rows_per_batch = a.Ho * a.Wo; a.residual = residual; a.ldr = Co;
   a.m_fastest = 0;
   set_prefetch(c, a, W, (size_t)Co * a.K * sizeof(half_t));
+  const GemmPlan pl = ia2p_gemm_plan(a.M, a.N, a.K, true, false);
+  T2 slab{(size_t)-1, nullptr};
+  if (pl.splitk > 1) { slab = wsalloc(c, (size_t)pl.splitk * a.M * a.N * 2); a.splitk = pl.splitk; a.partial = (float*)slab.p; }
+  struct Rel { ia2p_ctx* c; T2 t; ~Rel() { wsfree(c, t); } } rel{c, slab};
   ProfScope ps(c, PK_CONV0, 2.0 * a.M * (double)Co * a.K, 2.0 * ((double)B * Hs * Ws * Cin + (double)Co * a.K + (double)a.M * Co + (residual ? (double)a.M * Co : 0)));
   int pick = 0;
   CHECK_LAUNCH(c, ia2p_launch_gemm(a, true, c->stream, &pick), "conv3x3");
@@ -827,6 +835,18 @@ ia2p_status ia2p_gemm(void* stream, const void* A, const void* W, const void* bi
   a.m_fastest = M <= N;
   hipError_t e = ia2p_launch_gemm(a, false, (hipStream_t)stream, nullptr);
   RET_HIP(e, "gemm");
+}
+ia2p_status ia2p_gemm_splitk(void* stream, const void* A, const void* W, const void* bias, const void* residual, void* C, int M, int N, int K,
+                             int splitk, float* partial) {
+  if (!A || !W || !C || !partial) return fail(nullptr, IA2P_ERR_INVALID, "gemm_splitk: null argument");
+  if (K % 64 || N % 4 || splitk < 1 || splitk > K / 64) return fail(nullptr, IA2P_ERR_SHAPE, "gemm_splitk: K=%d N=%d splitk=%d", K, N, splitk);
+  GemmArgs a;
+  memset(&a, 0, sizeof a);
+  a.A = (const half_t*)A; a.W = (const half_t*)W; a.C = (half_t*)C; a.zero = zero_page(); a.M = M; a.N = N; a.K = K; a.lda = K; a.ldc = N;
+  a.bias = (const half_t*)bias; a.residual = (const half_t*)residual; a.ldr = N; a.rows_per_batch = 1; a.m_fastest = M <= N;
+  a.splitk = splitk; a.partial = partial;
+  hipError_t e = ia2p_launch_gemm(a, false, (hipStream_t)stream, nullptr);
+  RET_HIP(e, "gemm_splitk");
 }
 ia2p_status ia2p_conv3x3(void* stream, const void* x, const void* Wp, const void* bias, const void* rowvec, const void* residual, void* y,
                          int B, int Hs, int Ws, int Cin, int Co, int stride, int up) {

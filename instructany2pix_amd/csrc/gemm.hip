@@ -14,6 +14,7 @@
 // columns of one row (8-byte epilogue stores/loads along N).
 #include "common.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -45,9 +46,13 @@ __global__ __launch_bounds__(WGM * 128) void gemm_f16_kernel(const GemmArgs p) {
   // ---- tile of this workgroup; blocks b, b+8, ... share an XCD (its L2): give each XCD a contiguous tile range
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
   int bid = blockIdx.x;
-  if (bid >= tiles_m * tiles_n) {   // prefetch workgroup: touch its slice of the next kernel's weights and leave
+  const int nsplit = p.splitk > 1 ? p.splitk : 1;
+  const int split = bid / (tiles_m * tiles_n);          // >= nsplit: prefetch workgroup
+  if (split < nsplit) bid -= split * tiles_m * tiles_n;
+  if (split >= nsplit) {   // prefetch workgroup: touch its slice of the next kernel's weights and leave
+    bid -= nsplit * tiles_m * tiles_n;
     const long per = ((p.pf_bytes + p.pf_blocks - 1) / p.pf_blocks + 4095) & ~4095L;
-    const long lo = (long)(bid - tiles_m * tiles_n) * per, hi = min(lo + per, p.pf_bytes & ~15L);
+    const long lo = (long)bid * per, hi = min(lo + per, p.pf_bytes & ~15L);
     const char* src = (const char*)p.pf;
     unsigned acc = 0;
     constexpr long SW = NWAVE * 64 * 16;   // bytes swept by the workgroup per pass
@@ -111,7 +116,9 @@ __global__ __launch_bounds__(WGM * 128) void gemm_f16_kernel(const GemmArgs p) {
   }
 
   const int Hv = p.Hs << p.up, Wv = p.Ws << p.up;
-  int tap = 0, ci0 = 0;  // conv: position of the k-tile being staged
+  const int nk_all = p.K >> 6;
+  const int kt0 = (int)((long)split * nk_all / nsplit), kt1 = (int)((long)(split + 1) * nk_all / nsplit);   // this workgroup's k-tiles
+  int tap = (kt0 * 64) / (CONV ? p.Cin : 64), ci0 = CONV ? (kt0 * 64) % p.Cin : 0;  // conv: position of the k-tile being staged
 
   auto stage = [&](int kt, int buf) {
     char* sA = smem + buf * STAGE + wave * (A_PW * 1024);
@@ -129,10 +136,10 @@ __global__ __launch_bounds__(WGM * 128) void gemm_f16_kernel(const GemmArgs p) {
       if (ci0 >= p.Cin) { ci0 = 0; ++tap; }
     } else {
 #pragma unroll
-      for (int i = 0; i < A_PW; ++i) GLDS16(a_ptr[i] + (size_t)kt * a_inc[i], sA + i * 1024);
+      for (int i = 0; i < A_PW; ++i) GLDS16(a_ptr[i] + (size_t)(kt0 + kt) * a_inc[i], sA + i * 1024);
     }
 #pragma unroll
-    for (int i = 0; i < B_PW; ++i) GLDS16(w_ptr[i] + (size_t)kt * w_inc[i], sB + i * 1024);
+    for (int i = 0; i < B_PW; ++i) GLDS16(w_ptr[i] + (size_t)(kt0 + kt) * w_inc[i], sB + i * 1024);
   };
 
   // ---- fragment read offsets (wave tile origin is a multiple of 16, so swz(row) = (lane>>1)&7)
@@ -147,7 +154,7 @@ __global__ __launch_bounds__(WGM * 128) void gemm_f16_kernel(const GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < NR; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
 
-  const int nk = p.K >> 6;
+  const int nk = kt1 - kt0;
   constexpr int LPS = A_PW + B_PW;   // LDS-DMA pieces this wave issues per k-tile
   // NSTAGE-deep LDS ring: tiles kt+1 .. kt+NSTAGE-2 stay in flight across the barrier of step kt (counted vmcnt,
   // raw s_barrier -- cdna_hip_programming.md §5 "Pipelining across barriers"); ONE barrier per k-step.
@@ -203,6 +210,20 @@ __global__ __launch_bounds__(WGM * 128) void gemm_f16_kernel(const GemmArgs p) {
   }
 
   // ---- epilogue: acc[i][j][r] = C[m = bm0+wm0+16i+(lane&15)][n = bn0+wn0+16j+4*(lane>>4)+r]
+  if (nsplit > 1) {      // raw fp32 slab of this K range; splitk_reduce_kernel finishes
+    float* slab = p.partial + (size_t)split * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+      const int m = bm0 + wm0 + i * 16 + frow;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        const int n = bn0 + wn0 + j * 16 + fq * 4;
+        if (n < p.N) *(f4*)(slab + (size_t)m * p.N + n) = acc[i][j];
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < MR; ++i) {
     const int m = bm0 + wm0 + i * 16 + frow;
@@ -248,7 +269,7 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
   }
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   const int extra = (a.pf && a.pf_bytes >= 4096) ? a.pf_blocks : 0;
-  hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, NSTAGE, CONV, WGM>), dim3(tiles + extra), dim3(WGM * 128), smem, s, a);
+  hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, NSTAGE, CONV, WGM>), dim3(tiles * (a.splitk > 1 ? a.splitk : 1) + extra), dim3(WGM * 128), smem, s, a);
   return hipGetLastError();
 }
 
@@ -280,36 +301,84 @@ static const std::vector<ShapeRule>& shape_rules() {
   return rules;
 }
 
-template <bool CONV>
-static hipError_t launch_any(const GemmArgs& a, hipStream_t s, int* picked) {
-  auto tiles = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn); };
-  int v = -1;
-  for (const ShapeRule& r : shape_rules())
-    if (r.M == a.M && r.N == a.N && r.K == a.K) v = r.v;
-  if (g_force_variant >= 0) v = g_force_variant;
-  if (v < 0) {
-    int tile;
-    if (a.M <= 64) tile = 2;
-    else if (tiles(128, 128) >= 384) tile = (a.N % 128 != 0 && a.N % 64 == 0) ? 1 : 0;   // N = 320: exact 5 x 64 columns
-    else if (tiles(128, 64) >= 512) tile = 1;
-    else tile = 2;
-    v = tile * 2;
-    // (a 3-deep ring of 128x64 tiles for the long-K ff.net.2 measured 50 us in situ vs 46 us for 64x64 x2: not used)
-  }
-  if (picked) *picked = v;
-  switch (v) {
-    case 0: return launch_cfg<128, 128, 2, CONV>(a, s);
-    case 1: return launch_cfg<128, 128, 3, CONV>(a, s);
-    case 2: return launch_cfg<128, 64, 2, CONV>(a, s);
-    case 3: return launch_cfg<128, 64, 3, CONV>(a, s);
-    case 4: return launch_cfg<64, 64, 2, CONV>(a, s);
-    case 5: return launch_cfg<64, 64, 3, CONV>(a, s);
-    case 6: return launch_cfg<256, 128, 2, CONV, 4>(a, s);     // 8 waves, 85 FLOP per L2 byte
-    default: return launch_cfg<256, 320, 2, CONV, 4>(a, s);    // 8 waves, one workgroup per CU, 142 FLOP per L2 byte
+// C[m,n] = sum_s partial[s][m][n] + bias + rowvec + residual, fixed summation order
+__global__ void splitk_reduce_kernel(const GemmArgs p) {
+  const long total = (long)p.M * (p.N >> 2);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int m = (int)(i / (p.N >> 2)), n = (int)(i - (long)m * (p.N >> 2)) * 4;
+    f4 v = *(const f4*)(p.partial + (size_t)m * p.N + n);
+    for (int s = 1; s < p.splitk; ++s) {
+      const f4 w = *(const f4*)(p.partial + ((size_t)s * p.M + m) * p.N + n);
+      v[0] += w[0]; v[1] += w[1]; v[2] += w[2]; v[3] += w[3];
+    }
+    if (p.bias) { const h4 b = *(const h4*)(p.bias + n); v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3]; }
+    if (p.rowvec) { const h4 b = *(const h4*)(p.rowvec + (size_t)(m / p.rows_per_batch) * p.rowvec_ld + n); v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3]; }
+    if (p.residual) { const h4 b = *(const h4*)(p.residual + (size_t)m * p.ldr + n); v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3]; }
+    h4 o; o[0] = (half_t)v[0]; o[1] = (half_t)v[1]; o[2] = (half_t)v[2]; o[3] = (half_t)v[3];
+    *(h4*)(p.C + (size_t)m * p.ldc + n) = o;
   }
 }
 
-// *picked (optional) receives the variant id (see launch_any)
+static int g_force_splitk = -1;    // test/tuning hook
+extern "C" void ia2p_debug_set_gemm_splitk(int s) { g_force_splitk = s; }
+
+// Tile variant and split-K factor for a problem. Pure function of the shape (the executor sizes its workspace with it).
+GemmPlan ia2p_gemm_plan(int M, int N, int K, bool conv, bool geglu) {
+  auto tiles = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
+  GemmPlan pl{-1, 1};
+  for (const ShapeRule& r : shape_rules())
+    if (r.M == M && r.N == N && r.K == K) pl.variant = r.v;
+  if (g_force_variant >= 0) pl.variant = g_force_variant;
+  const int nk = K / 64;
+  if (pl.variant < 0) {
+    int tile;
+    if (M <= 64) tile = 2;
+    else if (tiles(128, 128) >= 384) tile = (N % 128 != 0 && N % 64 == 0) ? 1 : 0;   // N = 320: exact 5 x 64 columns
+    else if (tiles(128, 64) >= 512) tile = 1;
+    else tile = 2;
+    pl.variant = tile * 2;
+    // long-K problems with too few tiles to fill 256 CUs: split K over workgroups (deterministic slab reduce).
+    //  * 3x3 convs at 16x16 (2048 x 1280 x 11520..23040): 160 tiles of 128x128, 3 K-slices each
+    //  * small-batch projections (M <= 512): 64x64 tiles, K sliced so that >= ~256 workgroups exist
+    if (!geglu) {
+      if (conv && tiles(128, 128) >= 96 && tiles(128, 128) < 256 && nk >= 96) { pl.variant = 0; pl.splitk = 3; }
+      else if (tiles(64, 64) < 160 && nk >= 16) {
+        int s = (int)std::min<long>(8, (320 + tiles(64, 64) - 1) / tiles(64, 64));
+        while (s > 1 && nk / s < 4) --s;
+        pl.variant = 4; pl.splitk = s;
+      }
+    }
+  }
+  if (g_force_splitk >= 1 && !geglu) pl.splitk = g_force_splitk;
+  if (pl.splitk > nk) pl.splitk = nk;
+  if (pl.splitk < 1) pl.splitk = 1;
+  return pl;
+}
+
+template <bool CONV>
+static hipError_t launch_any(const GemmArgs& a, hipStream_t s, int* picked) {
+  const GemmPlan pl = ia2p_gemm_plan(a.M, a.N, a.K, CONV, a.geglu != 0);
+  const int v = pl.variant;
+  if (a.splitk > 1 && !a.partial) return hipErrorInvalidValue;
+  if (picked) *picked = v;
+  hipError_t e;
+  switch (v) {
+    case 0: e = launch_cfg<128, 128, 2, CONV>(a, s); break;
+    case 1: e = launch_cfg<128, 128, 3, CONV>(a, s); break;
+    case 2: e = launch_cfg<128, 64, 2, CONV>(a, s); break;
+    case 3: e = launch_cfg<128, 64, 3, CONV>(a, s); break;
+    case 4: e = launch_cfg<64, 64, 2, CONV>(a, s); break;
+    case 5: e = launch_cfg<64, 64, 3, CONV>(a, s); break;
+    case 6: e = launch_cfg<256, 128, 3, CONV, 4>(a, s); break;     // experimental: 8 waves, 3-deep ring, 1 block/CU
+    default: e = launch_cfg<256, 320, 2, CONV, 4>(a, s); break;    // experimental: 8 waves, one workgroup per CU
+  }
+  if (e != hipSuccess || a.splitk <= 1) return e;
+  const long total = (long)a.M * (a.N >> 2);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)std::min<long>(2048, (total + 255) / 256)), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// *picked (optional) receives the variant id. a.splitk / a.partial must follow ia2p_gemm_plan (the caller owns the slabs).
 hipError_t ia2p_launch_gemm(const GemmArgs& a, bool conv, hipStream_t s, int* picked) {
   return conv ? launch_any<true>(a, s, picked) : launch_any<false>(a, s, picked);
 }

@@ -61,6 +61,20 @@ def test_gemm_bias_residual(L, M, N, K, tile):
         assert torch.equal(out, A)
 
 
+@pytest.mark.parametrize("M,N,K,S", [(256, 1280, 5120, 8), (256, 1280, 1280, 4), (2048, 1280, 11520, 3), (77, 192, 640, 5), (300, 64, 128, 2)])
+def test_gemm_splitk_deterministic(L, M, N, K, S):
+    f = _ffi()
+    A, W, b, R = rnd(M, K, seed=41), rnd(N, K, seed=42, scale=K ** -0.5), rnd(N, seed=43), rnd(M, N, seed=44)
+    out, out2 = torch.empty(M, N, dtype=torch.half, device="cuda"), torch.empty(M, N, dtype=torch.half, device="cuda")
+    part = torch.empty(S * M * N, dtype=torch.float32, device="cuda")
+    run(L, "ia2p_gemm_splitk", f.ptr(A), f.ptr(W), f.ptr(b), f.ptr(R), f.ptr(out), M, N, K, S, C.c_void_p(part.data_ptr()))
+    ref = A.float() @ W.float().t() + b.float() + R.float()
+    assert rel_l2(out, ref) < 1e-3, rel_l2(out, ref)
+    part.fill_(float("nan"))                         # slabs are fully rewritten; summation order is fixed -> same bits
+    run(L, "ia2p_gemm_splitk", f.ptr(A), f.ptr(W), f.ptr(b), f.ptr(R), f.ptr(out2), M, N, K, S, C.c_void_p(part.data_ptr()))
+    assert torch.equal(out, out2)
+
+
 def test_gemm_no_bias_inplace_residual(L):
     f = _ffi()
     M, N, K = 512, 640, 640

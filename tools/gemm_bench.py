@@ -8,9 +8,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from instructany2pix_amd import _ffi
 
 L = _ffi.lib()
-VARS = [int(v) for v in os.environ.get("VARIANTS", "0,2,3,4").split(",")]
+VARS = [int(v) for v in os.environ.get("VARIANTS", "0,6").split(",")]
 NAMES = {v: f"{[128,128,64][v//2]}x{[128,64,64][v//2]}s{v%2+2}" for v in range(6)}
-NAMES[6] = "256x128s2"
+NAMES[6] = "256x128s3"
 NAMES[7] = "256x320s2"
 LIN = [  # (M, N, K, count/step, label)
     (2048, 3840, 1280, 60, "L2 qkv"), (2048, 1280, 1280, 192, "L2 proj"), (2048, 10240, 1280, 60, "L2 ff-in(geglu)"),
