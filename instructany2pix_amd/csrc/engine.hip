@@ -132,7 +132,7 @@ static const char* prof_name(int k) {
   if (k >= PK_ATTN) return other[k - PK_ATTN];
   static const int bm[8] = {128, 128, 128, 128, 64, 64, 256, 256}, bn[8] = {128, 128, 64, 64, 64, 64, 128, 320}, st[8] = {2, 3, 2, 3, 2, 3, 3, 2};
   const int v = k % 8;
-  snprintf(buf[k], sizeof buf[k], "gemm_f16_kernel<%d, %d, %d, %s>", bm[v], bn[v], st[v], k >= PK_CONV0 ? "true" : "false");
+  snprintf(buf[k], sizeof buf[k], "gemm_f16_kernel<%d, %d, %d, %s, %d>", bm[v], bn[v], st[v], k >= PK_CONV0 ? "true" : "false", v >= 6 ? 4 : 2);
   return buf[k];
 }
 

@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from instructany2pix_amd import _ffi
 
 L = _ffi.lib()
-VARS = [int(v) for v in os.environ.get("VARIANTS", "0,6").split(",")]
+VARS = [int(v) for v in os.environ.get("VARIANTS", "0,2,4").split(",")]
 NAMES = {v: f"{[128,128,64][v//2]}x{[128,64,64][v//2]}s{v%2+2}" for v in range(6)}
 NAMES[6] = "256x128s3"
 NAMES[7] = "256x320s2"
