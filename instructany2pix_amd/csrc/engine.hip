@@ -565,11 +565,19 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
   {
     ProfScope ps(c, PK_EMBED, 0, 0);
     CHECK_LAUNCH(c, ia2p_launch_embed(timestep, text_embeds, time_ids, tsin.p, addin.p, B, Tp, pooled, Ad, 6, c->stream), "embed");
-    CHECK_LAUNCH(c, ia2p_launch_linear_small(tsin.p, Tp, W_(c, c->te1w), W_(c, c->te1b), nullptr, 0, e1.p, T, B, T, Tp, 0, 1, c->stream), "time_embedding.linear_1");
-    CHECK_LAUNCH(c, ia2p_launch_linear_small(e1.p, T, W_(c, c->te2w), W_(c, c->te2b), nullptr, 0, emb0.p, T, B, T, T, 0, 0, c->stream), "time_embedding.linear_2");
-    CHECK_LAUNCH(c, ia2p_launch_linear_small(addin.p, Ain, W_(c, c->ae1w), W_(c, c->ae1b), nullptr, 0, a1.p, T, B, T, Ain, 0, 1, c->stream), "add_embedding.linear_1");
-    CHECK_LAUNCH(c, ia2p_launch_linear_small(a1.p, T, W_(c, c->ae2w), W_(c, c->ae2b), emb0.p, T, emb.p, T, B, T, T, 0, 0, c->stream), "add_embedding.linear_2");
-    CHECK_LAUNCH(c, ia2p_launch_linear_small(emb.p, T, W_(c, c->tw_all), W_(c, c->tb_all), nullptr, 0, f.temb_all.p, c->temb_total, B, c->temb_total, T, 1, 0, c->stream), "time_emb_proj (stacked)");
+    // skinny linears hold <= 16 rows per launch: larger batches go in row chunks
+    auto lin = [&](const half_t* X, int ldx, size_t w, size_t b, const half_t* add, int ldadd, half_t* o, int ldo, int N, int K, int si, int so, const char* what) {
+      for (int r0 = 0; r0 < B; r0 += 16) {
+        const int rows = std::min(16, B - r0);
+        CHECK_LAUNCH(c, ia2p_launch_linear_small(c->dry ? nullptr : X + (size_t)r0 * ldx, ldx, W_(c, w), W_(c, b), (c->dry || !add) ? nullptr : add + (size_t)r0 * ldadd, ldadd,
+                                                 c->dry ? nullptr : o + (size_t)r0 * ldo, ldo, rows, N, K, si, so, c->stream), what);
+      }
+    };
+    lin(tsin.p, Tp, c->te1w, c->te1b, nullptr, 0, e1.p, T, T, Tp, 0, 1, "time_embedding.linear_1");
+    lin(e1.p, T, c->te2w, c->te2b, nullptr, 0, emb0.p, T, T, T, 0, 0, "time_embedding.linear_2");
+    lin(addin.p, Ain, c->ae1w, c->ae1b, nullptr, 0, a1.p, T, T, Ain, 0, 1, "add_embedding.linear_1");
+    lin(a1.p, T, c->ae2w, c->ae2b, emb0.p, T, emb.p, T, T, T, 0, 0, "add_embedding.linear_2");
+    lin(emb.p, T, c->tw_all, c->tb_all, nullptr, 0, f.temb_all.p, c->temb_total, c->temb_total, T, 1, 0, "time_emb_proj (stacked)");
   }
   wsfree(c, tsin); wsfree(c, addin); wsfree(c, e1); wsfree(c, emb0); wsfree(c, a1); wsfree(c, emb);
 
@@ -757,7 +765,7 @@ ia2p_status ia2p_set_ip_adapter(ia2p_ctx* c, int enabled, int num_tokens, float 
 }
 
 static ia2p_status check_fwd_shape(ia2p_ctx* c, int B, int h, int w, int L) {
-  if (B < 1 || B > 16) return fail(c, IA2P_ERR_SHAPE, "batch %d outside 1..16 (embedding kernels hold <=16 rows)", B);
+  if (B < 1 || B > 1024) return fail(c, IA2P_ERR_SHAPE, "batch %d outside 1..1024", B);
   const int div = 1 << (c->cfg.n_blocks - 1);
   if (h < div || w < div || h % div || w % div) return fail(c, IA2P_ERR_SHAPE, "latent %dx%d must be divisible by %d", h, w, div);
   if (L < 1) return fail(c, IA2P_ERR_SHAPE, "context length %d", L);

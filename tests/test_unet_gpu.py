@@ -53,7 +53,7 @@ def _inputs(cfg, B, h, w, L, seed):
 
 
 @pytest.mark.parametrize("B,h,w,L,ip,t", [(2, 16, 16, 81, True, 981), (1, 16, 16, 77, False, 1), (2, 16, 24, 77, True, 501),
-                                          (3, 8, 8, 20, False, 261), (2, 32, 32, 81, True, 741)])
+                                          (3, 8, 8, 20, False, 261), (2, 32, 32, 81, True, 741), (20, 8, 8, 9, True, 61)])
 def test_unet_forward_vs_oracle(tiny_models, B, h, w, L, ip, t):
     cfg, sd, ipsd, hip, oracle = tiny_models
     x, ctx, te, tid = _inputs(cfg, B, h, w, L, seed=B * 100 + L)
