@@ -119,27 +119,41 @@ __global__ __launch_bounds__(WGM * 128) void gemm_f16_kernel(const GemmArgs p) {
   const int nk_all = p.K >> 6;
   const int kt0 = (int)((long)split * nk_all / nsplit), kt1 = (int)((long)(split + 1) * nk_all / nsplit);   // this workgroup's k-tiles
   int tap = (kt0 * 64) / (CONV ? p.Cin : 64), ci0 = CONV ? (kt0 * 64) % p.Cin : 0;  // conv: position of the k-tile being staged
+  bool tap_fresh = true;
+  if (kt0) {             // split-K: this workgroup starts at k-tile kt0
+    if (!CONV) {
+#pragma unroll
+      for (int i = 0; i < A_PW; ++i) a_ptr[i] += (size_t)kt0 * a_inc[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_PW; ++i) w_ptr[i] += (size_t)kt0 * w_inc[i];
+  }
 
   auto stage = [&](int kt, int buf) {
     char* sA = smem + buf * STAGE + wave * (A_PW * 1024);
     char* sB = smem + buf * STAGE + BM * 128 + wave * (B_PW * 1024);
     if (CONV) {
-      const int ky = tap / 3, kx = tap - ky * 3;
+      if (tap_fresh) {        // (wave-uniform) new filter tap: re-derive the gathered pixel of each row once per Cin/64 k-steps
+        const int ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
-      for (int i = 0; i < A_PW; ++i) {
-        const int iy = a_y[i] + ky, ix = a_x[i] + kx;
-        const bool ok = (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
-        const half_t* src = p.A + (size_t)(a_pix[i] + (iy >> p.up) * p.Ws + (ix >> p.up)) * p.lda + ci0 + a_ch[i];
-        GLDS16(ok ? src : p.zero, sA + i * 1024);
+        for (int i = 0; i < A_PW; ++i) {
+          const int iy = a_y[i] + ky, ix = a_x[i] + kx;
+          const bool ok = (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
+          a_ptr[i] = ok ? p.A + (size_t)(a_pix[i] + (iy >> p.up) * p.Ws + (ix >> p.up)) * p.lda + ci0 + a_ch[i] : p.zero;
+          a_inc[i] = ok ? 64 : 0;
+        }
+        tap_fresh = false;
       }
+#pragma unroll
+      for (int i = 0; i < A_PW; ++i) { GLDS16(a_ptr[i], sA + i * 1024); a_ptr[i] += a_inc[i]; }
       ci0 += 64;
-      if (ci0 >= p.Cin) { ci0 = 0; ++tap; }
+      if (ci0 >= p.Cin) { ci0 = 0; ++tap; tap_fresh = true; }
     } else {
 #pragma unroll
-      for (int i = 0; i < A_PW; ++i) GLDS16(a_ptr[i] + (size_t)(kt0 + kt) * a_inc[i], sA + i * 1024);
+      for (int i = 0; i < A_PW; ++i) { GLDS16(a_ptr[i], sA + i * 1024); a_ptr[i] += a_inc[i]; }   // running pointers: no per-step multiply
     }
 #pragma unroll
-    for (int i = 0; i < B_PW; ++i) GLDS16(w_ptr[i] + (size_t)(kt0 + kt) * w_inc[i], sB + i * 1024);
+    for (int i = 0; i < B_PW; ++i) { GLDS16(w_ptr[i], sB + i * 1024); w_ptr[i] += w_inc[i]; }
   };
 
   // ---- fragment read offsets (wave tile origin is a multiple of 16, so swz(row) = (lane>>1)&7)

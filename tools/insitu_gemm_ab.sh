@@ -1,4 +1,5 @@
-for r in "" "2048x1280x1280=2;2048x1280x5120=2" "2048x1280x1280=3;2048x1280x5120=3" "2048x1280x1280=5;2048x1280x5120=5" "2048x1280x1280=0;2048x1280x5120=0" "2048x1280x1280=1;2048x1280x5120=1"; do
+# in-situ A/B of GEMM variants: IA2P_GEMM_RULES overrides the tile choice for exact MxNxK shapes
+for r in "" "2048x1280x11520=4;2048x1280x17280=4;2048x1280x23040=4"; do
   echo "RULES=$r"
-  IA2P_GEMM_RULES="$r" timeout 200 python bench.py --steps 15 --warmup 3 --no-cpu-baseline 2>&1 | grep -E "false>|ms_per_step" | sed -E 's/.*"ms_per_step": ([0-9.]+).*/ms_per_step \1/' | cut -c1-120
+  IA2P_GEMM_RULES="$r" timeout 200 python bench.py --steps 15 --warmup 3 --no-cpu-baseline 2>&1 | grep -E "true, 2>|ms_per_step" | sed -E 's/.*"ms_per_step": ([0-9.]+).*/ms_per_step \1/' | cut -c1-120
 done
