@@ -152,7 +152,7 @@ class HipUNet2DConditionModel:
 
     # ---- forward -----------------------------------------------------------------------------------------------------
     def workspace_for(self, B: int, h: int, w: int, L: int) -> torch.Tensor:
-        key = (B, h, w, L, self._ip_sig[0] if self._ip_sig else None)
+        key = (B, h, w, L, self._ip_sig[:3] if self._ip_sig else None)     # (ip on/off, scale, tokens)
         if self._ws_key != key:
             n = self._lib.ia2p_workspace_bytes(self._ctx, B, h, w, L)
             if n == 0:

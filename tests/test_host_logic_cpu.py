@@ -1,0 +1,131 @@
+"""Host-side logic of the product package that needs no GPU: scheduler tables and DDIM coefficients (against the
+golden vectors generated from the reference files and against the oracle), parameter inventory, pipeline argument
+checks, config plumbing."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from instructany2pix_amd.config import sdxl_base, tiny
+from instructany2pix_amd.scheduler import DDIMScheduler
+from instructany2pix_amd.weights import attn_processor_names, hidden_size_of, ip_adapter_specs, param_count, unet_param_specs
+
+
+def test_scheduler_tables_match_golden(golden):
+    d = golden("schedule.npz")
+    s = DDIMScheduler()
+    assert np.abs(s.betas.numpy() - d["betas"]).max() < 1e-8
+    assert np.abs(s.alphas_cumprod.numpy() - d["alphas_cumprod"]).max() < 2e-6
+    g = golden("backward_ddim.npz")
+    for n in (20, 25, 50):
+        s.set_timesteps(n)
+        assert np.array_equal(s.timesteps.numpy(), g[f"timesteps{n}"])          # "leading" spacing + offset 1
+        assert np.array_equal(s.timesteps.numpy()[::-1], d[f"ts{n}"])
+    assert float(s.final_alpha_cumprod) == float(s.alphas_cumprod[0])            # set_alpha_to_one = False
+    s2 = DDIMScheduler.from_config(s.config)
+    assert torch.equal(s2.alphas_cumprod, s.alphas_cumprod)
+    with pytest.raises(NotImplementedError):
+        DDIMScheduler(beta_schedule="linear")
+    with pytest.raises(ValueError):
+        s.set_timesteps(2000)
+
+
+def test_inversion_coefficients_reproduce_backward_ddim(golden):
+    """out = c_x*x + c_e*eps with inversion_coeffs == reference _backward_ddim (pnp_pipeline.py:73-85) trajectory."""
+    d = golden("backward_ddim.npz")
+    s = DDIMScheduler()
+    for n in (20, 50):
+        s.set_timesteps(n)
+        lat = torch.from_numpy(d["x0"]).double()
+        prev = None
+        for i, t in enumerate(reversed(s.timesteps.tolist())):
+            a_t = float(s.alphas_cumprod[t])
+            a_p = float(s.alphas_cumprod[prev]) if prev is not None else float(s.final_alpha_cumprod)
+            prev = t
+            cx, ce = DDIMScheduler.inversion_coeffs(a_t, a_p)
+            lat = cx * lat + ce * torch.from_numpy(d["eps"][i]).double()
+            ref = d[f"traj{n}"][i]
+            assert np.abs(lat.numpy() - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max())
+
+
+def test_step_coefficients_match_oracle_step():
+    s, o = DDIMScheduler(), oracle.DDIMSchedulerRef()
+    g = torch.Generator().manual_seed(1)
+    x, e = torch.randn(2, 4, 8, 8, generator=g, dtype=torch.float64), torch.randn(2, 4, 8, 8, generator=g, dtype=torch.float64)
+    for n in (20, 25, 50):
+        s.set_timesteps(n); o.set_timesteps(n)
+        for t in s.timesteps.tolist():
+            cx, ce = s.step_coeffs(t)
+            ref = o.step(e, t, x)
+            assert (cx * x + ce * e - ref).abs().max() < 1e-6
+    # the last step lands on final_alpha_cumprod (prev timestep < 0)
+    s.set_timesteps(50)
+    cx, _ = s.step_coeffs(1)
+    assert math.isclose(cx, math.sqrt(float(s.final_alpha_cumprod) / float(s.alphas_cumprod[1])), rel_tol=1e-12)
+
+
+def test_parameter_inventory():
+    cfg = sdxl_base()
+    specs = unet_param_specs(cfg)
+    assert param_count(specs) == 2_567_463_684 and len(specs) == 1680             # published SDXL-base UNet size
+    names = attn_processor_names(cfg)
+    assert len(names) == 140 and names[0].startswith("down_blocks.1") and names[-1].startswith("mid_block")
+    assert names[0].endswith("attn1.processor") and names[1].endswith("attn2.processor")
+    ip = ip_adapter_specs(cfg)
+    keys = [k for k, _, _ in ip["ip_adapter"]]
+    assert keys[0] == "1.to_k_ip.weight" and keys[-1] == "139.to_v_ip.weight" and len(keys) == 140
+    assert param_count(ip["ip_adapter"]) == 340_787_200
+    assert hidden_size_of(cfg, "up_blocks.0.attentions.2.transformer_blocks.9.attn2.processor") == 1280
+    assert hidden_size_of(cfg, "up_blocks.1.attentions.0.transformer_blocks.0.attn2.processor") == 640
+    assert [k for k, _, _ in ip["image_proj"]] == ["proj.weight", "proj.bias", "norm.weight", "norm.bias", "raw_embed"]
+
+
+def test_oracle_and_product_enumerate_the_same_keys():
+    for cfg in (tiny(), tiny(depths=(0, 2, 1))):
+        with torch.device("meta"):
+            m = oracle.UNet2DConditionModelRef(cfg)
+        assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: s for k, s, _ in unet_param_specs(cfg)}
+        assert list(m.attn_processors.keys()) == attn_processor_names(cfg)
+
+
+def test_add_time_ids_and_argument_checks():
+    from types import SimpleNamespace
+    from instructany2pix_amd.ddim import SDXLDDIMPipeline, StableDiffusionXLPipeline, get_add_time_ids
+    cfg = sdxl_base()
+    fake = SimpleNamespace(config=cfg, device=torch.device("cpu"),
+                           add_embedding=SimpleNamespace(linear_1=SimpleNamespace(in_features=cfg.projection_class_embeddings_input_dim)))
+    ids = get_add_time_ids(fake, (1024, 1024), (0, 0), (1024, 1024), 1280, torch.float32)
+    assert ids.tolist() == [[1024.0, 1024.0, 0.0, 0.0, 1024.0, 1024.0]]
+    with pytest.raises(ValueError):                                  # embed-dim mismatch (reference pnp_pipeline.py:63-66)
+        get_add_time_ids(fake, (1024, 1024), (0, 0), (1024, 1024), 1024)
+    inv, smp = SDXLDDIMPipeline(fake), StableDiffusionXLPipeline(fake)
+    with pytest.raises(ValueError):
+        inv.inverse(prompt="a", prompt_embeds=torch.zeros(1, 77, 2048), pooled_prompt_embeds=torch.zeros(1, 1280))
+    with pytest.raises(ValueError):
+        inv.inverse(latents=torch.zeros(1, 4, 8, 8))                 # neither prompt nor prompt_embeds
+    with pytest.raises(ValueError):
+        inv.inverse(prompt_embeds=torch.zeros(1, 77, 2048), latents=torch.zeros(1, 4, 8, 8))   # pooled missing
+    with pytest.raises(ValueError):
+        inv.inverse(prompt_embeds=torch.zeros(1, 77, 2048), pooled_prompt_embeds=torch.zeros(1, 1280), latents=torch.zeros(1, 4, 8, 8), strength=1.5)
+    with pytest.raises(NotImplementedError):                         # text encoders are out of scope: needs an injected callable
+        inv.inverse(prompt="", latents=torch.zeros(1, 4, 8, 8))
+    with pytest.raises(ValueError):
+        smp(prompt_embeds=torch.zeros(1, 77, 2048), pooled_prompt_embeds=torch.zeros(1, 1280), guidance_scale=5.0)   # CFG needs negatives
+    with pytest.raises(ValueError):
+        smp(prompt_embeds=torch.zeros(1, 77, 2048), pooled_prompt_embeds=torch.zeros(1, 1280), guidance_scale=1.0, height=100, width=64)
+
+
+def test_polar_interpolate_and_fusion_match_golden(golden):
+    from instructany2pix_amd.pipeline import fuse_instruction_embedding, polar_intrtpolate
+    d = golden("misc.npz")
+    a, b = torch.from_numpy(d["pa"]), torch.from_numpy(d["pb"])
+    assert np.abs(polar_intrtpolate(a, b, 0.7).numpy() - d["polar_07"]).max() < 1e-6
+    assert np.array_equal(polar_intrtpolate(a.half(), b.half(), 0.7).float().numpy(), d["polar_half"])     # fp16 CPU arithmetic kept
+    g = torch.Generator().manual_seed(2)
+    be, ie, y = torch.randn(1024, generator=g), torch.randn(1, 1, 1024, generator=g), torch.randn(1, 1024, generator=g)
+    la = fuse_instruction_embedding(be, ie, y, [0.0, 0.4, 1.0], 20.0)      # reference pipeline.py:322-324
+    assert math.isclose(float(la.norm()), 20.0, rel_tol=1e-5)
+    ref = be * 0.0 + ie * 0.4 + y / y.norm() * 20.0
+    assert torch.allclose(la, ref / ref.norm() * 20.0, atol=1e-6)
