@@ -63,3 +63,35 @@ def tiny(depths=(0, 1, 2)) -> UNetConfig:
         addition_time_embed_dim=32, projection_class_embeddings_input_dim=6 * 32 + 64,
         time_embed_dim=256, time_proj_dim=64,
     ).validate()
+
+
+@dataclass
+class VAEConfig:
+    """diffusers `AutoencoderKL` fields of the SDXL VAE (the object behind `pipe.vae`, reference
+    instructany2pix/pipeline.py:109,134; ddim/sdxl_pipeline.py:859-871). First row of SURVEY.md §8f."""
+    in_channels: int = 3
+    out_channels: int = 3
+    latent_channels: int = 4
+    block_out_channels: Tuple[int, ...] = (128, 256, 512, 512)
+    layers_per_block: int = 2
+    norm_num_groups: int = 32
+    norm_eps: float = 1e-6
+    scaling_factor: float = 0.13025
+    force_upcast: bool = True        # the reference upcasts the VAE to fp32 (sdxl_pipeline.py:860-865); see vae.py
+
+    def __getitem__(self, k):
+        return getattr(self, k)
+
+    def validate(self):
+        for c in self.block_out_channels:
+            assert c % 64 == 0 and c % self.norm_num_groups == 0
+        assert self.in_channels * 9 <= 64 and self.latent_channels * 9 <= 64 and 2 * self.latent_channels <= 8 and self.out_channels <= 8
+        return self
+
+
+def sdxl_vae() -> VAEConfig:
+    return VAEConfig().validate()
+
+
+def tiny_vae() -> VAEConfig:
+    return VAEConfig(block_out_channels=(64, 128, 128), layers_per_block=1).validate()

@@ -210,3 +210,61 @@ def param_count(specs: List[Spec]) -> int:
             n *= d
         t += n
     return t
+
+
+# ---- VAE (diffusers AutoencoderKL key layout) ---------------------------------------------------------------------------
+def _vae_resnet(prefix: str, cin: int, cout: int) -> List[Spec]:
+    s: List[Spec] = [
+        (f"{prefix}.norm1.weight", (cin,), "gamma"), (f"{prefix}.norm1.bias", (cin,), "beta"),
+        (f"{prefix}.conv1.weight", (cout, cin, 3, 3), "w"), (f"{prefix}.conv1.bias", (cout,), "b"),
+        (f"{prefix}.norm2.weight", (cout,), "gamma"), (f"{prefix}.norm2.bias", (cout,), "beta"),
+        (f"{prefix}.conv2.weight", (cout, cout, 3, 3), "w_res"), (f"{prefix}.conv2.bias", (cout,), "b"),
+    ]
+    if cin != cout:
+        s += [(f"{prefix}.conv_shortcut.weight", (cout, cin, 1, 1), "w"), (f"{prefix}.conv_shortcut.bias", (cout,), "b")]
+    return s
+
+
+def _vae_mid(prefix: str, c: int) -> List[Spec]:
+    a = f"{prefix}.attentions.0"
+    return (_vae_resnet(f"{prefix}.resnets.0", c, c) + [
+        (f"{a}.group_norm.weight", (c,), "gamma"), (f"{a}.group_norm.bias", (c,), "beta"),
+        (f"{a}.to_q.weight", (c, c), "w"), (f"{a}.to_q.bias", (c,), "b"),
+        (f"{a}.to_k.weight", (c, c), "w"), (f"{a}.to_k.bias", (c,), "b"),
+        (f"{a}.to_v.weight", (c, c), "w"), (f"{a}.to_v.bias", (c,), "b"),
+        (f"{a}.to_out.0.weight", (c, c), "w_res"), (f"{a}.to_out.0.bias", (c,), "b"),
+    ] + _vae_resnet(f"{prefix}.resnets.1", c, c))
+
+
+def vae_param_specs(cfg) -> List[Spec]:
+    ch = list(cfg.block_out_channels)
+    n = len(ch)
+    z = cfg.latent_channels
+    s: List[Spec] = [("encoder.conv_in.weight", (ch[0], cfg.in_channels, 3, 3), "w"), ("encoder.conv_in.bias", (ch[0],), "b")]
+    cprev = ch[0]
+    for i in range(n):
+        for j in range(cfg.layers_per_block):
+            s += _vae_resnet(f"encoder.down_blocks.{i}.resnets.{j}", cprev if j == 0 else ch[i], ch[i])
+        cprev = ch[i]
+        if i != n - 1:
+            s += [(f"encoder.down_blocks.{i}.downsamplers.0.conv.weight", (ch[i], ch[i], 3, 3), "w"),
+                  (f"encoder.down_blocks.{i}.downsamplers.0.conv.bias", (ch[i],), "b")]
+    s += _vae_mid("encoder.mid_block", ch[-1])
+    s += [("encoder.conv_norm_out.weight", (ch[-1],), "gamma"), ("encoder.conv_norm_out.bias", (ch[-1],), "beta"),
+          ("encoder.conv_out.weight", (2 * z, ch[-1], 3, 3), "w_out"), ("encoder.conv_out.bias", (2 * z,), "b"),
+          ("quant_conv.weight", (2 * z, 2 * z, 1, 1), "w"), ("quant_conv.bias", (2 * z,), "b"),
+          ("post_quant_conv.weight", (z, z, 1, 1), "w"), ("post_quant_conv.bias", (z,), "b"),
+          ("decoder.conv_in.weight", (ch[-1], z, 3, 3), "w"), ("decoder.conv_in.bias", (ch[-1],), "b")]
+    s += _vae_mid("decoder.mid_block", ch[-1])
+    rch = ch[::-1]
+    cprev = ch[-1]
+    for i in range(n):
+        for j in range(cfg.layers_per_block + 1):
+            s += _vae_resnet(f"decoder.up_blocks.{i}.resnets.{j}", cprev if j == 0 else rch[i], rch[i])
+        cprev = rch[i]
+        if i != n - 1:
+            s += [(f"decoder.up_blocks.{i}.upsamplers.0.conv.weight", (rch[i], rch[i], 3, 3), "w"),
+                  (f"decoder.up_blocks.{i}.upsamplers.0.conv.bias", (rch[i],), "b")]
+    s += [("decoder.conv_norm_out.weight", (ch[0],), "gamma"), ("decoder.conv_norm_out.bias", (ch[0],), "beta"),
+          ("decoder.conv_out.weight", (cfg.out_channels, ch[0], 3, 3), "w_out"), ("decoder.conv_out.bias", (cfg.out_channels,), "b")]
+    return s

@@ -20,6 +20,7 @@ Fixtures:
   G6 ldm_blocks.npz    ldm ResnetBlock, SpatialTransformer, timestep_embedding
   G7 misc.npz          polar_intrtpolate, _get_add_time_ids
   G8 unet_refprocs.npz tiny UNet (oracle module tree) with the REFERENCE processor classes installed
+  G9 vae_ldm.npz       in-tree ldm Encoder / Decoder (the architecture the SDXL VAE descends from), small config
 """
 import ast
 import importlib
@@ -274,6 +275,27 @@ def main():
                         p_.scale = s
                 d[f"out_L{L}_t{t}_s{s}"] = npf(net(x, t, ctx, added_cond_kwargs=dict(text_embeds=te, time_ids=tid))[0])
     np.savez(os.path.join(HERE, "unet_refprocs.npz"), **d)
+    # ---- G9: ldm Encoder / Decoder (blocks.py:369-569) -------------------------------------------------------------------
+    import contextlib
+    import io
+    kw = dict(ch=64, out_ch=3, ch_mult=(1, 2, 2), num_res_blocks=1, attn_resolutions=[], dropout=0.0, in_channels=3,
+              resolution=32, z_channels=4)
+    with contextlib.redirect_stdout(io.StringIO()):
+        enc, dec = blocks.Encoder(double_z=True, **kw), blocks.Decoder(**kw)
+    # weights are NOT stored (3.7 M values): they are drawn from a seeded CPU generator in parameter order, and the test
+    # re-draws them in the recorded order (names/shapes below) -- only inputs and expected outputs travel
+    gg = torch.Generator().manual_seed(19)
+    names, shapes = [], []
+    for side, m_ in (("enc", enc), ("dec", dec)):
+        for k_, p_ in m_.named_parameters():
+            p_.copy_(torch.randn(p_.shape, generator=gg) * (0.5 / max(1, p_[0].numel()) ** 0.5 if p_.ndim > 1 else 0.2))
+            names.append(f"{side}.{k_}")
+            shapes.append(",".join(str(x) for x in p_.shape))
+    img = torch.randn(2, 3, 32, 32, generator=gg)
+    zz = torch.randn(2, 4, 8, 8, generator=gg)
+    np.savez(os.path.join(HERE, "vae_ldm.npz"), img=npf(img), z=npf(zz), enc_out=npf(enc(img)), dec_out=npf(dec(zz)),
+             names=np.array(names), shapes=np.array(shapes), seed=19)
+
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

@@ -164,3 +164,59 @@ def test_g8_unet_with_reference_processors(golden):
                 o = net(T(d["x"]), t, T(d[f"ctx{L}"]), added_cond_kwargs=added)[0]
                 ref = d[f"out_L{L}_t{t}_s{s}"]
                 assert np.abs(o.numpy() - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+
+
+def _ldm_to_diffusers_vae(d, cfg):
+    """Key renaming ldm (blocks.py Encoder/Decoder) -> diffusers AutoencoderKL, 1x1 conv -> Linear for the attention."""
+    n = len(cfg.block_out_channels)
+    sd = {}
+    g = torch.Generator().manual_seed(int(d["seed"]))        # weights re-drawn exactly as gen_goldens.py drew them
+    for k, shp in zip(d["names"].tolist(), d["shapes"].tolist()):
+        shape = tuple(int(x) for x in shp.split(","))
+        v = torch.randn(shape, generator=g)
+        v = v * (0.5 / max(1, v[0].numel()) ** 0.5 if v.ndim > 1 else 0.2)
+        side, rest = ("encoder", k[4:]) if k.startswith("enc.") else ("decoder", k[4:])
+        parts = rest.split(".")
+        if parts[0] in ("down", "up"):
+            lvl = int(parts[1])
+            blk = lvl if parts[0] == "down" else n - 1 - lvl        # ldm keeps `up` indexed by resolution level (blocks.py:524)
+            grp = "down_blocks" if parts[0] == "down" else "up_blocks"
+            if parts[2] == "block":
+                name = f"{side}.{grp}.{blk}.resnets.{parts[3]}." + ".".join(parts[4:])
+            else:
+                name = f"{side}.{grp}.{blk}.{'downsamplers' if parts[2] == 'downsample' else 'upsamplers'}.0." + ".".join(parts[3:])
+        elif parts[0] == "mid":
+            if parts[1] in ("block_1", "block_2"):
+                name = f"{side}.mid_block.resnets.{0 if parts[1] == 'block_1' else 1}." + ".".join(parts[2:])
+            else:
+                m = {"norm": "group_norm", "q": "to_q", "k": "to_k", "v": "to_v", "proj_out": "to_out.0"}[parts[2]]
+                name = f"{side}.mid_block.attentions.0.{m}.{parts[3]}"
+                if v.ndim == 4:
+                    v = v.reshape(v.shape[0], v.shape[1])
+        elif parts[0] == "norm_out":
+            name = f"{side}.conv_norm_out.{parts[1]}"
+        else:
+            name = f"{side}." + rest
+        sd[name.replace("nin_shortcut", "conv_shortcut")] = v
+    return sd
+
+
+@torch.no_grad()
+def test_g9_vae_against_in_tree_ldm_encoder_decoder(golden):
+    from instructany2pix_amd.config import VAEConfig
+    from instructany2pix_amd.weights import vae_param_specs
+    d = golden("vae_ldm.npz")
+    cfg = VAEConfig(block_out_channels=(64, 128, 128), layers_per_block=1).validate()
+    sd = _ldm_to_diffusers_vae(d, cfg)
+    z = cfg.latent_channels
+    sd["quant_conv.weight"] = torch.eye(2 * z).reshape(2 * z, 2 * z, 1, 1); sd["quant_conv.bias"] = torch.zeros(2 * z)
+    sd["post_quant_conv.weight"] = torch.eye(z).reshape(z, z, 1, 1); sd["post_quant_conv.bias"] = torch.zeros(z)
+    assert set(sd) == {k for k, _, _ in vae_param_specs(cfg)}
+    vae = oracle.build_vae(cfg, sd)
+    e = vae.encode_moments(T(d["img"]))
+    assert np.abs(e.numpy() - d["enc_out"]).max() < 2e-4 * max(1.0, np.abs(d["enc_out"]).max())       # ldm Encoder, blocks.py:435-460
+    o = vae.decode(T(d["z"]))
+    assert np.abs(o.numpy() - d["dec_out"]).max() < 2e-4 * max(1.0, np.abs(d["dec_out"]).max())       # ldm Decoder, blocks.py:536-569
+    mom = torch.cat([torch.ones(1, 4, 2, 2), torch.full((1, 4, 2, 2), 40.0)], dim=1)
+    s = oracle.sample_latents(mom, torch.ones(1, 4, 2, 2), 0.13025)
+    assert torch.allclose(s, (1 + torch.exp(torch.tensor(10.0))) * 0.13025 * torch.ones(1, 4, 2, 2))    # logvar clamp at 20
