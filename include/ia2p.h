@@ -128,6 +128,31 @@ int ia2p_profile_classes(void);
 /* sums since enable for class k: launches, milliseconds, algorithmic flops and bytes */
 ia2p_status ia2p_profile_read(ia2p_ctx* ctx, int k, char* name, int name_len, int64_t* launches, double* ms, double* flops, double* bytes);
 
+/* ---- VAE (diffusers AutoencoderKL): pipe.vae.encode / pipe.vae.decode ----------------------------
+ * reference call sites: ddim/pnp_pipeline.py:190-204 (prepare_latents of the img2img base class), ddim/sdxl_pipeline.py:859-871.
+ * NCHW fp16 at both ends; h, w are LATENT sizes in both directions (image side = latent side * 2^(n_blocks-1)).
+ * encode returns the posterior moments [B, 2*latent_channels, h, w] (mean | logvar); sampling and the 0.13025 scaling
+ * stay on the host. The reference upcasts this model to fp32; this build keeps fp16 storage with fp32 accumulation. */
+typedef struct ia2p_vae ia2p_vae;
+typedef struct {
+  int in_channels, out_channels, latent_channels;
+  int n_blocks;
+  int block_out_channels[IA2P_MAX_BLOCKS];
+  int layers_per_block;
+  int norm_num_groups;
+  float norm_eps;
+} ia2p_vae_config;
+ia2p_status ia2p_vae_create(const ia2p_vae_config* cfg, ia2p_vae** out);
+void ia2p_vae_destroy(ia2p_vae* vae);
+const char* ia2p_vae_last_error(ia2p_vae* vae);
+size_t ia2p_vae_arena_bytes(ia2p_vae* vae);
+ia2p_status ia2p_vae_bind_arena(ia2p_vae* vae, void* dev_arena, size_t bytes);
+ia2p_status ia2p_vae_load_tensor(ia2p_vae* vae, const char* key, const void* dev_src, const int64_t* shape, int ndim, void* stream);
+ia2p_status ia2p_vae_finalize_weights(ia2p_vae* vae);
+size_t ia2p_vae_workspace_bytes(ia2p_vae* vae, int B, int h, int w, int decode);
+ia2p_status ia2p_vae_decode(ia2p_vae* vae, void* stream, const void* latents, void* image, int B, int h, int w, void* workspace, size_t workspace_bytes);
+ia2p_status ia2p_vae_encode(ia2p_vae* vae, void* stream, const void* image, void* moments, int B, int h, int w, void* workspace, size_t workspace_bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,6 +26,12 @@ class UNetConfigC(C.Structure):
     ]
 
 
+class VAEConfigC(C.Structure):
+    _fields_ = [("in_channels", C.c_int), ("out_channels", C.c_int), ("latent_channels", C.c_int), ("n_blocks", C.c_int),
+                ("block_out_channels", C.c_int * MAX_BLOCKS), ("layers_per_block", C.c_int), ("norm_num_groups", C.c_int),
+                ("norm_eps", C.c_float)]
+
+
 # every symbol include/ia2p.h declares: name -> (restype, argtypes)
 _P, _I, _F, _SZ, _I64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_int64
 SIGNATURES = {
@@ -53,6 +59,16 @@ SIGNATURES = {
     "ia2p_attention": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _F, _P, _P, _I, _I, _F]),
     "ia2p_linear_small": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I]),
     "ia2p_debug_set_gemm_tile": (None, [_I]),
+    "ia2p_vae_create": (_I, [C.POINTER(VAEConfigC), C.POINTER(_P)]),
+    "ia2p_vae_destroy": (None, [_P]),
+    "ia2p_vae_last_error": (C.c_char_p, [_P]),
+    "ia2p_vae_arena_bytes": (_SZ, [_P]),
+    "ia2p_vae_bind_arena": (_I, [_P, _P, _SZ]),
+    "ia2p_vae_load_tensor": (_I, [_P, C.c_char_p, _P, C.POINTER(_I64), _I, _P]),
+    "ia2p_vae_finalize_weights": (_I, [_P]),
+    "ia2p_vae_workspace_bytes": (_SZ, [_P, _I, _I, _I, _I]),
+    "ia2p_vae_decode": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _SZ]),
+    "ia2p_vae_encode": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _SZ]),
     "ia2p_profile_enable": (_I, [_P, _I]),
     "ia2p_profile_classes": (_I, []),
     "ia2p_profile_read": (_I, [_P, _I, C.c_char_p, _I, C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -84,12 +100,12 @@ def lib() -> C.CDLL:
     return _lib
 
 
-def check(status: int, ctx=None):
+def check(status: int, ctx=None, vae=False):
     """Map ia2p_status to the exception types the reference raises at the same conditions
     (ValueError from check_inputs/_get_add_time_ids, reference pnp_pipeline.py:49-66)."""
     if status == IA2P_OK:
         return
-    msg = lib().ia2p_last_error(ctx)
+    msg = lib().ia2p_vae_last_error(ctx) if vae else lib().ia2p_last_error(ctx)
     msg = msg.decode() if msg else ""
     text = f"ia2p {_STATUS_NAMES.get(status, status)}: {msg}"
     if status in (1, 2):
@@ -130,4 +146,16 @@ def make_config(cfg) -> UNetConfigC:
     c.addition_time_embed_dim = cfg.addition_time_embed_dim
     c.projection_class_embeddings_input_dim = cfg.projection_class_embeddings_input_dim
     c.time_embed_dim, c.time_proj_dim = cfg.time_embed_dim, cfg.time_proj_dim
+    return c
+
+
+def make_vae_config(cfg) -> VAEConfigC:
+    c = VAEConfigC()
+    c.in_channels, c.out_channels, c.latent_channels = cfg.in_channels, cfg.out_channels, cfg.latent_channels
+    c.n_blocks = len(cfg.block_out_channels)
+    if c.n_blocks > MAX_BLOCKS:
+        raise ValueError(f"at most {MAX_BLOCKS} resolution levels are supported")
+    for i in range(c.n_blocks):
+        c.block_out_channels[i] = cfg.block_out_channels[i]
+    c.layers_per_block, c.norm_num_groups, c.norm_eps = cfg.layers_per_block, cfg.norm_num_groups, cfg.norm_eps
     return c

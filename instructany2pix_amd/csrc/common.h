@@ -37,13 +37,14 @@ struct GemmArgs {
   half_t* C;             // output [M, ldc]
   const half_t* zero;    // >=16 B of zeros (out-of-range rows / conv padding read this)
   int M, N, K;           // K % 64 == 0, N % 4 == 0
-  int lda, ldc;
+  int lda, ldc, ldw;     // row strides of A, C and W (ldw >= K)
   // LINEAR row map: src_row = (m / rpb) * bstride + (m % rpb) + roff   (rpb == 0: identity)
   int rpb, bstride, roff;
   // CONV3x3 gather (implicit GEMM): m = (b, oy, ox); k = (ky, kx, ci)
   int Hs, Ws;            // stored source height/width
   int Ho, Wo;            // output height/width
   int stride, up;        // conv stride (1|2); up=1 reads a nearest-x2 upsampled view of the source
+  int pad;               // zero rows/cols before the image (1; the VAE's stride-2 downsample pads only after: 0)
   int Cin;               // channels per tap (Cin % 64 == 0)
   // epilogue
   const half_t* bias;    // [N] (GEGLU: packed order) or null

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(WGM * 128) void gemm_f16_kernel(const GemmArgs p) {
         const int hw = p.Ho * p.Wo;
         const int b = m / hw, rem = m - b * hw;
         const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        a_y[i] = oy * p.stride - 1; a_x[i] = ox * p.stride - 1; a_pix[i] = b * p.Hs * p.Ws;
+        a_y[i] = oy * p.stride - p.pad; a_x[i] = ox * p.stride - p.pad; a_pix[i] = b * p.Hs * p.Ws;
       } else { a_y[i] = -(1 << 20); a_x[i] = 0; a_pix[i] = 0; }
     }
   }
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(WGM * 128) void gemm_f16_kernel(const GemmArgs p) {
     const int pi = wave * B_PW + i;
     const int n = bn0 + pi * 8 + srow;
     const int gch = (lane & 7) ^ (((pi & 1) << 2) | (srow >> 1));
-    if (n < p.N) { w_ptr[i] = p.W + (size_t)n * p.K + gch * 8; w_inc[i] = 64; }
+    if (n < p.N) { w_ptr[i] = p.W + (size_t)n * p.ldw + gch * 8; w_inc[i] = 64; }
     else         { w_ptr[i] = p.zero; w_inc[i] = 0; }
   }
 

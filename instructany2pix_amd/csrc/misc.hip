@@ -203,6 +203,67 @@ __global__ void pack_geglu_kernel(const half_t* src, half_t* dst, int rows, int 
   }
 }
 
+// ---- row softmax, in place: x[r, :] = softmax(scale * x[r, :]); one workgroup per row, row held in registers ----------------
+// (VAE mid-block attention: single head, head_dim = channels; scores materialised by the GEMM kernel)
+template <int NV>   // 16-byte vectors per thread: n <= NV * 256 * 8
+__global__ __launch_bounds__(256) void softmax_rows_kernel(half_t* x, long ld, int n, float scale_log2e) {
+  __shared__ float red[8];
+  half_t* row = x + (long)blockIdx.x * ld;
+  const int nvec = n >> 3, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float v[NV][8];
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = threadIdx.x + i * 256;
+    if (c < nvec) {
+      const h8 d = *(const h8*)(row + c * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v[i][e] = (float)d[e]; mx = fmaxf(mx, v[i][e]); }
+    }
+  }
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float mc = mx * scale_log2e;
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if (threadIdx.x + i * 256 < nvec) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v[i][e] = __builtin_amdgcn_exp2f(fmaf(v[i][e], scale_log2e, -mc)); sum += v[i][e]; }
+    }
+  sum = wave_sum(sum);
+  if (lane == 0) red[4 + wave] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = threadIdx.x + i * 256;
+    if (c < nvec) {
+      h8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (half_t)(v[i][e] * inv);
+      *(h8*)(row + c * 8) = o;
+    }
+  }
+}
+
+// ---- 1x1 convolution on a small-channel NCHW tensor (VAE quant_conv / post_quant_conv, <= 8 channels) -----------------------
+__global__ void conv1x1_nchw_kernel(const half_t* x, const half_t* w /*[Co][Ci]*/, const half_t* bias, half_t* y, int B, int Ci, int Co, long HW) {
+  const long total = (long)B * HW;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / HW, p = i - b * HW;
+    float in[8];
+    for (int c = 0; c < Ci; ++c) in[c] = (float)x[(b * Ci + c) * HW + p];
+    for (int o = 0; o < Co; ++o) {
+      float a = (float)bias[o];
+      for (int c = 0; c < Ci; ++c) a += in[c] * (float)w[o * Ci + c];
+      y[(b * Co + o) * HW + p] = (half_t)a;
+    }
+  }
+}
+
 // ---- host launchers -------------------------------------------------------------------------------------------------------
 static inline int grid_for(long n, int block) { long g = (n + block - 1) / block; return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
 
@@ -245,5 +306,21 @@ hipError_t ia2p_launch_pack_conv(const half_t* src, half_t* dst, int Co, int Ci,
 }
 hipError_t ia2p_launch_pack_geglu(const half_t* src, half_t* dst, int rows, int rowlen, hipStream_t s) {
   hipLaunchKernelGGL(pack_geglu_kernel, dim3(grid_for((long)rows * rowlen, 256)), dim3(256), 0, s, src, dst, rows, rowlen);
+  return hipGetLastError();
+}
+
+hipError_t ia2p_launch_softmax_rows(half_t* x, long ld, int rows, int n, float scale, hipStream_t s) {
+  if (n % 8 || n > 8 * 256 * 8) return hipErrorInvalidValue;
+  const float sl = scale * 1.4426950408889634f;
+  const int nv = (n / 8 + 255) / 256;
+  if (nv <= 1) hipLaunchKernelGGL(softmax_rows_kernel<1>, dim3(rows), dim3(256), 0, s, x, ld, n, sl);
+  else if (nv <= 2) hipLaunchKernelGGL(softmax_rows_kernel<2>, dim3(rows), dim3(256), 0, s, x, ld, n, sl);
+  else if (nv <= 4) hipLaunchKernelGGL(softmax_rows_kernel<4>, dim3(rows), dim3(256), 0, s, x, ld, n, sl);
+  else hipLaunchKernelGGL(softmax_rows_kernel<8>, dim3(rows), dim3(256), 0, s, x, ld, n, sl);
+  return hipGetLastError();
+}
+hipError_t ia2p_launch_conv1x1_nchw(const half_t* x, const half_t* w, const half_t* bias, half_t* y, int B, int Ci, int Co, long HW, hipStream_t s) {
+  if (Ci > 8 || Co > 8) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(conv1x1_nchw_kernel, dim3(grid_for((long)B * HW, 256)), dim3(256), 0, s, x, w, bias, y, B, Ci, Co, HW);
   return hipGetLastError();
 }
