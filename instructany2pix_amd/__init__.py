@@ -6,7 +6,7 @@ Importing this package touches no GPU and no native code; the HIP library (libia
 from .config import UNetConfig, sdxl_base, tiny
 
 __all__ = ["UNetConfig", "sdxl_base", "tiny", "InstructAny2PixPipeline", "HipUNet2DConditionModel", "DDIMScheduler",
-           "SDXLDDIMPipeline", "StableDiffusionXLPipeline", "IPAdapterXL", "ImageProjModel"]
+           "SDXLDDIMPipeline", "StableDiffusionXLPipeline", "IPAdapterXL", "ImageProjModel", "HipAutoencoderKL"]
 
 
 def __getattr__(name):          # lazy: keep `import instructany2pix_amd` free of torch/ctypes work
@@ -22,6 +22,8 @@ def __getattr__(name):          # lazy: keep `import instructany2pix_amd` free o
     elif name in ("IPAdapterXL", "ImageProjModel"):
         from . import ip_adapter
         v = getattr(ip_adapter, name)
+    elif name == "HipAutoencoderKL":
+        from .vae import HipAutoencoderKL as v
     else:
         raise AttributeError(name)
     return v

@@ -6,9 +6,10 @@
                                               instructany2pix/ddim/sdxl_pipeline.py:764-857
 Every tensor update runs on the GPU through the C ABI (UNet: ia2p_unet_forward; CFG + DDIM: ia2p_ddim_step).
 
-Out of scope here (SURVEY.md §8f "next"): CLIP text encoders (`encode_prompt`) and the VAE. They are
-injectable callables; without them the loops take `prompt_embeds` / `pooled_prompt_embeds` / `latents`
-directly, which is also how bench.py and the parity tests drive them.
+The stages either side are injectable callables: CLIP text encoders (`encode_prompt`, out of scope) and the VAE
+(`vae_encode` / `vae_decode`; `instructany2pix_amd.vae.HipAutoencoderKL` provides HIP implementations). Without them
+the loops take `prompt_embeds` / `pooled_prompt_embeds` / `latents` directly, which is also how bench.py and the
+parity tests drive them.
 """
 from __future__ import annotations
 
@@ -98,7 +99,7 @@ class SDXLDDIMPipeline(_PipelineBase):
             if self._vae_encode is None:
                 raise NotImplementedError("VAE encode is outside the denoise hot path: pass latents=, or construct with vae_encode=<callable>")
             latents = self._vae_encode(image)
-        latents = latents.to(device=dev, dtype=torch.float16).contiguous()
+        latents = latents.to(device=dev, dtype=torch.float16).contiguous().clone()    # the loop ping-pongs buffers: never the caller's tensor
         batch = latents.shape[0]
         self.scheduler.set_timesteps(num_inference_steps, device=dev)                           # :192
         height, width = latents.shape[-2] * self.vae_scale_factor, latents.shape[-1] * self.vae_scale_factor

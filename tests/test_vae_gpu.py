@@ -100,3 +100,61 @@ def test_vae_input_validation():
         hip.encode(torch.zeros(1, 3, 30, 32).half().to(DEV))
     with pytest.raises(ValueError):
         hip.decode(torch.zeros(1, 5, 8, 8).half().to(DEV))
+
+
+def test_image_to_image_hot_segment_with_vae():
+    """image -> VAE encode -> DDIM inversion -> polar mixing -> IP-Adapter guided CFG sampling -> VAE decode, every tensor
+    op on the HIP path; compared with the same chain on the CPU oracle (tiny configs, 8 steps)."""
+    import oracle
+    from instructany2pix_amd.config import tiny, tiny_vae
+    from instructany2pix_amd.pipeline import InstructAny2PixPipeline, polar_intrtpolate
+    from instructany2pix_amd.unet import HipUNet2DConditionModel
+    from instructany2pix_amd.weights import unet_param_specs, ip_adapter_specs, synthetic_state_dict
+    ucfg, vcfg = tiny(), tiny_vae()
+    vae, rvae = _build(vcfg)
+    sd = synthetic_state_dict(unet_param_specs(ucfg), seed=7)
+    specs = ip_adapter_specs(ucfg, 64)
+    ck = {"image_proj": synthetic_state_dict(specs["image_proj"], seed=7), "ip_adapter": synthetic_state_dict(specs["ip_adapter"], seed=7)}
+    unet = HipUNet2DConditionModel(ucfg, DEV)
+    unet.load_state_dict(sd)
+    pipe = InstructAny2PixPipeline(unet=unet, ip_ckpt=ck, device=DEV, clip_embeddings_dim=64,
+                                   vae_encode=vae.encode_to_latents, vae_decode=vae.decode_from_latents)
+    g = torch.Generator().manual_seed(12)
+    N, cfgs, alpha, scale = 8, 4.0, 0.7, 0.8
+    img = torch.randn(1, 3, 64, 64, generator=g).half()            # 64x64 image -> 16x16 latent (tiny VAE: factor 4)
+    la = torch.randn(64, generator=g)
+    ctx, nctx = torch.randn(1, 77, ucfg.cross_attention_dim, generator=g).half(), torch.randn(1, 77, ucfg.cross_attention_dim, generator=g).half()
+    pooled, npooled = torch.randn(1, ucfg.pooled_dim, generator=g).half(), torch.randn(1, ucfg.pooled_dim, generator=g).half()
+    egen = torch.Generator().manual_seed(1)
+    base = vae.encode_to_latents(img.to(DEV), egen)
+    noise = torch.randn(1, 4, 16, 16, generator=g).half()
+    lat, inv = pipe.denoise(base, la, prompt_embeds=ctx, pooled_prompt_embeds=pooled, negative_prompt_embeds=nctx,
+                            negative_pooled_prompt_embeds=npooled, alpha=alpha, num_inference_steps=N, cfg=cfgs, scale=scale, noise=noise)
+    out = vae.decode_from_latents(lat)
+    torch.cuda.synchronize()
+    # ---- oracle chain
+    # like the reference, inversion runs BEFORE generate() calls set_scale: it sees the processors' previous scale (1.0)
+    ref_net = oracle.build_unet(ucfg, sd, ck["ip_adapter"], ip_scale=1.0)
+    m = oracle.ImageProjModelRef(ucfg.cross_attention_dim, 64, 4)
+    m.load_state_dict({k: v.float() for k, v in ck["image_proj"].items()})
+    with torch.no_grad():
+        rmom = rvae.encode_moments(img.float())
+        rbase = oracle.sample_latents(rmom, torch.randn(rmom[:, :4].shape, generator=torch.Generator().manual_seed(1)), vcfg.scaling_factor)
+        H = 16 * 8                                                  # the pipelines derive micro-conditioning sizes with vae_scale_factor 8
+        tid = torch.tensor([[float(H), float(H), 0, 0, float(H), float(H)]])
+        sch = oracle.DDIMSchedulerRef()
+        rinv = oracle.invert_loop(ref_net, sch, rbase, nctx.float(), dict(text_embeds=npooled.float(), time_ids=tid), N)
+        mixed = oracle.polar_interpolate(rinv, noise.float(), alpha)
+        for pr in ref_net.attn_processors.values():
+            if hasattr(pr, "scale"):
+                pr.scale = scale
+        e = torch.stack([la.half().float()[None], torch.zeros(1, 64)], dim=1)
+        p, n_ = m(e, "global"), m(torch.zeros_like(e), "global")
+        rlat = oracle.sample_loop(ref_net, sch, mixed, torch.cat([ctx.float(), p], 1), dict(text_embeds=pooled.float(), time_ids=tid), N, cfgs,
+                                  torch.cat([nctx.float(), n_], 1), dict(text_embeds=npooled.float(), time_ids=tid))
+        rout = rvae.decode(rlat / vcfg.scaling_factor)
+    assert rel_l2(base, rbase) < 1.5e-2
+    a, b = inv.float().cpu().flatten(), rinv.flatten()
+    assert float((a - b).norm() / b.norm()) < 4e-2 and float(torch.dot(a, b) / (a.norm() * b.norm())) > 0.998
+    a, b = out.float().cpu().flatten(), rout.flatten()
+    assert float(torch.dot(a, b) / (a.norm() * b.norm())) > 0.995, float(torch.dot(a, b) / (a.norm() * b.norm()))
