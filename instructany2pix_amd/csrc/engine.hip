@@ -126,15 +126,16 @@ struct Arena {            // deterministic first-fit allocator over [0, cap)
 
 struct ProfRec { hipEvent_t e0, e1; int k; double flops, bytes; };
 // profile classes = device kernel names as rocprofv3 prints them (template arguments included)
-enum { PK_GEMM0 = 0, PK_CONV0 = 8, PK_ATTN = 16, PK_GN, PK_LN, PK_EMBED, PK_CONV_IN, PK_CONV_OUT, PK_CONCAT, PK_NCLASS };
+enum { PK_GEMM0 = 0, PK_CONV0 = 10, PK_ATTN = 20, PK_GN, PK_LN, PK_EMBED, PK_CONV_IN, PK_CONV_OUT, PK_CONCAT, PK_NCLASS };
 static const char* prof_name(int k) {
   static char buf[PK_NCLASS][64];
   static const char* const other[] = {"attention_f16_kernel", "gn_stats_kernel+gn_apply_kernel", "layernorm_kernel",
                                       "embed_kernel+linear_small_kernel", "conv_in_kernel", "conv_out_kernel", "concat_kernel"};
   if (k >= PK_ATTN) return other[k - PK_ATTN];
-  static const int bm[8] = {128, 128, 128, 128, 64, 64, 256, 256}, bn[8] = {128, 128, 64, 64, 64, 64, 128, 320}, st[8] = {2, 3, 2, 3, 2, 3, 3, 2};
-  const int v = k % 8;
-  snprintf(buf[k], sizeof buf[k], "gemm_f16_kernel<%d, %d, %d, %s, %d>", bm[v], bn[v], st[v], k >= PK_CONV0 ? "true" : "false", v >= 6 ? 4 : 2);
+  static const int bm[10] = {128, 128, 128, 128, 64, 64, 256, 256, 128, 256}, bn[10] = {128, 128, 64, 64, 64, 64, 128, 320, 128, 128},
+                   st[10] = {2, 3, 2, 3, 2, 3, 2, 2, 2, 3}, wg[10] = {2, 2, 2, 2, 2, 2, 2, 4, 2, 2}, bk[10] = {64, 64, 64, 64, 64, 64, 32, 64, 32, 32};
+  const int v = k % 10;
+  snprintf(buf[k], sizeof buf[k], "gemm_f16_kernel<%d, %d, %d, %s, %d, %d>", bm[v], bn[v], st[v], k >= PK_CONV0 ? "true" : "false", wg[v], bk[v]);
   return buf[k];
 }
 

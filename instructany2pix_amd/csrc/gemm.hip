@@ -30,13 +30,20 @@ template <int N> __device__ __forceinline__ void wait_vm_barrier() {
 }
 
 // BM x BN tile; WGM x 2 waves, each owning a (BM/WGM) x (BN/2) sub-tile
-template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2>
-__global__ __launch_bounds__(WGM * 128) void gemm_f16_kernel(const GemmArgs p) {
+// LDS image of a k-tile: rows of ROWB = 2*BK bytes, 16-byte chunks XOR-swizzled so that the ds_read_b128 fragment reads of
+// v_mfma_f32_16x16x32_f16 (16 rows x one chunk per 16-lane group) are bank-conflict free:
+//   BK = 64 (8 chunks/row):  chunk ^ ((row >> 1) & 7)        BK = 32 (4 chunks/row):  chunk ^ ((-(row >> 2)) & 3)
+template <int BK> __device__ __forceinline__ int lds_swz(int row) { return BK == 64 ? (row >> 1) & 7 : (-(row >> 2)) & 3; }
+
+template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int BK = 64>
+__global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const GemmArgs p) {   // >= 2 waves/SIMD: big tiles must fit 256 registers
   constexpr int NWAVE = WGM * 2;
   constexpr int WM = BM / WGM, WN = BN / 2;      // wave tile (waves arranged WGM x 2)
   constexpr int MR = WM / 16, NR = WN / 16;
-  constexpr int A_PW = BM / 8 / NWAVE, B_PW = BN / 8 / NWAVE;  // 1-KiB (8 rows x 128 B) staging pieces per wave
-  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int ROWB = 2 * BK, CPR = ROWB / 16, RPP = 1024 / ROWB;   // row bytes, chunks per row, rows per 1-KiB staging piece
+  constexpr int A_PW = BM / RPP / NWAVE, B_PW = BN / RPP / NWAVE;    // staging pieces per wave
+  constexpr int STAGE = (BM + BN) * ROWB;
+  constexpr int KSUB = BK / 32;                                       // 32-deep MFMA sub-steps per k-tile
   extern __shared__ __attribute__((aligned(1024))) char smem[];
 
   const int tid = threadIdx.x;
@@ -78,21 +85,21 @@ __global__ __launch_bounds__(WGM * 128) void gemm_f16_kernel(const GemmArgs p) {
 
   // ---- staging addresses. Piece `pi` covers tile rows pi*8 .. pi*8+7; lane -> (row pi*8 + lane/8, LDS chunk lane%8),
   //      which must hold global chunk (lane%8) ^ swz(row), swz(row) = (row>>1)&7.
-  const int srow = lane >> 3;
+  const int srow = lane / CPR, cpos = lane % CPR;
   const half_t* a_ptr[A_PW];
   int a_inc[A_PW];
   int a_y[A_PW], a_x[A_PW], a_pix[A_PW], a_ch[A_PW];
 #pragma unroll
   for (int i = 0; i < A_PW; ++i) {
     const int pi = wave * A_PW + i;
-    const int m = bm0 + pi * 8 + srow;
-    const int gch = (lane & 7) ^ (((pi & 1) << 2) | (srow >> 1));
+    const int m = bm0 + pi * RPP + srow;
+    const int gch = cpos ^ lds_swz<BK>(pi * RPP + srow);
     if (!CONV) {
       if (m < p.M) {
         int src = m;
         if (p.rpb) { const int b = m / p.rpb; src = b * p.bstride + (m - b * p.rpb) + p.roff; }
         a_ptr[i] = p.A + (size_t)src * p.lda + gch * 8;
-        a_inc[i] = 64;
+        a_inc[i] = BK;
       } else { a_ptr[i] = p.zero; a_inc[i] = 0; }
     } else {
       a_ch[i] = gch * 8;
@@ -109,16 +116,16 @@ __global__ __launch_bounds__(WGM * 128) void gemm_f16_kernel(const GemmArgs p) {
 #pragma unroll
   for (int i = 0; i < B_PW; ++i) {
     const int pi = wave * B_PW + i;
-    const int n = bn0 + pi * 8 + srow;
-    const int gch = (lane & 7) ^ (((pi & 1) << 2) | (srow >> 1));
-    if (n < p.N) { w_ptr[i] = p.W + (size_t)n * p.ldw + gch * 8; w_inc[i] = 64; }
+    const int n = bn0 + pi * RPP + srow;
+    const int gch = cpos ^ lds_swz<BK>(pi * RPP + srow);
+    if (n < p.N) { w_ptr[i] = p.W + (size_t)n * p.ldw + gch * 8; w_inc[i] = BK; }
     else         { w_ptr[i] = p.zero; w_inc[i] = 0; }
   }
 
   const int Hv = p.Hs << p.up, Wv = p.Ws << p.up;
-  const int nk_all = p.K >> 6;
+  const int nk_all = p.K / BK;
   const int kt0 = (int)((long)split * nk_all / nsplit), kt1 = (int)((long)(split + 1) * nk_all / nsplit);   // this workgroup's k-tiles
-  int tap = (kt0 * 64) / (CONV ? p.Cin : 64), ci0 = CONV ? (kt0 * 64) % p.Cin : 0;  // conv: position of the k-tile being staged
+  int tap = (kt0 * BK) / (CONV ? p.Cin : BK), ci0 = CONV ? (kt0 * BK) % p.Cin : 0;  // conv: position of the k-tile being staged
   bool tap_fresh = true;
   if (kt0) {             // split-K: this workgroup starts at k-tile kt0
     if (!CONV) {
@@ -131,7 +138,7 @@ __global__ __launch_bounds__(WGM * 128) void gemm_f16_kernel(const GemmArgs p) {
 
   auto stage = [&](int kt, int buf) {
     char* sA = smem + buf * STAGE + wave * (A_PW * 1024);
-    char* sB = smem + buf * STAGE + BM * 128 + wave * (B_PW * 1024);
+    char* sB = smem + buf * STAGE + BM * ROWB + wave * (B_PW * 1024);
     if (CONV) {
       if (tap_fresh) {        // (wave-uniform) new filter tap: re-derive the gathered pixel of each row once per Cin/64 k-steps
         const int ky = tap / 3, kx = tap - ky * 3;
@@ -140,13 +147,13 @@ __global__ __launch_bounds__(WGM * 128) void gemm_f16_kernel(const GemmArgs p) {
           const int iy = a_y[i] + ky, ix = a_x[i] + kx;
           const bool ok = (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
           a_ptr[i] = ok ? p.A + (size_t)(a_pix[i] + (iy >> p.up) * p.Ws + (ix >> p.up)) * p.lda + ci0 + a_ch[i] : p.zero;
-          a_inc[i] = ok ? 64 : 0;
+          a_inc[i] = ok ? BK : 0;
         }
         tap_fresh = false;
       }
 #pragma unroll
       for (int i = 0; i < A_PW; ++i) { GLDS16(a_ptr[i], sA + i * 1024); a_ptr[i] += a_inc[i]; }
-      ci0 += 64;
+      ci0 += BK;
       if (ci0 >= p.Cin) { ci0 = 0; ++tap; tap_fresh = true; }
     } else {
 #pragma unroll
@@ -159,8 +166,8 @@ __global__ __launch_bounds__(WGM * 128) void gemm_f16_kernel(const GemmArgs p) {
   // ---- fragment read offsets (wave tile origin is a multiple of 16, so swz(row) = (lane>>1)&7)
   const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;   // wave / 2 in [0, WGM)
   const int frow = lane & 15, fq = lane >> 4;
-  const int fswz = (lane >> 1) & 7;
-  const int a_off = (wm0 + frow) * 128, w_off = BM * 128 + (wn0 + frow) * 128;
+  const int fswz = lds_swz<BK>(frow);
+  const int a_off = (wm0 + frow) * ROWB, w_off = BM * ROWB + (wn0 + frow) * ROWB;
 
   f4 acc[MR][NR];
 #pragma unroll
@@ -185,18 +192,18 @@ __global__ __launch_bounds__(WGM * 128) void gemm_f16_kernel(const GemmArgs p) {
     const char* base = smem + cur * STAGE;
     if constexpr (MR * NR <= 16) {
       // all fragment reads of the k-step are issued before the first MFMA
-      h8 af[2][MR], wf[2][NR];
+      h8 af[KSUB][MR], wf[KSUB][NR];
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
+      for (int kk = 0; kk < KSUB; ++kk) {
         const int coff = ((kk * 4 + fq) ^ fswz) << 4;
 #pragma unroll
-        for (int i = 0; i < MR; ++i) af[kk][i] = *(const h8*)(base + a_off + i * 2048 + coff);
+        for (int i = 0; i < MR; ++i) af[kk][i] = *(const h8*)(base + a_off + i * 16 * ROWB + coff);
 #pragma unroll
-        for (int j = 0; j < NR; ++j) wf[kk][j] = *(const h8*)(base + w_off + j * 2048 + coff);
+        for (int j = 0; j < NR; ++j) wf[kk][j] = *(const h8*)(base + w_off + j * 16 * ROWB + coff);
       }
       __builtin_amdgcn_sched_barrier(0);   // keep hipcc from sinking the reads back between the MFMAs
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk)
+      for (int kk = 0; kk < KSUB; ++kk)
 #pragma unroll
         for (int i = 0; i < MR; ++i)
 #pragma unroll
@@ -205,13 +212,13 @@ __global__ __launch_bounds__(WGM * 128) void gemm_f16_kernel(const GemmArgs p) {
     } else {
       // big wave tiles: registers go to accumulators, fragments are read per 32-deep half
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
+      for (int kk = 0; kk < KSUB; ++kk) {
         const int coff = ((kk * 4 + fq) ^ fswz) << 4;
         h8 af[MR], wf[NR];
 #pragma unroll
-        for (int i = 0; i < MR; ++i) af[i] = *(const h8*)(base + a_off + i * 2048 + coff);
+        for (int i = 0; i < MR; ++i) af[i] = *(const h8*)(base + a_off + i * 16 * ROWB + coff);
 #pragma unroll
-        for (int j = 0; j < NR; ++j) wf[j] = *(const h8*)(base + w_off + j * 2048 + coff);
+        for (int j = 0; j < NR; ++j) wf[j] = *(const h8*)(base + w_off + j * 16 * ROWB + coff);
 #pragma unroll
         for (int i = 0; i < MR; ++i)
 #pragma unroll
@@ -272,18 +279,18 @@ __global__ __launch_bounds__(WGM * 128) void gemm_f16_kernel(const GemmArgs p) {
   }
 }
 
-template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2>
+template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int BK = 64>
 static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
-  constexpr int smem = NSTAGE * (BM + BN) * 128;
+  constexpr int smem = NSTAGE * (BM + BN) * 2 * BK;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_f16_kernel<BM, BN, NSTAGE, CONV, WGM>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_f16_kernel<BM, BN, NSTAGE, CONV, WGM, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   const int extra = (a.pf && a.pf_bytes >= 4096) ? a.pf_blocks : 0;
-  hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, NSTAGE, CONV, WGM>), dim3(tiles * (a.splitk > 1 ? a.splitk : 1) + extra), dim3(WGM * 128), smem, s, a);
+  hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, NSTAGE, CONV, WGM, BK>), dim3(tiles * (a.splitk > 1 ? a.splitk : 1) + extra), dim3(WGM * 128), smem, s, a);
   return hipGetLastError();
 }
 
@@ -383,8 +390,10 @@ static hipError_t launch_any(const GemmArgs& a, hipStream_t s, int* picked) {
     case 3: e = launch_cfg<128, 64, 3, CONV>(a, s); break;
     case 4: e = launch_cfg<64, 64, 2, CONV>(a, s); break;
     case 5: e = launch_cfg<64, 64, 3, CONV>(a, s); break;
-    case 6: e = launch_cfg<256, 128, 3, CONV, 4>(a, s); break;     // experimental: 8 waves, 3-deep ring, 1 block/CU
-    default: e = launch_cfg<256, 320, 2, CONV, 4>(a, s); break;    // experimental: 8 waves, one workgroup per CU
+    // Experimental tiles measured and dropped in round 1 (tools/gemm_bench.py): 8-wave 256x128 (2- and 3-stage) and
+    // 256x320 at one workgroup per CU; BK = 32 rings (256x128 / 128x128, more co-resident blocks) -- 64-byte rows halve the
+    // request efficiency. The kernel template still takes WGM and BK for later rounds.
+    default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess || a.splitk <= 1) return e;
   const long total = (long)a.M * (a.N >> 2);

@@ -41,7 +41,7 @@ def run(L, name, *args):
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("M,N,K", [(256, 320, 320), (2048, 1280, 1280), (616, 2560, 2048), (100, 64, 64), (37, 132, 128), (8192, 640, 2560)])
 def test_gemm_bias_residual(L, M, N, K, tile):
     f = _ffi()
