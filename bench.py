@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--ctx", type=int, default=81, help="context tokens (77 text + 4 image tokens)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-autotune", action="store_true", help="use the built-in cost model instead of measured kernel plans")
     ap.add_argument("--cpu-sample-batch", type=int, default=1)
     ap.add_argument("--kernel-table", default=None, help="write the per-kernel timing table (JSON) to this file")
     args = ap.parse_args()
@@ -104,7 +105,7 @@ def main():
     from instructany2pix_amd import dist as D
     from instructany2pix_amd.config import sdxl_base
     from instructany2pix_amd.scheduler import DDIMScheduler, fused_update
-    from instructany2pix_amd.unet import HipUNet2DConditionModel
+    from instructany2pix_amd.unet import HipUNet2DConditionModel, export_plans, import_plans
     from instructany2pix_amd.weights import unet_param_specs, ip_adapter_specs, iter_synthetic
 
     rank, world, local = D.init_distributed()
@@ -143,6 +144,24 @@ def main():
         c_x, c_e = sch.step_coeffs(t)
         fused_update(x, eps, None, 1.0, c_x, c_e, y)
 
+    # set-up, outside the timed region: measure the candidate (tile, K-split) plans of every GEMM / conv shape once on
+    # rank 0 (ia2p_autotune) and hand the table to the other ranks so that all ranks run identical kernels
+    plans = "cost model"
+    if not args.no_autotune:
+        t0 = time.time()
+        table = [None]
+        if rank == 0:
+            n = unet.autotune(lat, ts[0], ctx, added)
+            table[0] = export_plans()
+            log(f"[rank 0] autotune: {n} GEMM/conv shapes measured in {time.time() - t0:.1f}s")
+            if os.environ.get("IA2P_PRINT_PLANS"):
+                log("[rank 0] plans: " + table[0])
+        if world > 1:
+            torch.distributed.broadcast_object_list(table, src=0)
+            if rank != 0:
+                import_plans(table[0])
+        plans = f"measured in place at start-up ({table[0].count(';')} shapes)"
+
     x, y = lat.clone(), nxt
     for i in range(args.warmup):
         step(i, x, y)
@@ -167,7 +186,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": f"{'BASELINE configs[2]' if default_cfg else 'custom'}: {hw * 8}x{hw * 8} px, latent [{B},4,{hw},{hw}], 50-step DDIM schedule, "
                                f"context {L} tokens ({'77 text + %d IP-Adapter image tokens' % (L - 77) if use_ip else 'text only'}), SDXL-base UNet "
-                               f"(2.567 G params) + IP-Adapter, synthetic seeded weights", "global_batch": B * world, "parallelism": f"dp{world}",
+                               f"(2.567 G params) + IP-Adapter, synthetic seeded weights", "global_batch": B * world, "parallelism": f"dp{world}", "kernel_plans": plans,
                    "image_steps_per_s": world * B * args.steps / elapsed},
     }
 

@@ -89,6 +89,22 @@ ia2p_status ia2p_unet_forward(ia2p_ctx* ctx, void* stream, const void* sample, f
                               const void* text_embeds, const void* time_ids, void* out, int B, int h, int w,
                               void* workspace, size_t workspace_bytes);
 
+/* ---- measured kernel plans (optional) ---------------------------------------------------------------------------- */
+/* Same arguments as ia2p_unet_forward, plus reps (timed launches per candidate, <1 = 5). Runs one forward in which every
+ * GEMM / conv site of a shape without a measured plan times its candidate (tile, K-split) plans in place and records the
+ * fastest in a process-wide table that all later launches of that shape use; *sites (optional) = shapes measured.
+ * `out` is scratch. Tile choice never changes results; a K-split choice changes fp32 summation order (deterministic per
+ * choice), so export the table from one rank and import it on the others to keep ranks bit-identical. Without this call
+ * the library uses its built-in cost model. Call ia2p_workspace_bytes again afterwards. New: the reference has no
+ * counterpart (cuDNN/cuBLAS pick their kernels internally). */
+ia2p_status ia2p_autotune(ia2p_ctx* ctx, void* stream, const void* sample, float timestep, const void* context, int L,
+                          const void* text_embeds, const void* time_ids, void* out, int B, int h, int w,
+                          void* workspace, size_t workspace_bytes, int reps, int* sites);
+size_t ia2p_plan_export(char* buf, size_t len);   /* "M,N,K,conv,geglu,variant,splitk;..." -> buf; returns the length needed */
+int ia2p_plan_import(const char* text);           /* entries read, -1 if malformed */
+void ia2p_plan_clear(void);
+unsigned long long ia2p_plan_generation(void);   /* changes whenever the table does: re-query ia2p_workspace_bytes then */
+
 /* ---- sampler update --------------------------------------------------------------------------------------------- */
 /* out = c_x * x + c_e * (eps_u + g * (eps_c - eps_u)); eps_c may be NULL (no guidance); out2 may be NULL. */
 ia2p_status ia2p_ddim_step(void* stream, const void* x, const void* eps_u, const void* eps_c, float g, float c_x, float c_e,
@@ -119,7 +135,9 @@ ia2p_status ia2p_linear_small(void* stream, const void* X, const void* W, const 
                               int silu_in, int silu_out);
 
 void ia2p_debug_set_gemm_splitk(int splitk);  /* -1 auto (tests / tuning; engine path only) */
-void ia2p_debug_set_gemm_tile(int variant);   /* -1 auto; else tile*2 + (stages-2), tile 0: 128x128, 1: 128x64, 2: 64x64, stages 2..3 (tests / tuning) */
+void ia2p_debug_set_gemm_tile(int variant);   /* -1 auto; else index into IA2P_GEMM_TILES of csrc/common.h, 0..11 (tests / tuning) */
+/* the tile variant and K-split the library picks for a problem (pure function of the shape; host-only, no GPU needed) */
+void ia2p_debug_gemm_plan(int M, int N, int K, int conv, int geglu, int* variant, int* splitk);
 
 /* ---- per-kernel timing (bench.py roofline leg): HIP events on the launch stream around each launch ------------------
  * Classes are device kernel names as rocprofv3 prints them (e.g. "gemm_f16_kernel<128, 64, false>"). */

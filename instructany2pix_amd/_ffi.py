@@ -47,6 +47,11 @@ SIGNATURES = {
     "ia2p_set_ip_adapter": (_I, [_P, _I, _I, _F]),
     "ia2p_workspace_bytes": (_SZ, [_P, _I, _I, _I, _I]),
     "ia2p_unet_forward": (_I, [_P, _P, _P, _F, _P, _I, _P, _P, _P, _I, _I, _I, _P, _SZ]),
+    "ia2p_autotune": (_I, [_P, _P, _P, _F, _P, _I, _P, _P, _P, _I, _I, _I, _P, _SZ, _I, _P]),
+    "ia2p_plan_export": (_SZ, [_P, _SZ]),
+    "ia2p_plan_import": (_I, [C.c_char_p]),
+    "ia2p_plan_clear": (None, []),
+    "ia2p_plan_generation": (C.c_ulonglong, []),
     "ia2p_ddim_step": (_I, [_P, _P, _P, _P, _F, _F, _F, _P, _P, _I64]),
     "ia2p_groupnorm_silu": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
     "ia2p_layernorm": (_I, [_P, _P, _P, _P, _P, _I, _I, _F]),
@@ -59,6 +64,7 @@ SIGNATURES = {
     "ia2p_attention": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _F, _P, _P, _I, _I, _F]),
     "ia2p_linear_small": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I]),
     "ia2p_debug_set_gemm_tile": (None, [_I]),
+    "ia2p_debug_gemm_plan": (None, [_I, _I, _I, _I, _I, _P, _P]),
     "ia2p_vae_create": (_I, [C.POINTER(VAEConfigC), C.POINTER(_P)]),
     "ia2p_vae_destroy": (None, [_P]),
     "ia2p_vae_last_error": (C.c_char_p, [_P]),

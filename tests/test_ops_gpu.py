@@ -41,7 +41,7 @@ def run(L, name, *args):
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("tile", [-1] + list(range(12)))        # every entry of IA2P_GEMM_TILES (csrc/common.h)
 @pytest.mark.parametrize("M,N,K", [(256, 320, 320), (2048, 1280, 1280), (616, 2560, 2048), (100, 64, 64), (37, 132, 128), (8192, 640, 2560)])
 def test_gemm_bias_residual(L, M, N, K, tile):
     f = _ffi()
@@ -59,6 +59,24 @@ def test_gemm_bias_residual(L, M, N, K, tile):
         eye = torch.eye(K, dtype=torch.half, device="cuda")
         run(L, "ia2p_gemm", f.ptr(A), f.ptr(eye), None, None, f.ptr(out), M, N, K, 0)
         assert torch.equal(out, A)
+
+
+@pytest.mark.parametrize("M,N,K", [(2048, 1280, 1280), (333, 200, 192)])
+def test_gemm_tile_choice_never_changes_the_bits(L, M, N, K):
+    """every tile variant accumulates each output element over the same 32-deep MFMA chunks in the same order"""
+    f = _ffi()
+    A, W, b, R = rnd(M, K, seed=51), rnd(N, K, seed=52, scale=K ** -0.5), rnd(N, seed=53), rnd(M, N, seed=54)
+    outs = []
+    try:
+        for tile in range(12):
+            out = torch.empty(M, N, dtype=torch.half, device="cuda")
+            L.ia2p_debug_set_gemm_tile(tile)
+            run(L, "ia2p_gemm", f.ptr(A), f.ptr(W), f.ptr(b), f.ptr(R), f.ptr(out), M, N, K, 0)
+            outs.append(out)
+    finally:
+        L.ia2p_debug_set_gemm_tile(-1)
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
 
 
 @pytest.mark.parametrize("M,N,K,S", [(256, 1280, 5120, 8), (256, 1280, 1280, 4), (2048, 1280, 11520, 3), (77, 192, 640, 5), (300, 64, 128, 2)])
@@ -85,15 +103,24 @@ def test_gemm_no_bias_inplace_residual(L):
     assert rel_l2(X, ref) < 1e-3
 
 
+@pytest.mark.parametrize("tile", [-1, 0, 2, 4, 10])
 @pytest.mark.parametrize("M,C", [(256, 128), (2048, 1280), (130, 640)])
-def test_gemm_geglu(L, M, C):
+def test_gemm_geglu(L, M, C, tile):
     f = _ffi()
     A, W, b = rnd(M, C, seed=8), rnd(8 * C, C, seed=9, scale=C ** -0.5), rnd(8 * C, seed=10, scale=0.1)
     Wp, bp = torch.empty_like(W), torch.empty_like(b)
     run(L, "ia2p_pack_geglu", f.ptr(W), f.ptr(Wp), 8 * C, C)
     run(L, "ia2p_pack_geglu", f.ptr(b), f.ptr(bp), 8 * C, 1)
     out = torch.empty(M, 4 * C, dtype=torch.half, device="cuda")
-    run(L, "ia2p_gemm", f.ptr(A), f.ptr(Wp), f.ptr(bp), None, f.ptr(out), M, 8 * C, C, 1)
+    L.ia2p_debug_set_gemm_tile(tile)
+    try:
+        run(L, "ia2p_gemm", f.ptr(A), f.ptr(Wp), f.ptr(bp), None, f.ptr(out), M, 8 * C, C, 1)
+        if tile == 0:       # tiles whose waves own an odd number of 16-column groups cannot pair (value, gate): refused, not wrong
+            L.ia2p_debug_set_gemm_tile(8)
+            with pytest.raises(Exception):
+                f.check(L.ia2p_gemm(f.current_stream(), f.ptr(A), f.ptr(Wp), f.ptr(bp), None, f.ptr(out), M, 8 * C, C, 1))
+    finally:
+        L.ia2p_debug_set_gemm_tile(-1)
     h = A.float() @ W.float().t() + b.float()
     a, g = h.chunk(2, dim=-1)
     ref = a * F.gelu(g)                                   # exact-erf GELU
@@ -129,6 +156,16 @@ def test_conv3x3(L, B, H, W, Cin, Co, stride, up):
     y = torch.empty(B, Ho, Wo, Co, dtype=torch.half, device="cuda")
     run(L, "ia2p_conv3x3", f.ptr(x), f.ptr(wp), f.ptr(b), f.ptr(tv), f.ptr(res), f.ptr(y), B, H, W, Cin, Co, stride, up)
     assert rel_l2(y, ref) < 1e-3, rel_l2(y, ref)
+
+
+@pytest.mark.parametrize("tile", list(range(12)))
+@pytest.mark.parametrize("B,H,W,Cin,Co,stride,up", [(1, 32, 32, 320, 320, 1, 0), (2, 12, 20, 128, 192, 2, 0), (1, 10, 14, 64, 320, 1, 1)])
+def test_conv3x3_every_tile(L, tile, B, H, W, Cin, Co, stride, up):
+    L.ia2p_debug_set_gemm_tile(tile)
+    try:
+        test_conv3x3(L, B, H, W, Cin, Co, stride, up)
+    finally:
+        L.ia2p_debug_set_gemm_tile(-1)
 
 
 def _sdpa(q, k, v):

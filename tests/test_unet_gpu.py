@@ -109,6 +109,38 @@ def test_set_scale_and_disable_take_effect(tiny_models):
     assert torch.equal(c, d)
 
 
+def test_autotune_keeps_parity_and_plans_round_trip(tiny_models):
+    """ia2p_autotune measures plans in place; results stay within the oracle tolerance, tile-only changes keep the bits,
+    and an exported table re-imported gives the same bits again"""
+    from instructany2pix_amd.attention_processor import AttnProcessor2_0
+    from instructany2pix_amd.unet import clear_plans, export_plans, import_plans
+    cfg, sd, ipsd, hip, oracle = tiny_models
+    hip.set_attn_processor(AttnProcessor2_0())
+    x, ctx, te, tid = _inputs(cfg, 2, 16, 16, 77, seed=77)
+    kw = dict(encoder_hidden_states=ctx.to(DEV), added_cond_kwargs=dict(text_embeds=te.to(DEV), time_ids=tid.to(DEV)))
+    clear_plans()
+    try:
+        base = hip(x.to(DEV), 500, **kw)[0].clone()
+        n = hip.autotune(x.to(DEV), 500, kw["encoder_hidden_states"], kw["added_cond_kwargs"], reps=2)
+        assert n > 5
+        assert hip.autotune(x.to(DEV), 500, kw["encoder_hidden_states"], kw["added_cond_kwargs"], reps=2) == 0    # all shapes known now
+        table = export_plans()
+        assert table.count(";") == n
+        tuned = hip(x.to(DEV), 500, **kw)[0].clone()
+        with torch.no_grad():
+            ref = oracle.build_unet(cfg, sd)(x.float(), 500, ctx.float(), added_cond_kwargs=dict(text_embeds=te.float(), time_ids=tid.float()))[0]
+        assert rel_l2(tuned, ref) <= 5e-3 and rel_l2(base, ref) <= 5e-3
+        assert rel_l2(tuned, base) <= 2e-3                       # only K-split choices may move low-order bits
+        clear_plans()
+        assert import_plans(table) == n
+        again = hip(x.to(DEV), 500, **kw)[0]
+        assert torch.equal(again, tuned)
+        with pytest.raises(ValueError):
+            import_plans("1,2,3")
+    finally:
+        clear_plans()
+
+
 def test_unet_input_validation(tiny_models):
     cfg, sd, ipsd, hip, _ = tiny_models
     x, ctx, te, tid = [t.to(DEV) for t in _inputs(cfg, 1, 16, 16, 77, seed=4)]

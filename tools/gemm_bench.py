@@ -9,11 +9,9 @@ from instructany2pix_amd import _ffi
 
 L = _ffi.lib()
 VARS = [int(v) for v in os.environ.get("VARIANTS", "0,2,4").split(",")]
-NAMES = {v: f"{[128,128,64][v//2]}x{[128,64,64][v//2]}s{v%2+2}" for v in range(6)}
-NAMES[6] = "256x128k32"
-NAMES[7] = "256x320s2"
-NAMES[8] = "128x128k32"
-NAMES[9] = "256x128k32s3"
+TILES = [(128, 128, 2), (128, 128, 3), (128, 64, 2), (128, 64, 3), (64, 64, 2), (64, 64, 3), (64, 160, 2), (64, 160, 3), (128, 160, 2), (128, 160, 3),
+         (160, 128, 2), (160, 160, 2)]      # = IA2P_GEMM_TILES (csrc/common.h)
+NAMES = {v: "%dx%ds%d" % t for v, t in enumerate(TILES)}
 LIN = [  # (M, N, K, count/step, label)
     (2048, 3840, 1280, 60, "L2 qkv"), (2048, 1280, 1280, 192, "L2 proj"), (2048, 10240, 1280, 60, "L2 ff-in(geglu)"),
     (2048, 1280, 5120, 60, "L2 ff-out"), (8192, 1920, 640, 10, "L1 qkv"), (8192, 640, 640, 40, "L1 proj"),
