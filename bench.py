@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-autotune", action="store_true", help="use the built-in cost model instead of measured kernel plans")
+    ap.add_argument("--plans", default=None, help="import this kernel plan table instead of measuring (profiler runs: keeps the tuning launches out of the trace)")
+    ap.add_argument("--save-plans", default=None, help="write the kernel plan table in use to this file")
     ap.add_argument("--cpu-sample-batch", type=int, default=1)
     ap.add_argument("--kernel-table", default=None, help="write the per-kernel timing table (JSON) to this file")
     args = ap.parse_args()
@@ -147,7 +149,11 @@ def main():
     # set-up, outside the timed region: measure the candidate (tile, K-split) plans of every GEMM / conv shape once on
     # rank 0 (ia2p_autotune) and hand the table to the other ranks so that all ranks run identical kernels
     plans = "cost model"
-    if not args.no_autotune:
+    if args.plans:
+        text = open(args.plans).read().strip()
+        import_plans(text)
+        plans = f"imported from {os.path.basename(args.plans)} ({text.count(';')} shapes)"
+    elif not args.no_autotune:
         t0 = time.time()
         table = [None]
         if rank == 0:
@@ -161,6 +167,9 @@ def main():
             if rank != 0:
                 import_plans(table[0])
         plans = f"measured in place at start-up ({table[0].count(';')} shapes)"
+    if args.save_plans and rank == 0:
+        with open(args.save_plans, "w") as f:
+            f.write(export_plans() + "\n")
 
     x, y = lat.clone(), nxt
     for i in range(args.warmup):

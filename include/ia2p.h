@@ -61,6 +61,9 @@ typedef struct {
   int projection_class_embeddings_input_dim;
   int time_embed_dim;
   int time_proj_dim;
+  int mid_transformer_layers;   /* transformer layers of the mid block; < 0 = transformer_layers_per_block[n_blocks-1] (SDXL base). The
+                                 * SDXL refiner (pipeline.py:128-131) ends in a plain DownBlock2D but has 4 layers in its mid block. */
+  int num_time_ids;             /* micro-conditioning ids per sample: 6 (base: sizes + crop), 5 (refiner: + aesthetic score); <= 0 = 6 */
 } ia2p_unet_config;
 
 /* ---- lifetime ---------------------------------------------------------------------------------------------- */
@@ -84,7 +87,7 @@ ia2p_status ia2p_set_ip_adapter(ia2p_ctx* ctx, int enabled, int num_tokens, floa
 /* ---- the UNet callable ------------------------------------------------------------------------------------------- */
 size_t ia2p_workspace_bytes(ia2p_ctx* ctx, int B, int h, int w, int L);
 /* sample, out: [B, in/out_channels, h, w] NCHW; context: [B, L, cross_attention_dim]; text_embeds: [B, pooled];
- * time_ids: [B, 6]. With the IP-Adapter enabled the last num_tokens rows of each context are the image tokens. */
+ * time_ids: [B, num_time_ids]. With the IP-Adapter enabled the last num_tokens rows of each context are the image tokens. */
 ia2p_status ia2p_unet_forward(ia2p_ctx* ctx, void* stream, const void* sample, float timestep, const void* context, int L,
                               const void* text_embeds, const void* time_ids, void* out, int B, int h, int w,
                               void* workspace, size_t workspace_bytes);

@@ -3,9 +3,9 @@
 Importing this package touches no GPU and no native code; the HIP library (libia2p_hip.so, built by
 `python -m instructany2pix_amd.build`) is loaded on first use and there is no non-HIP fallback.
 """
-from .config import UNetConfig, sdxl_base, tiny
+from .config import UNetConfig, sdxl_base, sdxl_refiner, tiny
 
-__all__ = ["UNetConfig", "sdxl_base", "tiny", "InstructAny2PixPipeline", "HipUNet2DConditionModel", "DDIMScheduler",
+__all__ = ["UNetConfig", "sdxl_base", "sdxl_refiner", "tiny", "StableDiffusionXLImg2ImgPipeline", "EulerDiscreteScheduler", "InstructAny2PixPipeline", "HipUNet2DConditionModel", "DDIMScheduler",
            "SDXLDDIMPipeline", "StableDiffusionXLPipeline", "IPAdapterXL", "ImageProjModel", "HipAutoencoderKL"]
 
 
@@ -14,8 +14,11 @@ def __getattr__(name):          # lazy: keep `import instructany2pix_amd` free o
         from .pipeline import InstructAny2PixPipeline as v
     elif name == "HipUNet2DConditionModel":
         from .unet import HipUNet2DConditionModel as v
-    elif name == "DDIMScheduler":
-        from .scheduler import DDIMScheduler as v
+    elif name in ("DDIMScheduler", "EulerDiscreteScheduler"):
+        from . import scheduler
+        v = getattr(scheduler, name)
+    elif name == "StableDiffusionXLImg2ImgPipeline":
+        from .img2img import StableDiffusionXLImg2ImgPipeline as v
     elif name in ("SDXLDDIMPipeline", "StableDiffusionXLPipeline"):
         from . import ddim
         v = getattr(ddim, name)

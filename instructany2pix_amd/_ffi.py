@@ -23,6 +23,7 @@ class UNetConfigC(C.Structure):
         ("num_heads", C.c_int * MAX_BLOCKS), ("layers_per_block", C.c_int), ("cross_attention_dim", C.c_int),
         ("norm_num_groups", C.c_int), ("norm_eps", C.c_float), ("addition_time_embed_dim", C.c_int),
         ("projection_class_embeddings_input_dim", C.c_int), ("time_embed_dim", C.c_int), ("time_proj_dim", C.c_int),
+        ("mid_transformer_layers", C.c_int), ("num_time_ids", C.c_int),
     ]
 
 
@@ -152,6 +153,7 @@ def make_config(cfg) -> UNetConfigC:
     c.addition_time_embed_dim = cfg.addition_time_embed_dim
     c.projection_class_embeddings_input_dim = cfg.projection_class_embeddings_input_dim
     c.time_embed_dim, c.time_proj_dim = cfg.time_embed_dim, cfg.time_proj_dim
+    c.mid_transformer_layers, c.num_time_ids = cfg.mid_block_transformer_layers, cfg.num_time_ids
     return c
 
 

@@ -27,6 +27,14 @@ class UNetConfig:
     time_embed_dim: int = 1280           # block_out_channels[0] * 4
     time_proj_dim: int = 320             # block_out_channels[0]
     head_dim: int = 64
+    # diffusers takes the mid block's depth from transformer_layers_per_block[-1]; here a 0 in that tuple means "plain
+    # block", so a config whose last block is plain but whose mid block attends (the SDXL refiner) states it explicitly
+    mid_transformer_layers: int = -1     # -1 = transformer_layers_per_block[-1]
+    num_time_ids: int = 6                # 6 = (orig size, crop, target size); 5 = (orig size, crop, aesthetic score): refiner
+
+    @property
+    def mid_block_transformer_layers(self) -> int:
+        return self.mid_transformer_layers if self.mid_transformer_layers >= 0 else self.transformer_layers_per_block[-1]
 
     def __getitem__(self, k):            # diffusers FrozenDict-style access
         return getattr(self, k)
@@ -36,7 +44,7 @@ class UNetConfig:
 
     @property
     def pooled_dim(self) -> int:
-        return self.projection_class_embeddings_input_dim - 6 * self.addition_time_embed_dim
+        return self.projection_class_embeddings_input_dim - self.num_time_ids * self.addition_time_embed_dim
 
     def validate(self):
         n = len(self.block_out_channels)
@@ -46,6 +54,7 @@ class UNetConfig:
             assert c % 64 == 0, "channel counts must be multiples of 64 (MFMA K tile)"
             if d > 0:
                 assert h * self.head_dim == c, "inner dim must equal channels"
+        assert self.mid_block_transformer_layers >= 1 and self.attention_head_dim[-1] * self.head_dim == self.block_out_channels[-1]
         assert self.cross_attention_dim % 64 == 0
         assert self.time_embed_dim % 64 == 0 and self.projection_class_embeddings_input_dim % 64 == 0
         return self
@@ -53,6 +62,26 @@ class UNetConfig:
 
 def sdxl_base() -> UNetConfig:
     return UNetConfig().validate()
+
+
+def sdxl_refiner() -> UNetConfig:
+    """`stabilityai/stable-diffusion-xl-refiner-1.0` UNet, the second config of the same engine: the reference runs it as
+    `self.piperf` after sampling (instructany2pix/pipeline.py:128-131,358-361). 4 levels, attention on
+    the two middle ones and in the mid block (4 layers each), OpenCLIP-bigG context (1280), 5 micro-conditioning ids."""
+    return UNetConfig(
+        block_out_channels=(384, 768, 1536, 1536), transformer_layers_per_block=(0, 4, 4, 0), mid_transformer_layers=4,
+        attention_head_dim=(6, 12, 24, 24), cross_attention_dim=1280, projection_class_embeddings_input_dim=2560, num_time_ids=5,
+        time_embed_dim=1536, time_proj_dim=384,
+    ).validate()
+
+
+def tiny_refiner() -> UNetConfig:
+    """the refiner's topology at toy width (4 levels, plain outer blocks, attending mid block, 5 time ids)"""
+    return UNetConfig(
+        block_out_channels=(64, 128, 256, 256), transformer_layers_per_block=(0, 1, 2, 0), mid_transformer_layers=2,
+        attention_head_dim=(1, 2, 4, 4), cross_attention_dim=128, sample_size=32, addition_time_embed_dim=64,
+        projection_class_embeddings_input_dim=5 * 64 + 64, num_time_ids=5, time_embed_dim=256, time_proj_dim=64,
+    ).validate()
 
 
 def tiny(depths=(0, 1, 2)) -> UNetConfig:

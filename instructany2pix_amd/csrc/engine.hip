@@ -285,8 +285,13 @@ static ia2p_status build_plan(ia2p_ctx* c) {
   if (g.cross_attention_dim % 64 || g.time_embed_dim % 8 || g.projection_class_embeddings_input_dim % 8 || g.time_proj_dim % 8 || g.time_proj_dim % 2 || g.addition_time_embed_dim % 2)
     return fail(c, IA2P_ERR_SHAPE, "embedding / context dims violate the 8/64 divisibility rules");
   if (g.in_channels * 9 > 64 || g.out_channels > 8) return fail(c, IA2P_ERR_SHAPE, "latent channels too large for the boundary convolutions");
-  const int pooled = g.projection_class_embeddings_input_dim - 6 * g.addition_time_embed_dim;
-  if (pooled <= 0) return fail(c, IA2P_ERR_SHAPE, "projection_class_embeddings_input_dim smaller than 6 time ids");
+  if (c->cfg.num_time_ids <= 0) c->cfg.num_time_ids = 6;
+  if (c->cfg.mid_transformer_layers < 0) c->cfg.mid_transformer_layers = g.transformer_layers_per_block[n - 1];
+  if (g.num_time_ids > 8) return fail(c, IA2P_ERR_SHAPE, "num_time_ids %d out of range", g.num_time_ids);
+  if (g.mid_transformer_layers < 1 || g.num_heads[n - 1] * 64 != g.block_out_channels[n - 1])
+    return fail(c, IA2P_ERR_SHAPE, "mid block: needs >= 1 transformer layer and heads*64 == channels");
+  const int pooled = g.projection_class_embeddings_input_dim - g.num_time_ids * g.addition_time_embed_dim;
+  if (pooled <= 0) return fail(c, IA2P_ERR_SHAPE, "projection_class_embeddings_input_dim smaller than the time ids");
 
   Planner P{c};
   const int T = g.time_embed_dim, ctx = g.cross_attention_dim;
@@ -312,7 +317,7 @@ static ia2p_status build_plan(ia2p_ctx* c) {
   {
     int rows = 0;
     for (int i = 0; i < n; ++i) rows += g.layers_per_block * g.transformer_layers_per_block[i] * 2 * ch[i];          // down
-    rows += g.transformer_layers_per_block[n - 1] * 2 * ch[n - 1];                                                  // mid
+    rows += g.mid_transformer_layers * 2 * ch[n - 1];                                                               // mid
     for (int i = 0; i < n; ++i) rows += (g.layers_per_block + 1) * g.transformer_layers_per_block[n - 1 - i] * 2 * ch[n - 1 - i];   // up
     c->kv_rows = rows;
     c->kv_text_base = P.take((size_t)rows * ctx);
@@ -343,7 +348,7 @@ static ia2p_status build_plan(ia2p_ctx* c) {
   }
   const int cm = ch[n - 1];
   c->mid_r0 = P.resnet("mid_block.resnets.0", cm, cm, T, c->tw_all, c->tb_all);
-  c->mid_t = P.transformer("mid_block.attentions.0", cm, g.num_heads[n - 1], g.transformer_layers_per_block[n - 1], ctx, ipslots_mid);
+  c->mid_t = P.transformer("mid_block.attentions.0", cm, g.num_heads[n - 1], g.mid_transformer_layers, ctx, ipslots_mid);
   c->mid_r1 = P.resnet("mid_block.resnets.1", cm, cm, T, c->tw_all, c->tb_all);
   cprev = cm;
   for (int i = 0; i < n; ++i) {
@@ -614,7 +619,7 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
   const ia2p_unet_config& g = c->cfg;
   const int n = g.n_blocks;
   const int T = g.time_embed_dim, Tp = g.time_proj_dim, Ain = g.projection_class_embeddings_input_dim, Ad = g.addition_time_embed_dim;
-  const int pooled = Ain - 6 * Ad;
+  const int pooled = Ain - g.num_time_ids * Ad;
   Fwd f{c, B, h, w, L, context, T2{(size_t)-1, nullptr}, nullptr, T2{(size_t)-1, nullptr}, T2{(size_t)-1, nullptr}};
 
   // GroupNorm partial sums (fp32) live at the front of the workspace
@@ -626,7 +631,7 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
   f.temb_all = wsalloc(c, (size_t)B * c->temb_total);
   {
     ProfScope ps(c, PK_EMBED, 0, 0);
-    CHECK_LAUNCH(c, ia2p_launch_embed(timestep, text_embeds, time_ids, tsin.p, addin.p, B, Tp, pooled, Ad, 6, c->stream), "embed");
+    CHECK_LAUNCH(c, ia2p_launch_embed(timestep, text_embeds, time_ids, tsin.p, addin.p, B, Tp, pooled, Ad, g.num_time_ids, c->stream), "embed");
     // skinny linears hold <= 16 rows per launch: larger batches go in row chunks
     auto lin = [&](const half_t* X, int ldx, size_t w, size_t b, const half_t* add, int ldadd, half_t* o, int ldo, int N, int K, int si, int so, const char* what) {
       for (int r0 = 0; r0 < B; r0 += 16) {

@@ -7,7 +7,8 @@ The reference's `__call__` (:303-386) does, in order: LLM + ImageBind (`forward_
     :330      latent_inv = pipe_inversion.inverse(num_inference_steps=N, prompt='', image=img_base)
     :331-337  polar interpolation with fresh noise (CPU, fp16, global torch RNG)
     :342-354  ip_adapter_xl.generate(prompt=..., clip_image_embeds=latent_la[0], latents=latent_inv, guidance_scale=cfg, scale=scale)
-followed by the refiner and subject-consistency passes (adjacent, "next" rows of SURVEY.md §8f).
+followed by the refiner pass (:358-361; `self.piperf`, img2img.py — SURVEY.md §8f rank 2, built) and the subject-consistency
+pass (:363-368; rank 3, not built).
 
 This class keeps the constructor attributes other code touches (`.pipe`, `.pipe_inversion`, `.ip_adapter_xl`,
 `.cache`; serve.py:9 assigns `.pipe.scheduler`) and the `__call__` keyword surface. The off-path stages are
@@ -22,6 +23,7 @@ import torch
 
 from .config import UNetConfig, sdxl_base
 from .ddim import SDXLDDIMPipeline, StableDiffusionXLPipeline
+from .img2img import StableDiffusionXLImg2ImgPipeline
 from .ip_adapter import IPAdapterXL
 from .scheduler import DDIMScheduler
 from .unet import HipUNet2DConditionModel
@@ -47,7 +49,8 @@ class InstructAny2PixPipeline:
     def __init__(self, ckpt: str = "ckpts", llm_folder: str = "llm-retrained", *, unet: Optional[HipUNet2DConditionModel] = None,
                  unet_config: Optional[UNetConfig] = None, unet_state_dict=None, ip_ckpt=None, device: str = "cuda:0",
                  conditioner: Optional[Callable] = None, text_encoder: Optional[Callable] = None,
-                 vae_encode: Optional[Callable] = None, vae_decode: Optional[Callable] = None, clip_embeddings_dim: int = 1024):
+                 vae_encode: Optional[Callable] = None, vae_decode: Optional[Callable] = None, clip_embeddings_dim: int = 1024,
+                 refiner_unet: Optional[HipUNet2DConditionModel] = None, refiner_text_encoder: Optional[Callable] = None):
         if unet is None:
             unet = HipUNet2DConditionModel(unet_config or sdxl_base(), device)
             if unet_state_dict is not None:
@@ -57,6 +60,9 @@ class InstructAny2PixPipeline:
         # one shared UNet object for sampling and inversion (reference :106-116)
         self.pipe = StableDiffusionXLPipeline(unet, DDIMScheduler(), encode_prompt=text_encoder, vae_decode=vae_decode)
         self.pipe_inversion = SDXLDDIMPipeline(unet, new_sch, encode_prompt=text_encoder, vae_encode=vae_encode)
+        # the refiner pipeline object (:128-131): second UNet config of the same engine, Euler img2img loop (img2img.py)
+        self.piperf = StableDiffusionXLImg2ImgPipeline(refiner_unet, encode_prompt=refiner_text_encoder, vae_encode=vae_encode,
+                                                       vae_decode=vae_decode) if refiner_unet is not None else None
         self.conditioner = conditioner           # stands in for forward_llm + prior (:309-317)
         self.cache = None
         self.mode = "ipa_v2"
@@ -103,7 +109,15 @@ class InstructAny2PixPipeline:
                                           inv_prompt_embeds=c.get("inv_prompt_embeds"), inv_pooled_prompt_embeds=c.get("inv_pooled_prompt_embeds"),
                                           alpha=alpha, num_inference_steps=num_inference_steps, cfg=cfg, scale=scale)
         non_refined = images
-        if refinement > 0 or subject_strength > 0:
-            pass    # refiner (:358-361) and subject consistency (:363-368) are "next" rows; the hot path returns the base sample
+        oo = images
+        if refinement > 0 and self.piperf is not None:                                         # :358-361
+            # the reference hands the decoded PIL image over and the refiner re-encodes it with the shared VAE; in latent space
+            # that round trip is the identity up to VAE error, so the base latents go in directly. Conditioning = text encoder 2
+            # on caption + ',high quality,well-formed,award-winning' (out of scope: the conditioner supplies its embeddings).
+            oo = self.piperf(latents=images, strength=refinement, prompt_embeds=c["refiner_prompt_embeds"],
+                             pooled_prompt_embeds=c["refiner_pooled_prompt_embeds"], negative_prompt_embeds=c["refiner_negative_prompt_embeds"],
+                             negative_pooled_prompt_embeds=c["refiner_negative_pooled_prompt_embeds"], noise=c.get("refiner_noise"),
+                             output_type="latent").images
+        # subject consistency (:363-368) is a "next" row
         msg = "SUCCESS!" if not debug else dict(output_caption=c["caption"], latent_inv=latent_inv, latent_la=latent_la)
-        return non_refined, non_refined, msg
+        return non_refined, oo, msg

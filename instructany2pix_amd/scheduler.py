@@ -93,3 +93,93 @@ def fused_update(x, eps_u, eps_c, guidance, c_x, c_e, out, out2=None):
     _ffi.check(L.ia2p_ddim_step(_ffi.current_stream(), _ffi.ptr(x), _ffi.ptr(eps_u), _ffi.ptr(eps_c), float(guidance),
                                 float(c_x), float(c_e), _ffi.ptr(out), _ffi.ptr(out2), n))
     return out
+
+
+class EulerDiscreteScheduler:
+    """Euler (first-order, sigma-space) sampler of the SDXL refiner: the scheduler `StableDiffusionXLImg2ImgPipeline.
+    from_pretrained("stabilityai/stable-diffusion-xl-refiner-1.0")` instantiates for `self.piperf` (reference
+    instructany2pix/pipeline.py:128-131, run at :358-361). diffusers 0.26.3 semantics with the refiner's
+    `scheduler_config.json` (scaled-linear betas 0.00085..0.012, 1000 train steps, "leading" spacing, steps_offset 1,
+    linear sigma interpolation, epsilon prediction, no Karras sigmas, s_churn 0):
+
+        sigma_t = sqrt((1 - abar_t) / abar_t);   model input = x / sqrt(sigma^2 + 1);   x_next = x + (sigma_next - sigma) * eps
+
+    The tensor updates run in `ia2p_ddim_step` like the DDIM ones: every move is  out = c_x * x + c_e * eps.
+    """
+    order = 1
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                 steps_offset=1, timestep_spacing="leading", prediction_type="epsilon", interpolation_type="linear",
+                 use_karras_sigmas=False, **unused):
+        if (beta_schedule != "scaled_linear" or timestep_spacing != "leading" or prediction_type != "epsilon"
+                or interpolation_type != "linear" or use_karras_sigmas):
+            raise NotImplementedError("only the SDXL-refiner Euler configuration is implemented")
+        self.config = SimpleNamespace(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end,
+                                      beta_schedule=beta_schedule, steps_offset=steps_offset, timestep_spacing=timestep_spacing,
+                                      prediction_type=prediction_type, interpolation_type=interpolation_type,
+                                      use_karras_sigmas=use_karras_sigmas)
+        self.betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        self.alphas_cumprod = torch.cumprod(1.0 - self.betas, dim=0)
+        self._train_sigmas = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).numpy()      # float32, ascending in t
+        self.num_inference_steps: Optional[int] = None
+        self.timesteps = torch.from_numpy(np.linspace(0, num_train_timesteps - 1, num_train_timesteps, dtype=np.float32)[::-1].copy())
+        self.sigmas = torch.from_numpy(np.concatenate([self._train_sigmas[::-1], [0.0]]).astype(np.float32))
+        self._step_index: Optional[int] = None
+
+    @classmethod
+    def from_config(cls, config, **kw):
+        d = dict(vars(config)) if not isinstance(config, dict) else dict(config)
+        d.update(kw)
+        return cls(**d)
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        if num_inference_steps > self.config.num_train_timesteps:
+            raise ValueError("num_inference_steps exceeds num_train_timesteps")
+        self.num_inference_steps = num_inference_steps
+        ratio = self.config.num_train_timesteps // num_inference_steps
+        ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.float32) + self.config.steps_offset
+        sig = np.interp(ts, np.arange(0, len(self._train_sigmas)), self._train_sigmas)
+        self.sigmas = torch.from_numpy(np.concatenate([sig, [0.0]]).astype(np.float32))
+        self.timesteps = torch.from_numpy(ts)
+        self._step_index = None
+
+    @property
+    def init_noise_sigma(self) -> float:
+        return float((self.sigmas.max() ** 2 + 1) ** 0.5)          # "leading" spacing
+
+    def index_for_timestep(self, timestep) -> int:
+        idx = (self.timesteps == float(timestep)).nonzero()
+        if len(idx) == 0:
+            raise ValueError(f"timestep {timestep} is not on the current schedule")
+        return int(idx[1 if len(idx) > 1 else 0])                 # diffusers: second match when a timestep repeats
+
+    # ---- coefficients (all updates are  out = c_x * x + c_e * eps) -----------------------------------------------
+    def input_scale(self, index: int) -> float:
+        """`scale_model_input`: 1 / sqrt(sigma^2 + 1)"""
+        s = float(self.sigmas[index])
+        return 1.0 / math.sqrt(s * s + 1.0)
+
+    def step_coeffs(self, index: int):
+        """x_next = x + (sigma_{i+1} - sigma_i) * eps   (epsilon prediction: the derivative is eps itself)"""
+        return 1.0, float(self.sigmas[index + 1]) - float(self.sigmas[index])
+
+    def scale_model_input(self, sample, timestep):
+        i = self._step_index if self._step_index is not None else self.index_for_timestep(timestep)
+        out = torch.empty_like(sample)
+        return fused_update(sample, sample, None, 1.0, self.input_scale(i), 0.0, out)
+
+    def add_noise(self, original_samples, noise, timesteps):
+        """x_t = x_0 + sigma_t * noise (img2img start, sdxl img2img `prepare_latents`)"""
+        t = timesteps.reshape(-1)[0] if torch.is_tensor(timesteps) else timesteps
+        s = float(self.sigmas[self.index_for_timestep(t)])
+        out = torch.empty_like(original_samples)
+        return fused_update(original_samples.contiguous(), noise.to(original_samples.dtype).contiguous(), None, 1.0, 1.0, s, out)
+
+    def step(self, model_output, timestep, sample, return_dict: bool = False, **kw):
+        if self._step_index is None:
+            self._step_index = self.index_for_timestep(timestep)
+        c_x, c_e = self.step_coeffs(self._step_index)
+        out = torch.empty_like(sample)
+        fused_update(sample, model_output, None, 1.0, c_x, c_e, out)
+        self._step_index += 1
+        return (out,) if not return_dict else SimpleNamespace(prev_sample=out)

@@ -178,9 +178,9 @@ class HipUNet2DConditionModel:
         te, tid = f16(added_cond_kwargs["text_embeds"]), f16(added_cond_kwargs["time_ids"])
         if ctx.shape[0] != B or ctx.shape[2] != self.config.cross_attention_dim:
             raise ValueError(f"encoder_hidden_states must be [B, L, {self.config.cross_attention_dim}]")
-        if te.shape != (B, self.config.pooled_dim) or tid.shape != (B, 6):
+        if te.shape != (B, self.config.pooled_dim) or tid.shape != (B, self.config.num_time_ids):
             raise ValueError(f"Model expects an added time embedding vector of length {self.config.projection_class_embeddings_input_dim}, "
-                             f"but a vector of {te.shape[-1] + 6 * self.config.addition_time_embed_dim} was created.")
+                             f"but a vector of {te.shape[-1] + tid.shape[-1] * self.config.addition_time_embed_dim} was created.")
         L = ctx.shape[1]
         ws = self.workspace_for(B, h, w, L)
         if out is None:

@@ -92,7 +92,7 @@ def unet_param_specs(cfg: UNetConfig) -> List[Spec]:
     # mid
     cm = ch[-1]
     s += _resnet("mid_block.resnets.0", cm, cm, temb)
-    s += _transformer("mid_block.attentions.0", cm, depth[-1], ctx)
+    s += _transformer("mid_block.attentions.0", cm, cfg.mid_block_transformer_layers, ctx)
     s += _resnet("mid_block.resnets.1", cm, cm, temb)
     # up path
     rch = list(reversed(ch))
@@ -135,7 +135,7 @@ def attn_processor_names(cfg: UNetConfig) -> List[str]:
     for i in range(n):
         for j in range(cfg.layers_per_block + 1):
             add(f"up_blocks.{i}.attentions.{j}", rdepth[i])
-    add("mid_block.attentions.0", depth[-1])
+    add("mid_block.attentions.0", cfg.mid_block_transformer_layers)
     return names
 
 

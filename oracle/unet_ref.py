@@ -246,7 +246,7 @@ class UNet2DConditionModelRef(nn.Module):
             cprev = ch[i]
             self.down_blocks.append(blk)
         mid = _Block()
-        mid.attentions = nn.ModuleList([Transformer2DModel(ch[-1], heads[-1], cfg.head_dim, depth[-1], ctx, g)])
+        mid.attentions = nn.ModuleList([Transformer2DModel(ch[-1], heads[-1], cfg.head_dim, cfg.mid_block_transformer_layers, ctx, g)])
         mid.resnets = nn.ModuleList([ResnetBlock2D(ch[-1], ch[-1], temb, g, eps) for _ in range(2)])
         self.mid_block = mid
         rch, rdepth, rheads = ch[::-1], depth[::-1], heads[::-1]

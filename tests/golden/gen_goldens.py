@@ -21,6 +21,8 @@ Fixtures:
   G7 misc.npz          polar_intrtpolate, _get_add_time_ids
   G8 unet_refprocs.npz tiny UNet (oracle module tree) with the REFERENCE processor classes installed
   G9 vae_ldm.npz       in-tree ldm Encoder / Decoder (the architecture the SDXL VAE descends from), small config
+  G10 misc_refiner.npz _get_add_time_ids, requires_aesthetics_score branch (the refiner's 5 micro-conditioning ids) + its error cases
+                       (`python gen_goldens.py refiner` writes only this one)
 """
 import ast
 import importlib
@@ -301,5 +303,38 @@ def main():
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
 
 
+def gen_refiner():
+    """G10: the aesthetics-score branch of the reference's own `_get_add_time_ids` (pnp_pipeline.py:23-71)"""
+    fn = ast_extract("instructany2pix/ddim/pnp_pipeline.py", ["_get_add_time_ids"], {"torch": torch})["_get_add_time_ids"]
+
+    def fake(requires, in_features):
+        return types.SimpleNamespace(
+            config=types.SimpleNamespace(requires_aesthetics_score=requires),
+            unet=types.SimpleNamespace(config=types.SimpleNamespace(addition_time_embed_dim=256),
+                                       add_embedding=types.SimpleNamespace(linear_1=types.SimpleNamespace(in_features=in_features))),
+            text_encoder_2=types.SimpleNamespace(config=types.SimpleNamespace(projection_dim=1280)))
+
+    d = {}
+    ids, neg = fn(fake(True, 2560), (1024, 1024), (0, 0), (1024, 1024), 6.0, 2.5, (1024, 1024), (0, 0), (1024, 1024), torch.float32)
+    d["time_ids"], d["neg_time_ids"] = npf(ids), npf(neg)
+    ids, neg = fn(fake(True, 2560), (768, 512), (8, 16), (768, 512), 7.5, 1.0, (640, 384), (4, 2), (768, 512), torch.float32)
+    d["time_ids_b"], d["neg_time_ids_b"] = npf(ids), npf(neg)
+    msgs = []
+    for name, requires, feats in (("err_enable", False, 2560 + 512), ("err_enable2", True, 2816), ("err_disable", False, 2560), ("err_config", True, 2000)):
+        try:
+            fn(fake(requires, feats), (1024, 1024), (0, 0), (1024, 1024), 6.0, 2.5, (1024, 1024), (0, 0), (1024, 1024), torch.float32)
+            d[name] = 0
+        except ValueError as e:
+            d[name] = 1
+            msgs.append(f"{name}: {'enable' if 'to enable' in str(e) else 'disable' if 'to disable' in str(e) else 'config'}")
+    d["err_kinds"] = np.array(msgs)
+    np.savez(os.path.join(HERE, "misc_refiner.npz"), **d)
+    print(d["time_ids"], d["neg_time_ids"], msgs)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "refiner":
+        with torch.no_grad():
+            gen_refiner()
+    else:
+        main()

@@ -129,3 +129,73 @@ def test_polar_interpolate_and_fusion_match_golden(golden):
     assert math.isclose(float(la.norm()), 20.0, rel_tol=1e-5)
     ref = be * 0.0 + ie * 0.4 + y / y.norm() * 20.0
     assert torch.allclose(la, ref / ref.norm() * 20.0, atol=1e-6)
+
+
+# ---- refiner pass: Euler tables, schedule tail, 5-id micro-conditioning ----------------------
+def test_refiner_config_inventory():
+    from instructany2pix_amd.config import sdxl_refiner, tiny_refiner
+    cfg = sdxl_refiner()
+    assert param_count(unet_param_specs(cfg)) == 2_259_526_660           # = the 4.52 GB fp16 refiner UNet checkpoint
+    assert cfg.pooled_dim == 1280 and cfg.num_time_ids == 5 and cfg.mid_block_transformer_layers == 4
+    names = attn_processor_names(cfg)
+    assert len(names) == 2 * 4 * (2 * 2 + 3 * 2 + 1)                      # 4 layers x (down 2x2, up 2x3, mid) x (attn1, attn2)
+    assert names[-1] == "mid_block.attentions.0.transformer_blocks.3.attn2.processor"
+    for c in (cfg, tiny_refiner()):
+        with torch.device("meta"):
+            ref = oracle.UNet2DConditionModelRef(c)
+        assert {k: tuple(v.shape) for k, v in ref.state_dict().items()} == {k: s for k, s, _ in unet_param_specs(c)}
+        assert list(ref.attn_processors.keys()) == attn_processor_names(c)
+
+
+def test_euler_scheduler_tables_and_coefficients_match_oracle():
+    from instructany2pix_amd.scheduler import EulerDiscreteScheduler
+    s, r = EulerDiscreteScheduler(), oracle.EulerDiscreteSchedulerRef()
+    assert torch.equal(s.alphas_cumprod, DDIMScheduler().alphas_cumprod)    # same beta table (pinned by G5)
+    for n in (20, 50):
+        s.set_timesteps(n)
+        r.set_timesteps(n)
+        assert np.array_equal(s.timesteps.numpy(), r.timesteps)
+        assert np.allclose(s.sigmas.numpy(), r.sigmas, rtol=3e-7, atol=0)        # torch vs numpy float32 pow: 1 ulp
+        assert s.timesteps.dtype == torch.float32 and float(s.timesteps[0]) == 1000 // n * (n - 1) + 1 and float(s.sigmas[-1]) == 0.0
+        assert abs(s.init_noise_sigma - math.sqrt(float(r.sigmas.max()) ** 2 + 1)) < 1e-6
+        x, e = torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(n)), torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(n + 1))
+        for i in (0, n // 2, n - 1):
+            c_x, c_e = s.step_coeffs(i)
+            assert (c_x * x + c_e * e - r.step(e, i, x)).abs().max() < 2e-5
+            assert (s.input_scale(i) * x - r.scale_model_input(x, i)).abs().max() < 1e-6
+            assert s.index_for_timestep(s.timesteps[i]) == i
+    with pytest.raises(ValueError):
+        s.index_for_timestep(3.0)
+    with pytest.raises(NotImplementedError):
+        EulerDiscreteScheduler(use_karras_sigmas=True)
+
+
+def test_img2img_schedule_tail_and_time_ids_match_reference_golden(golden):
+    from types import SimpleNamespace
+    from instructany2pix_amd.img2img import StableDiffusionXLImg2ImgPipeline, get_add_time_ids_aesthetic
+    d = golden("misc_refiner.npz")
+
+    def unet(in_features):
+        return SimpleNamespace(config=SimpleNamespace(addition_time_embed_dim=256), add_embedding=SimpleNamespace(linear_1=SimpleNamespace(in_features=in_features)),
+                               device="cpu")
+    ids, neg = get_add_time_ids_aesthetic(unet(2560), (1024, 1024), (0, 0), (1024, 1024), 6.0, 2.5, (1024, 1024), (0, 0), (1024, 1024), 1280, True, torch.float32)
+    assert np.array_equal(ids.numpy(), d["time_ids"]) and np.array_equal(neg.numpy(), d["neg_time_ids"])
+    ids, neg = get_add_time_ids_aesthetic(unet(2560), (768, 512), (8, 16), (768, 512), 7.5, 1.0, (640, 384), (4, 2), (768, 512), 1280, True, torch.float32)
+    assert np.array_equal(ids.numpy(), d["time_ids_b"]) and np.array_equal(neg.numpy(), d["neg_time_ids_b"])
+    kinds = dict(k.split(": ") for k in d["err_kinds"])
+    for name, requires, feats in (("err_enable", False, 3072), ("err_enable2", True, 2816), ("err_disable", False, 2560), ("err_config", True, 2000)):
+        assert int(d[name]) == 1
+        with pytest.raises(ValueError) as ei:
+            get_add_time_ids_aesthetic(unet(feats), (1024, 1024), (0, 0), (1024, 1024), 6.0, 2.5, (1024, 1024), (0, 0), (1024, 1024), 1280, requires, torch.float32)
+        msg = str(ei.value)
+        assert kinds[name] == ("enable" if "to enable" in msg else "disable" if "to disable" in msg else "config")
+    p = StableDiffusionXLImg2ImgPipeline(unet(2560))
+    p.scheduler.set_timesteps(50)
+    ts, n, t0 = p.get_timesteps(50, 0.5)                         # the reference's default refinement = 0.5
+    assert n == 25 and t0 == 25 and float(ts[0]) == 481.0 and float(ts[-1]) == 1.0
+    ts, n, t0 = p.get_timesteps(50, 1.0)
+    assert n == 50 and t0 == 0
+    with pytest.raises(ValueError):
+        p(prompt_embeds=torch.zeros(1, 77, 1280), pooled_prompt_embeds=torch.zeros(1, 1280), latents=torch.zeros(1, 4, 8, 8), strength=1.5)
+    with pytest.raises(ValueError):
+        p(prompt_embeds=torch.zeros(1, 77, 1280), pooled_prompt_embeds=torch.zeros(1, 1280), latents=torch.zeros(1, 4, 8, 8), strength=0.0, guidance_scale=1.0)

@@ -220,3 +220,16 @@ def test_g9_vae_against_in_tree_ldm_encoder_decoder(golden):
     mom = torch.cat([torch.ones(1, 4, 2, 2), torch.full((1, 4, 2, 2), 40.0)], dim=1)
     s = oracle.sample_latents(mom, torch.ones(1, 4, 2, 2), 0.13025)
     assert torch.allclose(s, (1 + torch.exp(torch.tensor(10.0))) * 0.13025 * torch.ones(1, 4, 2, 2))    # logvar clamp at 20
+
+
+def test_g10_refiner_time_ids(golden):
+    """the oracle's aesthetics-score ids == the reference's `_get_add_time_ids` (pnp_pipeline.py:23-71, requires_aesthetics_score)"""
+    d = golden("misc_refiner.npz")
+    ids, neg = oracle.get_add_time_ids_aesthetic((1024, 1024), (0, 0), (1024, 1024), 6.0, 2.5, (1024, 1024), (0, 0), (1024, 1024), 256, 1280, 2560)
+    assert np.array_equal(ids.numpy(), d["time_ids"]) and np.array_equal(neg.numpy(), d["neg_time_ids"])
+    ids, neg = oracle.get_add_time_ids_aesthetic((768, 512), (8, 16), (768, 512), 7.5, 1.0, (640, 384), (4, 2), (768, 512), 256, 1280, 2560)
+    assert np.array_equal(ids.numpy(), d["time_ids_b"]) and np.array_equal(neg.numpy(), d["neg_time_ids_b"])
+    for name, requires, feats in (("err_enable", False, 3072), ("err_enable2", True, 2816), ("err_disable", False, 2560), ("err_config", True, 2000)):
+        assert int(d[name]) == 1
+        with pytest.raises(ValueError):
+            oracle.get_add_time_ids_aesthetic((1024, 1024), (0, 0), (1024, 1024), 6.0, 2.5, (1024, 1024), (0, 0), (1024, 1024), 256, 1280, feats, requires)
