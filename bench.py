@@ -42,7 +42,7 @@ def make_inputs(cfg, B, hw, L, device, cfg_id=3):
     ip = torch.nn.functional.layer_norm(torch.randn(B, L - 77, cfg.cross_attention_dim, generator=g(3000 + cfg_id)), (cfg.cross_attention_dim,)) if L > 77 else text[:, :0]
     ctx = torch.cat([text, ip], dim=1).half()
     pooled = torch.randn(B, cfg.pooled_dim, generator=g(4000 + cfg_id)).half()
-    tid = torch.tensor([[hw * 8.0, hw * 8.0, 0.0, 0.0, hw * 8.0, hw * 8.0]] * B).half()
+    tid = torch.tensor([[hw * 8.0, hw * 8.0, 0.0, 0.0, hw * 8.0, hw * 8.0][:cfg.num_time_ids - 1] + ([hw * 8.0] if cfg.num_time_ids == 6 else [6.0])] * B).half()
     return [t.to(device).contiguous() for t in (lat, ctx, pooled, tid)]
 
 
@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--latent", type=int, default=64, help="latent side (64 = 512x512 pixels)")
     ap.add_argument("--ctx", type=int, default=81, help="context tokens (77 text + 4 image tokens)")
+    ap.add_argument("--unet", choices=["base", "refiner"], default="base", help="refiner = the second engine config (non-headline; use --ctx 77)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-autotune", action="store_true", help="use the built-in cost model instead of measured kernel plans")
@@ -105,7 +106,7 @@ def main():
 
     import torch
     from instructany2pix_amd import dist as D
-    from instructany2pix_amd.config import sdxl_base
+    from instructany2pix_amd.config import sdxl_base, sdxl_refiner
     from instructany2pix_amd.scheduler import DDIMScheduler, fused_update
     from instructany2pix_amd.unet import HipUNet2DConditionModel, export_plans, import_plans
     from instructany2pix_amd.weights import unet_param_specs, ip_adapter_specs, iter_synthetic
@@ -115,7 +116,7 @@ def main():
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}")
     dev = torch.device(f"cuda:{os.environ.get('IA2P_FORCE_DEVICE', local)}")     # (override: tests with several ranks on one GPU)
     torch.cuda.set_device(dev)
-    cfg = sdxl_base()
+    cfg = sdxl_base() if args.unet == "base" else sdxl_refiner()
     seed = 7
     unet_specs, ip_specs = unet_param_specs(cfg), ip_adapter_specs(cfg)["ip_adapter"]
     use_ip = args.ctx > 77
@@ -186,16 +187,16 @@ def main():
     elapsed = D.max_over_ranks(time.perf_counter() - t0, device=dev if world > 1 else "cpu")
     assert torch.isfinite(x).all(), "non-finite latents after the timed run"
 
-    default_cfg = (args.batch, args.latent, args.ctx) == (8, 64, 81)
+    default_cfg = (args.batch, args.latent, args.ctx, args.unet) == (8, 64, 81, "base")
     metric = "denoise-steps/sec (512x512, 50-step DDIM, batch 8)" if default_cfg else \
-        f"denoise-steps/sec ({args.latent * 8}x{args.latent * 8}, 50-step DDIM, batch {args.batch}) [non-headline shape]"
+        f"denoise-steps/sec ({args.latent * 8}x{args.latent * 8}, 50-step DDIM, batch {args.batch}{', SDXL-refiner UNet' if args.unet == 'refiner' else ''}) [non-headline shape]"
     res = {
         "metric": metric, "value": world * args.steps / elapsed, "unit": "steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": f"{'BASELINE configs[2]' if default_cfg else 'custom'}: {hw * 8}x{hw * 8} px, latent [{B},4,{hw},{hw}], 50-step DDIM schedule, "
-                               f"context {L} tokens ({'77 text + %d IP-Adapter image tokens' % (L - 77) if use_ip else 'text only'}), SDXL-base UNet "
-                               f"(2.567 G params) + IP-Adapter, synthetic seeded weights", "global_batch": B * world, "parallelism": f"dp{world}", "kernel_plans": plans,
+                               f"context {L} tokens ({'77 text + %d IP-Adapter image tokens' % (L - 77) if use_ip else 'text only'}), {'SDXL-base UNet (2.567 G params) + IP-Adapter' if args.unet == 'base' else 'SDXL-refiner UNet (2.260 G params)'}, "
+                               f"synthetic seeded weights", "global_batch": B * world, "parallelism": f"dp{world}", "kernel_plans": plans,
                    "image_steps_per_s": world * B * args.steps / elapsed},
     }
 
