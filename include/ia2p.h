@@ -112,6 +112,12 @@ unsigned long long ia2p_plan_generation(void);   /* changes whenever the table d
 /* out = c_x * x + c_e * (eps_u + g * (eps_c - eps_u)); eps_c may be NULL (no guidance); out2 may be NULL. */
 ia2p_status ia2p_ddim_step(void* stream, const void* x, const void* eps_u, const void* eps_c, float g, float c_x, float c_e,
                            void* out, void* out2, int64_t n);
+/* out = (1 - m) * (c0 * init + c1 * noise) + m * x with m = mask[b, 0, :, :] ([B,1,h,w], shared by the C channels): the per-step
+ * blend of the inpainting loop behind `pipe_inpainting` (reference pipeline.py:132-139, gdino/lib.py:89-102; diffusers
+ * StableDiffusionXLInpaintPipeline, 4-channel UNet branch). c0 = sqrt(abar_next), c1 = sqrt(1 - abar_next) re-noise the known
+ * region to the next timestep (DDIM add_noise); c0 = 1, c1 = 0 after the last step. out2 may be NULL. HW = h * w. */
+ia2p_status ia2p_mask_blend(void* stream, const void* x, const void* init, const void* noise, const void* mask, float c0, float c1,
+                            void* out, void* out2, int B, int C, int64_t HW);
 
 /* ---- per-operator entry points (unit tests, and hosts that keep their own module tree) ----------------------------- */
 ia2p_status ia2p_groupnorm_silu(void* stream, const void* x, void* y, const void* gamma, const void* beta, int B, int HW, int C,

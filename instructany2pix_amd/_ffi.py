@@ -54,6 +54,7 @@ SIGNATURES = {
     "ia2p_plan_clear": (None, []),
     "ia2p_plan_generation": (C.c_ulonglong, []),
     "ia2p_ddim_step": (_I, [_P, _P, _P, _P, _F, _F, _F, _P, _P, _I64]),
+    "ia2p_mask_blend": (_I, [_P, _P, _P, _P, _P, _F, _F, _P, _P, _I, _I, _I64]),
     "ia2p_groupnorm_silu": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
     "ia2p_layernorm": (_I, [_P, _P, _P, _P, _P, _I, _I, _F]),
     "ia2p_gemm": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I]),

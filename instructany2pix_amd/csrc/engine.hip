@@ -42,6 +42,8 @@ hipError_t ia2p_launch_conv_out(const half_t* x, int ldx, const half_t* w, const
 hipError_t ia2p_launch_concat(const half_t* a, int lda, int Ca, const half_t* b, int ldb, int Cb, half_t* y, long M, hipStream_t s);
 hipError_t ia2p_launch_ddim_step(const half_t* x, const half_t* eps_u, const half_t* eps_c, float g, float c_x, float c_e,
                                  half_t* out, half_t* out2, long n, hipStream_t s);
+hipError_t ia2p_launch_mask_blend(const half_t* x, const half_t* init, const half_t* noise, const half_t* mask, float c0, float c1,
+                                  half_t* out, half_t* out2, int B, int C, long HW, hipStream_t s);
 hipError_t ia2p_launch_pack_conv(const half_t* src, half_t* dst, int Co, int Ci, hipStream_t s);
 hipError_t ia2p_launch_pack_geglu(const half_t* src, half_t* dst, int rows, int rowlen, hipStream_t s);
 hipError_t ia2p_launch_softmax_rows(half_t* x, long ld, int rows, int n, float scale, hipStream_t s);
@@ -914,6 +916,14 @@ ia2p_status ia2p_ddim_step(void* stream, const void* x, const void* eu, const vo
   if (!x || !eu || !out || n < 0) return fail(nullptr, IA2P_ERR_INVALID, "ddim_step: null argument");
   hipError_t e = ia2p_launch_ddim_step((const half_t*)x, (const half_t*)eu, (const half_t*)ec, g, c_x, c_e, (half_t*)out, (half_t*)out2, (long)n, (hipStream_t)stream);
   return e == hipSuccess ? IA2P_OK : fail(nullptr, IA2P_ERR_HIP, "ddim_step: %s", hipGetErrorString(e));
+}
+
+ia2p_status ia2p_mask_blend(void* stream, const void* x, const void* init, const void* noise, const void* mask, float c0, float c1,
+                            void* out, void* out2, int B, int C, int64_t HW) {
+  if (!x || !init || !noise || !mask || !out || B < 0 || C < 1 || HW < 1) return fail(nullptr, IA2P_ERR_INVALID, "mask_blend: bad argument");
+  hipError_t e = ia2p_launch_mask_blend((const half_t*)x, (const half_t*)init, (const half_t*)noise, (const half_t*)mask, c0, c1, (half_t*)out, (half_t*)out2,
+                                        B, C, (long)HW, (hipStream_t)stream);
+  return e == hipSuccess ? IA2P_OK : fail(nullptr, IA2P_ERR_HIP, "mask_blend: %s", hipGetErrorString(e));
 }
 
 // ---- per-operator entry points ---------------------------------------------------------------------------------------

@@ -180,6 +180,21 @@ __global__ void ddim_step_kernel(const half_t* x, const half_t* eps_u, const hal
   }
 }
 
+// out = (1 - m) * (c0 * init + c1 * noise) + m * x, m = mask[b, 0, y, x] shared by the C channels: the per-step latent blend of
+// the inpainting loop (diffusers StableDiffusionXLInpaintPipeline, 4-channel UNet branch: known region re-noised to the next
+// timestep with DDIM add_noise, c0 = sqrt(abar), c1 = sqrt(1 - abar); c0 = 1, c1 = 0 after the last step). out2 optional.
+__global__ void mask_blend_kernel(const half_t* x, const half_t* init, const half_t* noise, const half_t* mask, float c0, float c1,
+                                  half_t* out, half_t* out2, int C, long HW, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / (C * HW), p = i % HW;
+    const float m = (float)mask[b * HW + p];
+    const float keep = c0 * (float)init[i] + c1 * (float)noise[i];
+    const half_t o = (half_t)((1.f - m) * keep + m * (float)x[i]);
+    out[i] = o;
+    if (out2) out2[i] = o;
+  }
+}
+
 // ---- one-time weight re-layouts -----------------------------------------------------------------------------------------
 // conv [Co][Ci][3][3] -> [Co][ky][kx][Ci] (implicit-GEMM K order)
 __global__ void pack_conv_kernel(const half_t* src, half_t* dst, int Co, int Ci) {
@@ -298,6 +313,12 @@ hipError_t ia2p_launch_concat(const half_t* a, int lda, int Ca, const half_t* b,
 hipError_t ia2p_launch_ddim_step(const half_t* x, const half_t* eps_u, const half_t* eps_c, float g, float c_x, float c_e,
                                  half_t* out, half_t* out2, long n, hipStream_t s) {
   hipLaunchKernelGGL(ddim_step_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, x, eps_u, eps_c, g, c_x, c_e, out, out2, n);
+  return hipGetLastError();
+}
+hipError_t ia2p_launch_mask_blend(const half_t* x, const half_t* init, const half_t* noise, const half_t* mask, float c0, float c1,
+                                  half_t* out, half_t* out2, int B, int C, long HW, hipStream_t s) {
+  const long n = (long)B * C * HW;
+  hipLaunchKernelGGL(mask_blend_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, x, init, noise, mask, c0, c1, out, out2, C, HW, n);
   return hipGetLastError();
 }
 hipError_t ia2p_launch_pack_conv(const half_t* src, half_t* dst, int Co, int Ci, hipStream_t s) {

@@ -8,7 +8,8 @@ The reference's `__call__` (:303-386) does, in order: LLM + ImageBind (`forward_
     :331-337  polar interpolation with fresh noise (CPU, fp16, global torch RNG)
     :342-354  ip_adapter_xl.generate(prompt=..., clip_image_embeds=latent_la[0], latents=latent_inv, guidance_scale=cfg, scale=scale)
 followed by the refiner pass (:358-361; `self.piperf`, img2img.py — SURVEY.md §8f rank 2, built) and the subject-consistency
-pass (:363-368; rank 3, not built).
+pass (:363-368; `self.pipe_inpainting` / `ip_adapter_xl_inpaint`, inpaint.py — rank 3, built; its masks come from SAM / GroundingDINO,
+which stay outside).
 
 This class keeps the constructor attributes other code touches (`.pipe`, `.pipe_inversion`, `.ip_adapter_xl`,
 `.cache`; serve.py:9 assigns `.pipe.scheduler`) and the `__call__` keyword surface. The off-path stages are
@@ -24,6 +25,7 @@ import torch
 from .config import UNetConfig, sdxl_base
 from .ddim import SDXLDDIMPipeline, StableDiffusionXLPipeline
 from .img2img import StableDiffusionXLImg2ImgPipeline
+from .inpaint import StableDiffusionXLInpaintPipeline, subject_consistency
 from .ip_adapter import IPAdapterXL
 from .scheduler import DDIMScheduler
 from .unet import HipUNet2DConditionModel
@@ -63,10 +65,16 @@ class InstructAny2PixPipeline:
         # the refiner pipeline object (:128-131): second UNet config of the same engine, Euler img2img loop (img2img.py)
         self.piperf = StableDiffusionXLImg2ImgPipeline(refiner_unet, encode_prompt=refiner_text_encoder, vae_encode=vae_encode,
                                                        vae_decode=vae_decode) if refiner_unet is not None else None
+        # inpainting pipeline assembled from the base pipeline's own modules: same UNet object, same scheduler object (:132-139)
+        self.pipe_inpainting = StableDiffusionXLInpaintPipeline(unet, self.pipe.scheduler, encode_prompt=text_encoder, vae_encode=vae_encode,
+                                                                vae_decode=vae_decode)
         self.conditioner = conditioner           # stands in for forward_llm + prior (:309-317)
         self.cache = None
         self.mode = "ipa_v2"
         self.ip_adapter_xl = IPAdapterXL(self.pipe, "", ip_ckpt=ip_ckpt, device=device, clip_embeddings_dim=clip_embeddings_dim) if ip_ckpt is not None else None
+        # second adapter object over the same UNet (:143-146): it re-installs the same processors and weights
+        self.ip_adapter_xl_inpaint = IPAdapterXL(self.pipe_inpainting, "", ip_ckpt=ip_ckpt, device=device,
+                                                 clip_embeddings_dim=clip_embeddings_dim) if ip_ckpt is not None else None
 
     # ---- the hot segment on explicit conditioning ------------------------------------------------------------------
     @torch.no_grad()
@@ -118,6 +126,11 @@ class InstructAny2PixPipeline:
                              pooled_prompt_embeds=c["refiner_pooled_prompt_embeds"], negative_prompt_embeds=c["refiner_negative_prompt_embeds"],
                              negative_pooled_prompt_embeds=c["refiner_negative_pooled_prompt_embeds"], noise=c.get("refiner_noise"),
                              output_type="latent").images
-        # subject consistency (:363-368) is a "next" row
+        subject_data = c.get("subject_data") or []
+        if subject_strength > 0 and len(subject_data) > 0:                                     # :363-368 (masks: SAM / GroundingDINO, off-path)
+            oo = subject_consistency(subject_data, oo, self.ip_adapter_xl_inpaint, subject_strength, output_type="latent",
+                                     prompt_embeds=c["subject_prompt_embeds"], pooled_prompt_embeds=c["subject_pooled_prompt_embeds"],
+                                     negative_prompt_embeds=c["subject_negative_prompt_embeds"],
+                                     negative_pooled_prompt_embeds=c["subject_negative_pooled_prompt_embeds"], noise=c.get("subject_noise"))
         msg = "SUCCESS!" if not debug else dict(output_caption=c["caption"], latent_inv=latent_inv, latent_la=latent_la)
         return non_refined, oo, msg

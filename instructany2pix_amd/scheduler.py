@@ -74,6 +74,17 @@ class DDIMScheduler:
         a, b = float(alpha_t), float(alpha_tm1)
         return math.sqrt(a / b), math.sqrt(a) * (math.sqrt(1.0 / a - 1.0) - math.sqrt(1.0 / b - 1.0))
 
+    def add_noise_coeffs(self, t: int):
+        """x_t = sqrt(abar_t) x_0 + sqrt(1 - abar_t) noise (inpainting: start latents and the re-noised known region)"""
+        a = float(self.alphas_cumprod[int(t)])
+        return math.sqrt(a), math.sqrt(1.0 - a)
+
+    def add_noise(self, original_samples, noise, timesteps):
+        t = timesteps.reshape(-1)[0] if torch.is_tensor(timesteps) else timesteps
+        c0, c1 = self.add_noise_coeffs(int(t))
+        out = torch.empty_like(original_samples)
+        return fused_update(original_samples.contiguous(), noise.to(original_samples.dtype).contiguous(), None, 1.0, c0, c1, out)
+
     def step(self, model_output, timestep, sample, eta: float = 0.0, generator=None, return_dict: bool = False, **kw):
         if eta != 0.0:
             raise NotImplementedError("eta != 0 is not on the reference's path")
@@ -81,6 +92,17 @@ class DDIMScheduler:
         out = torch.empty_like(sample)
         fused_update(sample, model_output, None, 1.0, c_x, c_e, out)
         return (out,) if not return_dict else SimpleNamespace(prev_sample=out)
+
+
+def mask_blend(x, init, noise, mask, c0, c1, out, out2=None):
+    """out = (1 - mask) * (c0*init + c1*noise) + mask * x on the current stream (ia2p_mask_blend); mask is [B,1,h,w]."""
+    B, Cc, h, w = x.shape
+    for t in (x, init, noise, mask, out):
+        assert t.dtype == torch.float16 and t.is_cuda and t.is_contiguous(), "latents and mask must be contiguous fp16 device tensors"
+    assert init.shape == x.shape and noise.shape == x.shape and out.shape == x.shape and tuple(mask.shape) == (B, 1, h, w)
+    _ffi.check(_ffi.lib().ia2p_mask_blend(_ffi.current_stream(), _ffi.ptr(x), _ffi.ptr(init), _ffi.ptr(noise), _ffi.ptr(mask), float(c0), float(c1),
+                                          _ffi.ptr(out), _ffi.ptr(out2), B, Cc, h * w))
+    return out
 
 
 def fused_update(x, eps_u, eps_c, guidance, c_x, c_e, out, out2=None):

@@ -8,6 +8,9 @@ files themselves, tests/golden/gen_goldens.py):
   polar_interpolate     <- polar_intrtpolate              instructany2pix/pipeline.py:295-300
   ImageProjModelRef     <- ImageProjModel                 instructany2pix/diffusion/ip_adapter/ip_adapter.py:28-67
   sample_loop / cfg     <- vendored SDXL loop text        instructany2pix/ddim/sdxl_pipeline.py:823-857
+  inpaint_loop          <- diffusers 0.26.3 StableDiffusionXLInpaintPipeline.__call__ (4-channel UNet branch), the class behind
+                           `pipe_inpainting` (instructany2pix/pipeline.py:132-139; driven from gdino/lib.py:89-102): PARITY UNPINNED
+                           (un-vendored dependency, no reference test or vector for it)
 Third-party algorithm restated (diffusers==0.26.3 DDIMScheduler, absent from /root/reference; config per
 SURVEY.md Appendix A.8). Its schedule tables are pinned against the in-tree ldm schedule utilities
 (llm/model/vae/modules/util.py:141-194) by fixture G5.
@@ -48,6 +51,12 @@ class DDIMSchedulerRef:
         a_prev = self.alphas_cumprod[prev] if prev >= 0 else self.final_alpha_cumprod
         x0 = (x - (1 - a_t) ** 0.5 * eps) / a_t ** 0.5
         return a_prev ** 0.5 * x0 + (1 - a_prev) ** 0.5 * eps
+
+
+def add_noise(sched, x0, noise, t):
+    """DDIMScheduler.add_noise: sqrt(abar_t) x0 + sqrt(1 - abar_t) noise"""
+    a = sched.alphas_cumprod[int(t)]
+    return a ** 0.5 * x0 + (1 - a) ** 0.5 * noise
 
 
 def backward_ddim(x_tm1, alpha_t, alpha_tm1, eps_xt):
@@ -145,3 +154,28 @@ def sample_loop(unet, sched: DDIMSchedulerRef, latents, ctx, added, num_inferenc
         if trace is not None:
             trace.append(latents.clone())
     return latents
+
+
+@torch.no_grad()
+def inpaint_loop(unet, sched: DDIMSchedulerRef, image_latents, noise, mask, ctx, added, num_inference_steps, strength, guidance_scale=7.5,
+                 neg_ctx=None, neg_added=None):
+    """mask: [B,1,H,W] in [0,1] at any resolution; binarised at 0.5 and resized to the latent grid with nearest interpolation"""
+    sched.set_timesteps(num_inference_steps)
+    init = min(int(num_inference_steps * strength), num_inference_steps)
+    ts = sched.timesteps[max(num_inference_steps - init, 0):]
+    m = torch.nn.functional.interpolate((mask.float() >= 0.5).float(), size=image_latents.shape[-2:])
+    do_cfg = neg_ctx is not None and guidance_scale > 1.0
+    if do_cfg:
+        ctx2 = torch.cat([neg_ctx, ctx], dim=0)
+        added2 = {k: torch.cat([neg_added[k], added[k]], dim=0) for k in ("text_embeds", "time_ids")}
+    x = noise * sched.init_noise_sigma if strength == 1.0 else add_noise(sched, image_latents, noise, ts[0])
+    for i, t in enumerate(ts):
+        if do_cfg:
+            eu, ec = _eps(unet, torch.cat([x] * 2), t, ctx2, added2).chunk(2)
+            eps = cfg_combine(eu, ec, guidance_scale)
+        else:
+            eps = _eps(unet, x, t, ctx, added)
+        x = sched.step(eps, t, x)
+        keep = add_noise(sched, image_latents, noise, ts[i + 1]) if i < len(ts) - 1 else image_latents
+        x = (1 - m) * keep + m * x
+    return x

@@ -199,3 +199,23 @@ def test_img2img_schedule_tail_and_time_ids_match_reference_golden(golden):
         p(prompt_embeds=torch.zeros(1, 77, 1280), pooled_prompt_embeds=torch.zeros(1, 1280), latents=torch.zeros(1, 4, 8, 8), strength=1.5)
     with pytest.raises(ValueError):
         p(prompt_embeds=torch.zeros(1, 77, 1280), pooled_prompt_embeds=torch.zeros(1, 1280), latents=torch.zeros(1, 4, 8, 8), strength=0.0, guidance_scale=1.0)
+
+
+def test_inpaint_mask_preparation_and_add_noise_coefficients():
+    from instructany2pix_amd.inpaint import prepare_mask
+    g = torch.Generator().manual_seed(4)
+    soft = torch.rand(128, 128, generator=g)
+    m = prepare_mask(soft, 16, 16, "cpu")
+    assert m.shape == (1, 1, 16, 16) and m.dtype == torch.float16 and set(m.unique().tolist()) <= {0.0, 1.0}
+    ref = torch.nn.functional.interpolate((soft[None, None] >= 0.5).float(), size=(16, 16))        # binarise, then nearest resize
+    assert torch.equal(m.float(), ref)
+    u8 = (soft * 255).to(torch.uint8)
+    assert torch.equal(prepare_mask(u8, 16, 16, "cpu").float(), torch.nn.functional.interpolate((u8.float()[None, None] / 255 >= 0.5).float(), size=(16, 16)))
+    assert prepare_mask(torch.ones(2, 1, 32, 32), 8, 8, "cpu").shape == (2, 1, 8, 8)
+    with pytest.raises(ValueError):
+        prepare_mask(torch.ones(1, 3, 8, 8), 8, 8, "cpu")
+    s, r = DDIMScheduler(), oracle.DDIMSchedulerRef()
+    x0, n = torch.randn(1, 4, 8, 8, generator=g), torch.randn(1, 4, 8, 8, generator=g)
+    for t in (1, 481, 981):
+        c0, c1 = s.add_noise_coeffs(t)
+        assert (c0 * x0 + c1 * n - oracle.add_noise(r, x0, n, t)).abs().max() < 1e-6 and abs(c0 * c0 + c1 * c1 - 1) < 1e-6
