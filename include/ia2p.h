@@ -126,6 +126,21 @@ ia2p_status ia2p_layernorm(void* stream, const void* x, void* y, const void* gam
 /* C[M,N] = A[M,K] . W[N,K]^T + bias + residual ; geglu: W/bias packed by ia2p_pack_geglu, C is [M, N/2] */
 ia2p_status ia2p_gemm(void* stream, const void* A, const void* W, const void* bias, const void* residual, void* C,
                       int M, int N, int K, int geglu);
+/* LayerNorm folded into the contraction that consumes it (what the executor does for norm1/2/3 of every BasicTransformerBlock;
+ * reference call sites: diffusers BasicTransformerBlock `attn1(norm1(x))`, `attn2(norm2(x), ctx)`, `ff(norm3(x))` behind
+ * pnp_pipeline.py:253-260). Two pieces:
+ *   ia2p_fold_layernorm: W [N,K], gamma/beta [K], bias [N] or NULL  ->  Wf = fp16(W * gamma), colsum[n] = sum_k Wf[n][k], fbias = bias + W . beta
+ *   ia2p_gemm_ex:        C = epilogue(A . W^T) like ia2p_gemm, plus
+ *       ln != NULL   : A holds the UN-normalised rows, W = Wf; out = rstd_m * (acc - mean_m * colsum[n]) + fbias[n] (then GEGLU if geglu);
+ *                      mean/rstd from ln->stats = {sum, sum of squares} partials per row, `slots` of them ([slot][M] float2), eps = ln->eps
+ *       stats_out    : this launch also writes the {sum, sum^2} partials of ITS fp16 output rows (for the next folded LayerNorm);
+ *                      *stats_slots = number of slots written; stats_out must hold (N/64 + 1) * M float2
+ *       splitk > 1   : K split as in ia2p_gemm_splitk (partial: splitk*M*N floats); 0/1 = the library's unsplit choice */
+typedef struct { const float* stats; int slots; const float* colsum; const float* fbias; float eps; } ia2p_ln_fold;
+ia2p_status ia2p_fold_layernorm(void* stream, const void* W, const void* gamma, const void* beta, const void* bias, void* Wf,
+                                float* colsum, float* fbias, int N, int K);
+ia2p_status ia2p_gemm_ex(void* stream, const void* A, const void* W, const void* bias, const void* residual, void* C, int M, int N, int K,
+                         int geglu, const ia2p_ln_fold* ln, float* stats_out, int* stats_slots, int splitk, float* partial);
 /* same with K split over `splitk` workgroups per tile; partial holds splitk*M*N floats (deterministic slab reduce) */
 ia2p_status ia2p_gemm_splitk(void* stream, const void* A, const void* W, const void* bias, const void* residual, void* C,
                              int M, int N, int K, int splitk, float* partial);

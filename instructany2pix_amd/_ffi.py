@@ -27,6 +27,10 @@ class UNetConfigC(C.Structure):
     ]
 
 
+class LnFoldC(C.Structure):
+    _fields_ = [("stats", C.c_void_p), ("slots", C.c_int), ("colsum", C.c_void_p), ("fbias", C.c_void_p), ("eps", C.c_float)]
+
+
 class VAEConfigC(C.Structure):
     _fields_ = [("in_channels", C.c_int), ("out_channels", C.c_int), ("latent_channels", C.c_int), ("n_blocks", C.c_int),
                 ("block_out_channels", C.c_int * MAX_BLOCKS), ("layers_per_block", C.c_int), ("norm_num_groups", C.c_int),
@@ -59,6 +63,8 @@ SIGNATURES = {
     "ia2p_layernorm": (_I, [_P, _P, _P, _P, _P, _I, _I, _F]),
     "ia2p_gemm": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I]),
     "ia2p_gemm_splitk": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ia2p_fold_layernorm": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I]),
+    "ia2p_gemm_ex": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
     "ia2p_debug_set_gemm_splitk": (None, [_I]),
     "ia2p_conv3x3": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I]),
     "ia2p_pack_conv3x3": (_I, [_P, _P, _P, _I, _I]),

@@ -63,6 +63,19 @@ struct GemmArgs {
   // splitk_reduce_kernel then sums them in slab order (deterministic) and applies the epilogue
   int splitk;            // 0/1 = off
   float* partial;
+  // LayerNorm folded into this contraction (consumer side). A is the un-normalised residual stream [M, K], W was pre-scaled by
+  // the norm's gamma when the weights were finalized (fold_ln_kernel), and the epilogue finishes the normalisation:
+  //   out[m][n] = rstd_m * (acc[m][n] - mean_m * ln_cs[n]) + ln_bias[n]        ln_cs[n] = sum_k W'[n][k],  ln_bias = b + W.beta
+  // mean_m / rstd_m come from ln_stats: per row and slot a float2 {sum x, sum x^2} over K features, written by the producer
+  // of A (stats_out below); ln_slots partial sums per row are added up in slot order (deterministic).
+  const float* ln_stats;
+  int ln_slots;
+  const float* ln_cs;
+  const float* ln_bias;
+  float ln_eps;
+  // producer side: row statistics of THIS launch's fp16 output, for the folded LayerNorm of the next contraction.
+  // stats_out[(slot * M + m) * 2 + {0, 1}], slot = tile_n (or 0 for a K-split launch: the reduce kernel writes it)
+  float* stats_out;
 };
 
 struct GemmPlan { int variant; int splitk; };

@@ -44,6 +44,8 @@ hipError_t ia2p_launch_ddim_step(const half_t* x, const half_t* eps_u, const hal
                                  half_t* out, half_t* out2, long n, hipStream_t s);
 hipError_t ia2p_launch_mask_blend(const half_t* x, const half_t* init, const half_t* noise, const half_t* mask, float c0, float c1,
                                   half_t* out, half_t* out2, int B, int C, long HW, hipStream_t s);
+hipError_t ia2p_launch_fold_ln(const half_t* W, const half_t* gamma, const half_t* beta, const half_t* bias, half_t* Wf, float* cs, float* lb,
+                               int N, int K, hipStream_t s);
 hipError_t ia2p_launch_pack_conv(const half_t* src, half_t* dst, int Co, int Ci, hipStream_t s);
 hipError_t ia2p_launch_pack_geglu(const half_t* src, half_t* dst, int rows, int rowlen, hipStream_t s);
 hipError_t ia2p_launch_softmax_rows(half_t* x, long ld, int rows, int n, float scale, hipStream_t s);
@@ -80,6 +82,9 @@ struct Resnet {
 };
 struct TBlock {
   size_t ln1g, ln1b, wqkv, wo1, bo1, ln2g, ln2b, wq2, wkv2, wkvip, wo2, bo2, ln3g, ln3b, wff1, bff1, wff2, bff2;
+  // LayerNorms folded into their consumers at finalize (fold_all): gamma-scaled weight copies + fp32 column sums / biases.
+  // The raw tensors above stay as loaded, so finalize can be repeated and single tensors reloaded.
+  size_t fqkv, fq2, fff1, cs1, lb1, cs2, lb2, cs3, lb3;
   int kv_col;   // column of this layer's [K | V] block in the batched context projection
 };
 struct Transformer {
@@ -161,6 +166,7 @@ struct RunCtx {
   bool record = false;
   int wseq_key = -1;
   bool prefetch = true;
+  bool ln_fold = true;       // LayerNorms folded into their consumer GEMMs (IA2P_LN_FOLD=0: separate layernorm_kernel launches, for A/B runs)
   bool prof = false;
   // autotune pass (ia2p_autotune): every GEMM / conv site of an unmeasured shape times its candidate plans in place
   bool tuning = false;
@@ -173,6 +179,7 @@ struct RunCtx {
   int64_t p_n[PK_NCLASS];
   RunCtx() {
     if (const char* e = getenv("IA2P_PREFETCH")) prefetch = atoi(e) != 0;
+    if (const char* e = getenv("IA2P_LN_FOLD")) ln_fold = atoi(e) != 0;
     for (int k = 0; k < PK_NCLASS; ++k) { p_ms[k] = p_fl[k] = p_by[k] = 0; p_n[k] = 0; }
   }
   ~RunCtx() {
@@ -267,6 +274,10 @@ struct Planner {
       b.wff1 = take((size_t)8 * ch * ch); reg(q + ".ff.net.0.proj.weight", b.wff1, (size_t)8 * ch * ch, PK_GEGLU_W, 8 * ch, ch);
       b.bff1 = take((size_t)8 * ch); reg(q + ".ff.net.0.proj.bias", b.bff1, (size_t)8 * ch, PK_GEGLU_B, 8 * ch, 1);
       b.wff2 = mat(q + ".ff.net.2.weight", ch, 4 * ch); b.bff2 = vec(q + ".ff.net.2.bias", ch);
+      b.fqkv = take((size_t)3 * ch * ch); b.fq2 = take((size_t)ch * ch); b.fff1 = take((size_t)8 * ch * ch);
+      b.cs1 = take((size_t)2 * 3 * ch); b.lb1 = take((size_t)2 * 3 * ch);         // fp32 arrays: 2 half-slots per value
+      b.cs2 = take((size_t)2 * ch); b.lb2 = take((size_t)2 * ch);
+      b.cs3 = take((size_t)2 * 8 * ch); b.lb3 = take((size_t)2 * 8 * ch);
       t.blocks.push_back(b);
     }
     t.wout = mat(p + ".proj_out.weight", ch, ch); t.bout = vec(p + ".proj_out.bias", ch);
@@ -471,9 +482,13 @@ static void tune_site(RunCtx* c, const GemmArgs& a, bool conv) {
 }
 
 // plan, K-split slabs, profiling class and launch of one GEMM / implicit-GEMM conv
-static void run_gemm(RunCtx* c, GemmArgs& a, bool conv, const char* what, double flops, double bytes) {
+// LayerNorm folded into a GEMM: where the consumer finds the row statistics and the folded constants
+struct LnIn { const float* stats; int slots; const float* cs; const float* lb; float eps; };
+
+static void run_gemm(RunCtx* c, GemmArgs& a, bool conv, const char* what, double flops, double bytes, int* stat_slots = nullptr) {
   if (c->tuning && !c->dry && !c->failed) tune_site(c, a, conv);
   const GemmPlan pl = ia2p_gemm_plan(a.M, a.N, a.K, conv, a.geglu != 0);
+  if (stat_slots) *stat_slots = pl.splitk > 1 ? 1 : (a.N + IA2P_GEMM_TILES[pl.variant].bn - 1) / IA2P_GEMM_TILES[pl.variant].bn;
   T2 slab{(size_t)-1, nullptr};
   if (pl.splitk > 1) {
     a.splitk = pl.splitk;
@@ -486,16 +501,19 @@ static void run_gemm(RunCtx* c, GemmArgs& a, bool conv, const char* what, double
 }
 
 static void op_gemm(RunCtx* c, const half_t* A, int lda, const half_t* W, const half_t* bias, const half_t* residual, int ldr,
-                    half_t* C, int ldc, int M, int N, int K, int geglu = 0, int rpb = 0, int bstride = 0, int roff = 0, int ldw = 0) {
+                    half_t* C, int ldc, int M, int N, int K, int geglu = 0, int rpb = 0, int bstride = 0, int roff = 0, int ldw = 0,
+                    const LnIn* ln = nullptr, float* stats_out = nullptr, int* stat_slots = nullptr) {
   GemmArgs a;
   memset(&a, 0, sizeof a);
   a.pad = 1;
+  if (ln) { a.ln_stats = ln->stats; a.ln_slots = ln->slots; a.ln_cs = ln->cs; a.ln_bias = ln->lb; a.ln_eps = ln->eps; }
+  a.stats_out = stats_out;
   a.A = A; a.W = W; a.C = C; a.zero = zero_page(); a.M = M; a.N = N; a.K = K; a.ldw = ldw ? ldw : K; a.lda = lda; a.ldc = ldc;
   a.rpb = rpb; a.bstride = bstride; a.roff = roff; a.bias = bias; a.residual = residual; a.ldr = ldr; a.geglu = geglu;
   a.rows_per_batch = 1;
   a.m_fastest = (long)M * K <= (long)N * K ? 1 : 0;
   set_prefetch(c, a, W, (size_t)N * K * sizeof(half_t));
-  run_gemm(c, a, false, "gemm", 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * (geglu ? N / 2 : N) + (residual ? (double)M * N : 0)));
+  run_gemm(c, a, false, "gemm", 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * (geglu ? N / 2 : N) + (residual ? (double)M * N : 0)), stat_slots);
 }
 static void op_conv3(RunCtx* c, const half_t* X, int B, int Hs, int Ws, int Cin, const half_t* W, const half_t* bias, int Co,
                      int stride, int up, const half_t* rowvec, int rowvec_ld, const half_t* residual, half_t* Y, int pad_lo = 1) {
@@ -570,16 +588,32 @@ static T2 run_transformer(Fwd& f, const Transformer& t, T2 x, int H, int Wd) {
   const float sl2e = 0.125f * 1.4426950408889634f;
   T2 n = wsalloc(c, (size_t)M * C);
   op_gn(c, x.p, n.p, t.ng, t.nb, f.B, HW, C, 1e-6f, 0, f.gn_partial);
+  // The three LayerNorms of a block never run as kernels: every GEMM that writes the token stream `tk` also emits per-row
+  // {sum, sum of squares} partials of its fp16 output (`st`), and the GEMM that consumes LN(tk) reads raw `tk` against the
+  // gamma-folded weights and finishes the normalisation in its epilogue (LnIn; GemmArgs.ln_* in common.h).
   T2 tk = wsalloc(c, (size_t)M * C);
-  op_gemm(c, n.p, C, W_(c, t.win), W_(c, t.bin), nullptr, 0, tk.p, C, M, C, C);
+  T2 stt = wsalloc(c, (size_t)M * ((C + 63) / 64) * 2 * 2);                // float2 per row and slot (one slot per tile column, tiles >= 64 wide)
+  float* st = (float*)stt.p;
+  int slots = 0;
+  const float eps = 1e-5f;
+  auto F_ = [&](size_t off) { return (const float*)(c->arena + off); };
+  const bool fold = c->ln_fold;
+  if (!fold) st = nullptr;
+  op_gemm(c, n.p, C, W_(c, t.win), W_(c, t.bin), nullptr, 0, tk.p, C, M, C, C, 0, 0, 0, 0, 0, nullptr, st, &slots);
   wsfree(c, n);
-  T2 ln = wsalloc(c, (size_t)M * C), qkv = wsalloc(c, (size_t)M * 3 * C), att = wsalloc(c, (size_t)M * C);
+  T2 lnb = fold ? T2{(size_t)-1, nullptr} : wsalloc(c, (size_t)M * C);
+  T2 qkv = wsalloc(c, (size_t)M * 3 * C), att = wsalloc(c, (size_t)M * C);
   T2 ff = wsalloc(c, (size_t)M * 4 * C);
   const int ldkv = c->kv_rows;
   for (const TBlock& b : t.blocks) {
     // self-attention (AttnProcessor2_0, reference attention_processor.py:205-279)
-    op_ln(c, tk.p, ln.p, b.ln1g, b.ln1b, M, C);
-    op_gemm(c, ln.p, C, W_(c, b.wqkv), nullptr, nullptr, 0, qkv.p, 3 * C, M, 3 * C, C);
+    if (fold) {
+      const LnIn ln{st, slots, F_(b.cs1), F_(b.lb1), eps};
+      op_gemm(c, tk.p, C, W_(c, b.fqkv), nullptr, nullptr, 0, qkv.p, 3 * C, M, 3 * C, C, 0, 0, 0, 0, 0, &ln);
+    } else {
+      op_ln(c, tk.p, lnb.p, b.ln1g, b.ln1b, M, C);
+      op_gemm(c, lnb.p, C, W_(c, b.wqkv), nullptr, nullptr, 0, qkv.p, 3 * C, M, 3 * C, C);
+    }
     {
       AttnArgs a;
       memset(&a, 0, sizeof a);
@@ -588,10 +622,15 @@ static T2 run_transformer(Fwd& f, const Transformer& t, T2 x, int H, int Wd) {
       a.seg[0].nkeys = HW; a.seg[0].ld = 3 * C; a.seg[0].rows_per_batch = HW; a.seg[0].weight = 1.f;
       op_attn(c, a);
     }
-    op_gemm(c, att.p, C, W_(c, b.wo1), W_(c, b.bo1), tk.p, C, tk.p, C, M, C, C);
+    op_gemm(c, att.p, C, W_(c, b.wo1), W_(c, b.bo1), tk.p, C, tk.p, C, M, C, C, 0, 0, 0, 0, 0, nullptr, st, &slots);
     // cross-attention (IPAttnProcessor2_0 :310-412 when the adapter is installed, else AttnProcessor2_0)
-    op_ln(c, tk.p, ln.p, b.ln2g, b.ln2b, M, C);
-    op_gemm(c, ln.p, C, W_(c, b.wq2), nullptr, nullptr, 0, qkv.p, C, M, C, C);
+    if (fold) {
+      const LnIn ln{st, slots, F_(b.cs2), F_(b.lb2), eps};
+      op_gemm(c, tk.p, C, W_(c, b.fq2), nullptr, nullptr, 0, qkv.p, C, M, C, C, 0, 0, 0, 0, 0, &ln);
+    } else {
+      op_ln(c, tk.p, lnb.p, b.ln2g, b.ln2b, M, C);
+      op_gemm(c, lnb.p, C, W_(c, b.wq2), nullptr, nullptr, 0, qkv.p, C, M, C, C);
+    }
     {
       AttnArgs a;
       memset(&a, 0, sizeof a);
@@ -602,13 +641,18 @@ static T2 run_transformer(Fwd& f, const Transformer& t, T2 x, int H, int Wd) {
       a.seg[1].K = ki; a.seg[1].V = ki ? ki + C : nullptr; a.seg[1].nkeys = Li; a.seg[1].ld = ldkv; a.seg[1].rows_per_batch = Li; a.seg[1].weight = c->ip_scale;
       op_attn(c, a);
     }
-    op_gemm(c, att.p, C, W_(c, b.wo2), W_(c, b.bo2), tk.p, C, tk.p, C, M, C, C);
+    op_gemm(c, att.p, C, W_(c, b.wo2), W_(c, b.bo2), tk.p, C, tk.p, C, M, C, C, 0, 0, 0, 0, 0, nullptr, st, &slots);
     // GEGLU feed-forward
-    op_ln(c, tk.p, ln.p, b.ln3g, b.ln3b, M, C);
-    op_gemm(c, ln.p, C, W_(c, b.wff1), W_(c, b.bff1), nullptr, 0, ff.p, 4 * C, M, 8 * C, C, 1);
-    op_gemm(c, ff.p, 4 * C, W_(c, b.wff2), W_(c, b.bff2), tk.p, C, tk.p, C, M, C, 4 * C);
+    if (fold) {
+      const LnIn ln{st, slots, F_(b.cs3), F_(b.lb3), eps};
+      op_gemm(c, tk.p, C, W_(c, b.fff1), W_(c, b.bff1), nullptr, 0, ff.p, 4 * C, M, 8 * C, C, 1, 0, 0, 0, 0, &ln);
+    } else {
+      op_ln(c, tk.p, lnb.p, b.ln3g, b.ln3b, M, C);
+      op_gemm(c, lnb.p, C, W_(c, b.wff1), W_(c, b.bff1), nullptr, 0, ff.p, 4 * C, M, 8 * C, C, 1);
+    }
+    op_gemm(c, ff.p, 4 * C, W_(c, b.wff2), W_(c, b.bff2), tk.p, C, tk.p, C, M, C, 4 * C, 0, 0, 0, 0, 0, nullptr, st, &slots);
   }
-  wsfree(c, ln); wsfree(c, qkv); wsfree(c, att); wsfree(c, ff);
+  wsfree(c, stt); wsfree(c, lnb); wsfree(c, qkv); wsfree(c, att); wsfree(c, ff);
   (void)ctxd;
   T2 out = wsalloc(c, (size_t)M * C);
   op_gemm(c, tk.p, C, W_(c, t.wout), W_(c, t.bout), x.p, C, out.p, C, M, C, C);
@@ -818,7 +862,29 @@ ia2p_status ia2p_bind_arena(ia2p_ctx* c, void* dev, size_t bytes) { return rc_bi
 ia2p_status ia2p_load_tensor(ia2p_ctx* c, const char* key, const void* src, const int64_t* shape, int ndim, void* stream) {
   return rc_load_tensor(c, key, src, shape, ndim, stream);
 }
-ia2p_status ia2p_finalize_weights(ia2p_ctx* c) { return rc_finalize(c, "UNet"); }
+// LayerNorm folding pass over every transformer block (idempotent: reads the raw tensors, writes the folded copies)
+static ia2p_status fold_all(ia2p_ctx* c) {
+  std::vector<const Transformer*> ts;
+  for (const Stage& s : c->down) for (const Transformer& t : s.att) ts.push_back(&t);
+  ts.push_back(&c->mid_t);
+  for (const Stage& s : c->up) for (const Transformer& t : s.att) ts.push_back(&t);
+  hipError_t e = hipSuccess;
+  auto H = [&](size_t off) { return c->arena + off; };
+  auto F = [&](size_t off) { return (float*)(c->arena + off); };
+  for (const Transformer* t : ts)
+    for (const TBlock& b : t->blocks) {
+      const int C = t->c;
+      if (e == hipSuccess) e = ia2p_launch_fold_ln(H(b.wqkv), H(b.ln1g), H(b.ln1b), nullptr, H(b.fqkv), F(b.cs1), F(b.lb1), 3 * C, C, nullptr);
+      if (e == hipSuccess) e = ia2p_launch_fold_ln(H(b.wq2), H(b.ln2g), H(b.ln2b), nullptr, H(b.fq2), F(b.cs2), F(b.lb2), C, C, nullptr);
+      if (e == hipSuccess) e = ia2p_launch_fold_ln(H(b.wff1), H(b.ln3g), H(b.ln3b), H(b.bff1), H(b.fff1), F(b.cs3), F(b.lb3), 8 * C, C, nullptr);
+    }
+  if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+  return e == hipSuccess ? IA2P_OK : fail(c, IA2P_ERR_HIP, "LayerNorm folding: %s", hipGetErrorString(e));
+}
+ia2p_status ia2p_finalize_weights(ia2p_ctx* c) {
+  const ia2p_status st = rc_finalize(c, "UNet");
+  return st == IA2P_OK ? fold_all(c) : st;
+}
 ia2p_status ia2p_adopt_arena(ia2p_ctx* c) { return rc_adopt(c); }
 
 ia2p_status ia2p_set_ip_adapter(ia2p_ctx* c, int enabled, int num_tokens, float scale) {
@@ -953,6 +1019,34 @@ ia2p_status ia2p_gemm(void* stream, const void* A, const void* W, const void* bi
   a.m_fastest = M <= N;
   hipError_t e = ia2p_launch_gemm(a, false, (hipStream_t)stream, nullptr);
   RET_HIP(e, "gemm");
+}
+ia2p_status ia2p_fold_layernorm(void* stream, const void* W, const void* gamma, const void* beta, const void* bias, void* Wf, float* colsum,
+                                float* fbias, int N, int K) {
+  if (!W || !gamma || !beta || !Wf || !colsum || !fbias || N < 1 || K < 1) return fail(nullptr, IA2P_ERR_INVALID, "fold_layernorm: bad argument");
+  hipError_t e = ia2p_launch_fold_ln((const half_t*)W, (const half_t*)gamma, (const half_t*)beta, (const half_t*)bias, (half_t*)Wf, colsum, fbias, N, K, (hipStream_t)stream);
+  RET_HIP(e, "fold_layernorm");
+}
+ia2p_status ia2p_gemm_ex(void* stream, const void* A, const void* W, const void* bias, const void* residual, void* C, int M, int N, int K, int geglu,
+                         const ia2p_ln_fold* ln, float* stats_out, int* stats_slots, int splitk, float* partial) {
+  if (!A || !W || !C) return fail(nullptr, IA2P_ERR_INVALID, "gemm_ex: null argument");
+  if (K % 64 || N % 4 || (geglu && (N % 32 || (!bias && !ln)))) return fail(nullptr, IA2P_ERR_SHAPE, "gemm_ex: K=%d must be a multiple of 64, N=%d of 4 (GEGLU: 32, with bias)", K, N);
+  if (splitk > 1 && (!partial || geglu || splitk > K / 64)) return fail(nullptr, IA2P_ERR_SHAPE, "gemm_ex: splitk=%d needs a slab, no GEGLU, and <= K/64", splitk);
+  if (ln && (!ln->stats || !ln->colsum || !ln->fbias || ln->slots < 1)) return fail(nullptr, IA2P_ERR_INVALID, "gemm_ex: incomplete ia2p_ln_fold");
+  if (stats_out && geglu) return fail(nullptr, IA2P_ERR_INVALID, "gemm_ex: row statistics of a GEGLU output are not provided");
+  GemmArgs a;
+  memset(&a, 0, sizeof a);
+  a.pad = 1;
+  const int No = geglu ? N / 2 : N;
+  a.A = (const half_t*)A; a.W = (const half_t*)W; a.C = (half_t*)C; a.zero = zero_page(); a.M = M; a.N = N; a.K = K; a.ldw = a.K; a.lda = K; a.ldc = No;
+  a.bias = (const half_t*)bias; a.residual = (const half_t*)residual; a.ldr = No; a.geglu = geglu; a.rows_per_batch = 1;
+  a.m_fastest = M <= N;
+  if (ln) { a.ln_stats = ln->stats; a.ln_slots = ln->slots; a.ln_cs = ln->colsum; a.ln_bias = ln->fbias; a.ln_eps = ln->eps; }
+  a.stats_out = stats_out;
+  if (splitk > 1) { a.splitk = splitk; a.partial = partial; }
+  int pick = 0;
+  hipError_t e = ia2p_launch_gemm(a, false, (hipStream_t)stream, &pick);
+  if (stats_slots) *stats_slots = splitk > 1 ? 1 : (N + IA2P_GEMM_TILES[pick].bn - 1) / IA2P_GEMM_TILES[pick].bn;
+  RET_HIP(e, "gemm_ex");
 }
 ia2p_status ia2p_gemm_splitk(void* stream, const void* A, const void* W, const void* bias, const void* residual, void* C, int M, int N, int K,
                              int splitk, float* partial) {

@@ -187,6 +187,23 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const GemmArgs p
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < nk) stage(s, s);
+  // ---- folded LayerNorm (consumer): thread r < BM collects the {sum, sum of squares} partials of tile row r. Issued behind the
+  //      first tile loads, all slots in flight at once (slot order kept in the sums); turned into mean / rstd after the k-loop.
+  float ln_s1 = 0.f, ln_s2 = 0.f;
+  if (p.ln_stats && tid < BM && bm0 + tid < p.M) {
+    const float2* st = (const float2*)p.ln_stats + (bm0 + tid);
+    constexpr int MAXS = 24;
+    if (p.ln_slots <= MAXS) {
+      float2 v[MAXS];
+#pragma unroll
+      for (int u = 0; u < MAXS; ++u) v[u] = st[(size_t)min(u, p.ln_slots - 1) * p.M];
+#pragma unroll
+      for (int u = 0; u < MAXS; ++u)
+        if (u < p.ln_slots) { ln_s1 += v[u].x; ln_s2 += v[u].y; }
+    } else {
+      for (int sl = 0; sl < p.ln_slots; ++sl) { const float2 v = st[(size_t)sl * p.M]; ln_s1 += v.x; ln_s2 += v.y; }
+    }
+  }
   int cur = 0, nxt = NSTAGE - 1;      // ring slots: `cur` is consumed this step, `nxt` is refilled
   for (int kt = 0; kt < nk; ++kt) {
     const int ahead = nk - 1 - kt;    // tiles issued after tile kt that may remain in flight
@@ -235,6 +252,25 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const GemmArgs p
     nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
   }
 
+  float* ln_rows = (float*)smem;      // [0, BM): mean, [BM, 2 BM): rstd, then BN column sums and BN folded biases of this tile
+  float* ln_cs = ln_rows + 2 * BM;
+  float* ln_lb = ln_cs + BN;
+  if (p.ln_stats) {
+    __syncthreads();                  // every wave has finished reading the stage buffers
+    if (tid < BM) {
+      const float inv = 1.f / (float)p.K;
+      const float mean = ln_s1 * inv;
+      const float var = fmaxf(ln_s2 * inv - mean * mean, 0.f);
+      ln_rows[tid] = mean;
+      ln_rows[BM + tid] = rsqrtf(var + p.ln_eps);
+    }
+    if (tid < BN / 4 && bn0 + tid * 4 < p.N) {
+      *(f4*)(ln_cs + tid * 4) = *(const f4*)(p.ln_cs + bn0 + tid * 4);
+      *(f4*)(ln_lb + tid * 4) = *(const f4*)(p.ln_bias + bn0 + tid * 4);
+    }
+    __syncthreads();
+  }
+
   // ---- epilogue: acc[i][j][r] = C[m = bm0+wm0+16i+(lane&15)][n = bn0+wn0+16j+4*(lane>>4)+r]
   if (nsplit > 1) {      // raw fp32 slab of this K range; splitk_reduce_kernel finishes
     float* slab = p.partial + (size_t)split * p.M * p.N;
@@ -250,35 +286,82 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const GemmArgs p
     }
     return;
   }
+  float2 row_st[MR];
+#pragma unroll
+  for (int i = 0; i < MR; ++i) row_st[i] = make_float2(0.f, 0.f);
 #pragma unroll
   for (int i = 0; i < MR; ++i) {
     const int m = bm0 + wm0 + i * 16 + frow;
     if (m >= p.M) continue;
     const half_t* rv = nullptr;
     if (p.rowvec) rv = p.rowvec + (size_t)(m / p.rows_per_batch) * p.rowvec_ld;
+    float mu = 0.f, rs = 1.f;
+    if (p.ln_stats) { mu = ln_rows[wm0 + i * 16 + frow]; rs = ln_rows[BM + wm0 + i * 16 + frow]; }
+    float st1 = 0.f, st2 = 0.f;       // row statistics of the fp16 output (producer side of a folded LayerNorm)
     if (!p.geglu) {
 #pragma unroll
       for (int j = 0; j < NR; ++j) {
         const int n = bn0 + wn0 + j * 16 + fq * 4;
         if (n >= p.N) continue;
         f4 v = acc[i][j];
+        if (p.ln_stats) {
+          const f4 cs = *(const f4*)(ln_cs + n - bn0), lb = *(const f4*)(ln_lb + n - bn0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = rs * (v[r] - mu * cs[r]) + lb[r];
+        } else
         if (p.bias) { const h4 b = *(const h4*)(p.bias + n); v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3]; }
         if (rv) { const h4 b = *(const h4*)(rv + n); v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3]; }
         if (p.residual) { const h4 b = *(const h4*)(p.residual + (size_t)m * p.ldr + n); v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3]; }
         h4 o; o[0] = (half_t)v[0]; o[1] = (half_t)v[1]; o[2] = (half_t)v[2]; o[3] = (half_t)v[3];
         *(h4*)(p.C + (size_t)m * p.ldc + n) = o;
+        if (p.stats_out) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const float f = (float)o[r]; st1 += f; st2 += f * f; }
+        }
+      }
+      if (p.stats_out) {               // the 4 lanes l, l+16, l+32, l+48 hold the same row: fold them
+        st1 += __shfl_xor(st1, 16); st2 += __shfl_xor(st2, 16);
+        st1 += __shfl_xor(st1, 32); st2 += __shfl_xor(st2, 32);
+        row_st[i] = make_float2(st1, st2);
       }
     } else {
 #pragma unroll
       for (int j = 0; j < NR; j += 2) {
         const int n = bn0 + wn0 + j * 16 + fq * 4;     // packed row of the `a` half; gate rows sit 16 further
         if (n >= p.N) continue;
-        const h4 ba = *(const h4*)(p.bias + n), bg = *(const h4*)(p.bias + n + 16);
         h4 o;
+        if (p.ln_stats) {
+          const f4 ca = *(const f4*)(ln_cs + n - bn0), cg = *(const f4*)(ln_cs + n - bn0 + 16), la = *(const f4*)(ln_lb + n - bn0), lg = *(const f4*)(ln_lb + n - bn0 + 16);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            o[r] = (half_t)((rs * (acc[i][j][r] - mu * ca[r]) + la[r]) * gelu_erf_f(rs * (acc[i][j + 1][r] - mu * cg[r]) + lg[r]));
+        } else {
+        const h4 ba = *(const h4*)(p.bias + n), bg = *(const h4*)(p.bias + n + 16);
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = (half_t)((acc[i][j][r] + (float)ba[r]) * gelu_erf_f(acc[i][j + 1][r] + (float)bg[r]));
+        }
         const int nout = ((bn0 + wn0 + j * 16) >> 1) + fq * 4;
         *(h4*)(p.C + (size_t)m * p.ldc + nout) = o;
+      }
+    }
+  }
+  if (p.stats_out) {
+    // the two waves that share tile rows (N halves) add up through LDS, so a tile contributes ONE partial per row: slot = tile_n.
+    // (The stage buffers are free here; floats [0, 2 BM) may hold the consumer-side mean / rstd of this same launch.)
+    float2* xch = (float2*)(smem + (2 * BM + 2 * BN) * sizeof(float));
+    __syncthreads();
+    if ((wave & 1) && fq == 0) {
+#pragma unroll
+      for (int i = 0; i < MR; ++i) xch[wm0 + i * 16 + frow] = row_st[i];
+    }
+    __syncthreads();
+    if (!(wave & 1) && fq == 0) {
+#pragma unroll
+      for (int i = 0; i < MR; ++i) {
+        const int m = bm0 + wm0 + i * 16 + frow;
+        if (m >= p.M) continue;
+        const float2 o = xch[wm0 + i * 16 + frow];
+        ((float2*)p.stats_out)[(size_t)tn * p.M + m] = make_float2(row_st[i].x + o.x, row_st[i].y + o.y);
       }
     }
   }
@@ -327,21 +410,50 @@ static const std::vector<ShapeRule>& shape_rules() {
   return rules;
 }
 
-// C[m,n] = sum_s partial[s][m][n] + bias + rowvec + residual, fixed summation order
-__global__ void splitk_reduce_kernel(const GemmArgs p) {
-  const long total = (long)p.M * (p.N >> 2);
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int m = (int)(i / (p.N >> 2)), n = (int)(i - (long)m * (p.N >> 2)) * 4;
-    f4 v = *(const f4*)(p.partial + (size_t)m * p.N + n);
-    for (int s = 1; s < p.splitk; ++s) {
-      const f4 w = *(const f4*)(p.partial + ((size_t)s * p.M + m) * p.N + n);
-      v[0] += w[0]; v[1] += w[1]; v[2] += w[2]; v[3] += w[3];
+// C[m,n] = epilogue(sum_s partial[s][m][n]), fixed summation order. One wave per output row (64 lanes x 4 columns per pass),
+// so the row-wise extras of the folded LayerNorm are wave reductions: mean / rstd of the row for a consumer launch
+// (ln_stats), {sum, sum of squares} of the fp16 output row for a producer launch (stats_out, slot 0). No GEGLU here.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
+  const int lane = threadIdx.x & 63;
+  const int nq = p.N >> 2;
+  for (int m = blockIdx.x * 4 + (threadIdx.x >> 6); m < p.M; m += gridDim.x * 4) {
+    float mu = 0.f, rs = 1.f;
+    if (p.ln_stats) {
+      float s1 = 0.f, s2 = 0.f;
+      for (int sl = lane; sl < p.ln_slots; sl += 64) { const float2 v = ((const float2*)p.ln_stats)[(size_t)sl * p.M + m]; s1 += v.x; s2 += v.y; }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+      const float inv = 1.f / (float)p.K;
+      mu = s1 * inv;
+      rs = rsqrtf(fmaxf(s2 * inv - mu * mu, 0.f) + p.ln_eps);
     }
-    if (p.bias) { const h4 b = *(const h4*)(p.bias + n); v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3]; }
-    if (p.rowvec) { const h4 b = *(const h4*)(p.rowvec + (size_t)(m / p.rows_per_batch) * p.rowvec_ld + n); v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3]; }
-    if (p.residual) { const h4 b = *(const h4*)(p.residual + (size_t)m * p.ldr + n); v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3]; }
-    h4 o; o[0] = (half_t)v[0]; o[1] = (half_t)v[1]; o[2] = (half_t)v[2]; o[3] = (half_t)v[3];
-    *(h4*)(p.C + (size_t)m * p.ldc + n) = o;
+    float st1 = 0.f, st2 = 0.f;
+    for (int q = lane; q < nq; q += 64) {
+      const int n = q * 4;
+      f4 v = *(const f4*)(p.partial + (size_t)m * p.N + n);
+      for (int s = 1; s < p.splitk; ++s) {
+        const f4 w = *(const f4*)(p.partial + ((size_t)s * p.M + m) * p.N + n);
+        v[0] += w[0]; v[1] += w[1]; v[2] += w[2]; v[3] += w[3];
+      }
+      if (p.ln_stats) {
+        const f4 cs = *(const f4*)(p.ln_cs + n), lb = *(const f4*)(p.ln_bias + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = rs * (v[r] - mu * cs[r]) + lb[r];
+      } else if (p.bias) { const h4 b = *(const h4*)(p.bias + n); v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3]; }
+      if (p.rowvec) { const h4 b = *(const h4*)(p.rowvec + (size_t)(m / p.rows_per_batch) * p.rowvec_ld + n); v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3]; }
+      if (p.residual) { const h4 b = *(const h4*)(p.residual + (size_t)m * p.ldr + n); v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3]; }
+      h4 o; o[0] = (half_t)v[0]; o[1] = (half_t)v[1]; o[2] = (half_t)v[2]; o[3] = (half_t)v[3];
+      *(h4*)(p.C + (size_t)m * p.ldc + n) = o;
+      if (p.stats_out) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float f = (float)o[r]; st1 += f; st2 += f * f; }
+      }
+    }
+    if (p.stats_out) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { st1 += __shfl_xor(st1, o); st2 += __shfl_xor(st2, o); }
+      if (lane == 0) ((float2*)p.stats_out)[m] = make_float2(st1, st2);
+    }
   }
 }
 
@@ -517,8 +629,7 @@ static hipError_t launch_any(const GemmArgs& a, int v, hipStream_t s) {
     default: return hipErrorInvalidValue;
   }
   if (e != hipSuccess || a.splitk <= 1) return e;
-  const long total = (long)a.M * (a.N >> 2);
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)std::min<long>(2048, (total + 255) / 256)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(std::min(4096, (a.M + 3) / 4)), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 

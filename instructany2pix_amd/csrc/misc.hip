@@ -195,6 +195,31 @@ __global__ void mask_blend_kernel(const half_t* x, const half_t* init, const hal
   }
 }
 
+// Fold a LayerNorm (gamma, beta over K features) into the linear layer that consumes it (weights finalize, once):
+//   Wf[n][k] = fp16(W[n][k] * gamma[k]);  cs[n] = sum_k Wf[n][k] (of the ROUNDED values the MFMA will see);  lb[n] = bias[n] + sum_k W[n][k] * beta[k]
+// so that  LN(x) . W^T + bias = rstd * (x . Wf^T - mean * cs) + lb  (gemm_f16_kernel epilogue). One workgroup per output row.
+__global__ __launch_bounds__(256) void fold_ln_kernel(const half_t* W, const half_t* gamma, const half_t* beta, const half_t* bias,
+                                                      half_t* Wf, float* cs, float* lb, int K) {
+  __shared__ float red[2][4];
+  const int n = blockIdx.x;
+  float s = 0.f, t = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    const float w = (float)W[(size_t)n * K + k];
+    const half_t wf = (half_t)(w * (float)gamma[k]);
+    Wf[(size_t)n * K + k] = wf;
+    s += (float)wf;
+    t += w * (float)beta[k];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); t += __shfl_xor(t, o); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = t; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    cs[n] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    lb[n] = (bias ? (float)bias[n] : 0.f) + ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+  }
+}
+
 // ---- one-time weight re-layouts -----------------------------------------------------------------------------------------
 // conv [Co][Ci][3][3] -> [Co][ky][kx][Ci] (implicit-GEMM K order)
 __global__ void pack_conv_kernel(const half_t* src, half_t* dst, int Co, int Ci) {
@@ -319,6 +344,11 @@ hipError_t ia2p_launch_mask_blend(const half_t* x, const half_t* init, const hal
                                   half_t* out, half_t* out2, int B, int C, long HW, hipStream_t s) {
   const long n = (long)B * C * HW;
   hipLaunchKernelGGL(mask_blend_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, x, init, noise, mask, c0, c1, out, out2, C, HW, n);
+  return hipGetLastError();
+}
+hipError_t ia2p_launch_fold_ln(const half_t* W, const half_t* gamma, const half_t* beta, const half_t* bias, half_t* Wf, float* cs, float* lb,
+                               int N, int K, hipStream_t s) {
+  hipLaunchKernelGGL(fold_ln_kernel, dim3(N), dim3(256), 0, s, W, gamma, beta, bias, Wf, cs, lb, K);
   return hipGetLastError();
 }
 hipError_t ia2p_launch_pack_conv(const half_t* src, half_t* dst, int Co, int Ci, hipStream_t s) {

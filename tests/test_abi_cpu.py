@@ -40,7 +40,8 @@ def test_create_plan_and_errors(lib):
         ipn = param_count(ip_adapter_specs(cfg)["ip_adapter"])
         n = param_count(unet_param_specs(cfg)) + ipn
         arena = lib.ia2p_arena_bytes(ctx)
-        assert n * 2 <= arena < n * 2 * 1.02 + (1 << 20)      # fp16, small alignment padding only
+        # fp16 parameters + the gamma-folded copies of the LayerNorm-consuming weights (12 C^2 of ~32 C^2 per transformer block)
+        assert n * 2 <= arena < n * 2 * 1.5 + (1 << 20)
         # workspace sizing is a pure host dry run
         assert lib.ia2p_workspace_bytes(ctx, 1, 16, 16, 77) > 0
         assert lib.ia2p_workspace_bytes(ctx, 1, 15, 16, 77) == 0     # not divisible by 4

@@ -127,6 +127,72 @@ def test_gemm_geglu(L, M, C, tile):
     assert rel_l2(out, ref) < 1.5e-3, rel_l2(out, ref)
 
 
+def _ln_fold_setup(L, M, C_, N, seed, bias=True):
+    """x -> (producer GEMM with stats) -> t; then LayerNorm(t) . W^T + b through the folded path"""
+    f = _ffi()
+    X, Wp, R = rnd(M, C_, seed=seed), rnd(C_, C_, seed=seed + 1, scale=C_ ** -0.5), rnd(M, C_, seed=seed + 2, scale=2.0)
+    gamma, beta = (1.0 + 0.3 * torch.randn(C_, generator=torch.Generator().manual_seed(seed + 3))).half().cuda(), rnd(C_, seed=seed + 4, scale=0.2)
+    W, b = rnd(N, C_, seed=seed + 5, scale=C_ ** -0.5), (rnd(N, seed=seed + 6, scale=0.3) if bias else None)
+    Wf = torch.empty_like(W)
+    cs, fb = torch.empty(N, dtype=torch.float32, device="cuda"), torch.empty(N, dtype=torch.float32, device="cuda")
+    run(L, "ia2p_fold_layernorm", f.ptr(W), f.ptr(gamma), f.ptr(beta), f.ptr(b), f.ptr(Wf), f.ptr(cs), f.ptr(fb), N, C_)
+    return f, X, Wp, R, gamma, beta, W, b, Wf, cs, fb
+
+
+@pytest.mark.parametrize("tile", [-1, 0, 4, 6, 8, 11])
+@pytest.mark.parametrize("M,C_,N,psplit,csplit", [(2048, 1280, 3840, 1, 1), (300, 256, 768, 1, 1), (256, 1280, 1280, 3, 2), (77, 128, 132, 2, 1)])
+def test_layernorm_folded_into_gemm(L, M, C_, N, psplit, csplit, tile):
+    """producer GEMM emits row statistics, consumer GEMM reads the raw rows against gamma-folded weights: equals
+    LayerNorm(eps 1e-5) -> Linear in torch, for every tile shape and with either side K-split"""
+    f, X, Wp, R, gamma, beta, W, b, Wf, cs, fb = _ln_fold_setup(L, M, C_, N, seed=60 + M % 7)
+    t = torch.empty(M, C_, dtype=torch.half, device="cuda")
+    stats = torch.zeros((C_ // 64 + 1) * M * 2, dtype=torch.float32, device="cuda")
+    part = torch.empty(4 * M * max(N, C_), dtype=torch.float32, device="cuda")
+    slots = C.c_int(0)
+    L.ia2p_debug_set_gemm_tile(tile)
+    try:
+        run(L, "ia2p_gemm_ex", f.ptr(X), f.ptr(Wp), None, f.ptr(R), f.ptr(t), M, C_, C_, 0, None, f.ptr(stats), C.addressof(slots), psplit, f.ptr(part))
+        tf = t.float()
+        st = stats.view(-1, M, 2)[:slots.value].sum(0)
+        assert slots.value >= 1 and torch.allclose(st[:, 0], tf.sum(1), rtol=1e-4, atol=1e-2) and torch.allclose(st[:, 1], (tf * tf).sum(1), rtol=1e-4, atol=1e-2)
+        ln = f.LnFoldC(stats.data_ptr(), slots.value, cs.data_ptr(), fb.data_ptr(), 1e-5)
+        out = torch.empty(M, N, dtype=torch.half, device="cuda")
+        run(L, "ia2p_gemm_ex", f.ptr(t), f.ptr(Wf), None, None, f.ptr(out), M, N, C_, 0, C.addressof(ln), None, None, csplit, f.ptr(part))
+    finally:
+        L.ia2p_debug_set_gemm_tile(-1)
+    ref = F.layer_norm(tf, (C_,), gamma.float(), beta.float(), 1e-5) @ W.float().t() + b.float()
+    assert rel_l2(out, ref) < 1.5e-3, rel_l2(out, ref)
+    # the separate-kernel path (fp16 LayerNorm output, then the plain GEMM) is no closer to fp32 than the folded one
+    y = torch.empty_like(t)
+    run(L, "ia2p_layernorm", f.ptr(t), f.ptr(y), f.ptr(gamma), f.ptr(beta), M, C_, 1e-5)
+    sep = torch.empty_like(out)
+    run(L, "ia2p_gemm", f.ptr(y), f.ptr(W), f.ptr(b), None, f.ptr(sep), M, N, C_, 0)
+    assert rel_l2(out, ref) <= rel_l2(sep, ref) * 1.2 + 1e-4
+
+
+@pytest.mark.parametrize("M,C_", [(2048, 640), (130, 128)])
+def test_layernorm_folded_into_geglu(L, M, C_):
+    f, X, Wp, R, gamma, beta, W, b, _, _, _ = _ln_fold_setup(L, M, C_, 8 * C_, seed=70)
+    Wpk, bpk = torch.empty_like(W), torch.empty_like(b)
+    run(L, "ia2p_pack_geglu", f.ptr(W), f.ptr(Wpk), 8 * C_, C_)
+    run(L, "ia2p_pack_geglu", f.ptr(b), f.ptr(bpk), 8 * C_, 1)
+    Wf = torch.empty_like(W)
+    cs, fb = torch.empty(8 * C_, dtype=torch.float32, device="cuda"), torch.empty(8 * C_, dtype=torch.float32, device="cuda")
+    run(L, "ia2p_fold_layernorm", f.ptr(Wpk), f.ptr(gamma), f.ptr(beta), f.ptr(bpk), f.ptr(Wf), f.ptr(cs), f.ptr(fb), 8 * C_, C_)   # row-wise: packing first is fine
+    t = torch.empty(M, C_, dtype=torch.half, device="cuda")
+    stats = torch.zeros((C_ // 64 + 1) * M * 2, dtype=torch.float32, device="cuda")
+    slots = C.c_int(0)
+    run(L, "ia2p_gemm_ex", f.ptr(X), f.ptr(Wp), None, f.ptr(R), f.ptr(t), M, C_, C_, 0, None, f.ptr(stats), C.addressof(slots), 1, None)
+    ln = f.LnFoldC(stats.data_ptr(), slots.value, cs.data_ptr(), fb.data_ptr(), 1e-5)
+    out = torch.empty(M, 4 * C_, dtype=torch.half, device="cuda")
+    run(L, "ia2p_gemm_ex", f.ptr(t), f.ptr(Wf), None, None, f.ptr(out), M, 8 * C_, C_, 1, C.addressof(ln), None, None, 1, None)
+    h = F.layer_norm(t.float(), (C_,), gamma.float(), beta.float(), 1e-5) @ W.float().t() + b.float()
+    a, g = h.chunk(2, dim=-1)
+    assert rel_l2(out, a * F.gelu(g)) < 2e-3
+    with pytest.raises(ValueError):
+        f.check(L.ia2p_gemm_ex(f.current_stream(), f.ptr(t), f.ptr(Wf), None, None, f.ptr(out), M, 8 * C_, C_, 1, None, None, None, 1, None))   # GEGLU without bias or fold
+
+
 def test_gemm_rejects_bad_shapes(L):
     f = _ffi()
     A, W, out = rnd(64, 96), rnd(64, 96), torch.empty(64, 64, dtype=torch.half, device="cuda")

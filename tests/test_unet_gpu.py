@@ -301,3 +301,23 @@ def test_sdxl_base_full_size_batch_properties():
     text_only = run(x, ctx[:, :77].contiguous(), te, tid)
     assert torch.equal(zero, text_only)
     assert not torch.equal(zero, out)
+
+
+def test_layernorm_fold_switch_agrees(tiny_models, monkeypatch):
+    """The executor folds norm1/2/3 into their consumer GEMMs; IA2P_LN_FOLD=0 (read when a context is created) runs them as
+    layernorm_kernel launches instead. Both stay within the oracle tolerance and agree with each other to fp16 accuracy."""
+    from instructany2pix_amd.attention_processor import AttnProcessor2_0
+    from instructany2pix_amd.unet import HipUNet2DConditionModel
+    cfg, sd, ipsd, hip, oracle = tiny_models
+    hip.set_attn_processor(AttnProcessor2_0())
+    monkeypatch.setenv("IA2P_LN_FOLD", "0")
+    plain = HipUNet2DConditionModel(cfg, DEV)
+    monkeypatch.delenv("IA2P_LN_FOLD")
+    plain.load_state_dict(sd)
+    x, ctx, te, tid = _inputs(cfg, 2, 16, 16, 77, seed=41)
+    kw = dict(encoder_hidden_states=ctx.to(DEV), added_cond_kwargs=dict(text_embeds=te.to(DEV), time_ids=tid.to(DEV)))
+    a, b = hip(x.to(DEV), 301, **kw)[0], plain(x.to(DEV), 301, **kw)[0]
+    with torch.no_grad():
+        ref = oracle.build_unet(cfg, sd)(x.float(), 301, ctx.float(), added_cond_kwargs=dict(text_embeds=te.float(), time_ids=tid.float()))[0]
+    assert rel_l2(a, ref) <= 5e-3 and rel_l2(b, ref) <= 5e-3
+    assert rel_l2(a, b) <= 3e-3 and not torch.equal(a, b)
