@@ -4,7 +4,7 @@ The reference is single-process, single-GPU (instructany2pix/pipeline.py:124,131
 addition. One process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm, "gloo" in
 CPU tests). The path has NO per-step exchange: every request's trajectory depends only on its own latents and
 conditioning (GroupNorm / LayerNorm / attention are per-sample, CFG pairs stay on one GPU). The only collective
-is the one-time broadcast of the flat weight arena (UNet + IP-Adapter, ~5.8 GB fp16) from rank 0 over xGMI,
+is the one-time broadcast of the flat weight arena (UNet + IP-Adapter with the LayerNorm-folded weight copies, ~8.3 GB fp16) from rank 0 over xGMI,
 plus an optional all-gather of the final latents (64 KB per rank at cfg 4).
 """
 from __future__ import annotations
