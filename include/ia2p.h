@@ -195,6 +195,35 @@ size_t ia2p_vae_workspace_bytes(ia2p_vae* vae, int B, int h, int w, int decode);
 ia2p_status ia2p_vae_decode(ia2p_vae* vae, void* stream, const void* latents, void* image, int B, int h, int w, void* workspace, size_t workspace_bytes);
 ia2p_status ia2p_vae_encode(ia2p_vae* vae, void* stream, const void* image, void* moments, int B, int h, int w, void* workspace, size_t workspace_bytes);
 
+/* ---- CLIP text encoders (conditioning side): the two encoders behind `encode_prompt` ------------------
+ * (reference ddim/sdxl_pipeline.py:202-395: `text_encoder(ids, output_hidden_states=True)`, `.hidden_states[-2]` of both encoders
+ * concatenated, pooled `[0]` of the second). transformers `CLIPTextModel` / `CLIPTextModelWithProjection` semantics: token + position
+ * embeddings, pre-LayerNorm blocks with causal self-attention (head_dim 64) and a GELU / quick-GELU MLP, final LayerNorm, pooled row
+ * = final-normed hidden state at the EOS position (eos_token_id 2: position of the largest id), optional bias-free projection.
+ * Parameter keys are the transformers state-dict keys ("text_model.encoder.layers.0.self_attn.q_proj.weight", ...). */
+typedef struct ia2p_clip ia2p_clip;
+typedef struct {
+  int vocab_size, hidden_size, num_layers, num_heads, intermediate_size, max_positions;
+  int projection_dim;     /* 0: no text_projection (CLIPTextModel) */
+  int hidden_act;         /* 1 = gelu, 2 = quick_gelu */
+  int eos_token_id;
+  float layer_norm_eps;
+} ia2p_clip_config;
+ia2p_status ia2p_clip_create(const ia2p_clip_config* cfg, ia2p_clip** out);
+void ia2p_clip_destroy(ia2p_clip* clip);
+const char* ia2p_clip_last_error(ia2p_clip* clip);
+size_t ia2p_clip_arena_bytes(ia2p_clip* clip);
+ia2p_status ia2p_clip_bind_arena(ia2p_clip* clip, void* dev_arena, size_t bytes);
+ia2p_status ia2p_clip_load_tensor(ia2p_clip* clip, const char* key, const void* dev_src, const int64_t* shape, int ndim, void* stream);
+ia2p_status ia2p_clip_finalize_weights(ia2p_clip* clip);
+size_t ia2p_clip_workspace_bytes(ia2p_clip* clip, int B, int T);
+/* input_ids: int32 [B, T] on the device (T <= max_positions, <= 128). Outputs (each may be NULL): hidden_penultimate [B, T, hidden]
+ * (= hidden_states[-2], the input of the last layer), last_hidden [B, T, hidden] (= last_hidden_state: final LayerNorm of the last
+ * layer's output), pooled [B, projection_dim or hidden] (text_embeds / pooler_output). The last layer is skipped when only
+ * hidden_penultimate is requested. */
+ia2p_status ia2p_clip_encode(ia2p_clip* clip, void* stream, const int32_t* input_ids, int B, int T, void* hidden_penultimate,
+                             void* last_hidden, void* pooled, void* workspace, size_t workspace_bytes);
+
 #ifdef __cplusplus
 }
 #endif

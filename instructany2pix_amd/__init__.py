@@ -5,7 +5,7 @@ Importing this package touches no GPU and no native code; the HIP library (libia
 """
 from .config import UNetConfig, sdxl_base, sdxl_refiner, tiny
 
-__all__ = ["UNetConfig", "sdxl_base", "sdxl_refiner", "tiny", "StableDiffusionXLImg2ImgPipeline", "EulerDiscreteScheduler", "InstructAny2PixPipeline", "HipUNet2DConditionModel", "DDIMScheduler",
+__all__ = ["HipCLIPTextModel", "SDXLTextEncoders", "UNetConfig", "sdxl_base", "sdxl_refiner", "tiny", "StableDiffusionXLImg2ImgPipeline", "EulerDiscreteScheduler", "InstructAny2PixPipeline", "HipUNet2DConditionModel", "DDIMScheduler",
            "SDXLDDIMPipeline", "StableDiffusionXLPipeline", "IPAdapterXL", "ImageProjModel", "HipAutoencoderKL"]
 
 
@@ -25,6 +25,9 @@ def __getattr__(name):          # lazy: keep `import instructany2pix_amd` free o
     elif name in ("IPAdapterXL", "ImageProjModel"):
         from . import ip_adapter
         v = getattr(ip_adapter, name)
+    elif name in ("HipCLIPTextModel", "SDXLTextEncoders"):
+        from . import clip
+        v = getattr(clip, name)
     elif name == "HipAutoencoderKL":
         from .vae import HipAutoencoderKL as v
     else:

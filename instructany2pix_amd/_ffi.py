@@ -31,6 +31,11 @@ class LnFoldC(C.Structure):
     _fields_ = [("stats", C.c_void_p), ("slots", C.c_int), ("colsum", C.c_void_p), ("fbias", C.c_void_p), ("eps", C.c_float)]
 
 
+class CLIPConfigC(C.Structure):
+    _fields_ = [("vocab_size", C.c_int), ("hidden_size", C.c_int), ("num_layers", C.c_int), ("num_heads", C.c_int), ("intermediate_size", C.c_int),
+                ("max_positions", C.c_int), ("projection_dim", C.c_int), ("hidden_act", C.c_int), ("eos_token_id", C.c_int), ("layer_norm_eps", C.c_float)]
+
+
 class VAEConfigC(C.Structure):
     _fields_ = [("in_channels", C.c_int), ("out_channels", C.c_int), ("latent_channels", C.c_int), ("n_blocks", C.c_int),
                 ("block_out_channels", C.c_int * MAX_BLOCKS), ("layers_per_block", C.c_int), ("norm_num_groups", C.c_int),
@@ -73,6 +78,15 @@ SIGNATURES = {
     "ia2p_linear_small": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I]),
     "ia2p_debug_set_gemm_tile": (None, [_I]),
     "ia2p_debug_gemm_plan": (None, [_I, _I, _I, _I, _I, _P, _P]),
+    "ia2p_clip_create": (_I, [C.POINTER(CLIPConfigC), C.POINTER(_P)]),
+    "ia2p_clip_destroy": (None, [_P]),
+    "ia2p_clip_last_error": (C.c_char_p, [_P]),
+    "ia2p_clip_arena_bytes": (_SZ, [_P]),
+    "ia2p_clip_bind_arena": (_I, [_P, _P, _SZ]),
+    "ia2p_clip_load_tensor": (_I, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), _I, _P]),
+    "ia2p_clip_finalize_weights": (_I, [_P]),
+    "ia2p_clip_workspace_bytes": (_SZ, [_P, _I, _I]),
+    "ia2p_clip_encode": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _SZ]),
     "ia2p_vae_create": (_I, [C.POINTER(VAEConfigC), C.POINTER(_P)]),
     "ia2p_vae_destroy": (None, [_P]),
     "ia2p_vae_last_error": (C.c_char_p, [_P]),
@@ -114,12 +128,12 @@ def lib() -> C.CDLL:
     return _lib
 
 
-def check(status: int, ctx=None, vae=False):
+def check(status: int, ctx=None, vae=False, clip=False):
     """Map ia2p_status to the exception types the reference raises at the same conditions
     (ValueError from check_inputs/_get_add_time_ids, reference pnp_pipeline.py:49-66)."""
     if status == IA2P_OK:
         return
-    msg = lib().ia2p_vae_last_error(ctx) if vae else lib().ia2p_last_error(ctx)
+    msg = lib().ia2p_clip_last_error(ctx) if clip else lib().ia2p_vae_last_error(ctx) if vae else lib().ia2p_last_error(ctx)
     msg = msg.decode() if msg else ""
     text = f"ia2p {_STATUS_NAMES.get(status, status)}: {msg}"
     if status in (1, 2):
@@ -161,6 +175,15 @@ def make_config(cfg) -> UNetConfigC:
     c.projection_class_embeddings_input_dim = cfg.projection_class_embeddings_input_dim
     c.time_embed_dim, c.time_proj_dim = cfg.time_embed_dim, cfg.time_proj_dim
     c.mid_transformer_layers, c.num_time_ids = cfg.mid_block_transformer_layers, cfg.num_time_ids
+    return c
+
+
+def make_clip_config(cfg) -> CLIPConfigC:
+    c = CLIPConfigC()
+    c.vocab_size, c.hidden_size, c.num_layers, c.num_heads = cfg.vocab_size, cfg.hidden_size, cfg.num_hidden_layers, cfg.num_attention_heads
+    c.intermediate_size, c.max_positions, c.projection_dim = cfg.intermediate_size, cfg.max_position_embeddings, cfg.projection_dim
+    c.hidden_act = {"gelu": 1, "quick_gelu": 2}[cfg.hidden_act]
+    c.eos_token_id, c.layer_norm_eps = cfg.eos_token_id, cfg.layer_norm_eps
     return c
 
 

@@ -124,3 +124,42 @@ def sdxl_vae() -> VAEConfig:
 
 def tiny_vae() -> VAEConfig:
     return VAEConfig(block_out_channels=(64, 128, 128), layers_per_block=1).validate()
+
+
+@dataclass
+class CLIPTextConfig:
+    """transformers `CLIPTextConfig` fields of SDXL's two text encoders (`pipe.text_encoder`: CLIP ViT-L/14 text tower;
+    `pipe.text_encoder_2`: OpenCLIP ViT-bigG/14 text tower with projection) — the models behind `encode_prompt`
+    (reference instructany2pix/ddim/sdxl_pipeline.py:202-395). Last row of SURVEY.md §8f."""
+    vocab_size: int = 49408
+    hidden_size: int = 768
+    num_hidden_layers: int = 12
+    num_attention_heads: int = 12
+    intermediate_size: int = 3072
+    max_position_embeddings: int = 77
+    hidden_act: str = "quick_gelu"
+    projection_dim: int = 0              # 0 = CLIPTextModel (no text_projection); > 0 = CLIPTextModelWithProjection
+    eos_token_id: int = 2                # SDXL checkpoints keep the legacy value: pooled row = position of the largest token id
+    layer_norm_eps: float = 1e-5
+
+    def __getitem__(self, k):
+        return getattr(self, k)
+
+    def validate(self):
+        assert self.hidden_size == 64 * self.num_attention_heads and self.intermediate_size % 64 == 0
+        assert self.hidden_act in ("gelu", "quick_gelu") and self.max_position_embeddings <= 128 and self.projection_dim % 8 == 0
+        return self
+
+
+def sdxl_text_encoder() -> CLIPTextConfig:
+    return CLIPTextConfig().validate()
+
+
+def sdxl_text_encoder_2() -> CLIPTextConfig:
+    return CLIPTextConfig(hidden_size=1280, num_hidden_layers=32, num_attention_heads=20, intermediate_size=5120, hidden_act="gelu",
+                          projection_dim=1280).validate()
+
+
+def tiny_clip(projection_dim: int = 0, hidden_act: str = "quick_gelu") -> CLIPTextConfig:
+    return CLIPTextConfig(vocab_size=1000, hidden_size=128, num_hidden_layers=3, num_attention_heads=2, intermediate_size=256,
+                          hidden_act=hidden_act, projection_dim=projection_dim).validate()

@@ -28,6 +28,8 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float act_f(float x, int act) { return act == 1 ? gelu_erf_f(x) : act == 2 ? quick_gelu_f(x) : x; }
 
 // ---- launch descriptors shared by kernels and the host executor --------------------------------------
 
@@ -63,6 +65,7 @@ struct GemmArgs {
   // splitk_reduce_kernel then sums them in slab order (deterministic) and applies the epilogue
   int splitk;            // 0/1 = off
   float* partial;
+  int act;               // activation on (acc + bias) before rowvec / residual: 0 none, 1 GELU (erf), 2 quick-GELU x*sigmoid(1.702x) (CLIP MLPs)
   // LayerNorm folded into this contraction (consumer side). A is the un-normalised residual stream [M, K], W was pre-scaled by
   // the norm's gamma when the weights were finalized (fold_ln_kernel), and the epilogue finishes the normalisation:
   //   out[m][n] = rstd_m * (acc[m][n] - mean_m * ln_cs[n]) + ln_bias[n]        ln_cs[n] = sum_k W'[n][k],  ln_bias = b + W.beta

@@ -220,6 +220,112 @@ __global__ __launch_bounds__(256) void fold_ln_kernel(const half_t* W, const hal
   }
 }
 
+// ---- CLIP text encoders (conditioning side of the path; reference encode_prompt, ddim/sdxl_pipeline.py:202-395) -----------------
+// x[row] = token_embedding[ids[row]] + position_embedding[row % T]; also the {sum, sum^2} of the fp16 row for the folded LayerNorm
+// of the first layer (slot 0). One wave per token row.
+__global__ __launch_bounds__(256) void clip_embed_kernel(const int* ids, const half_t* tok, const half_t* pos, half_t* x, float* stats,
+                                                         int rows, int T, int H, int vocab) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  int id = ids[row];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+  const half_t* a = tok + (size_t)id * H;
+  const half_t* b = pos + (size_t)(row % T) * H;
+  float s1 = 0.f, s2 = 0.f;
+  for (int k = lane * 8; k < H; k += 512) {
+    const h8 va = *(const h8*)(a + k), vb = *(const h8*)(b + k);
+    h8 o;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { o[u] = (half_t)((float)va[u] + (float)vb[u]); const float f = (float)o[u]; s1 += f; s2 += f * f; }
+    *(h8*)(x + (size_t)row * H + k) = o;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+  if (lane == 0) ((float2*)stats)[row] = make_float2(s1, s2);
+}
+
+// Causal self-attention over short sequences (T <= 128, head_dim 64): one workgroup per (batch, head); K and V of the head in LDS
+// (rows padded to 66 halves: conflict-free column walks), one wave per query row at a time, fp32 softmax over keys 0..q.
+// qkv: [B*T, 3*H] rows = [q | k | v]; out: [B*T, H]. Tiny problem (77 x 77 per head): VALU, no MFMA.
+__global__ __launch_bounds__(256) void causal_attention_small_kernel(const half_t* qkv, half_t* out, int T, int heads) {
+  constexpr int D = 64, LD = 66, TMAX = 128;
+  __shared__ half_t sk[TMAX * LD], sv[TMAX * LD];
+  __shared__ float sq[4][D], sp[4][TMAX];
+  const int b = blockIdx.x / heads, hd = blockIdx.x % heads;
+  const int H = heads * D;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const half_t* base = qkv + (size_t)b * T * 3 * H + hd * D;
+  for (int i = threadIdx.x; i < T * D; i += 256) {
+    const int t = i / D, d = i % D;
+    sk[t * LD + d] = base[(size_t)t * 3 * H + H + d];
+    sv[t * LD + d] = base[(size_t)t * 3 * H + 2 * H + d];
+  }
+  __syncthreads();
+  for (int q = wave; q < T; q += 4) {
+    sq[wave][lane] = (float)base[(size_t)q * 3 * H + lane] * 0.125f;
+    __builtin_amdgcn_wave_barrier();
+    float s[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int k = lane + u * 64;
+      float a = -INFINITY;
+      if (k <= q) {
+        a = 0.f;
+#pragma unroll 16
+        for (int d = 0; d < D; ++d) a += sq[wave][d] * (float)sk[k * LD + d];
+      }
+      s[u] = a;
+    }
+    float m = fmaxf(s[0], s[1]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    const float e0 = __expf(s[0] - m), e1 = lane + 64 <= q ? __expf(s[1] - m) : 0.f;
+    float sum = e0 + e1;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float inv = 1.f / sum;
+    sp[wave][lane] = e0 * inv;
+    if (lane + 64 < TMAX) sp[wave][lane + 64] = e1 * inv;
+    __builtin_amdgcn_wave_barrier();
+    float acc = 0.f;
+    for (int k = 0; k <= q; ++k) acc += sp[wave][k] * (float)sv[k * LD + lane];
+    out[((size_t)b * T + q) * H + hd * D + lane] = (half_t)acc;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// pooled rows: for each sequence the EOS position (eos_id == 2: position of the largest id, the legacy CLIP rule; else the first
+// occurrence of eos_id), then final LayerNorm of that row of the last hidden state. One workgroup (one wave) per sequence.
+__global__ __launch_bounds__(64) void clip_pool_kernel(const int* ids, const half_t* x, const half_t* gamma, const half_t* beta, half_t* out,
+                                                       int T, int H, int eos_id, float eps) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  int best = -1, pos = 0x7fffffff;
+  for (int t = lane; t < T; t += 64) {
+    const int id = ids[b * T + t];
+    const int key = eos_id == 2 ? id : (id == eos_id ? 1 : 0);
+    if (key > best || (key == best && t < pos)) { best = key; pos = t; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int ob = __shfl_xor(best, o), op = __shfl_xor(pos, o);
+    if (ob > best || (ob == best && op < pos)) { best = ob; pos = op; }
+  }
+  const half_t* row = x + ((size_t)b * T + pos) * H;
+  float s1 = 0.f, s2 = 0.f;
+  for (int k = lane; k < H; k += 64) { const float f = (float)row[k]; s1 += f; s2 += f * f; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+  const float mean = s1 / H;
+  float var = 0.f;
+  for (int k = lane; k < H; k += 64) { const float f = (float)row[k] - mean; var += f * f; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o);
+  const float rstd = rsqrtf(var / H + eps);
+  (void)s2;
+  for (int k = lane; k < H; k += 64) out[(size_t)b * H + k] = (half_t)(((float)row[k] - mean) * rstd * (float)gamma[k] + (float)beta[k]);
+}
+
 // ---- one-time weight re-layouts -----------------------------------------------------------------------------------------
 // conv [Co][Ci][3][3] -> [Co][ky][kx][Ci] (implicit-GEMM K order)
 __global__ void pack_conv_kernel(const half_t* src, half_t* dst, int Co, int Ci) {
@@ -349,6 +455,21 @@ hipError_t ia2p_launch_mask_blend(const half_t* x, const half_t* init, const hal
 hipError_t ia2p_launch_fold_ln(const half_t* W, const half_t* gamma, const half_t* beta, const half_t* bias, half_t* Wf, float* cs, float* lb,
                                int N, int K, hipStream_t s) {
   hipLaunchKernelGGL(fold_ln_kernel, dim3(N), dim3(256), 0, s, W, gamma, beta, bias, Wf, cs, lb, K);
+  return hipGetLastError();
+}
+hipError_t ia2p_launch_clip_embed(const int* ids, const half_t* tok, const half_t* pos, half_t* x, float* stats, int rows, int T, int H, int vocab, hipStream_t s) {
+  if (H % 8) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(clip_embed_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, ids, tok, pos, x, stats, rows, T, H, vocab);
+  return hipGetLastError();
+}
+hipError_t ia2p_launch_causal_attention_small(const half_t* qkv, half_t* out, int B, int T, int heads, hipStream_t s) {
+  if (T < 1 || T > 128) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(causal_attention_small_kernel, dim3(B * heads), dim3(256), 0, s, qkv, out, T, heads);
+  return hipGetLastError();
+}
+hipError_t ia2p_launch_clip_pool(const int* ids, const half_t* x, const half_t* gamma, const half_t* beta, half_t* out, int B, int T, int H, int eos_id,
+                                 float eps, hipStream_t s) {
+  hipLaunchKernelGGL(clip_pool_kernel, dim3(B), dim3(64), 0, s, ids, x, gamma, beta, out, T, H, eos_id, eps);
   return hipGetLastError();
 }
 hipError_t ia2p_launch_pack_conv(const half_t* src, half_t* dst, int Co, int Ci, hipStream_t s) {

@@ -180,6 +180,8 @@ def _make(key: str, shape, kind: str, seed: int, device, dtype) -> torch.Tensor:
         r.mul_(0.3 * _fan_in(shape) ** -0.5)
     elif kind == "w_out":        # conv_out: input is ~N(0,1) after GroupNorm+SiLU (rms ~0.6)
         r.mul_(1.6 * _fan_in(shape) ** -0.5)
+    elif kind == "emb":          # embedding tables: unit-scale rows would swamp nothing; CLIP uses ~0.02, use 0.5 to keep LayerNorm honest
+        r.mul_(0.5)
     elif kind == "b":
         r.mul_(0.02)
     elif kind == "gamma":
@@ -267,4 +269,24 @@ def vae_param_specs(cfg) -> List[Spec]:
                   (f"decoder.up_blocks.{i}.upsamplers.0.conv.bias", (rch[i],), "b")]
     s += [("decoder.conv_norm_out.weight", (ch[0],), "gamma"), ("decoder.conv_norm_out.bias", (ch[0],), "beta"),
           ("decoder.conv_out.weight", (cfg.out_channels, ch[0], 3, 3), "w_out"), ("decoder.conv_out.bias", (cfg.out_channels,), "b")]
+    return s
+
+
+def clip_param_specs(cfg) -> List[Tuple[str, Tuple[int, ...], str]]:
+    """transformers `CLIPTextModel(WithProjection).state_dict()` keys and shapes, in module-registration order."""
+    H, I = cfg.hidden_size, cfg.intermediate_size
+    s = [("text_model.embeddings.token_embedding.weight", (cfg.vocab_size, H), "emb"),
+         ("text_model.embeddings.position_embedding.weight", (cfg.max_position_embeddings, H), "emb")]
+    for i in range(cfg.num_hidden_layers):
+        p = f"text_model.encoder.layers.{i}."
+        for n in ("k_proj", "v_proj", "q_proj"):
+            s += [(p + f"self_attn.{n}.weight", (H, H), "w"), (p + f"self_attn.{n}.bias", (H,), "b")]
+        s += [(p + "self_attn.out_proj.weight", (H, H), "w_res"), (p + "self_attn.out_proj.bias", (H,), "b"),
+              (p + "layer_norm1.weight", (H,), "gamma"), (p + "layer_norm1.bias", (H,), "beta"),
+              (p + "mlp.fc1.weight", (I, H), "w"), (p + "mlp.fc1.bias", (I,), "b"),
+              (p + "mlp.fc2.weight", (H, I), "w_res"), (p + "mlp.fc2.bias", (H,), "b"),
+              (p + "layer_norm2.weight", (H,), "gamma"), (p + "layer_norm2.bias", (H,), "beta")]
+    s += [("text_model.final_layer_norm.weight", (H,), "gamma"), ("text_model.final_layer_norm.bias", (H,), "beta")]
+    if cfg.projection_dim:
+        s += [("text_projection.weight", (cfg.projection_dim, H), "w")]
     return s

@@ -14,6 +14,7 @@ from .attn_processors_ref import AttnProcessor2_0Ref, IPAttnProcessor2_0Ref
 from .vae_ref import AutoencoderKLRef, build_vae, sample_latents
 from .ddim_ref import (DDIMSchedulerRef, backward_ddim, cfg_combine, get_add_time_ids, polar_interpolate,
                        ImageProjModelRef, invert_loop, sample_loop, inpaint_loop, add_noise)
+from .clip_ref import CLIPTextModelRef, build_clip, encode_prompt_ref
 from .euler_ref import EulerDiscreteSchedulerRef, get_add_time_ids_aesthetic, img2img_loop
 
 

@@ -233,3 +233,39 @@ def test_g10_refiner_time_ids(golden):
         assert int(d[name]) == 1
         with pytest.raises(ValueError):
             oracle.get_add_time_ids_aesthetic((1024, 1024), (0, 0), (1024, 1024), 6.0, 2.5, (1024, 1024), (0, 0), (1024, 1024), 256, 1280, feats, requires)
+
+
+@pytest.mark.parametrize("proj,act,eos", [(0, "quick_gelu", 2), (64, "gelu", 2), (64, "gelu", 999)])
+def test_clip_restatement_matches_transformers(proj, act, eos):
+    """The oracle's CLIP text model against the real transformers classes the reference's pipelines hold (`CLIPTextModel`,
+    `CLIPTextModelWithProjection`), same random weights: pooled output, last_hidden_state and every hidden state."""
+    tf = pytest.importorskip("transformers")
+    from instructany2pix_amd.config import tiny_clip
+    cfg = tiny_clip(proj, act)
+    cfg.eos_token_id = eos
+    hf_cfg = tf.CLIPTextConfig(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
+                               num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
+                               max_position_embeddings=cfg.max_position_embeddings, hidden_act=act, projection_dim=proj or 512,
+                               layer_norm_eps=cfg.layer_norm_eps, eos_token_id=eos, bos_token_id=0, pad_token_id=1, attn_implementation="eager")
+    torch.manual_seed(3)
+    hf = (tf.CLIPTextModelWithProjection if proj else tf.CLIPTextModel)(hf_cfg).eval()
+    sd = {k: v for k, v in hf.state_dict().items() if not k.endswith("position_ids")}
+    # checkpoints (and transformers 4.x, the reference's era) name the tower `text_model.*`; transformers 5 flattened CLIPTextModel
+    sd = {(k if k.startswith(("text_model.", "text_projection.")) else "text_model." + k): v for k, v in sd.items()}
+    ref = oracle.build_clip(cfg, sd)
+    ids = torch.randint(3, cfg.vocab_size - 1, (3, 77), generator=torch.Generator().manual_seed(4))
+    ids[:, 0] = 0
+    for b, n in enumerate((10, 40, 76)):
+        ids[b, n] = eos if eos != 2 else cfg.vocab_size - 1          # EOS: the largest id (legacy rule) or the configured id
+        ids[b, n + 1:] = 1 if eos != 2 else cfg.vocab_size - 1       # padding (SDXL pads with EOS for encoder 1)
+    with torch.no_grad():
+        out = hf(input_ids=ids, output_hidden_states=True)
+    pooled, last, hidden = ref(ids)
+    want_pooled = out.text_embeds if proj else out.pooler_output
+    assert (pooled - want_pooled).abs().max() < 2e-5
+    assert (last - out.last_hidden_state).abs().max() < 2e-5
+    assert len(hidden) == len(out.hidden_states) == cfg.num_hidden_layers + 1
+    for a, b in zip(hidden, out.hidden_states):
+        assert (a - b).abs().max() < 2e-5
+    from instructany2pix_amd.weights import clip_param_specs
+    assert {k: tuple(v.shape) for k, v in sd.items()} == {k: s for k, s, _ in clip_param_specs(cfg)}
