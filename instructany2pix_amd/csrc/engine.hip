@@ -492,6 +492,7 @@ struct LnIn { const float* stats; int slots; const float* cs; const float* lb; f
 static void run_gemm(RunCtx* c, GemmArgs& a, bool conv, const char* what, double flops, double bytes, int* stat_slots = nullptr) {
   if (c->tuning && !c->dry && !c->failed) tune_site(c, a, conv);
   const GemmPlan pl = ia2p_gemm_plan(a.M, a.N, a.K, conv, a.geglu != 0);
+  if (pl.variant < 0 || pl.variant >= IA2P_GEMM_NVARIANT) { fail(c, IA2P_ERR_INVALID, "%s: tile variant %d out of range", what, pl.variant); return; }
   if (stat_slots) *stat_slots = pl.splitk > 1 ? 1 : (a.N + IA2P_GEMM_TILES[pl.variant].bn - 1) / IA2P_GEMM_TILES[pl.variant].bn;
   T2 slab{(size_t)-1, nullptr};
   if (pl.splitk > 1) {
@@ -1050,7 +1051,7 @@ ia2p_status ia2p_gemm_ex(void* stream, const void* A, const void* W, const void*
   if (splitk > 1) { a.splitk = splitk; a.partial = partial; }
   int pick = 0;
   hipError_t e = ia2p_launch_gemm(a, false, (hipStream_t)stream, &pick);
-  if (stats_slots) *stats_slots = splitk > 1 ? 1 : (N + IA2P_GEMM_TILES[pick].bn - 1) / IA2P_GEMM_TILES[pick].bn;
+  if (stats_slots && pick >= 0 && pick < IA2P_GEMM_NVARIANT) *stats_slots = splitk > 1 ? 1 : (N + IA2P_GEMM_TILES[pick].bn - 1) / IA2P_GEMM_TILES[pick].bn;
   RET_HIP(e, "gemm_ex");
 }
 ia2p_status ia2p_gemm_splitk(void* stream, const void* A, const void* W, const void* bias, const void* residual, void* C, int M, int N, int K,

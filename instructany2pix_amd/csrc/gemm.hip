@@ -401,7 +401,7 @@ static const std::vector<ShapeRule>& shape_rules() {
       while (*p) {
         ShapeRule x;
         int n = 0;
-        if (sscanf(p, "%dx%dx%d=%d%n", &x.M, &x.N, &x.K, &x.v, &n) == 4) { r.push_back(x); p += n; }
+        if (sscanf(p, "%dx%dx%d=%d%n", &x.M, &x.N, &x.K, &x.v, &n) == 4) { if (x.v >= 0 && x.v < IA2P_GEMM_NVARIANT) r.push_back(x); p += n; }
         while (*p && *p != ';') ++p;
         if (*p == ';') ++p;
       }
