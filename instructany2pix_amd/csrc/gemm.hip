@@ -479,7 +479,7 @@ extern "C" void ia2p_debug_set_gemm_splitk(int s) { g_force_splitk = s; }
 // best is always within 1.55 x of the modelled best (the autotuner's candidate filter uses 1.7).
 static double plan_cost_us(int M, int N, int K, bool conv, const GemmTile& t, int sk) {
   constexpr double LAT_US = 0.7, FILL_B_PER_US = 80000.0, MFMA_EFF = 0.5, LONE_EFF = 0.55, RAMP_US = 1.0, BASE_US = 3.0,
-                   REDUCE_B_PER_US = 5.0e6, REDUCE_US = 2.0, CU_FLOPS_PER_US = 2.5e15 / 256.0 / 1e6;   // 2.5 PFLOP/s dense fp16 over 256 CUs
+                   REDUCE_B_PER_US = 5.0e6, REDUCE_US = 5.0, CU_FLOPS_PER_US = 2.5e15 / 256.0 / 1e6;   // 2.5 PFLOP/s dense fp16 over 256 CUs
   const long tiles = (long)((M + t.bm - 1) / t.bm) * ((N + t.bn - 1) / t.bn) * sk;
   const int nk = std::max(1, (K / 64) / sk);
   const int lds = t.stages * (t.bm + t.bn) * 128;
