@@ -92,6 +92,18 @@ ia2p_status ia2p_unet_forward(ia2p_ctx* ctx, void* stream, const void* sample, f
                               const void* text_embeds, const void* time_ids, void* out, int B, int h, int w,
                               void* workspace, size_t workspace_bytes);
 
+/* ---- context K/V hoisted out of the step (optional) ------------------------------------------------------------------
+ * The K/V projections of every cross-attention layer (reference attention_processor.py:358-359,379-380) depend only on the context and the
+ * weights; over the 25-50 denoise steps of a request the context does not change. ia2p_project_context computes them once into a caller-owned
+ * buffer (ia2p_context_kv_bytes), ia2p_unet_forward_kv is ia2p_unet_forward reading them from there: same kernels, same bits, one 420-GFLOP GEMM
+ * and 1.36 GB of weight streaming less per step. Re-project after changing the context, the weights, or ia2p_set_ip_adapter(enabled, tokens). */
+size_t ia2p_context_kv_bytes(ia2p_ctx* ctx, int B, int L);
+ia2p_status ia2p_project_context(ia2p_ctx* ctx, void* stream, const void* context, int L, int B, void* kv, size_t kv_bytes,
+                                 void* workspace, size_t workspace_bytes);
+ia2p_status ia2p_unet_forward_kv(ia2p_ctx* ctx, void* stream, const void* sample, float timestep, const void* kv, int L,
+                                 const void* text_embeds, const void* time_ids, void* out, int B, int h, int w,
+                                 void* workspace, size_t workspace_bytes);
+
 /* ---- measured kernel plans (optional) ---------------------------------------------------------------------------- */
 /* Same arguments as ia2p_unet_forward, plus reps (timed launches per candidate, <1 = 5). Runs one forward in which every
  * GEMM / conv site of a shape without a measured plan times its candidate (tile, K-split) plans in place and records the

@@ -57,6 +57,9 @@ SIGNATURES = {
     "ia2p_set_ip_adapter": (_I, [_P, _I, _I, _F]),
     "ia2p_workspace_bytes": (_SZ, [_P, _I, _I, _I, _I]),
     "ia2p_unet_forward": (_I, [_P, _P, _P, _F, _P, _I, _P, _P, _P, _I, _I, _I, _P, _SZ]),
+    "ia2p_context_kv_bytes": (_SZ, [_P, _I, _I]),
+    "ia2p_project_context": (_I, [_P, _P, _P, _I, _I, _P, _SZ, _P, _SZ]),
+    "ia2p_unet_forward_kv": (_I, [_P, _P, _P, _F, _P, _I, _P, _P, _P, _I, _I, _I, _P, _SZ]),
     "ia2p_autotune": (_I, [_P, _P, _P, _F, _P, _I, _P, _P, _P, _I, _I, _I, _P, _SZ, _I, _P]),
     "ia2p_plan_export": (_SZ, [_P, _SZ]),
     "ia2p_plan_import": (_I, [C.c_char_p]),

@@ -666,8 +666,19 @@ static T2 run_transformer(Fwd& f, const Transformer& t, T2 x, int H, int Wd) {
   return out;
 }
 
+// context K/V of every cross-attention layer in one GEMM each (text rows / image-token rows of ctx); per layer: reference
+// attention_processor.py:358-359 (to_k/to_v) and :379-380 (to_k_ip/to_v_ip). kv_text: [B*Lt, kv_rows], kv_ip: [B*Li, kv_rows].
+static void project_context(ia2p_ctx* c, const half_t* context, int L, int B, half_t* kv_text, half_t* kv_ip) {
+  const int ctxd = c->cfg.cross_attention_dim;
+  const int Lt = c->ip_enabled ? L - c->ip_tokens : L, Li = c->ip_enabled ? c->ip_tokens : 0;
+  op_gemm(c, context, ctxd, W_(c, c->kv_text_base), nullptr, nullptr, 0, kv_text, c->kv_rows, B * Lt, c->kv_rows, ctxd, 0, Lt, L, 0);
+  if (Li) op_gemm(c, context, ctxd, W_(c, c->kv_ip_base), nullptr, nullptr, 0, kv_ip, c->kv_rows, B * Li, c->kv_rows, ctxd, 0, Li, L, Lt);
+}
+
+// kv_cached != nullptr: the context projections were computed before (ia2p_project_context) and are read from there
 static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep, const half_t* context, int L,
-                               const half_t* text_embeds, const half_t* time_ids, half_t* out, int B, int h, int w) {
+                               const half_t* text_embeds, const half_t* time_ids, half_t* out, int B, int h, int w,
+                               const half_t* kv_cached = nullptr) {
   const ia2p_unet_config& g = c->cfg;
   const int n = g.n_blocks;
   const int T = g.time_embed_dim, Tp = g.time_proj_dim, Ain = g.projection_class_embeddings_input_dim, Ad = g.addition_time_embed_dim;
@@ -703,13 +714,14 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
   // ---- context K/V for every cross-attention layer in one GEMM each (text rows / image-token rows of ctx);
   //      per layer: reference attention_processor.py:358-359 (to_k/to_v) and :379-380 (to_k_ip/to_v_ip)
   if (c->kv_rows > 0) {
-    const int ctxd = g.cross_attention_dim;
     const int Lt = c->ip_enabled ? L - c->ip_tokens : L, Li = c->ip_enabled ? c->ip_tokens : 0;
-    f.kv_text = wsalloc(c, (size_t)B * Lt * c->kv_rows);
-    op_gemm(c, context, ctxd, W_(c, c->kv_text_base), nullptr, nullptr, 0, f.kv_text.p, c->kv_rows, B * Lt, c->kv_rows, ctxd, 0, Lt, L, 0);
-    if (Li) {
-      f.kv_ip = wsalloc(c, (size_t)B * Li * c->kv_rows);
-      op_gemm(c, context, ctxd, W_(c, c->kv_ip_base), nullptr, nullptr, 0, f.kv_ip.p, c->kv_rows, B * Li, c->kv_rows, ctxd, 0, Li, L, Lt);
+    if (kv_cached) {
+      f.kv_text.p = const_cast<half_t*>(kv_cached);
+      if (Li) f.kv_ip.p = const_cast<half_t*>(kv_cached) + (size_t)B * Lt * c->kv_rows;
+    } else {
+      f.kv_text = wsalloc(c, (size_t)B * Lt * c->kv_rows);
+      if (Li) f.kv_ip = wsalloc(c, (size_t)B * Li * c->kv_rows);
+      project_context(c, context, L, B, f.kv_text.p, f.kv_ip.p);
     }
   }
 
@@ -923,21 +935,21 @@ size_t ia2p_workspace_bytes(ia2p_ctx* c, int B, int h, int w, int L) {
   return c->failed ? 0 : c->ws.high + 256;
 }
 
-ia2p_status ia2p_unet_forward(ia2p_ctx* c, void* stream, const void* sample, float timestep, const void* context, int L,
-                              const void* text_embeds, const void* time_ids, void* out, int B, int h, int w, void* ws, size_t ws_bytes) {
-  if (!c || !sample || !context || !text_embeds || !time_ids || !out || !ws) return fail(c, IA2P_ERR_INVALID, "unet_forward: null argument");
+static ia2p_status unet_forward_impl(ia2p_ctx* c, void* stream, const void* sample, float timestep, const void* context, const void* kv, int L,
+                                     const void* text_embeds, const void* time_ids, void* out, int B, int h, int w, void* ws, size_t ws_bytes) {
+  if (!c || !sample || (!context && !kv) || !text_embeds || !time_ids || !out || !ws) return fail(c, IA2P_ERR_INVALID, "unet_forward: null argument");
   if (!c->finalized) return fail(c, IA2P_ERR_STATE, "unet_forward before weights were finalized");
   ia2p_status st = check_fwd_shape(c, B, h, w, L);
   if (st != IA2P_OK) return st;
   if (!zero_page()) return fail(c, IA2P_ERR_HIP, "cannot allocate zero page");
   const uintptr_t base = ((uintptr_t)ws + 255) & ~(uintptr_t)255;
   const size_t usable = ws_bytes - (base - (uintptr_t)ws);
-  const int key = c->ip_enabled ? 1 + c->ip_tokens : 0;
+  const int key = (c->ip_enabled ? 1 + c->ip_tokens : 0) + (kv ? 1000 : 0);
   if (c->wseq_key != key) {          // (re)build the weight launch sequence with a dry pass of the same code path
     c->wseq.clear();
     c->dry = true; c->record = true; c->failed = false;
     c->ws.reset((size_t)1 << 46); c->ws_base = nullptr;
-    (void)run_forward(c, nullptr, 0.f, nullptr, L, nullptr, nullptr, nullptr, B, h, w);
+    (void)run_forward(c, nullptr, 0.f, nullptr, L, nullptr, nullptr, nullptr, B, h, w, kv ? (const half_t*)1 : nullptr);
     c->dry = false; c->record = false;
     c->wseq_key = key;
   }
@@ -945,10 +957,47 @@ ia2p_status ia2p_unet_forward(ia2p_ctx* c, void* stream, const void* sample, flo
   c->dry = false; c->failed = false; c->stream = (hipStream_t)stream;
   c->ws.reset(usable);
   c->ws_base = (char*)base;
-  st = run_forward(c, (const half_t*)sample, timestep, (const half_t*)context, L, (const half_t*)text_embeds, (const half_t*)time_ids, (half_t*)out, B, h, w);
+  st = run_forward(c, (const half_t*)sample, timestep, (const half_t*)context, L, (const half_t*)text_embeds, (const half_t*)time_ids, (half_t*)out, B, h, w,
+                   (const half_t*)kv);
   if (c->failed && st == IA2P_OK) st = IA2P_ERR_HIP;
   if (c->failed && c->err == "workspace too small") st = IA2P_ERR_NOMEM;
   return st;
+}
+ia2p_status ia2p_unet_forward(ia2p_ctx* c, void* stream, const void* sample, float timestep, const void* context, int L,
+                              const void* text_embeds, const void* time_ids, void* out, int B, int h, int w, void* ws, size_t ws_bytes) {
+  if (!context) return fail(c, IA2P_ERR_INVALID, "unet_forward: null argument");
+  return unet_forward_impl(c, stream, sample, timestep, context, nullptr, L, text_embeds, time_ids, out, B, h, w, ws, ws_bytes);
+}
+
+// ---- context K/V hoisted out of the step: the projections depend on (context, weights) only, constant over a request's steps
+size_t ia2p_context_kv_bytes(ia2p_ctx* c, int B, int L) {
+  if (!c || B < 1 || L < 1 || (c->ip_enabled && L <= c->ip_tokens)) return 0;
+  return (size_t)B * L * c->kv_rows * sizeof(half_t);
+}
+ia2p_status ia2p_project_context(ia2p_ctx* c, void* stream, const void* context, int L, int B, void* kv, size_t kv_bytes, void* ws, size_t ws_bytes) {
+  if (!c || !context || !kv || !ws) return fail(c, IA2P_ERR_INVALID, "project_context: null argument");
+  if (!c->finalized) return fail(c, IA2P_ERR_STATE, "project_context before weights were finalized");
+  const size_t need = ia2p_context_kv_bytes(c, B, L);
+  if (!need) return fail(c, IA2P_ERR_SHAPE, "project_context: B=%d L=%d", B, L);
+  if (kv_bytes < need) return fail(c, IA2P_ERR_NOMEM, "project_context: kv buffer holds %zu bytes, needs %zu", kv_bytes, need);
+  if (!zero_page()) return fail(c, IA2P_ERR_HIP, "cannot allocate zero page");
+  const uintptr_t base = ((uintptr_t)ws + 255) & ~(uintptr_t)255;
+  const bool pf = c->prefetch;
+  c->prefetch = false;               // a stand-alone call: no "next launch" to stream weights for
+  c->widx = 0; c->dry = false; c->failed = false; c->stream = (hipStream_t)stream;
+  c->ws.reset(ws_bytes - (base - (uintptr_t)ws));
+  c->ws_base = (char*)base;
+  const int Lt = c->ip_enabled ? L - c->ip_tokens : L;
+  project_context(c, (const half_t*)context, L, B, (half_t*)kv, (half_t*)kv + (size_t)B * Lt * c->kv_rows);
+  c->prefetch = pf;
+  c->wseq_key = -1;                  // the launch sequence of the next forward is rebuilt
+  if (c->failed) return c->err == "workspace too small" ? IA2P_ERR_NOMEM : IA2P_ERR_HIP;
+  return IA2P_OK;
+}
+ia2p_status ia2p_unet_forward_kv(ia2p_ctx* c, void* stream, const void* sample, float timestep, const void* kv, int L, const void* text_embeds,
+                                 const void* time_ids, void* out, int B, int h, int w, void* ws, size_t ws_bytes) {
+  if (!kv) return fail(c, IA2P_ERR_INVALID, "unet_forward_kv: null argument");
+  return unet_forward_impl(c, stream, sample, timestep, nullptr, kv, L, text_embeds, time_ids, out, B, h, w, ws, ws_bytes);
 }
 
 // Measure-and-pick pass: one forward in which every GEMM / conv site whose shape has no measured plan yet times its

@@ -45,6 +45,11 @@ class HipUNet2DConditionModel:
         _ffi.check(self._lib.ia2p_bind_arena(self._ctx, _ffi.ptr(self.arena), nbytes), self._ctx)
         self._workspace: Optional[torch.Tensor] = None
         self._ws_key = None
+        # context K/V hoisting: the cross-attention K/V projections of a context are computed once and reused while the SAME context
+        # tensor object (unmodified: torch's version counter) keeps arriving, i.e. over the denoise steps of a request
+        self.cache_context_kv = True
+        self._kv = None                 # (context tensor kept alive, its _version, ip (enabled, tokens), weight generation, kv buffer)
+        self._weights_gen = 0
         self._names = attn_processor_names(config)
         self._procs: "OrderedDict[str, torch.nn.Module]" = OrderedDict((n, AttnProcessor2_0()) for n in self._names)
         self._ip_sig = None
@@ -78,6 +83,7 @@ class HipUNet2DConditionModel:
             _ffi.check(self._lib.ia2p_finalize_weights(self._ctx), self._ctx)
 
     def _load(self, key: str, v: torch.Tensor):
+        self._weights_gen += 1
         t = v.detach().to(device=self.device, dtype=torch.float16).contiguous()
         shape = (C.c_int64 * t.ndim)(*t.shape)
         _ffi.check(self._lib.ia2p_load_tensor(self._ctx, key.encode(), _ffi.ptr(t), shape, t.ndim, _ffi.current_stream()), self._ctx)
@@ -86,6 +92,7 @@ class HipUNet2DConditionModel:
     def adopt_arena(self):
         """Arena bytes were produced elsewhere (RCCL broadcast from rank 0): mark parameters present."""
         _ffi.check(self._lib.ia2p_adopt_arena(self._ctx), self._ctx)
+        self._weights_gen += 1
 
     # ---- operator-plugin API (reference ip_adapter.py:120-154) ----------------------------------------------------
     @property
@@ -174,6 +181,7 @@ class HipUNet2DConditionModel:
         if c_in != self.config.in_channels:
             raise ValueError(f"sample has {c_in} channels, expected {self.config.in_channels}")
         f16 = lambda t: t.to(device=self.device, dtype=torch.float16).contiguous()
+        ctx_in = encoder_hidden_states
         sample, ctx = f16(sample), f16(encoder_hidden_states)
         te, tid = f16(added_cond_kwargs["text_embeds"]), f16(added_cond_kwargs["time_ids"])
         if ctx.shape[0] != B or ctx.shape[2] != self.config.cross_attention_dim:
@@ -192,8 +200,29 @@ class HipUNet2DConditionModel:
             sites = C.c_int(0)
             _ffi.check(self._lib.ia2p_autotune(*args, int(_tune_reps), C.addressof(sites)), self._ctx)
             return sites.value
-        _ffi.check(self._lib.ia2p_unet_forward(*args), self._ctx)
+        if self.cache_context_kv:
+            kv = self._context_kv(ctx_in, ctx, B, L, ws)
+            _ffi.check(self._lib.ia2p_unet_forward_kv(self._ctx, _ffi.current_stream(), _ffi.ptr(sample), t, _ffi.ptr(kv), L, _ffi.ptr(te), _ffi.ptr(tid),
+                                                      _ffi.ptr(out), B, h, w, _ffi.ptr(ws), ws.numel()), self._ctx)
+        else:
+            _ffi.check(self._lib.ia2p_unet_forward(*args), self._ctx)
         return (out,) if not return_dict else SimpleNamespace(sample=out)
+
+    def _context_kv(self, ctx_in, ctx, B, L, ws):
+        """K/V projections of `ctx` (ia2p_project_context), cached while the same unmodified tensor object arrives with the same weights
+        and IP-Adapter topology. The source tensor is kept alive so its address cannot be handed to another tensor."""
+        ip = self._ip_sig[:1] + self._ip_sig[2:3] if self._ip_sig else None          # (on/off, tokens): the split of the context rows
+        k = self._kv
+        if k is not None and k[0] is ctx_in and k[1] == ctx_in._version and k[2] == ip and k[3] == self._weights_gen and k[4] == (B, L):
+            return k[5]
+        n = self._lib.ia2p_context_kv_bytes(self._ctx, B, L)
+        if n == 0:
+            _ffi.check(2, self._ctx)
+        buf = k[5] if (k is not None and k[5].numel() == n) else torch.empty(n, dtype=torch.uint8, device=self.device)
+        self._kv = None
+        _ffi.check(self._lib.ia2p_project_context(self._ctx, _ffi.current_stream(), _ffi.ptr(ctx), L, B, _ffi.ptr(buf), n, _ffi.ptr(ws), ws.numel()), self._ctx)
+        self._kv = (ctx_in, ctx_in._version, ip, self._weights_gen, (B, L), buf)
+        return buf
 
     def autotune(self, sample, timestep, encoder_hidden_states, added_cond_kwargs, reps: int = 5) -> int:
         """Measure the candidate (tile, K-split) plans of every GEMM / conv shape of this call in place and keep the fastest

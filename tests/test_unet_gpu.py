@@ -321,3 +321,45 @@ def test_layernorm_fold_switch_agrees(tiny_models, monkeypatch):
         ref = oracle.build_unet(cfg, sd)(x.float(), 301, ctx.float(), added_cond_kwargs=dict(text_embeds=te.float(), time_ids=tid.float()))[0]
     assert rel_l2(a, ref) <= 5e-3 and rel_l2(b, ref) <= 5e-3
     assert rel_l2(a, b) <= 3e-3 and not torch.equal(a, b)
+
+
+def test_context_kv_hoisting_is_bit_identical_and_invalidates(tiny_models):
+    """`ia2p_project_context` + `ia2p_unet_forward_kv` == `ia2p_unet_forward`, bit for bit; the Python cache re-projects when the
+    context tensor is another object, was modified in place, or the weights / IP-Adapter topology changed."""
+    cfg, sd, ipsd, hip, oracle = tiny_models
+    _install_ip(hip, cfg, ipsd, 0.8)
+    x, ctx, te, tid = (t.to(DEV) for t in _inputs(cfg, 2, 16, 16, 81, seed=5))
+    kw = dict(added_cond_kwargs=dict(text_embeds=te, time_ids=tid))
+    hip.cache_context_kv = False
+    plain = hip(x, 321, encoder_hidden_states=ctx, **kw)[0].clone()
+    hip.cache_context_kv = True
+    try:
+        hip._kv = None
+        a = hip(x, 321, encoder_hidden_states=ctx, **kw)[0].clone()
+        buf = hip._kv[5]
+        b = hip(x, 301, encoder_hidden_states=ctx, **kw)[0].clone()               # next step, same context object: no re-projection
+        assert hip._kv[5] is buf and torch.equal(a, plain)
+        hip.cache_context_kv = False
+        assert torch.equal(hip(x, 301, encoder_hidden_states=ctx, **kw)[0], b)
+        hip.cache_context_kv = True
+        ctx.mul_(0.5)                                                              # in-place change: version counter moves
+        c2 = hip(x, 321, encoder_hidden_states=ctx, **kw)[0].clone()
+        hip.cache_context_kv = False
+        assert torch.equal(hip(x, 321, encoder_hidden_states=ctx, **kw)[0], c2) and not torch.equal(c2, a)
+        hip.cache_context_kv = True
+        other = ctx.clone()                                                        # same values, other object
+        assert torch.equal(hip(x, 321, encoder_hidden_states=other, **kw)[0], c2) and hip._kv[0] is other
+        from instructany2pix_amd.attention_processor import AttnProcessor2_0
+        hip.set_attn_processor(AttnProcessor2_0())                                 # topology change: all 81 rows are text now
+        d = hip(x, 321, encoder_hidden_states=other, **kw)[0].clone()
+        hip.cache_context_kv = False
+        assert torch.equal(hip(x, 321, encoder_hidden_states=other, **kw)[0], d) and not torch.equal(d, c2)
+        hip.cache_context_kv = True
+        hip(x, 321, encoder_hidden_states=other, **kw)
+        gen = hip._weights_gen
+        hip.load_state_dict(sd)                                                    # weight reload
+        assert hip._weights_gen > gen
+        e = hip(x, 321, encoder_hidden_states=other, **kw)[0]
+        assert hip._kv[3] == hip._weights_gen and torch.equal(e, d)
+    finally:
+        hip.cache_context_kv = True
