@@ -142,6 +142,8 @@ def main():
     eps, nxt = torch.empty_like(lat), torch.empty_like(lat)
 
     def step(i, x, y):
+        if i % len(ts) == 0:          # a new request every 50 steps: start again from the seeded latents (keeps any --steps finite)
+            x.copy_(lat)
         t = ts[i % len(ts)]
         unet(x, t, encoder_hidden_states=ctx, added_cond_kwargs=added, out=eps)
         c_x, c_e = sch.step_coeffs(t)
