@@ -224,10 +224,12 @@ class HipUNet2DConditionModel:
         self._kv = (ctx_in, ctx_in._version, ip, self._weights_gen, (B, L), buf)
         return buf
 
-    def autotune(self, sample, timestep, encoder_hidden_states, added_cond_kwargs, reps: int = 5) -> int:
+    def autotune(self, sample, timestep, encoder_hidden_states, added_cond_kwargs, reps: int = 7) -> int:
         """Measure the candidate (tile, K-split) plans of every GEMM / conv shape of this call in place and keep the fastest
         (ia2p_autotune; process-wide table, see export_plans / import_plans). Returns the number of shapes measured.
         Use inputs shaped like the real ones (random values, not zeros). Optional: without it the built-in cost model picks."""
+        for _ in range(4):          # bring the clocks up first: candidates measured on a cold GPU would all look slow, the first ones most
+            self(sample, timestep, encoder_hidden_states=encoder_hidden_states, added_cond_kwargs=added_cond_kwargs)
         return self(sample, timestep, encoder_hidden_states=encoder_hidden_states, added_cond_kwargs=added_cond_kwargs, _tune_reps=reps)
 
     # ---- per-kernel-class timing for the roofline leg of bench.py ------------------------------------------------
