@@ -25,7 +25,8 @@
 
 // ---- kernel launchers (gemm.hip, attention.hip, norm.hip, misc.hip) ------------------------------------------
 hipError_t ia2p_launch_gemm(const GemmArgs& a, bool conv, hipStream_t s, int* picked);
-hipError_t ia2p_launch_gemm_variant(const GemmArgs& a, bool conv, int variant, hipStream_t s);
+hipError_t ia2p_launch_gemm_variant(const GemmArgs& a, bool conv, int variant, hipStream_t s, bool with_reduce = true);
+hipError_t ia2p_launch_splitk_reduce(const GemmArgs& a, hipStream_t s);
 void ia2p_gemm_candidates(int M, int N, int K, bool conv, bool geglu, size_t max_slab_bytes, double slack, std::vector<GemmPlan>* out);
 hipError_t ia2p_launch_attention(const AttnArgs& a, hipStream_t s);
 int ia2p_gn_chunks(int B, int HW);
@@ -139,11 +140,11 @@ struct Arena {            // deterministic first-fit allocator over [0, cap)
 
 struct ProfRec { hipEvent_t e0, e1; int k; double flops, bytes; };
 // profile classes = device kernel names as rocprofv3 prints them (template arguments included)
-enum { PK_GEMM0 = 0, PK_CONV0 = 16, PK_ATTN = 32, PK_GN, PK_LN, PK_EMBED, PK_CONV_IN, PK_CONV_OUT, PK_CONCAT, PK_NCLASS };
+enum { PK_GEMM0 = 0, PK_CONV0 = 16, PK_ATTN = 32, PK_GN, PK_LN, PK_EMBED, PK_CONV_IN, PK_CONV_OUT, PK_CONCAT, PK_REDUCE, PK_NCLASS };
 static const char* prof_name(int k) {
   static char buf[PK_NCLASS][64];
   static const char* const other[] = {"attention_f16_kernel", "gn_stats_kernel+gn_apply_kernel", "layernorm_kernel",
-                                      "embed_kernel+linear_small_kernel", "conv_in_kernel", "conv_out_kernel", "concat_kernel"};
+                                      "embed_kernel+linear_small_kernel", "conv_in_kernel", "conv_out_kernel", "concat_kernel", "splitk_reduce_kernel"};
   if (k >= PK_ATTN) return other[k - PK_ATTN];
   const GemmTile t = IA2P_GEMM_TILES[(k % PK_CONV0) % IA2P_GEMM_NVARIANT];
   snprintf(buf[k], sizeof buf[k], "gemm_f16_kernel<%d, %d, %d, %s, 2, 64>", t.bm, t.bn, t.stages, k >= PK_CONV0 ? "true" : "false");
@@ -509,8 +510,14 @@ static void run_gemm(RunCtx* c, GemmArgs& a, bool conv, const char* what, double
     else { slab = wsalloc(c, (size_t)pl.splitk * a.M * a.N * 2); a.partial = (float*)slab.p; }
   }
   struct Rel { RunCtx* c; T2 t; ~Rel() { wsfree(c, t); } } rel{c, slab};
-  ProfScope ps(c, (conv ? PK_CONV0 : PK_GEMM0) + pl.variant, flops, bytes);
-  CHECK_LAUNCH(c, ia2p_launch_gemm_variant(a, conv, pl.variant, c->stream), what);
+  {
+    ProfScope ps(c, (conv ? PK_CONV0 : PK_GEMM0) + pl.variant, flops, bytes);
+    CHECK_LAUNCH(c, ia2p_launch_gemm_variant(a, conv, pl.variant, c->stream, false), what);
+  }
+  if (pl.splitk > 1) {
+    ProfScope ps(c, PK_REDUCE, 0, (double)pl.splitk * a.M * a.N * 4 + 2.0 * a.M * a.N);
+    CHECK_LAUNCH(c, ia2p_launch_splitk_reduce(a, c->stream), what);
+  }
 }
 
 static void op_gemm(RunCtx* c, const half_t* A, int lda, const half_t* W, const half_t* bias, const half_t* residual, int ldr,

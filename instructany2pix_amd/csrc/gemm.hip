@@ -607,8 +607,13 @@ extern "C" void ia2p_debug_gemm_plan(int M, int N, int K, int conv, int geglu, i
   if (splitk) *splitk = pl.splitk;
 }
 
+hipError_t ia2p_launch_splitk_reduce(const GemmArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(std::min(16384, a.M)), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
 template <bool CONV>
-static hipError_t launch_any(const GemmArgs& a, int v, hipStream_t s) {
+static hipError_t launch_any(const GemmArgs& a, int v, hipStream_t s, bool with_reduce) {
   if (a.splitk > 1 && !a.partial) return hipErrorInvalidValue;
   hipError_t e;
   if (v < 0 || v >= IA2P_GEMM_NVARIANT) return hipErrorInvalidValue;
@@ -636,18 +641,18 @@ static hipError_t launch_any(const GemmArgs& a, int v, hipStream_t s) {
     // workgroup per CU; BK = 32 rings (64-byte rows halve the request efficiency). The template still takes WGM and BK.
     default: return hipErrorInvalidValue;
   }
-  if (e != hipSuccess || a.splitk <= 1) return e;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(std::min(16384, a.M)), dim3(256), 0, s, a);
-  return hipGetLastError();
+  if (e != hipSuccess || a.splitk <= 1 || !with_reduce) return e;
+  return ia2p_launch_splitk_reduce(a, s);
 }
 
 // launch with an explicit tile variant (a.splitk / a.partial as the caller set them)
-hipError_t ia2p_launch_gemm_variant(const GemmArgs& a, bool conv, int variant, hipStream_t s) {
-  return conv ? launch_any<true>(a, variant, s) : launch_any<false>(a, variant, s);
+// with_reduce = false: a K-split launch leaves its slabs for a separate ia2p_launch_splitk_reduce (the executor times the two apart)
+hipError_t ia2p_launch_gemm_variant(const GemmArgs& a, bool conv, int variant, hipStream_t s, bool with_reduce) {
+  return conv ? launch_any<true>(a, variant, s, with_reduce) : launch_any<false>(a, variant, s, with_reduce);
 }
 // *picked (optional) receives the variant id. a.splitk / a.partial must follow ia2p_gemm_plan (the caller owns the slabs).
 hipError_t ia2p_launch_gemm(const GemmArgs& a, bool conv, hipStream_t s, int* picked) {
   const GemmPlan pl = ia2p_gemm_plan(a.M, a.N, a.K, conv, a.geglu != 0);
   if (picked) *picked = pl.variant;
-  return ia2p_launch_gemm_variant(a, conv, pl.variant, s);
+  return ia2p_launch_gemm_variant(a, conv, pl.variant, s, true);
 }

@@ -1,5 +1,6 @@
 #!/bin/bash
-# One profiling round on the GPU box: measured plans -> PMC traffic passes -> rocprofv3 kernel stats -> the default bench line.
+# One profiling round on the GPU box: measured plans -> PMC traffic passes -> rocprofv3 kernel stats -> the bench line, all four on the
+# SAME measured plan table (saved by the first run) so that the per-kernel figures of the artefacts describe the same launches.
 # usage (inside gpurun): bash tools/profile_round.sh r01e        outputs under gpurun_out/<tag>_* (copy what is judged into profiles/)
 TAG=${1:-rXX}
 R=$GRAFT_REPO_ROOT
@@ -16,7 +17,7 @@ cd /tmp
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG} --output-format csv -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-roofline --plans $R/gpurun_out/${TAG}_plans_cfg3.txt > $R/gpurun_out/prof_${TAG}.log 2>&1
 cd $R
 find gpurun_out/prof_${TAG} -name "*kernel_stats.csv" -exec cp {} gpurun_out/${TAG}_kernel_stats_bench_cfg3.csv \;
-python3 bench.py --steps 50 --warmup 3 --kernel-table gpurun_out/${TAG}_kernel_table.json > gpurun_out/${TAG}_bench_cfg3.json 2> gpurun_out/${TAG}_bench_cfg3.err
+python3 bench.py --steps 50 --warmup 3 --plans gpurun_out/${TAG}_plans_cfg3.txt --kernel-table gpurun_out/${TAG}_kernel_table.json > gpurun_out/${TAG}_bench_cfg3.json 2> gpurun_out/${TAG}_bench_cfg3.err
 tail -1 gpurun_out/${TAG}_bench_cfg3.json | cut -c1-1800
 grep -E "launches/step" gpurun_out/${TAG}_bench_cfg3.err | head -20
 # keep the merge small: drop the raw per-dispatch traces
