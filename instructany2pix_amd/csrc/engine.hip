@@ -171,6 +171,8 @@ struct RunCtx {
   bool record = false;
   int wseq_key = -1;
   bool prefetch = true;
+  const half_t* tail_pf = nullptr;   // what the LAST contraction of a pass prefetches: the first weights of the next pass (embedding MLPs)
+  size_t tail_pf_bytes = 0;
   bool ln_fold = true;       // LayerNorms folded into their consumer GEMMs (IA2P_LN_FOLD=0: separate layernorm_kernel launches, for A/B runs)
   bool prof = false;
   // autotune pass (ia2p_autotune): every GEMM / conv site of an unmeasured shape times its candidate plans in place
@@ -200,6 +202,7 @@ struct ia2p_ctx : RunCtx {
   // plan
   size_t conv_in_w, conv_in_b, te1w, te1b, te2w, te2b, ae1w, ae1b, ae2w, ae2b, tw_all, tb_all, ngo, nbo, conv_out_w, conv_out_b;
   int temb_total = 0;
+  size_t embed_lo = 0, embed_hi = 0;
   // context K/V projection weights of ALL cross-attention layers, stacked [kv_rows, ctx] (text) / (image tokens):
   // the context is the same for every layer, so one GEMM per step projects it for all of them
   size_t kv_text_base = 0, kv_ip_base = 0;
@@ -331,6 +334,7 @@ static ia2p_status build_plan(ia2p_ctx* c) {
   }
   c->tw_all = P.take((size_t)tot * T);
   c->tb_all = P.take(tot);
+  c->embed_lo = c->te1w; c->embed_hi = P.cur;      // [time/add embedding MLPs | stacked time_emb_proj]: the first weights a pass reads
   c->temb_total = 0;
   {
     int rows = 0;
@@ -440,8 +444,10 @@ static inline const half_t* W_(RunCtx* c, size_t off) { return c->arena + off; }
 
 static void set_prefetch(RunCtx* c, GemmArgs& a, const half_t* W, size_t bytes) {
   if (c->dry) { if (c->record) c->wseq.push_back({W, bytes}); return; }
-  if (!c->prefetch || c->widx + 1 >= c->wseq.size()) { ++c->widx; return; }
-  const auto& nx = c->wseq[c->widx + 1];
+  if (!c->prefetch || c->widx + 1 > c->wseq.size()) { ++c->widx; return; }
+  const bool last = c->widx + 1 == c->wseq.size();
+  if (last && !c->tail_pf) { ++c->widx; return; }
+  const std::pair<const half_t*, size_t> nx = last ? std::make_pair(c->tail_pf, c->tail_pf_bytes) : c->wseq[c->widx + 1];
   ++c->widx;
   if (nx.second > ((size_t)96 << 20)) return;           // larger than the Infinity Cache can usefully hold
   a.pf = nx.first; a.pf_bytes = (long)nx.second;
@@ -972,6 +978,7 @@ static ia2p_status unet_forward_impl(ia2p_ctx* c, void* stream, const void* samp
   c->dry = false; c->failed = false; c->stream = (hipStream_t)stream;
   c->ws.reset(usable);
   c->ws_base = (char*)base;
+  c->tail_pf = c->arena + c->embed_lo; c->tail_pf_bytes = (c->embed_hi - c->embed_lo) * sizeof(half_t);   // the next step starts with these
   st = run_forward(c, (const half_t*)sample, timestep, (const half_t*)context, L, (const half_t*)text_embeds, (const half_t*)time_ids, (half_t*)out, B, h, w,
                    (const half_t*)kv);
   if (c->failed && st == IA2P_OK) st = IA2P_ERR_HIP;

@@ -30,11 +30,11 @@ __global__ void embed_kernel(float t, const half_t* text_embeds, const half_t* t
 }
 
 // ---- out[M<=16, N] = act_out( f_in(X)[M,K] . W[N,K]^T + bias + addend ), one wave per 4 output columns ---------------
-__global__ __launch_bounds__(256) void linear_small_kernel(const half_t* X, int ldx, const half_t* W, const half_t* bias,
+__global__ __launch_bounds__(64) void linear_small_kernel(const half_t* X, int ldx, const half_t* W, const half_t* bias,
                                                            const half_t* addend, int ldadd, half_t* out, int ldo,
                                                            int M, int N, int K, int silu_in, int silu_out) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n0 = (blockIdx.x * 4 + wave) * 4;
+  const int lane = threadIdx.x;
+  const int n0 = blockIdx.x * 4;            // one wave per workgroup: N / 4 workgroups spread over the CUs
   if (n0 >= N) return;
   float acc[4][16];
 #pragma unroll
@@ -65,19 +65,31 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const half_t* X, int 
       }
     }
   }
+  // 64 partial sums per lane -> lane l keeps the total of acc[l / 16][l % 16]: butterfly reduce-scatter, 63 shuffles instead of 64 x 6
+  float v[64];
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
-    for (int m = 0; m < 16; ++m) {
-      const float s = wave_sum(acc[c][m]);
-      if (lane == c * 16 + m && m < M && n0 + c < N) {
-        float v = s;
-        if (bias) v += (float)bias[n0 + c];
-        if (addend) v += (float)addend[(size_t)m * ldadd + n0 + c];
-        if (silu_out) v = silu_f(v);
-        out[(size_t)m * ldo + n0 + c] = (half_t)v;
-      }
+    for (int m = 0; m < 16; ++m) v[c * 16 + m] = acc[c][m];
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) {
+    const bool up = (lane & s) != 0;
+#pragma unroll
+    for (int i = 0; i < s; ++i) {
+      const float give = up ? v[i] : v[i + s], keep = up ? v[i + s] : v[i];
+      v[i] = keep + __shfl_xor(give, s);
     }
+  }
+  {
+    const int c = lane >> 4, m = lane & 15;
+    if (m < M && n0 + c < N) {
+      float r = v[0];
+      if (bias) r += (float)bias[n0 + c];
+      if (addend) r += (float)addend[(size_t)m * ldadd + n0 + c];
+      if (silu_out) r = silu_f(r);
+      out[(size_t)m * ldo + n0 + c] = (half_t)r;
+    }
+  }
 }
 
 // ---- conv_in: latent NCHW [B,Cin,H,W] -> channels-last [B*H*W, Co], 3x3 pad 1 (Cin*9 <= 64 taps) --------------------
@@ -421,7 +433,7 @@ hipError_t ia2p_launch_embed(float t, const half_t* text_embeds, const half_t* t
 hipError_t ia2p_launch_linear_small(const half_t* X, int ldx, const half_t* W, const half_t* bias, const half_t* addend, int ldadd,
                                     half_t* out, int ldo, int M, int N, int K, int silu_in, int silu_out, hipStream_t s) {
   if (M > 16 || K % 8) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(linear_small_kernel, dim3((N + 15) / 16), dim3(256), 0, s, X, ldx, W, bias, addend, ldadd, out, ldo, M, N, K, silu_in, silu_out);
+  hipLaunchKernelGGL(linear_small_kernel, dim3((N + 3) / 4), dim3(64), 0, s, X, ldx, W, bias, addend, ldadd, out, ldo, M, N, K, silu_in, silu_out);
   return hipGetLastError();
 }
 hipError_t ia2p_launch_conv_in(const half_t* x, const half_t* w, const half_t* bias, half_t* y, int B, int Cin, int H, int W, int Co, hipStream_t s) {
