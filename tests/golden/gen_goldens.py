@@ -23,6 +23,8 @@ Fixtures:
   G9 vae_ldm.npz       in-tree ldm Encoder / Decoder (the architecture the SDXL VAE descends from), small config
   G10 misc_refiner.npz _get_add_time_ids, requires_aesthetics_score branch (the refiner's 5 micro-conditioning ids) + its error cases
                        (`python gen_goldens.py refiner` writes only this one)
+  G11 encode_prompt.npz the reference's vendored `encode_prompt` (ddim/sdxl_pipeline.py:202-395) driven with stand-in tokenizers and the
+                       oracle's CLIP towers on seeded weights (`python gen_goldens.py encode_prompt`)
 """
 import ast
 import importlib
@@ -332,8 +334,62 @@ def gen_refiner():
     print(d["time_ids"], d["neg_time_ids"], msgs)
 
 
+def gen_encode_prompt():
+    """G11: run the reference's own encode_prompt text (AST-extracted method) on stand-in tokenizers and the oracle CLIP towers"""
+    import logging
+    from typing import List, Optional
+    import oracle
+    sys.path.insert(0, os.path.dirname(HERE))
+    from stub_tokenizer import StubTokenizer
+    from instructany2pix_amd.config import tiny_clip
+    from instructany2pix_amd.weights import clip_param_specs, synthetic_state_dict
+    fn = ast_extract("instructany2pix/ddim/sdxl_pipeline.py", ["encode_prompt"],
+                     {"torch": torch, "List": List, "Optional": Optional, "LoraLoaderMixin": type("L", (), {}), "TextualInversionLoaderMixin": type("T", (), {}),
+                      "adjust_lora_scale_text_encoder": lambda *a: None, "logger": logging.getLogger("golden")})["encode_prompt"]
+    c1, c2 = tiny_clip(0, "quick_gelu"), tiny_clip(64, "gelu")
+    r1 = oracle.build_clip(c1, synthetic_state_dict(clip_param_specs(c1), seed=31))
+    r2 = oracle.build_clip(c2, synthetic_state_dict(clip_param_specs(c2), seed=32))
+
+    class Enc:                                     # transformers-style output: [0] = pooled / text_embeds, .hidden_states
+        dtype = torch.float32
+
+        def __init__(self, m):
+            self.m = m
+
+        def __call__(self, ids, output_hidden_states=True):
+            pooled, last, hidden = self.m(ids)
+            out = types.SimpleNamespace(hidden_states=hidden)
+            return type("O", (), {"__getitem__": lambda s, i: pooled, "hidden_states": hidden})()
+
+    def pipe(force_zeros):
+        return types.SimpleNamespace(tokenizer=StubTokenizer(1, c1.vocab_size), tokenizer_2=StubTokenizer(2, c1.vocab_size), text_encoder=Enc(r1), text_encoder_2=Enc(r2),
+                                     config=types.SimpleNamespace(force_zeros_for_empty_prompt=force_zeros), _execution_device="cpu")
+    prompts, negs = ["a photo of a cat", "two dogs on the beach at sunset"], ["blurry", "low quality, bad anatomy"]
+    d = {}
+    for tag, args in (("pair", dict(prompt=prompts, negative_prompt=negs, num_images_per_prompt=2)),
+                      ("zeros", dict(prompt="a photo of a cat")),
+                      ("empty", dict(prompt="a photo of a cat", _force=False)),
+                      ("nocfg", dict(prompt=prompts, do_classifier_free_guidance=False))):
+        force = args.pop("_force", True)
+        pe, ne, pp, npl = fn(pipe(force), **args)
+        d[tag + "_pe"], d[tag + "_pp"] = npf(pe), npf(pp)
+        if ne is not None:
+            d[tag + "_ne"], d[tag + "_np"] = npf(ne), npf(npl)
+    for name, kw, exc in (("err_type", dict(prompt="a cat", negative_prompt=["x"]), TypeError), ("err_batch", dict(prompt=["a", "b"], negative_prompt=["x"]), ValueError)):
+        try:
+            fn(pipe(True), **kw)
+            d[name] = 0
+        except exc:
+            d[name] = 1
+    np.savez_compressed(os.path.join(HERE, "encode_prompt.npz"), **d)
+    print({k: (v.shape if hasattr(v, "shape") else v) for k, v in d.items()})
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "refiner":
+    if len(sys.argv) > 1 and sys.argv[1] == "encode_prompt":
+        with torch.no_grad():
+            gen_encode_prompt()
+    elif len(sys.argv) > 1 and sys.argv[1] == "refiner":
         with torch.no_grad():
             gen_refiner()
     else:

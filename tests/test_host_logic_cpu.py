@@ -219,3 +219,44 @@ def test_inpaint_mask_preparation_and_add_noise_coefficients():
     for t in (1, 481, 981):
         c0, c1 = s.add_noise_coeffs(t)
         assert (c0 * x0 + c1 * n - oracle.add_noise(r, x0, n, t)).abs().max() < 1e-6 and abs(c0 * c0 + c1 * c1 - 1) < 1e-6
+
+
+def test_encode_prompt_host_logic_matches_reference_golden(golden):
+    """`SDXLTextEncoders.encode_prompt` (the product's host logic, here over CPU stand-in encoders) against fixture G11, the output of
+    the reference's own `encode_prompt` text: every branch the reference has (negatives, zeros, empty string, no CFG, both errors)."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from stub_tokenizer import StubTokenizer
+    from types import SimpleNamespace
+    from instructany2pix_amd.clip import SDXLTextEncoders
+    from instructany2pix_amd.config import tiny_clip
+    from instructany2pix_amd.weights import clip_param_specs, synthetic_state_dict
+    d = golden("encode_prompt.npz")
+    c1, c2 = tiny_clip(0, "quick_gelu"), tiny_clip(64, "gelu")
+    r1 = oracle.build_clip(c1, synthetic_state_dict(clip_param_specs(c1), seed=31))
+    r2 = oracle.build_clip(c2, synthetic_state_dict(clip_param_specs(c2), seed=32))
+
+    class Enc:                                            # what HipCLIPTextModel returns, computed by the oracle on the CPU
+        def __init__(self, m):
+            self.m = m
+
+        def __call__(self, ids, output_hidden_states=True, want_pooled=True):
+            pooled, last, hidden = self.m(ids)
+            out = SimpleNamespace(hidden_states=hidden)
+            return type("O", (), {"__getitem__": lambda s, i: pooled if want_pooled else None, "hidden_states": hidden})()
+
+    mk = lambda force: SDXLTextEncoders(StubTokenizer(1, c1.vocab_size), StubTokenizer(2, c1.vocab_size), Enc(r1), Enc(r2), force_zeros_for_empty_prompt=force)
+    prompts, negs = ["a photo of a cat", "two dogs on the beach at sunset"], ["blurry", "low quality, bad anatomy"]
+    close = lambda a, k: np.abs(a.numpy() - d[k]).max() < 1e-5
+    pe, ne, pp, npl = mk(True).encode_prompt(prompts, negative_prompt=negs, num_images_per_prompt=2)
+    assert close(pe, "pair_pe") and close(ne, "pair_ne") and close(pp, "pair_pp") and close(npl, "pair_np")
+    pe, ne, pp, npl = mk(True).encode_prompt("a photo of a cat")
+    assert close(pe, "zeros_pe") and close(pp, "zeros_pp") and close(ne, "zeros_ne") and close(npl, "zeros_np")
+    pe, ne, pp, npl = mk(False).encode_prompt("a photo of a cat")
+    assert close(pe, "empty_pe") and close(ne, "empty_ne") and close(npl, "empty_np")
+    pe, ne, pp, npl = mk(True).encode_prompt(prompts, do_classifier_free_guidance=False)
+    assert close(pe, "nocfg_pe") and close(pp, "nocfg_pp") and ne is None and npl is None
+    with pytest.raises(TypeError):
+        mk(True).encode_prompt("a cat", negative_prompt=["x"])
+    with pytest.raises(ValueError):
+        mk(True).encode_prompt(["a", "b"], negative_prompt=["x"])

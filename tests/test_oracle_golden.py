@@ -269,3 +269,33 @@ def test_clip_restatement_matches_transformers(proj, act, eos):
         assert (a - b).abs().max() < 2e-5
     from instructany2pix_amd.weights import clip_param_specs
     assert {k: tuple(v.shape) for k, v in sd.items()} == {k: s for k, s, _ in clip_param_specs(cfg)}
+
+
+def _clip_pair():
+    from instructany2pix_amd.config import tiny_clip
+    from instructany2pix_amd.weights import clip_param_specs, synthetic_state_dict
+    c1, c2 = tiny_clip(0, "quick_gelu"), tiny_clip(64, "gelu")
+    return (c1, oracle.build_clip(c1, synthetic_state_dict(clip_param_specs(c1), seed=31)),
+            c2, oracle.build_clip(c2, synthetic_state_dict(clip_param_specs(c2), seed=32)))
+
+
+def test_g11_encode_prompt_matches_reference_function(golden):
+    """oracle.encode_prompt_ref == the reference's vendored `encode_prompt` (ddim/sdxl_pipeline.py:202-395) run on the same stand-in
+    tokenizers and CLIP towers: concat of both penultimate states, pooled of tower 2, zero / empty negatives, per-image repeat"""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from stub_tokenizer import StubTokenizer
+    d = golden("encode_prompt.npz")
+    c1, r1, c2, r2 = _clip_pair()
+    t1, t2 = StubTokenizer(1, c1.vocab_size), StubTokenizer(2, c1.vocab_size)
+    ids = lambda t, x: t(x, padding="max_length", max_length=77, truncation=True).input_ids
+    prompts, negs = ["a photo of a cat", "two dogs on the beach at sunset"], ["blurry", "low quality, bad anatomy"]
+    pe, ne, pp, npl = oracle.encode_prompt_ref(r1, r2, ids(t1, prompts), ids(t2, prompts), ids(t1, negs), ids(t2, negs), 2)
+    for a, k in ((pe, "pair_pe"), (ne, "pair_ne"), (pp, "pair_pp"), (npl, "pair_np")):
+        assert np.abs(a.numpy() - d[k]).max() < 1e-5, k
+    one = ["a photo of a cat"]
+    pe, ne, pp, npl = oracle.encode_prompt_ref(r1, r2, ids(t1, one), ids(t2, one), zero_negative=True)
+    assert np.abs(pe.numpy() - d["zeros_pe"]).max() < 1e-5 and not d["zeros_ne"].any() and not d["zeros_np"].any()
+    pe, ne, pp, npl = oracle.encode_prompt_ref(r1, r2, ids(t1, one), ids(t2, one), ids(t1, [""]), ids(t2, [""]))
+    assert np.abs(ne.numpy() - d["empty_ne"]).max() < 1e-5 and np.abs(npl.numpy() - d["empty_np"]).max() < 1e-5
+    assert int(d["err_type"]) == 1 and int(d["err_batch"]) == 1
