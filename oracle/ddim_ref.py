@@ -1,7 +1,7 @@
 """ORACLE (test infrastructure): CPU restatement of the DDIM loop, scheduler and conditioning helpers.
 
-Reference-owned code restated here (pinned by golden fixtures G3/G4/G7 generated from the reference
-files themselves, tests/golden/gen_goldens.py):
+Reference-owned code restated here (pinned by golden fixtures G3/G4/G7 and, for the loops, G12/G13 = the outputs of the
+reference's own `inverse` / `generate` / `__call__` method text run over this oracle's UNet; tests/golden/gen_goldens.py):
   backward_ddim         <- _backward_ddim                 instructany2pix/ddim/pnp_pipeline.py:73-85
   invert_loop           <- SDXLDDIMPipeline.inverse loop  instructany2pix/ddim/pnp_pipeline.py:249-278
   get_add_time_ids      <- _get_add_time_ids              instructany2pix/ddim/pnp_pipeline.py:23-71

@@ -23,6 +23,11 @@ Fixtures:
   G9 vae_ldm.npz       in-tree ldm Encoder / Decoder (the architecture the SDXL VAE descends from), small config
   G10 misc_refiner.npz _get_add_time_ids, requires_aesthetics_score branch (the refiner's 5 micro-conditioning ids) + its error cases
                        (`python gen_goldens.py refiner` writes only this one)
+  G12 inverse_loop.npz  the reference's own `SDXLDDIMPipeline.inverse` text (ddim/pnp_pipeline.py:92-278) driving the oracle UNet (tiny config, seeded
+                       weights, IP processors installed) with the oracle DDIM tables as the scheduler object (`python gen_goldens.py inverse`)
+  G13 sample_loop.npz   the vendored SDXL `__call__` text (ddim/sdxl_pipeline.py:544-886, with its own prepare_latents / _get_add_time_ids /
+                       check_inputs / prepare_extra_step_kwargs) driven by the reference's `IPAdapterXL.generate` (ip_adapter.py:289-356) and its
+                       AST-extracted `ImageProjModel`, over the oracle UNet + oracle DDIM tables (`python gen_goldens.py sample`)
   G11 encode_prompt.npz the reference's vendored `encode_prompt` (ddim/sdxl_pipeline.py:202-395) driven with stand-in tokenizers and the
                        oracle's CLIP towers on seeded weights (`python gen_goldens.py encode_prompt`)
 """
@@ -69,6 +74,22 @@ def ast_extract(relpath, names, glb):
             ns = dict(glb)
             exec(compile(mod, relpath, "exec"), ns)
             out[node.name] = ns[node.name]
+    missing = set(names) - set(out)
+    assert not missing, missing
+    return out
+
+
+def ast_extract_method(relpath, cls, names, glb):
+    """Compile selected methods of ONE class of a reference file from its AST (several classes may define the same name)."""
+    tree = ast.parse(open(os.path.join(REF, relpath)).read())
+    out = {}
+    for node in tree.body:
+        if isinstance(node, ast.ClassDef) and node.name == cls:
+            for sub in node.body:
+                if isinstance(sub, ast.FunctionDef) and sub.name in names:
+                    ns = dict(glb)
+                    exec(compile(ast.Module(body=[sub], type_ignores=[]), relpath, "exec"), ns)
+                    out[sub.name] = ns[sub.name]
     missing = set(names) - set(out)
     assert not missing, missing
     return out
@@ -385,8 +406,143 @@ def gen_encode_prompt():
     print({k: (v.shape if hasattr(v, "shape") else v) for k, v in d.items()})
 
 
+def gen_inverse():
+    """G12: the reference's inversion loop itself (method text compiled from its AST) over the oracle UNet"""
+    from typing import Any, Callable, Dict, List, Optional, Tuple, Union
+    import oracle
+    from instructany2pix_amd.config import tiny
+    from instructany2pix_amd.weights import unet_param_specs, ip_adapter_specs, synthetic_state_dict
+    ns = {"torch": torch, "np": np, "List": List, "Optional": Optional, "Union": Union, "Callable": Callable, "Dict": Dict, "Any": Any, "Tuple": Tuple,
+          "PIL": types.SimpleNamespace(Image=types.SimpleNamespace(Image=object)), "tqdm": lambda it: it,
+          "StableDiffusionXLPipelineOutput": lambda images: types.SimpleNamespace(images=images)}
+    fns = ast_extract("instructany2pix/ddim/pnp_pipeline.py", ["_backward_ddim", "_get_add_time_ids"], {"torch": torch})
+    ns.update(fns)
+
+    class SchedStandIn(oracle.DDIMSchedulerRef):          # diffusers' DDIMScheduler is absent: the oracle's tables (pinned by G5) stand in
+        config = types.SimpleNamespace()
+
+        @classmethod
+        def from_config(cls, config):
+            return cls()
+    ns["DDIMScheduler"] = SchedStandIn
+    inverse = ast_extract("instructany2pix/ddim/pnp_pipeline.py", ["inverse"], ns)["inverse"]
+    cfg = tiny()
+    sd = synthetic_state_dict(unet_param_specs(cfg), seed=7)
+    ipsd = synthetic_state_dict(ip_adapter_specs(cfg, 64)["ip_adapter"], seed=7)
+    unet = oracle.build_unet(cfg, sd, ipsd, ip_scale=1.0)
+    g = torch.Generator().manual_seed(23)
+    B, h, w = 2, 16, 16
+    x0 = torch.randn(B, 4, h, w, generator=g)
+    ctx = torch.randn(B, 77, cfg.cross_attention_dim, generator=g)          # the inversion runs with the 77-token context on the IP-enabled UNet
+    pooled = torch.randn(B, cfg.pooled_dim, generator=g)
+    pipe = types.SimpleNamespace(
+        scheduler=SchedStandIn(), unet=unet, _execution_device="cpu", vae_scale_factor=8, check_inputs=lambda *a, **k: None,
+        encode_prompt=lambda **k: (k["prompt_embeds"], None, k["pooled_prompt_embeds"], None),
+        image_processor=types.SimpleNamespace(preprocess=lambda im: im), prepare_latents=lambda image, *a: image,
+        text_encoder_2=types.SimpleNamespace(config=types.SimpleNamespace(projection_dim=cfg.pooled_dim)),
+        config=types.SimpleNamespace(requires_aesthetics_score=False))
+    d = dict(x0=npf(x0), ctx=npf(ctx), pooled=npf(pooled))
+    for n in (5, 12):
+        out = inverse(pipe, prompt_embeds=ctx, pooled_prompt_embeds=pooled, image=x0.clone(), num_inference_steps=n)
+        d[f"inv{n}"] = npf(out.images)
+    np.savez_compressed(os.path.join(HERE, "inverse_loop.npz"), **d)
+    print({k: v.shape for k, v in d.items()})
+
+
+def gen_sample():
+    """G13: IPAdapterXL.generate -> StableDiffusionXLPipeline.__call__ (both the reference's own text) over the oracle UNet"""
+    import inspect
+    from typing import Any, Callable, Dict, List, Optional, Tuple, Union
+    import oracle
+    from instructany2pix_amd.config import tiny
+    from instructany2pix_amd.weights import unet_param_specs, ip_adapter_specs, synthetic_state_dict
+    ns = {"torch": torch, "np": np, "inspect": inspect, "List": List, "Optional": Optional, "Union": Union, "Callable": Callable, "Dict": Dict, "Any": Any,
+          "Tuple": Tuple, "replace_example_docstring": lambda doc: (lambda f: f), "EXAMPLE_DOC_STRING": "",
+          "StableDiffusionXLPipelineOutput": lambda images: types.SimpleNamespace(images=images)}
+    ns.update(ast_extract("instructany2pix/ddim/sdxl_pipeline.py", ["rescale_noise_cfg"], {"torch": torch}))
+    m = ast_extract("instructany2pix/ddim/sdxl_pipeline.py", ["__call__", "prepare_latents", "_get_add_time_ids", "prepare_extra_step_kwargs", "check_inputs"], ns)
+
+    class Sched(oracle.DDIMSchedulerRef):               # stand-in for diffusers' DDIMScheduler object (absent): oracle tables + step
+        order = 1
+        config = types.SimpleNamespace(num_train_timesteps=1000)
+
+        def set_timesteps(self, n, device=None):
+            super().set_timesteps(n)
+
+        def step(self, model_output, timestep, sample, eta=0.0, return_dict=False):
+            return (super().step(model_output, timestep, sample),)
+
+    cfg = tiny()
+    sd = synthetic_state_dict(unet_param_specs(cfg), seed=7)
+    specs = ip_adapter_specs(cfg, 64)
+    ipsd = synthetic_state_dict(specs["ip_adapter"], seed=7)
+    unet = oracle.build_unet(cfg, sd, ipsd, ip_scale=1.0)
+    unet.add_embedding = types.SimpleNamespace(linear_1=types.SimpleNamespace(in_features=cfg.projection_class_embeddings_input_dim)) if not hasattr(unet.add_embedding, "linear_1") else unet.add_embedding
+
+    class Bar:
+        def __init__(self, total): pass
+        def __enter__(self): return self
+        def __exit__(self, *a): return False
+        def update(self): pass
+
+    class Pipe:
+        pass
+    pipe = Pipe()
+    for k, f in m.items():
+        setattr(Pipe, k, f)
+    pipe.unet, pipe.scheduler, pipe._execution_device, pipe.vae_scale_factor, pipe.default_sample_size = unet, Sched(), "cpu", 8, 16
+    pipe.text_encoder_2 = types.SimpleNamespace(config=types.SimpleNamespace(projection_dim=cfg.pooled_dim), dtype=torch.float32)
+    Pipe.progress_bar = lambda self, total=None: Bar(total)
+    Pipe.maybe_free_model_hooks = lambda self: None
+    Pipe.to = lambda self, *a, **k: self
+
+    # IPAdapterXL.generate + get_image_embeds + set_scale: the reference's own text over the reference's ImageProjModel
+    ipn = {"torch": torch, "List": List, "Image": types.SimpleNamespace(Image=type("NoImage", (), {})), "get_generator": lambda seed, device: None,
+           "IPAttnProcessor": oracle.IPAttnProcessor2_0Ref}
+    gen = ast_extract_method("instructany2pix/diffusion/ip_adapter/ip_adapter.py", "IPAdapter", ["get_image_embeds", "set_scale"], ipn)
+    gen.update(ast_extract_method("instructany2pix/diffusion/ip_adapter/ip_adapter.py", "IPAdapterXL", ["generate"], ipn))
+    IPM = ast_extract("instructany2pix/diffusion/ip_adapter/ip_adapter.py", ["ImageProjModel"], {"torch": torch})["ImageProjModel"]
+    proj = IPM(cross_attention_dim=cfg.cross_attention_dim, clip_embeddings_dim=64, clip_extra_context_tokens=4)
+    proj.load_state_dict({k: v.float() for k, v in synthetic_state_dict(specs["image_proj"], seed=7).items()})
+
+    class Adapter:
+        pass
+    for k, f in gen.items():
+        setattr(Adapter, k, f)
+    ad = Adapter()
+    ad.pipe, ad.device, ad.image_proj_model = pipe, "cpu", proj
+    g = torch.Generator().manual_seed(29)
+    B, h, w, N = 1, 16, 16, 6
+    emb = torch.randn(64, generator=g)
+    ctx, nctx = torch.randn(B, 77, cfg.cross_attention_dim, generator=g), torch.randn(B, 77, cfg.cross_attention_dim, generator=g)
+    pooled, npooled = torch.randn(B, cfg.pooled_dim, generator=g), torch.randn(B, cfg.pooled_dim, generator=g)
+    xT = torch.randn(B, 4, h, w, generator=g)
+    # text encoders are stand-ins: a prompt string maps to fixed embeddings; pre-computed embeddings pass through (as :281 does)
+    Pipe.encode_prompt = lambda self, *a, **k: ((k["prompt_embeds"], k["negative_prompt_embeds"], k["pooled_prompt_embeds"], k["negative_pooled_prompt_embeds"])
+                                                if k.get("prompt_embeds") is not None else (ctx, nctx, pooled, npooled))
+    # generate() runs get_image_embeds in fp16 on the device in the reference; on the CPU stand-in keep fp32
+    orig_to = torch.Tensor.to
+    d = dict(emb=npf(emb), ctx=npf(ctx), nctx=npf(nctx), pooled=npf(pooled), npooled=npf(npooled), xT=npf(xT))
+    try:
+        torch.Tensor.to = lambda self, *a, **k: orig_to(self, *[x for x in a if x is not torch.float16], **{kk: vv for kk, vv in k.items() if vv is not torch.float16})
+        for tag, kw in (("g4_s07", dict(scale=0.7, guidance_scale=4.0)), ("g10_s10", dict(scale=1.0, guidance_scale=10.0))):
+            out = ad.generate(None, clip_image_embeds=emb[None], num_inference_steps=N, mode="global", latents=xT.clone(), height=h * 8, width=w * 8,
+                              output_type="latent", **kw)
+            d[tag] = npf(out)
+    finally:
+        torch.Tensor.to = orig_to
+    np.savez_compressed(os.path.join(HERE, "sample_loop.npz"), **d)
+    print({k: v.shape for k, v in d.items()})
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "encode_prompt":
+    if len(sys.argv) > 1 and sys.argv[1] == "sample":
+        with torch.no_grad():
+            gen_sample()
+    elif len(sys.argv) > 1 and sys.argv[1] == "inverse":
+        with torch.no_grad():
+            gen_inverse()
+    elif len(sys.argv) > 1 and sys.argv[1] == "encode_prompt":
         with torch.no_grad():
             gen_encode_prompt()
     elif len(sys.argv) > 1 and sys.argv[1] == "refiner":

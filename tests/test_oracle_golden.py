@@ -299,3 +299,43 @@ def test_g11_encode_prompt_matches_reference_function(golden):
     pe, ne, pp, npl = oracle.encode_prompt_ref(r1, r2, ids(t1, one), ids(t2, one), ids(t1, [""]), ids(t2, [""]))
     assert np.abs(ne.numpy() - d["empty_ne"]).max() < 1e-5 and np.abs(npl.numpy() - d["empty_np"]).max() < 1e-5
     assert int(d["err_type"]) == 1 and int(d["err_batch"]) == 1
+
+
+@torch.no_grad()
+def test_g12_inversion_loop_matches_reference_method(golden):
+    """oracle.invert_loop == the reference's `SDXLDDIMPipeline.inverse` text (ddim/pnp_pipeline.py:92-278) run over the same oracle
+    UNet: ascending timesteps, final_alpha_cumprod on the first move, no guidance, `[H, W, 0, 0, H, W]` ids, 77-token context"""
+    from instructany2pix_amd.config import tiny
+    from instructany2pix_amd.weights import unet_param_specs, ip_adapter_specs, synthetic_state_dict
+    d = golden("inverse_loop.npz")
+    cfg = tiny()
+    unet = oracle.build_unet(cfg, synthetic_state_dict(unet_param_specs(cfg), seed=7), synthetic_state_dict(ip_adapter_specs(cfg, 64)["ip_adapter"], seed=7), ip_scale=1.0)
+    x0, ctx, pooled = T(d["x0"]), T(d["ctx"]), T(d["pooled"])
+    tid = torch.tensor([[128.0, 128.0, 0, 0, 128.0, 128.0]] * 2)
+    for n in (5, 12):
+        out = oracle.invert_loop(unet, oracle.DDIMSchedulerRef(), x0.clone(), ctx, dict(text_embeds=pooled, time_ids=tid), n)
+        assert np.abs(out.numpy() - d[f"inv{n}"]).max() < 2e-5 * np.abs(d[f"inv{n}"]).max()
+
+
+@torch.no_grad()
+def test_g13_sampling_loop_matches_reference_methods(golden):
+    """oracle.sample_loop (+ ImageProjModelRef, set_scale) == the reference's `IPAdapterXL.generate` (ip_adapter.py:289-356) calling the
+    vendored SDXL `__call__` (ddim/sdxl_pipeline.py:544-886) over the same oracle UNet: image tokens appended to both contexts, zero
+    embedding for the unconditional branch, cat([latents]*2), CFG combine, DDIM step, `[H,W,0,0,H,W]` ids on both halves"""
+    from instructany2pix_amd.config import tiny
+    from instructany2pix_amd.weights import unet_param_specs, ip_adapter_specs, synthetic_state_dict
+    d = golden("sample_loop.npz")
+    cfg = tiny()
+    specs = ip_adapter_specs(cfg, 64)
+    sd, ipsd = synthetic_state_dict(unet_param_specs(cfg), seed=7), synthetic_state_dict(specs["ip_adapter"], seed=7)
+    m = oracle.ImageProjModelRef(cfg.cross_attention_dim, 64, 4)
+    m.load_state_dict({k: v.float() for k, v in synthetic_state_dict(specs["image_proj"], seed=7).items()})
+    emb, ctx, nctx, pooled, npooled, xT = (T(d[k]) for k in ("emb", "ctx", "nctx", "pooled", "npooled", "xT"))
+    e = torch.stack([emb[None], torch.zeros(1, 64)], dim=1)
+    p, n = m(e, "global"), m(torch.zeros_like(e), "global")
+    tid = torch.tensor([[128.0, 128.0, 0, 0, 128.0, 128.0]])
+    for tag, scale, g in (("g4_s07", 0.7, 4.0), ("g10_s10", 1.0, 10.0)):
+        unet = oracle.build_unet(cfg, sd, ipsd, ip_scale=scale)
+        out = oracle.sample_loop(unet, oracle.DDIMSchedulerRef(), xT.clone(), torch.cat([ctx, p], 1), dict(text_embeds=pooled, time_ids=tid), 6, g,
+                                 torch.cat([nctx, n], 1), dict(text_embeds=npooled, time_ids=tid))
+        assert np.abs(out.numpy() - d[tag]).max() < 2e-5 * np.abs(d[tag]).max(), tag
