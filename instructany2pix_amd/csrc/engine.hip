@@ -51,6 +51,7 @@ hipError_t ia2p_launch_clip_embed(const int* ids, const half_t* tok, const half_
 hipError_t ia2p_launch_causal_attention_small(const half_t* qkv, half_t* out, int B, int T, int heads, hipStream_t s);
 hipError_t ia2p_launch_clip_pool(const int* ids, const half_t* x, const half_t* gamma, const half_t* beta, half_t* out, int B, int T, int H, int eos_id,
                                  float eps, hipStream_t s);
+hipError_t ia2p_launch_touch(const void* p, size_t bytes, unsigned* sink, hipStream_t s);
 hipError_t ia2p_launch_pack_conv(const half_t* src, half_t* dst, int Co, int Ci, hipStream_t s);
 hipError_t ia2p_launch_pack_geglu(const half_t* src, half_t* dst, int rows, int rowlen, hipStream_t s);
 hipError_t ia2p_launch_softmax_rows(half_t* x, long ld, int rows, int n, float scale, hipStream_t s);
@@ -456,7 +457,7 @@ static void set_prefetch(RunCtx* c, GemmArgs& a, const half_t* W, size_t bytes) 
 
 // In-place measurement of the candidate plans of one GEMM / conv site (autotune pass). Every candidate runs once untimed and
 // tune_reps times bracketed by events (round-robin over the candidates), with the L2s flushed (a memset over the flush region)
-// before every launch: in the real sequence the activations were just written and the weights sit in the Infinity Cache (prefetched by
+// before every launch and the site's activations read back in: in the real sequence the activations were just written and the weights sit in the Infinity Cache (prefetched by
 // the previous launch), not in L2. The prefetch workgroups of the site are part of every candidate launch. The fastest
 // goes into the plan table. Re-running a site is harmless: outputs are rewritten (in-place residuals only drift).
 static void tune_site(RunCtx* c, const GemmArgs& a, bool conv) {
@@ -476,6 +477,11 @@ static void tune_site(RunCtx* c, const GemmArgs& a, bool conv) {
       b.splitk = cands[i].splitk > 1 ? cands[i].splitk : 0;
       b.partial = cands[i].splitk > 1 ? (float*)c->tune_scratch : nullptr;
       bool good = hipMemsetAsync(c->tune_scratch + c->tune_slab_bytes, r & 1, c->tune_flush_bytes, c->stream) == hipSuccess;
+      // ... but the site's activations (and residual) were written by the launch just before it in the real sequence: warm them again
+      const size_t a_bytes = conv ? (size_t)(a.M / std::max(1, a.Ho * a.Wo)) * a.Hs * a.Ws * a.Cin * sizeof(half_t)
+                                  : (a.rpb ? 0 : (size_t)a.M * a.lda * sizeof(half_t));
+      good = good && ia2p_launch_touch(a.A, std::min<size_t>(a_bytes, (size_t)64 << 20), (unsigned*)c->tune_scratch, c->stream) == hipSuccess;
+      if (a.residual) good = good && ia2p_launch_touch(a.residual, std::min<size_t>((size_t)a.M * a.ldr * sizeof(half_t), (size_t)64 << 20), (unsigned*)c->tune_scratch, c->stream) == hipSuccess;
       good = good && hipEventRecord(e0, c->stream) == hipSuccess;
       good = good && ia2p_launch_gemm_variant(b, conv, cands[i].variant, c->stream) == hipSuccess;
       good = good && hipEventRecord(e1, c->stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess;

@@ -3,6 +3,8 @@
 // the fused CFG + DDIM update, and the one-time weight re-layouts.
 #include "common.h"
 
+#include <algorithm>
+
 // ---- sinusoidal embeddings (diffusers Timesteps(flip_sin_to_cos=True, freq_shift=0)) ------------------
 // tsin[b, :]   = [cos(t f_i), sin(t f_i)], i < Tp/2
 // addin[b, :]  = [text_embeds[b, :P], sinusoid(time_ids[b,0]), ..., sinusoid(time_ids[b,5])]
@@ -338,6 +340,14 @@ __global__ __launch_bounds__(64) void clip_pool_kernel(const int* ids, const hal
   for (int k = lane; k < H; k += 64) out[(size_t)b * H + k] = (half_t)(((float)row[k] - mean) * rstd * (float)gamma[k] + (float)beta[k]);
 }
 
+// reads a buffer once (16 B per lane) so that it sits in L2 / Infinity Cache again: the autotuner re-warms a site's ACTIVATIONS after
+// flushing the caches, because in the real sequence they were written by the launch just before
+__global__ void touch_kernel(const uint4* p, size_t n16, unsigned* sink) {
+  unsigned acc = 0;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) { const uint4 v = p[i]; acc ^= v.x ^ v.w; }
+  if (acc == 0x9e3779b9u) *sink = acc;
+}
+
 // ---- one-time weight re-layouts -----------------------------------------------------------------------------------------
 // conv [Co][Ci][3][3] -> [Co][ky][kx][Ci] (implicit-GEMM K order)
 __global__ void pack_conv_kernel(const half_t* src, half_t* dst, int Co, int Ci) {
@@ -482,6 +492,12 @@ hipError_t ia2p_launch_causal_attention_small(const half_t* qkv, half_t* out, in
 hipError_t ia2p_launch_clip_pool(const int* ids, const half_t* x, const half_t* gamma, const half_t* beta, half_t* out, int B, int T, int H, int eos_id,
                                  float eps, hipStream_t s) {
   hipLaunchKernelGGL(clip_pool_kernel, dim3(B), dim3(64), 0, s, ids, x, gamma, beta, out, T, H, eos_id, eps);
+  return hipGetLastError();
+}
+hipError_t ia2p_launch_touch(const void* p, size_t bytes, unsigned* sink, hipStream_t s) {
+  const size_t n16 = bytes / 16;
+  if (!n16) return hipSuccess;
+  hipLaunchKernelGGL(touch_kernel, dim3((unsigned)std::min<size_t>(2048, (n16 + 255) / 256)), dim3(256), 0, s, (const uint4*)p, n16, sink);
   return hipGetLastError();
 }
 hipError_t ia2p_launch_pack_conv(const half_t* src, half_t* dst, int Co, int Ci, hipStream_t s) {
