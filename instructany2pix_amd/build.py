@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include", "ia2p.h")
 OUT = os.path.join(HERE, "libia2p_hip.so")
-SOURCES = ["gemm.hip", "attention.hip", "norm.hip", "misc.hip", "engine.hip"]
+SOURCES = ["gemm.hip", "attention.hip", "norm.hip", "misc.hip", "engine.hip", "vae_engine.hip", "clip_engine.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
 # attention: MFMA results feed VALU softmax directly; the VGPR form avoids ~250 v_accvgpr_read/write per key tile

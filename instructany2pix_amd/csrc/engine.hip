@@ -8,58 +8,11 @@
 // Memory: weights live in ONE flat fp16 arena whose layout depends only on the config (so data-parallel ranks
 // can receive it with a single RCCL broadcast); activations come from a caller-provided workspace managed by a
 // deterministic first-fit allocator (sized by a dry run of the same code path).
-#include <hip/hip_runtime.h>
+#include "engine_rt.h"
 
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <algorithm>
-#include <cstdlib>
-#include <cstring>
-#include <string>
-#include <unordered_map>
-#include <vector>
+thread_local std::string g_err;
 
-#include "../../include/ia2p.h"
-#include "common.h"
-
-// ---- kernel launchers (gemm.hip, attention.hip, norm.hip, misc.hip) ------------------------------------------
-hipError_t ia2p_launch_gemm(const GemmArgs& a, bool conv, hipStream_t s, int* picked);
-hipError_t ia2p_launch_gemm_variant(const GemmArgs& a, bool conv, int variant, hipStream_t s, bool with_reduce = true);
-hipError_t ia2p_launch_splitk_reduce(const GemmArgs& a, hipStream_t s);
-void ia2p_gemm_candidates(int M, int N, int K, bool conv, bool geglu, size_t max_slab_bytes, double slack, std::vector<GemmPlan>* out);
-hipError_t ia2p_launch_attention(const AttnArgs& a, hipStream_t s);
-int ia2p_gn_chunks(int B, int HW);
-hipError_t ia2p_launch_groupnorm(const half_t* x, int ldx, half_t* y, int ldy, const half_t* gamma, const half_t* beta,
-                                 float* partial, int B, int HW, int C, int G, float eps, int silu, hipStream_t s);
-hipError_t ia2p_launch_layernorm(const half_t* x, int ldx, half_t* y, int ldy, const half_t* gamma, const half_t* beta,
-                                 int M, int C, float eps, hipStream_t s);
-hipError_t ia2p_launch_embed(float t, const half_t* text_embeds, const half_t* time_ids, half_t* tsin, half_t* addin,
-                             int B, int Tp, int P, int Ad, int nids, hipStream_t s);
-hipError_t ia2p_launch_linear_small(const half_t* X, int ldx, const half_t* W, const half_t* bias, const half_t* addend, int ldadd,
-                                    half_t* out, int ldo, int M, int N, int K, int silu_in, int silu_out, hipStream_t s);
-hipError_t ia2p_launch_conv_in(const half_t* x, const half_t* w, const half_t* bias, half_t* y, int B, int Cin, int H, int W, int Co, hipStream_t s);
-hipError_t ia2p_launch_conv_out(const half_t* x, int ldx, const half_t* w, const half_t* bias, half_t* y, int B, int C, int H, int W, int Co, hipStream_t s);
-hipError_t ia2p_launch_concat(const half_t* a, int lda, int Ca, const half_t* b, int ldb, int Cb, half_t* y, long M, hipStream_t s);
-hipError_t ia2p_launch_ddim_step(const half_t* x, const half_t* eps_u, const half_t* eps_c, float g, float c_x, float c_e,
-                                 half_t* out, half_t* out2, long n, hipStream_t s);
-hipError_t ia2p_launch_mask_blend(const half_t* x, const half_t* init, const half_t* noise, const half_t* mask, float c0, float c1,
-                                  half_t* out, half_t* out2, int B, int C, long HW, hipStream_t s);
-hipError_t ia2p_launch_fold_ln(const half_t* W, const half_t* gamma, const half_t* beta, const half_t* bias, half_t* Wf, float* cs, float* lb,
-                               int N, int K, hipStream_t s);
-hipError_t ia2p_launch_clip_embed(const int* ids, const half_t* tok, const half_t* pos, half_t* x, float* stats, int rows, int T, int H, int vocab, hipStream_t s);
-hipError_t ia2p_launch_causal_attention_small(const half_t* qkv, half_t* out, int B, int T, int heads, hipStream_t s);
-hipError_t ia2p_launch_clip_pool(const int* ids, const half_t* x, const half_t* gamma, const half_t* beta, half_t* out, int B, int T, int H, int eos_id,
-                                 float eps, hipStream_t s);
-hipError_t ia2p_launch_touch(const void* p, size_t bytes, unsigned* sink, hipStream_t s);
-hipError_t ia2p_launch_pack_conv(const half_t* src, half_t* dst, int Co, int Ci, hipStream_t s);
-hipError_t ia2p_launch_pack_geglu(const half_t* src, half_t* dst, int rows, int rowlen, hipStream_t s);
-hipError_t ia2p_launch_softmax_rows(half_t* x, long ld, int rows, int n, float scale, hipStream_t s);
-hipError_t ia2p_launch_conv1x1_nchw(const half_t* x, const half_t* w, const half_t* bias, half_t* y, int B, int Ci, int Co, long HW, hipStream_t s);
-
-static thread_local std::string g_err;   // error of a failed ia2p_create / ctx-less entry point
-
-static const half_t* zero_page() {
+const half_t* zero_page() {
   static thread_local void* z[16] = {nullptr};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
@@ -69,17 +22,6 @@ static const half_t* zero_page() {
   }
   return (const half_t*)z[dev];
 }
-
-enum PKind { PK_COPY = 0, PK_CONV = 1, PK_GEGLU_W = 2, PK_GEGLU_B = 3 };
-
-struct Param {
-  size_t off;       // element offset in the arena
-  size_t elems;
-  int kind;
-  int d0, d1;       // conv: Co, Ci ; geglu: rows, rowlen
-  bool loaded;
-  bool optional;    // IP-Adapter tensors
-};
 
 struct Resnet {
   int cin, cout, temb_off;
@@ -106,43 +48,7 @@ struct Stage {            // one down/up block
   int rc;
 };
 
-struct Block { size_t off, size; bool free_; };
-
-struct Arena {            // deterministic first-fit allocator over [0, cap)
-  std::vector<Block> blocks;
-  size_t cap, high;
-  void reset(size_t c) { cap = c; high = 0; blocks.clear(); blocks.push_back({0, c, true}); }
-  size_t alloc(size_t bytes) {
-    bytes = (bytes + 255) & ~(size_t)255;
-    for (size_t i = 0; i < blocks.size(); ++i)
-      if (blocks[i].free_ && blocks[i].size >= bytes) {
-        const size_t off = blocks[i].off;
-        if (blocks[i].size > bytes) {
-          Block rest{off + bytes, blocks[i].size - bytes, true};
-          blocks[i].size = bytes;
-          blocks.insert(blocks.begin() + i + 1, rest);
-        }
-        blocks[i].free_ = false;
-        if (off + bytes > high) high = off + bytes;
-        return off;
-      }
-    return (size_t)-1;
-  }
-  void release(size_t off) {
-    for (size_t i = 0; i < blocks.size(); ++i)
-      if (blocks[i].off == off && !blocks[i].free_) {
-        blocks[i].free_ = true;
-        if (i + 1 < blocks.size() && blocks[i + 1].free_) { blocks[i].size += blocks[i + 1].size; blocks.erase(blocks.begin() + i + 1); }
-        if (i > 0 && blocks[i - 1].free_) { blocks[i - 1].size += blocks[i].size; blocks.erase(blocks.begin() + i); }
-        return;
-      }
-  }
-};
-
-struct ProfRec { hipEvent_t e0, e1; int k; double flops, bytes; };
-// profile classes = device kernel names as rocprofv3 prints them (template arguments included)
-enum { PK_GEMM0 = 0, PK_CONV0 = 16, PK_ATTN = 32, PK_GN, PK_LN, PK_EMBED, PK_CONV_IN, PK_CONV_OUT, PK_CONCAT, PK_REDUCE, PK_NCLASS };
-static const char* prof_name(int k) {
+const char* prof_name(int k) {
   static char buf[PK_NCLASS][64];
   static const char* const other[] = {"attention_f16_kernel", "gn_stats_kernel+gn_apply_kernel", "layernorm_kernel",
                                       "embed_kernel+linear_small_kernel", "conv_in_kernel", "conv_out_kernel", "concat_kernel", "splitk_reduce_kernel"};
@@ -151,50 +57,6 @@ static const char* prof_name(int k) {
   snprintf(buf[k], sizeof buf[k], "gemm_f16_kernel<%d, %d, %d, %s, 2, 64>", t.bm, t.bn, t.stages, k >= PK_CONV0 ? "true" : "false");
   return buf[k];
 }
-
-// state shared by the executors (conditional UNet, VAE): weights, workspace, prefetch plan, per-kernel timing
-struct RunCtx {
-  std::string err;
-  std::unordered_map<std::string, Param> params;
-  size_t arena_elems = 0;
-  half_t* arena = nullptr;
-  bool finalized = false;
-  int groups = 32;          // GroupNorm groups
-  // run state
-  Arena ws;
-  char* ws_base = nullptr;
-  bool dry = false;
-  hipStream_t stream = nullptr;
-  bool failed = false;
-  // weight prefetch plan: weights of every GEMM/conv launch of a pass, in launch order
-  std::vector<std::pair<const half_t*, size_t>> wseq;
-  size_t widx = 0;
-  bool record = false;
-  int wseq_key = -1;
-  bool prefetch = true;
-  const half_t* tail_pf = nullptr;   // what the LAST contraction of a pass prefetches: the first weights of the next pass (embedding MLPs)
-  size_t tail_pf_bytes = 0;
-  bool ln_fold = true;       // LayerNorms folded into their consumer GEMMs (IA2P_LN_FOLD=0: separate layernorm_kernel launches, for A/B runs)
-  bool prof = false;
-  // autotune pass (ia2p_autotune): every GEMM / conv site of an unmeasured shape times its candidate plans in place
-  bool tuning = false;
-  int tune_reps = 5, tune_sites = 0;
-  char* tune_scratch = nullptr;                 // [slab region | flush region]
-  size_t tune_slab_bytes = 0, tune_flush_bytes = 0;
-  std::vector<ProfRec> recs;
-  std::vector<hipEvent_t> evpool;
-  double p_ms[PK_NCLASS], p_fl[PK_NCLASS], p_by[PK_NCLASS];
-  int64_t p_n[PK_NCLASS];
-  RunCtx() {
-    if (const char* e = getenv("IA2P_PREFETCH")) prefetch = atoi(e) != 0;
-    if (const char* e = getenv("IA2P_LN_FOLD")) ln_fold = atoi(e) != 0;
-    for (int k = 0; k < PK_NCLASS; ++k) { p_ms[k] = p_fl[k] = p_by[k] = 0; p_n[k] = 0; }
-  }
-  ~RunCtx() {
-    for (auto& r : recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
-    for (auto e : evpool) (void)hipEventDestroy(e);
-  }
-};
 
 struct ia2p_ctx : RunCtx {
   ia2p_unet_config cfg;
@@ -214,7 +76,7 @@ struct ia2p_ctx : RunCtx {
   int n_attn2 = 0;
 };
 
-static ia2p_status fail(RunCtx* c, ia2p_status st, const char* fmt, ...) {
+ia2p_status fail(RunCtx* c, ia2p_status st, const char* fmt, ...) {
   char buf[512];
   va_list ap;
   va_start(ap, fmt);
@@ -417,32 +279,17 @@ static ia2p_status build_plan(ia2p_ctx* c) {
 // ---------------------------------------------------------------------------------------------------------------------
 // run helpers
 // ---------------------------------------------------------------------------------------------------------------------
-struct T2 { size_t off; half_t* p; };   // workspace tensor
-
-static T2 wsalloc(RunCtx* c, size_t elems) {
+T2 wsalloc(RunCtx* c, size_t elems) {
   const size_t off = c->ws.alloc(elems * sizeof(half_t));
   if (off == (size_t)-1) { if (!c->failed) fail(c, IA2P_ERR_NOMEM, "workspace too small"); return T2{off, nullptr}; }
   return T2{off, c->dry ? nullptr : (half_t*)(c->ws_base + off)};
 }
-static void wsfree(RunCtx* c, T2 t) { if (t.off != (size_t)-1) c->ws.release(t.off); }
+void wsfree(RunCtx* c, T2 t) { if (t.off != (size_t)-1) c->ws.release(t.off); }
 
-static hipEvent_t get_event(RunCtx* c) {
+hipEvent_t get_event(RunCtx* c) {
   if (!c->evpool.empty()) { hipEvent_t e = c->evpool.back(); c->evpool.pop_back(); return e; }
   hipEvent_t e; (void)hipEventCreate(&e); return e;
 }
-struct ProfScope {
-  RunCtx* c; int k; double fl, by; hipEvent_t e0, e1; bool on;
-  ProfScope(RunCtx* c_, int k_, double fl_, double by_) : c(c_), k(k_), fl(fl_), by(by_), on(c_ && c_->prof && !c_->dry) {
-    if (on) { e0 = get_event(c); e1 = get_event(c); (void)hipEventRecord(e0, c->stream); }
-  }
-  ~ProfScope() { if (on) { (void)hipEventRecord(e1, c->stream); c->recs.push_back(ProfRec{e0, e1, k, fl, by}); } }
-  void set_class(int kk) { k = kk; }
-};
-#define CHECK_LAUNCH(c, expr, what)                                                             \
-  do { if (!(c)->dry && !(c)->failed) { hipError_t e_ = (expr); if (e_ != hipSuccess) fail((c), IA2P_ERR_HIP, "%s: %s", what, hipGetErrorString(e_)); } } while (0)
-
-static inline const half_t* W_(RunCtx* c, size_t off) { return c->arena + off; }
-
 static void set_prefetch(RunCtx* c, GemmArgs& a, const half_t* W, size_t bytes) {
   if (c->dry) { if (c->record) c->wseq.push_back({W, bytes}); return; }
   if (!c->prefetch || c->widx + 1 > c->wseq.size()) { ++c->widx; return; }
@@ -507,9 +354,6 @@ static void tune_site(RunCtx* c, const GemmArgs& a, bool conv) {
 }
 
 // plan, K-split slabs, profiling class and launch of one GEMM / implicit-GEMM conv
-// LayerNorm folded into a GEMM: where the consumer finds the row statistics and the folded constants
-struct LnIn { const float* stats; int slots; const float* cs; const float* lb; float eps; };
-
 static void run_gemm(RunCtx* c, GemmArgs& a, bool conv, const char* what, double flops, double bytes, int* stat_slots = nullptr) {
   if (c->tuning && !c->dry && !c->failed) tune_site(c, a, conv);
   const GemmPlan pl = ia2p_gemm_plan(a.M, a.N, a.K, conv, a.geglu != 0);
@@ -532,9 +376,9 @@ static void run_gemm(RunCtx* c, GemmArgs& a, bool conv, const char* what, double
   }
 }
 
-static void op_gemm(RunCtx* c, const half_t* A, int lda, const half_t* W, const half_t* bias, const half_t* residual, int ldr,
-                    half_t* C, int ldc, int M, int N, int K, int geglu = 0, int rpb = 0, int bstride = 0, int roff = 0, int ldw = 0,
-                    const LnIn* ln = nullptr, float* stats_out = nullptr, int* stat_slots = nullptr, int act = 0) {
+void op_gemm(RunCtx* c, const half_t* A, int lda, const half_t* W, const half_t* bias, const half_t* residual, int ldr,
+             half_t* C, int ldc, int M, int N, int K, int geglu, int rpb, int bstride, int roff, int ldw,
+             const LnIn* ln, float* stats_out, int* stat_slots, int act) {
   GemmArgs a;
   memset(&a, 0, sizeof a);
   a.pad = 1;
@@ -548,8 +392,8 @@ static void op_gemm(RunCtx* c, const half_t* A, int lda, const half_t* W, const 
   set_prefetch(c, a, W, (size_t)N * K * sizeof(half_t));
   run_gemm(c, a, false, "gemm", 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * (geglu ? N / 2 : N) + (residual ? (double)M * N : 0)), stat_slots);
 }
-static void op_conv3(RunCtx* c, const half_t* X, int B, int Hs, int Ws, int Cin, const half_t* W, const half_t* bias, int Co,
-                     int stride, int up, const half_t* rowvec, int rowvec_ld, const half_t* residual, half_t* Y, int pad_lo = 1) {
+void op_conv3(RunCtx* c, const half_t* X, int B, int Hs, int Ws, int Cin, const half_t* W, const half_t* bias, int Co,
+              int stride, int up, const half_t* rowvec, int rowvec_ld, const half_t* residual, half_t* Y, int pad_lo) {
   GemmArgs a;
   memset(&a, 0, sizeof a);
   a.pad = pad_lo;           // zero rows/cols before the image; one row/col of zeros after it in every mode
@@ -562,11 +406,11 @@ static void op_conv3(RunCtx* c, const half_t* X, int B, int Hs, int Ws, int Cin,
   set_prefetch(c, a, W, (size_t)Co * a.K * sizeof(half_t));
   run_gemm(c, a, true, "conv3x3", 2.0 * a.M * (double)Co * a.K, 2.0 * ((double)B * Hs * Ws * Cin + (double)Co * a.K + (double)a.M * Co + (residual ? (double)a.M * Co : 0)));
 }
-static void op_gn(RunCtx* c, const half_t* x, half_t* y, size_t g, size_t b, int B, int HW, int C, float eps, int silu, float* partial) {
+void op_gn(RunCtx* c, const half_t* x, half_t* y, size_t g, size_t b, int B, int HW, int C, float eps, int silu, float* partial) {
   ProfScope ps(c, PK_GN, 8.0 * B * HW * C, 4.0 * B * HW * C);
   CHECK_LAUNCH(c, ia2p_launch_groupnorm(x, C, y, C, W_(c, g), W_(c, b), partial, B, HW, C, c->groups, eps, silu, c->stream), "groupnorm");
 }
-static void op_ln(RunCtx* c, const half_t* x, half_t* y, size_t g, size_t b, int M, int C) {
+void op_ln(RunCtx* c, const half_t* x, half_t* y, size_t g, size_t b, int M, int C) {
   ProfScope ps(c, PK_LN, 8.0 * M * C, 4.0 * M * C);
   CHECK_LAUNCH(c, ia2p_launch_layernorm(x, C, y, C, W_(c, g), W_(c, b), M, C, 1e-5f, c->stream), "layernorm");
 }
@@ -828,6 +672,55 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
 // ---------------------------------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------------------------------
+// ---- weight arena plumbing shared by the UNet, VAE and CLIP contexts
+ia2p_status rc_bind_arena(RunCtx* c, void* dev, size_t bytes) {
+  if (!c || !dev) return fail(c, IA2P_ERR_INVALID, "bind_arena: null argument");
+  if (bytes < c->arena_elems * sizeof(half_t)) return fail(c, IA2P_ERR_NOMEM, "arena needs %zu bytes, got %zu", c->arena_elems * sizeof(half_t), bytes);
+  if (((uintptr_t)dev) & 255) return fail(c, IA2P_ERR_INVALID, "arena must be 256-byte aligned");
+  c->arena = (half_t*)dev;
+  c->finalized = false;
+  c->wseq_key = -1;
+  return IA2P_OK;
+}
+ia2p_status rc_load_tensor(RunCtx* c, const char* key, const void* src, const int64_t* shape, int ndim, void* stream) {
+  if (!c || !key || !src || !shape) return fail(c, IA2P_ERR_INVALID, "load_tensor: null argument");
+  if (!c->arena) return fail(c, IA2P_ERR_STATE, "load_tensor before bind_arena");
+  auto it = c->params.find(key);
+  if (it == c->params.end()) return fail(c, IA2P_ERR_KEY, "unknown parameter key '%s'", key);
+  Param& p = it->second;
+  size_t n = 1;
+  for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
+  if (n != p.elems) return fail(c, IA2P_ERR_SHAPE, "parameter '%s': expected %zu elements, got %zu", key, p.elems, n);
+  hipStream_t s = (hipStream_t)stream;
+  half_t* dst = c->arena + p.off;
+  hipError_t e = hipSuccess;
+  switch (p.kind) {
+    case PK_COPY: e = hipMemcpyAsync(dst, src, n * sizeof(half_t), hipMemcpyDeviceToDevice, s); break;
+    case PK_CONV: e = ia2p_launch_pack_conv((const half_t*)src, dst, p.d0, p.d1, s); break;
+    case PK_GEGLU_W: case PK_GEGLU_B: e = ia2p_launch_pack_geglu((const half_t*)src, dst, p.d0, p.d1, s); break;
+  }
+  if (e != hipSuccess) return fail(c, IA2P_ERR_HIP, "load '%s': %s", key, hipGetErrorString(e));
+  p.loaded = true;
+  return IA2P_OK;
+}
+ia2p_status rc_finalize(RunCtx* c, const char* what) {
+  if (!c) return IA2P_ERR_INVALID;
+  if (!c->arena) return fail(c, IA2P_ERR_STATE, "finalize before bind_arena");
+  int missing = 0;
+  std::string first;
+  for (auto& kv : c->params)
+    if (!kv.second.loaded && !kv.second.optional) { if (!missing) first = kv.first; ++missing; }
+  if (missing) return fail(c, IA2P_ERR_KEY, "%d %s parameters not loaded (e.g. '%s')", missing, what, first.c_str());
+  c->finalized = true;
+  return IA2P_OK;
+}
+ia2p_status rc_adopt(RunCtx* c) {
+  if (!c || !c->arena) return fail(c, IA2P_ERR_STATE, "adopt_arena before bind_arena");
+  for (auto& kv : c->params) kv.second.loaded = true;
+  c->finalized = true;
+  return IA2P_OK;
+}
+
 extern "C" {
 
 int ia2p_device_is_gfx950(void) {
@@ -854,54 +747,6 @@ void ia2p_destroy(ia2p_ctx* c) { delete c; }
 const char* ia2p_last_error(ia2p_ctx* c) { return c ? c->err.c_str() : g_err.c_str(); }
 
 size_t ia2p_arena_bytes(ia2p_ctx* c) { return c ? c->arena_elems * sizeof(half_t) : 0; }
-
-static ia2p_status rc_bind_arena(RunCtx* c, void* dev, size_t bytes) {
-  if (!c || !dev) return fail(c, IA2P_ERR_INVALID, "bind_arena: null argument");
-  if (bytes < c->arena_elems * sizeof(half_t)) return fail(c, IA2P_ERR_NOMEM, "arena needs %zu bytes, got %zu", c->arena_elems * sizeof(half_t), bytes);
-  if (((uintptr_t)dev) & 255) return fail(c, IA2P_ERR_INVALID, "arena must be 256-byte aligned");
-  c->arena = (half_t*)dev;
-  c->finalized = false;
-  c->wseq_key = -1;
-  return IA2P_OK;
-}
-static ia2p_status rc_load_tensor(RunCtx* c, const char* key, const void* src, const int64_t* shape, int ndim, void* stream) {
-  if (!c || !key || !src || !shape) return fail(c, IA2P_ERR_INVALID, "load_tensor: null argument");
-  if (!c->arena) return fail(c, IA2P_ERR_STATE, "load_tensor before bind_arena");
-  auto it = c->params.find(key);
-  if (it == c->params.end()) return fail(c, IA2P_ERR_KEY, "unknown parameter key '%s'", key);
-  Param& p = it->second;
-  size_t n = 1;
-  for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
-  if (n != p.elems) return fail(c, IA2P_ERR_SHAPE, "parameter '%s': expected %zu elements, got %zu", key, p.elems, n);
-  hipStream_t s = (hipStream_t)stream;
-  half_t* dst = c->arena + p.off;
-  hipError_t e = hipSuccess;
-  switch (p.kind) {
-    case PK_COPY: e = hipMemcpyAsync(dst, src, n * sizeof(half_t), hipMemcpyDeviceToDevice, s); break;
-    case PK_CONV: e = ia2p_launch_pack_conv((const half_t*)src, dst, p.d0, p.d1, s); break;
-    case PK_GEGLU_W: case PK_GEGLU_B: e = ia2p_launch_pack_geglu((const half_t*)src, dst, p.d0, p.d1, s); break;
-  }
-  if (e != hipSuccess) return fail(c, IA2P_ERR_HIP, "load '%s': %s", key, hipGetErrorString(e));
-  p.loaded = true;
-  return IA2P_OK;
-}
-static ia2p_status rc_finalize(RunCtx* c, const char* what) {
-  if (!c) return IA2P_ERR_INVALID;
-  if (!c->arena) return fail(c, IA2P_ERR_STATE, "finalize before bind_arena");
-  int missing = 0;
-  std::string first;
-  for (auto& kv : c->params)
-    if (!kv.second.loaded && !kv.second.optional) { if (!missing) first = kv.first; ++missing; }
-  if (missing) return fail(c, IA2P_ERR_KEY, "%d %s parameters not loaded (e.g. '%s')", missing, what, first.c_str());
-  c->finalized = true;
-  return IA2P_OK;
-}
-static ia2p_status rc_adopt(RunCtx* c) {
-  if (!c || !c->arena) return fail(c, IA2P_ERR_STATE, "adopt_arena before bind_arena");
-  for (auto& kv : c->params) kv.second.loaded = true;
-  c->finalized = true;
-  return IA2P_OK;
-}
 
 ia2p_status ia2p_bind_arena(ia2p_ctx* c, void* dev, size_t bytes) { return rc_bind_arena(c, dev, bytes); }
 ia2p_status ia2p_load_tensor(ia2p_ctx* c, const char* key, const void* src, const int64_t* shape, int ndim, void* stream) {
@@ -1076,7 +921,6 @@ ia2p_status ia2p_mask_blend(void* stream, const void* x, const void* init, const
 }
 
 // ---- per-operator entry points ---------------------------------------------------------------------------------------
-#define RET_HIP(e, what) return (e) == hipSuccess ? IA2P_OK : fail(nullptr, IA2P_ERR_HIP, "%s: %s", what, hipGetErrorString(e))
 
 ia2p_status ia2p_groupnorm_silu(void* stream, const void* x, void* y, const void* gamma, const void* beta, int B, int HW, int C, int groups, float eps, int silu, float* partial) {
   if (!x || !y || !gamma || !beta || !partial) return fail(nullptr, IA2P_ERR_INVALID, "groupnorm: null argument");
@@ -1217,481 +1061,3 @@ ia2p_status ia2p_profile_read(ia2p_ctx* c, int k, char* name, int name_len, int6
 }
 
 }  // extern "C"
-
-// =====================================================================================================================
-// VAE (diffusers AutoencoderKL, SDXL config): image -> latent moments before DDIM inversion, latent -> image after
-// sampling (reference call sites: ddim/pnp_pipeline.py:190-204 via prepare_latents; ddim/sdxl_pipeline.py:859-871).
-// First "next" row of SURVEY.md §8f. Same kernels as the UNet: implicit-GEMM 3x3 convs (the stride-2 downsample
-// pads only after the image: `pad = 0`), GroupNorm+SiLU, the GEMM kernel for the single-head mid-block attention
-// (head_dim = channels: scores are materialised per image, S = Q.K^T, row softmax, O = P.V with V^T produced directly
-// as W_v.X^T), direct kernels at the 3/4/8-channel boundaries.
-// =====================================================================================================================
-struct VRes { int cin, cout; bool shortcut; size_t n1g, n1b, w1, b1, n2g, n2b, w2, b2, wsc, bsc; };
-struct VMid { int c; VRes r0, r1; size_t gg, gb, wqk, bqk, wv, bv, wo, bo; };
-struct VStage { std::vector<VRes> res; bool resample; size_t rw, rb; int rc; };
-
-struct ia2p_vae : RunCtx {
-  ia2p_vae_config cfg;
-  size_t e_in_w, e_in_b, e_ng, e_nb, e_out_w, e_out_b, q_w, q_b, pq_w, pq_b, d_in_w, d_in_b, d_ng, d_nb, d_out_w, d_out_b;
-  std::vector<VStage> enc, dec;
-  VMid emid, dmid;
-};
-
-struct VPlanner {
-  ia2p_vae* c;
-  size_t cur = 0;
-  size_t take(size_t e) { size_t o = cur; cur += (e + 127) & ~(size_t)127; return o; }
-  size_t vec(const std::string& k, int n) { size_t o = take(n); c->params[k] = Param{o, (size_t)n, PK_COPY, 0, 0, false, false}; return o; }
-  size_t mat(const std::string& k, int r, int cc) { size_t o = take((size_t)r * cc); c->params[k] = Param{o, (size_t)r * cc, PK_COPY, 0, 0, false, false}; return o; }
-  size_t conv3(const std::string& k, int co, int ci) { size_t o = take((size_t)co * ci * 9); c->params[k] = Param{o, (size_t)co * ci * 9, PK_CONV, co, ci, false, false}; return o; }
-  VRes resnet(const std::string& p, int cin, int cout) {
-    VRes r;
-    r.cin = cin; r.cout = cout; r.shortcut = cin != cout;
-    r.n1g = vec(p + ".norm1.weight", cin); r.n1b = vec(p + ".norm1.bias", cin);
-    r.w1 = conv3(p + ".conv1.weight", cout, cin); r.b1 = vec(p + ".conv1.bias", cout);
-    r.n2g = vec(p + ".norm2.weight", cout); r.n2b = vec(p + ".norm2.bias", cout);
-    r.w2 = conv3(p + ".conv2.weight", cout, cout); r.b2 = vec(p + ".conv2.bias", cout);
-    r.wsc = r.bsc = 0;
-    if (r.shortcut) { r.wsc = mat(p + ".conv_shortcut.weight", cout, cin); r.bsc = vec(p + ".conv_shortcut.bias", cout); }
-    return r;
-  }
-  VMid mid(const std::string& p, int ch) {
-    VMid m;
-    m.c = ch;
-    m.r0 = resnet(p + ".resnets.0", ch, ch);
-    const std::string a = p + ".attentions.0";
-    m.gg = vec(a + ".group_norm.weight", ch); m.gb = vec(a + ".group_norm.bias", ch);
-    m.wqk = take((size_t)2 * ch * ch); m.bqk = take(2 * ch);      // to_q | to_k stacked: one projection GEMM
-    c->params[a + ".to_q.weight"] = Param{m.wqk, (size_t)ch * ch, PK_COPY, 0, 0, false, false};
-    c->params[a + ".to_k.weight"] = Param{m.wqk + (size_t)ch * ch, (size_t)ch * ch, PK_COPY, 0, 0, false, false};
-    c->params[a + ".to_q.bias"] = Param{m.bqk, (size_t)ch, PK_COPY, 0, 0, false, false};
-    c->params[a + ".to_k.bias"] = Param{m.bqk + ch, (size_t)ch, PK_COPY, 0, 0, false, false};
-    m.wv = mat(a + ".to_v.weight", ch, ch); m.bv = vec(a + ".to_v.bias", ch);
-    m.wo = mat(a + ".to_out.0.weight", ch, ch); m.bo = vec(a + ".to_out.0.bias", ch);
-    m.r1 = resnet(p + ".resnets.1", ch, ch);
-    return m;
-  }
-};
-
-static ia2p_status vae_plan(ia2p_vae* c) {
-  const ia2p_vae_config& g = c->cfg;
-  const int n = g.n_blocks;
-  if (n < 1 || n > IA2P_MAX_BLOCKS) return fail(c, IA2P_ERR_INVALID, "n_blocks %d out of range", n);
-  for (int i = 0; i < n; ++i)
-    if (g.block_out_channels[i] % 64 || g.block_out_channels[i] % g.norm_num_groups)
-      return fail(c, IA2P_ERR_SHAPE, "block_out_channels[%d]=%d must be a multiple of 64 and of norm_num_groups", i, g.block_out_channels[i]);
-  if (g.in_channels * 9 > 64 || g.latent_channels * 9 > 64 || 2 * g.latent_channels > 8 || g.out_channels > 8)
-    return fail(c, IA2P_ERR_SHAPE, "boundary channel counts too large for the direct kernels");
-  const int* ch = g.block_out_channels;
-  const int z = g.latent_channels;
-  VPlanner P{c};
-  c->e_in_w = P.mat("encoder.conv_in.weight", ch[0], g.in_channels * 9); c->e_in_b = P.vec("encoder.conv_in.bias", ch[0]);
-  int cprev = ch[0];
-  for (int i = 0; i < n; ++i) {
-    VStage st;
-    for (int j = 0; j < g.layers_per_block; ++j)
-      st.res.push_back(P.resnet("encoder.down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), j == 0 ? cprev : ch[i], ch[i]));
-    cprev = ch[i];
-    st.resample = i != n - 1; st.rc = ch[i]; st.rw = st.rb = 0;
-    if (st.resample) {
-      st.rw = P.conv3("encoder.down_blocks." + std::to_string(i) + ".downsamplers.0.conv.weight", ch[i], ch[i]);
-      st.rb = P.vec("encoder.down_blocks." + std::to_string(i) + ".downsamplers.0.conv.bias", ch[i]);
-    }
-    c->enc.push_back(st);
-  }
-  c->emid = P.mid("encoder.mid_block", ch[n - 1]);
-  c->e_ng = P.vec("encoder.conv_norm_out.weight", ch[n - 1]); c->e_nb = P.vec("encoder.conv_norm_out.bias", ch[n - 1]);
-  c->e_out_w = P.conv3("encoder.conv_out.weight", 2 * z, ch[n - 1]); c->e_out_b = P.vec("encoder.conv_out.bias", 2 * z);
-  c->q_w = P.mat("quant_conv.weight", 2 * z, 2 * z); c->q_b = P.vec("quant_conv.bias", 2 * z);
-  c->pq_w = P.mat("post_quant_conv.weight", z, z); c->pq_b = P.vec("post_quant_conv.bias", z);
-  c->d_in_w = P.mat("decoder.conv_in.weight", ch[n - 1], z * 9); c->d_in_b = P.vec("decoder.conv_in.bias", ch[n - 1]);
-  c->dmid = P.mid("decoder.mid_block", ch[n - 1]);
-  cprev = ch[n - 1];
-  for (int i = 0; i < n; ++i) {
-    VStage st;
-    const int co = ch[n - 1 - i];
-    for (int j = 0; j < g.layers_per_block + 1; ++j)
-      st.res.push_back(P.resnet("decoder.up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), j == 0 ? cprev : co, co));
-    cprev = co;
-    st.resample = i != n - 1; st.rc = co; st.rw = st.rb = 0;
-    if (st.resample) {
-      st.rw = P.conv3("decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv.weight", co, co);
-      st.rb = P.vec("decoder.up_blocks." + std::to_string(i) + ".upsamplers.0.conv.bias", co);
-    }
-    c->dec.push_back(st);
-  }
-  c->d_ng = P.vec("decoder.conv_norm_out.weight", ch[0]); c->d_nb = P.vec("decoder.conv_norm_out.bias", ch[0]);
-  c->d_out_w = P.conv3("decoder.conv_out.weight", g.out_channels, ch[0]); c->d_out_b = P.vec("decoder.conv_out.bias", g.out_channels);
-  c->arena_elems = P.cur;
-  return IA2P_OK;
-}
-
-static T2 vae_resnet(ia2p_vae* c, const VRes& r, T2 x, int B, int H, int Wd, float* gnp) {
-  const int HW = H * Wd;
-  const long M = (long)B * HW;
-  T2 n1 = wsalloc(c, (size_t)M * r.cin);
-  op_gn(c, x.p, n1.p, r.n1g, r.n1b, B, HW, r.cin, c->cfg.norm_eps, 1, gnp);
-  T2 hh = wsalloc(c, (size_t)M * r.cout);
-  op_conv3(c, n1.p, B, H, Wd, r.cin, W_(c, r.w1), W_(c, r.b1), r.cout, 1, 0, nullptr, 0, nullptr, hh.p);
-  wsfree(c, n1);
-  T2 n2 = wsalloc(c, (size_t)M * r.cout);
-  op_gn(c, hh.p, n2.p, r.n2g, r.n2b, B, HW, r.cout, c->cfg.norm_eps, 1, gnp);
-  wsfree(c, hh);
-  T2 xs{(size_t)-1, nullptr};
-  const half_t* resid = x.p;
-  if (r.shortcut) {
-    xs = wsalloc(c, (size_t)M * r.cout);
-    op_gemm(c, x.p, r.cin, W_(c, r.wsc), W_(c, r.bsc), nullptr, 0, xs.p, r.cout, (int)M, r.cout, r.cin);
-    resid = xs.p;
-  }
-  T2 out = wsalloc(c, (size_t)M * r.cout);
-  op_conv3(c, n2.p, B, H, Wd, r.cout, W_(c, r.w2), W_(c, r.b2), r.cout, 1, 0, nullptr, 0, c->dry ? nullptr : resid, out.p);
-  wsfree(c, n2);
-  if (r.shortcut) wsfree(c, xs);
-  return out;
-}
-
-static T2 vae_mid(ia2p_vae* c, const VMid& m, T2 x, int B, int H, int Wd, float* gnp) {
-  const int HW = H * Wd, C = m.c;
-  T2 a = vae_resnet(c, m.r0, x, B, H, Wd, gnp);
-  wsfree(c, x);
-  // attention (ldm AttnBlock, blocks.py:179-203): x + to_out(softmax(QK^T / sqrt(C)) V), one head of width C
-  T2 n = wsalloc(c, (size_t)B * HW * C);
-  op_gn(c, a.p, n.p, m.gg, m.gb, B, HW, C, c->cfg.norm_eps, 0, gnp);
-  T2 qk = wsalloc(c, (size_t)HW * 2 * C), vt = wsalloc(c, (size_t)C * HW), sc = wsalloc(c, (size_t)HW * HW), o = wsalloc(c, (size_t)HW * C);
-  T2 out = wsalloc(c, (size_t)B * HW * C);
-  for (int b = 0; b < B; ++b) {
-    const half_t* nb = c->dry ? nullptr : n.p + (size_t)b * HW * C;
-    op_gemm(c, nb, C, W_(c, m.wqk), W_(c, m.bqk), nullptr, 0, qk.p, 2 * C, HW, 2 * C, C);                  // [q | k]
-    op_gemm(c, W_(c, m.wv), C, nb, nullptr, nullptr, 0, vt.p, HW, C, HW, C);                              // V^T = W_v . X^T (bias added after P.V: rows of P sum to 1)
-    op_gemm(c, qk.p, 2 * C, c->dry ? nullptr : qk.p + C, nullptr, nullptr, 0, sc.p, HW, HW, HW, C, 0, 0, 0, 0, 2 * C);   // S = Q . K^T
-    {
-      ProfScope ps(c, PK_ATTN, 0, 4.0 * HW * HW);
-      CHECK_LAUNCH(c, ia2p_launch_softmax_rows(sc.p, HW, HW, HW, 1.0f / sqrtf((float)C), c->stream), "vae softmax");
-    }
-    op_gemm(c, sc.p, HW, vt.p, W_(c, m.bv), nullptr, 0, o.p, C, HW, C, HW);                                // O = P . V + b_v
-    op_gemm(c, o.p, C, W_(c, m.wo), W_(c, m.bo), c->dry ? nullptr : a.p + (size_t)b * HW * C, C,
-            c->dry ? nullptr : out.p + (size_t)b * HW * C, C, HW, C, C);                                  // + residual
-  }
-  wsfree(c, n); wsfree(c, qk); wsfree(c, vt); wsfree(c, sc); wsfree(c, o); wsfree(c, a);
-  T2 r = vae_resnet(c, m.r1, out, B, H, Wd, gnp);
-  wsfree(c, out);
-  return r;
-}
-
-static ia2p_status vae_check(ia2p_vae* c, int B, int h, int w) {
-  if (B < 1 || B > 1024) return fail(c, IA2P_ERR_SHAPE, "batch %d outside 1..1024", B);
-  if (h < 1 || w < 1 || (long)h * w % 64 || (long)h * w > 16384) return fail(c, IA2P_ERR_SHAPE, "latent %dx%d: h*w must be a multiple of 64 and <= 16384 (mid-block attention over all pixels)", h, w);
-  return IA2P_OK;
-}
-
-// z [B, zc, h, w] NCHW -> image [B, out, h*2^(n-1), w*2^(n-1)] NCHW
-static ia2p_status vae_run_decode(ia2p_vae* c, const half_t* zin, half_t* img, int B, int h, int w) {
-  const ia2p_vae_config& g = c->cfg;
-  const int n = g.n_blocks, z = g.latent_channels, cm = g.block_out_channels[n - 1];
-  T2 gnp = wsalloc(c, (size_t)B * 64 * g.norm_num_groups * 2 * 2);
-  float* gp = (float*)gnp.p;
-  T2 zq = wsalloc(c, (size_t)B * z * h * w);
-  { ProfScope ps(c, PK_CONV_IN, 0, 0);
-    CHECK_LAUNCH(c, ia2p_launch_conv1x1_nchw(zin, W_(c, c->pq_w), W_(c, c->pq_b), zq.p, B, z, z, (long)h * w, c->stream), "post_quant_conv");
-  }
-  T2 x = wsalloc(c, (size_t)B * h * w * cm);
-  { ProfScope ps(c, PK_CONV_IN, 0, 0);
-    CHECK_LAUNCH(c, ia2p_launch_conv_in(zq.p, W_(c, c->d_in_w), W_(c, c->d_in_b), x.p, B, z, h, w, cm, c->stream), "decoder.conv_in");
-  }
-  wsfree(c, zq);
-  x = vae_mid(c, c->dmid, x, B, h, w, gp);
-  int H = h, Wd = w;
-  for (int i = 0; i < n; ++i) {
-    const VStage& st = c->dec[i];
-    for (const VRes& r : st.res) { T2 y = vae_resnet(c, r, x, B, H, Wd, gp); wsfree(c, x); x = y; }
-    if (st.resample) {
-      T2 u = wsalloc(c, (size_t)B * (2 * H) * (2 * Wd) * st.rc);
-      op_conv3(c, x.p, B, H, Wd, st.rc, W_(c, st.rw), W_(c, st.rb), st.rc, 1, 1, nullptr, 0, nullptr, u.p);
-      wsfree(c, x); x = u; H *= 2; Wd *= 2;
-    }
-  }
-  const int c0 = g.block_out_channels[0];
-  T2 no = wsalloc(c, (size_t)B * H * Wd * c0);
-  op_gn(c, x.p, no.p, c->d_ng, c->d_nb, B, H * Wd, c0, g.norm_eps, 1, gp);
-  wsfree(c, x);
-  { ProfScope ps(c, PK_CONV_OUT, 0, 0);
-    CHECK_LAUNCH(c, ia2p_launch_conv_out(no.p, c0, W_(c, c->d_out_w), W_(c, c->d_out_b), img, B, c0, H, Wd, g.out_channels, c->stream), "decoder.conv_out");
-  }
-  wsfree(c, no); wsfree(c, gnp);
-  return c->failed ? IA2P_ERR_HIP : IA2P_OK;
-}
-
-// image [B, in, H, W] NCHW -> moments [B, 2*zc, H/2^(n-1), W/2^(n-1)] NCHW (mean | logvar)
-static ia2p_status vae_run_encode(ia2p_vae* c, const half_t* img, half_t* moments, int B, int Hi, int Wi) {
-  const ia2p_vae_config& g = c->cfg;
-  const int n = g.n_blocks, z = g.latent_channels;
-  T2 gnp = wsalloc(c, (size_t)B * 64 * g.norm_num_groups * 2 * 2);
-  float* gp = (float*)gnp.p;
-  int H = Hi, Wd = Wi;
-  T2 x = wsalloc(c, (size_t)B * H * Wd * g.block_out_channels[0]);
-  { ProfScope ps(c, PK_CONV_IN, 0, 0);
-    CHECK_LAUNCH(c, ia2p_launch_conv_in(img, W_(c, c->e_in_w), W_(c, c->e_in_b), x.p, B, g.in_channels, H, Wd, g.block_out_channels[0], c->stream), "encoder.conv_in");
-  }
-  for (int i = 0; i < n; ++i) {
-    const VStage& st = c->enc[i];
-    for (const VRes& r : st.res) { T2 y = vae_resnet(c, r, x, B, H, Wd, gp); wsfree(c, x); x = y; }
-    if (st.resample) {       // F.pad(x, (0,1,0,1)) + conv stride 2 padding 0 (ldm Downsample, blocks.py:73-77)
-      T2 d = wsalloc(c, (size_t)B * (H / 2) * (Wd / 2) * st.rc);
-      op_conv3(c, x.p, B, H, Wd, st.rc, W_(c, st.rw), W_(c, st.rb), st.rc, 2, 0, nullptr, 0, nullptr, d.p, 0);
-      wsfree(c, x); x = d; H /= 2; Wd /= 2;
-    }
-  }
-  x = vae_mid(c, c->emid, x, B, H, Wd, gp);
-  const int cm = g.block_out_channels[n - 1];
-  T2 no = wsalloc(c, (size_t)B * H * Wd * cm);
-  op_gn(c, x.p, no.p, c->e_ng, c->e_nb, B, H * Wd, cm, g.norm_eps, 1, gp);
-  wsfree(c, x);
-  T2 m0 = wsalloc(c, (size_t)B * 2 * z * H * Wd);
-  { ProfScope ps(c, PK_CONV_OUT, 0, 0);
-    CHECK_LAUNCH(c, ia2p_launch_conv_out(no.p, cm, W_(c, c->e_out_w), W_(c, c->e_out_b), m0.p, B, cm, H, Wd, 2 * z, c->stream), "encoder.conv_out");
-    CHECK_LAUNCH(c, ia2p_launch_conv1x1_nchw(m0.p, W_(c, c->q_w), W_(c, c->q_b), moments, B, 2 * z, 2 * z, (long)H * Wd, c->stream), "quant_conv");
-  }
-  wsfree(c, no); wsfree(c, m0); wsfree(c, gnp);
-  return c->failed ? IA2P_ERR_HIP : IA2P_OK;
-}
-
-extern "C" {
-
-ia2p_status ia2p_vae_create(const ia2p_vae_config* cfg, ia2p_vae** out) {
-  if (!cfg || !out) return fail(nullptr, IA2P_ERR_INVALID, "ia2p_vae_create: null argument");
-  ia2p_vae* c = new ia2p_vae();
-  c->cfg = *cfg;
-  c->groups = cfg->norm_num_groups;
-  ia2p_status st = vae_plan(c);
-  if (st != IA2P_OK) { g_err = c->err; delete c; *out = nullptr; return st; }
-  c->failed = false;
-  *out = c;
-  return IA2P_OK;
-}
-void ia2p_vae_destroy(ia2p_vae* c) { delete c; }
-const char* ia2p_vae_last_error(ia2p_vae* c) { return c ? c->err.c_str() : g_err.c_str(); }
-size_t ia2p_vae_arena_bytes(ia2p_vae* c) { return c ? c->arena_elems * sizeof(half_t) : 0; }
-ia2p_status ia2p_vae_bind_arena(ia2p_vae* c, void* dev, size_t bytes) { return rc_bind_arena(c, dev, bytes); }
-ia2p_status ia2p_vae_load_tensor(ia2p_vae* c, const char* key, const void* src, const int64_t* shape, int ndim, void* stream) {
-  return rc_load_tensor(c, key, src, shape, ndim, stream);
-}
-ia2p_status ia2p_vae_finalize_weights(ia2p_vae* c) { return rc_finalize(c, "VAE"); }
-
-// h, w: LATENT height/width for both directions (image = latent * 2^(n_blocks-1))
-size_t ia2p_vae_workspace_bytes(ia2p_vae* c, int B, int h, int w, int decode) {
-  if (!c || vae_check(c, B, h, w) != IA2P_OK) return 0;
-  const int f = 1 << (c->cfg.n_blocks - 1);
-  c->dry = true; c->failed = false; c->record = false;
-  c->ws.reset((size_t)1 << 46); c->ws_base = nullptr;
-  if (decode) (void)vae_run_decode(c, nullptr, nullptr, B, h, w); else (void)vae_run_encode(c, nullptr, nullptr, B, h * f, w * f);
-  c->dry = false;
-  return c->failed ? 0 : c->ws.high + 256;
-}
-
-static ia2p_status vae_run(ia2p_vae* c, void* stream, const void* in, void* out, int B, int h, int w, void* ws, size_t ws_bytes, bool decode) {
-  if (!c || !in || !out || !ws) return fail(c, IA2P_ERR_INVALID, "vae: null argument");
-  if (!c->finalized) return fail(c, IA2P_ERR_STATE, "vae called before weights were finalized");
-  ia2p_status st = vae_check(c, B, h, w);
-  if (st != IA2P_OK) return st;
-  if (!zero_page()) return fail(c, IA2P_ERR_HIP, "cannot allocate zero page");
-  const int f = 1 << (c->cfg.n_blocks - 1);
-  const uintptr_t base = ((uintptr_t)ws + 255) & ~(uintptr_t)255;
-  const size_t usable = ws_bytes - (base - (uintptr_t)ws);
-  const int key = decode ? 1 : 2;
-  if (c->wseq_key != key) {
-    c->wseq.clear();
-    c->dry = true; c->record = true; c->failed = false;
-    c->ws.reset((size_t)1 << 46); c->ws_base = nullptr;
-    if (decode) (void)vae_run_decode(c, nullptr, nullptr, B, h, w); else (void)vae_run_encode(c, nullptr, nullptr, B, h * f, w * f);
-    c->dry = false; c->record = false; c->wseq_key = key;
-  }
-  c->widx = 0; c->dry = false; c->failed = false; c->stream = (hipStream_t)stream;
-  c->ws.reset(usable); c->ws_base = (char*)base;
-  st = decode ? vae_run_decode(c, (const half_t*)in, (half_t*)out, B, h, w) : vae_run_encode(c, (const half_t*)in, (half_t*)out, B, h * f, w * f);
-  if (c->failed && st == IA2P_OK) st = IA2P_ERR_HIP;
-  if (c->failed && c->err == "workspace too small") st = IA2P_ERR_NOMEM;
-  return st;
-}
-ia2p_status ia2p_vae_decode(ia2p_vae* c, void* stream, const void* latents, void* image, int B, int h, int w, void* ws, size_t ws_bytes) {
-  return vae_run(c, stream, latents, image, B, h, w, ws, ws_bytes, true);
-}
-ia2p_status ia2p_vae_encode(ia2p_vae* c, void* stream, const void* image, void* moments, int B, int h, int w, void* ws, size_t ws_bytes) {
-  return vae_run(c, stream, image, moments, B, h, w, ws, ws_bytes, false);
-}
-
-}  // extern "C"
-
-// =====================================================================================================================
-// CLIP text encoders: the conditioning side of the path, on the same GEMM kernel.
-// transformers CLIPTextModel / CLIPTextModelWithProjection (reference encode_prompt, ddim/sdxl_pipeline.py:202-395).
-// Per layer: 4 GEMMs (QKV with layer_norm1 folded, out-proj + residual, fc1 with layer_norm2 folded + activation,
-// fc2 + residual) and one causal attention launch; no LayerNorm launches (row statistics travel as in the UNet).
-// =====================================================================================================================
-struct CLayer { size_t ln1g, ln1b, wqkv, bqkv, wo, bo, ln2g, ln2b, w1, b1, w2, b2, fqkv, cs1, lb1, f1, cs2, lb2; };
-struct ia2p_clip : RunCtx {
-  ia2p_clip_config cfg;
-  size_t tok, pos, lnfg, lnfb, wproj;
-  std::vector<CLayer> layers;
-};
-
-static ia2p_status clip_plan(ia2p_clip* c) {
-  const ia2p_clip_config& g = c->cfg;
-  const int H = g.hidden_size, I = g.intermediate_size;
-  if (g.num_layers < 1 || H % 64 || g.num_heads * 64 != H || I % 64 || g.vocab_size < 1 || g.max_positions < 1 || g.max_positions > 128)
-    return fail(c, IA2P_ERR_SHAPE, "clip: hidden %d must be heads*64, intermediate %d a multiple of 64, 1..128 positions", H, I);
-  if (g.hidden_act != 1 && g.hidden_act != 2) return fail(c, IA2P_ERR_INVALID, "clip: hidden_act must be 1 (gelu) or 2 (quick_gelu)");
-  if (g.projection_dim < 0 || g.projection_dim % 8) return fail(c, IA2P_ERR_SHAPE, "clip: projection_dim %d", g.projection_dim);
-  size_t cur = 0;
-  auto take = [&](size_t e) { size_t o = cur; cur += (e + 127) & ~(size_t)127; return o; };
-  auto reg = [&](const std::string& k, size_t off, size_t n) { c->params[k] = Param{off, n, PK_COPY, 0, 0, false, false}; };
-  auto par = [&](const std::string& k, size_t n) { size_t o = take(n); reg(k, o, n); return o; };
-  const std::string tm = "text_model.";
-  c->tok = par(tm + "embeddings.token_embedding.weight", (size_t)g.vocab_size * H);
-  c->pos = par(tm + "embeddings.position_embedding.weight", (size_t)g.max_positions * H);
-  for (int i = 0; i < g.num_layers; ++i) {
-    const std::string p = tm + "encoder.layers." + std::to_string(i) + ".";
-    CLayer l;
-    l.ln1g = par(p + "layer_norm1.weight", H); l.ln1b = par(p + "layer_norm1.bias", H);
-    l.wqkv = take((size_t)3 * H * H); l.bqkv = take((size_t)3 * H);
-    const char* nm[3] = {"q_proj", "k_proj", "v_proj"};
-    for (int j = 0; j < 3; ++j) {
-      reg(p + "self_attn." + nm[j] + ".weight", l.wqkv + (size_t)j * H * H, (size_t)H * H);
-      reg(p + "self_attn." + nm[j] + ".bias", l.bqkv + (size_t)j * H, H);
-    }
-    l.wo = par(p + "self_attn.out_proj.weight", (size_t)H * H); l.bo = par(p + "self_attn.out_proj.bias", H);
-    l.ln2g = par(p + "layer_norm2.weight", H); l.ln2b = par(p + "layer_norm2.bias", H);
-    l.w1 = par(p + "mlp.fc1.weight", (size_t)I * H); l.b1 = par(p + "mlp.fc1.bias", I);
-    l.w2 = par(p + "mlp.fc2.weight", (size_t)H * I); l.b2 = par(p + "mlp.fc2.bias", H);
-    l.fqkv = take((size_t)3 * H * H); l.cs1 = take((size_t)2 * 3 * H); l.lb1 = take((size_t)2 * 3 * H);
-    l.f1 = take((size_t)I * H); l.cs2 = take((size_t)2 * I); l.lb2 = take((size_t)2 * I);
-    c->layers.push_back(l);
-  }
-  c->lnfg = par(tm + "final_layer_norm.weight", H); c->lnfb = par(tm + "final_layer_norm.bias", H);
-  c->wproj = g.projection_dim ? par("text_projection.weight", (size_t)g.projection_dim * H) : 0;
-  c->arena_elems = cur;
-  return IA2P_OK;
-}
-
-static ia2p_status clip_fold(ia2p_clip* c) {
-  const int H = c->cfg.hidden_size, I = c->cfg.intermediate_size;
-  hipError_t e = hipSuccess;
-  auto Hp = [&](size_t off) { return c->arena + off; };
-  auto Fp = [&](size_t off) { return (float*)(c->arena + off); };
-  for (const CLayer& l : c->layers) {
-    if (e == hipSuccess) e = ia2p_launch_fold_ln(Hp(l.wqkv), Hp(l.ln1g), Hp(l.ln1b), Hp(l.bqkv), Hp(l.fqkv), Fp(l.cs1), Fp(l.lb1), 3 * H, H, nullptr);
-    if (e == hipSuccess) e = ia2p_launch_fold_ln(Hp(l.w1), Hp(l.ln2g), Hp(l.ln2b), Hp(l.b1), Hp(l.f1), Fp(l.cs2), Fp(l.lb2), I, H, nullptr);
-  }
-  if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
-  return e == hipSuccess ? IA2P_OK : fail(c, IA2P_ERR_HIP, "clip LayerNorm folding: %s", hipGetErrorString(e));
-}
-
-static ia2p_status clip_run(ia2p_clip* c, const int* ids, int B, int T, half_t* hid2, half_t* last, half_t* pooled) {
-  const ia2p_clip_config& g = c->cfg;
-  const int H = g.hidden_size, I = g.intermediate_size, M = B * T, L = g.num_layers;
-  auto Fp = [&](size_t off) { return (const float*)(c->arena + off); };
-  T2 x = wsalloc(c, (size_t)M * H), qkv = wsalloc(c, (size_t)M * 3 * H), att = wsalloc(c, (size_t)M * H), ff = wsalloc(c, (size_t)M * I);
-  T2 stt = wsalloc(c, (size_t)M * ((H + 63) / 64) * 2 * 2);
-  float* st = (float*)stt.p;
-  int slots = 1;
-  CHECK_LAUNCH(c, ia2p_launch_clip_embed(ids, W_(c, c->tok), W_(c, c->pos), x.p, st, M, T, H, g.vocab_size, c->stream), "clip embeddings");
-  const bool need_last = last || pooled;
-  const int run_layers = need_last ? L : L - 1;
-  for (int i = 0; i < run_layers; ++i) {
-    const CLayer& l = c->layers[i];
-    if (i == L - 1 && hid2 && !c->dry && !c->failed) {     // hidden_states[-2]: what the last layer reads
-      hipError_t e = hipMemcpyAsync(hid2, x.p, (size_t)M * H * sizeof(half_t), hipMemcpyDeviceToDevice, c->stream);
-      if (e != hipSuccess) fail(c, IA2P_ERR_HIP, "clip: %s", hipGetErrorString(e));
-    }
-    {
-      const LnIn ln{st, slots, Fp(l.cs1), Fp(l.lb1), g.layer_norm_eps};
-      op_gemm(c, x.p, H, W_(c, l.fqkv), nullptr, nullptr, 0, qkv.p, 3 * H, M, 3 * H, H, 0, 0, 0, 0, 0, &ln);
-    }
-    CHECK_LAUNCH(c, ia2p_launch_causal_attention_small(qkv.p, att.p, B, T, g.num_heads, c->stream), "clip attention");
-    op_gemm(c, att.p, H, W_(c, l.wo), W_(c, l.bo), x.p, H, x.p, H, M, H, H, 0, 0, 0, 0, 0, nullptr, st, &slots);
-    {
-      const LnIn ln{st, slots, Fp(l.cs2), Fp(l.lb2), g.layer_norm_eps};
-      op_gemm(c, x.p, H, W_(c, l.f1), nullptr, nullptr, 0, ff.p, I, M, I, H, 0, 0, 0, 0, 0, &ln, nullptr, nullptr, g.hidden_act);
-    }
-    op_gemm(c, ff.p, I, W_(c, l.w2), W_(c, l.b2), x.p, H, x.p, H, M, H, I, 0, 0, 0, 0, 0, nullptr, st, &slots);
-  }
-  if (!need_last && hid2 && !c->dry && !c->failed) {
-    hipError_t e = hipMemcpyAsync(hid2, x.p, (size_t)M * H * sizeof(half_t), hipMemcpyDeviceToDevice, c->stream);
-    if (e != hipSuccess) fail(c, IA2P_ERR_HIP, "clip: %s", hipGetErrorString(e));
-  }
-  if (last) CHECK_LAUNCH(c, ia2p_launch_layernorm(x.p, H, last, H, W_(c, c->lnfg), W_(c, c->lnfb), M, H, g.layer_norm_eps, c->stream), "clip final_layer_norm");
-  if (pooled) {
-    T2 pr = wsalloc(c, (size_t)B * H);
-    half_t* dst = g.projection_dim ? pr.p : pooled;
-    CHECK_LAUNCH(c, ia2p_launch_clip_pool(ids, x.p, W_(c, c->lnfg), W_(c, c->lnfb), dst, B, T, H, g.eos_token_id, g.layer_norm_eps, c->stream), "clip pooling");
-    if (g.projection_dim)
-      for (int r0 = 0; r0 < B; r0 += 16) {
-        const int rows = std::min(16, B - r0);
-        CHECK_LAUNCH(c, ia2p_launch_linear_small(c->dry ? nullptr : pr.p + (size_t)r0 * H, H, W_(c, c->wproj), nullptr, nullptr, 0,
-                                                 c->dry ? nullptr : pooled + (size_t)r0 * g.projection_dim, g.projection_dim, rows, g.projection_dim, H, 0, 0, c->stream),
-                     "clip text_projection");
-      }
-    wsfree(c, pr);
-  }
-  wsfree(c, stt); wsfree(c, ff); wsfree(c, att); wsfree(c, qkv); wsfree(c, x);
-  return c->failed ? IA2P_ERR_HIP : IA2P_OK;
-}
-
-ia2p_status ia2p_clip_create(const ia2p_clip_config* cfg, ia2p_clip** out) {
-  if (!cfg || !out) return fail(nullptr, IA2P_ERR_INVALID, "ia2p_clip_create: null argument");
-  ia2p_clip* c = new ia2p_clip();
-  c->cfg = *cfg;
-  if (c->cfg.layer_norm_eps <= 0.f) c->cfg.layer_norm_eps = 1e-5f;
-  ia2p_status st = clip_plan(c);
-  if (st != IA2P_OK) { g_err = c->err; delete c; *out = nullptr; return st; }
-  c->failed = false;
-  *out = c;
-  return IA2P_OK;
-}
-void ia2p_clip_destroy(ia2p_clip* c) { delete c; }
-const char* ia2p_clip_last_error(ia2p_clip* c) { return c ? c->err.c_str() : g_err.c_str(); }
-size_t ia2p_clip_arena_bytes(ia2p_clip* c) { return c ? c->arena_elems * sizeof(half_t) : 0; }
-ia2p_status ia2p_clip_bind_arena(ia2p_clip* c, void* dev, size_t bytes) { return rc_bind_arena(c, dev, bytes); }
-ia2p_status ia2p_clip_load_tensor(ia2p_clip* c, const char* key, const void* src, const int64_t* shape, int ndim, void* stream) {
-  return rc_load_tensor(c, key, src, shape, ndim, stream);
-}
-ia2p_status ia2p_clip_finalize_weights(ia2p_clip* c) {
-  const ia2p_status st = rc_finalize(c, "CLIP text encoder");
-  return st == IA2P_OK ? clip_fold(c) : st;
-}
-static ia2p_status clip_check(ia2p_clip* c, int B, int T) {
-  if (B < 1 || T < 1 || T > c->cfg.max_positions) return fail(c, IA2P_ERR_SHAPE, "clip: B=%d, T=%d (1..%d tokens)", B, T, c->cfg.max_positions);
-  return IA2P_OK;
-}
-size_t ia2p_clip_workspace_bytes(ia2p_clip* c, int B, int T) {
-  if (!c || clip_check(c, B, T) != IA2P_OK) return 0;
-  c->dry = true; c->failed = false; c->record = false;
-  c->ws.reset((size_t)1 << 46); c->ws_base = nullptr;
-  (void)clip_run(c, nullptr, B, T, nullptr, (half_t*)1, (half_t*)1);
-  c->dry = false;
-  return c->failed ? 0 : c->ws.high + 256;
-}
-ia2p_status ia2p_clip_encode(ia2p_clip* c, void* stream, const int32_t* ids, int B, int T, void* hid2, void* last, void* pooled, void* ws, size_t ws_bytes) {
-  if (!c || !ids || !ws || (!hid2 && !last && !pooled)) return fail(c, IA2P_ERR_INVALID, "clip_encode: null argument");
-  if (!c->finalized) return fail(c, IA2P_ERR_STATE, "clip_encode before weights were finalized");
-  ia2p_status st = clip_check(c, B, T);
-  if (st != IA2P_OK) return st;
-  if (!zero_page()) return fail(c, IA2P_ERR_HIP, "cannot allocate zero page");
-  const uintptr_t base = ((uintptr_t)ws + 255) & ~(uintptr_t)255;
-  const size_t usable = ws_bytes - (base - (uintptr_t)ws);
-  const int key = (last || pooled) ? 1 : 2;
-  if (c->wseq_key != key) {
-    c->wseq.clear();
-    c->dry = true; c->record = true; c->failed = false;
-    c->ws.reset((size_t)1 << 46); c->ws_base = nullptr;
-    (void)clip_run(c, nullptr, B, T, nullptr, key == 1 ? (half_t*)1 : nullptr, nullptr);
-    c->dry = false; c->record = false; c->wseq_key = key;
-  }
-  c->widx = 0; c->dry = false; c->failed = false; c->stream = (hipStream_t)stream;
-  c->ws.reset(usable); c->ws_base = (char*)base;
-  st = clip_run(c, ids, B, T, (half_t*)hid2, (half_t*)last, (half_t*)pooled);
-  if (c->failed && st == IA2P_OK) st = IA2P_ERR_HIP;
-  if (c->failed && c->err == "workspace too small") st = IA2P_ERR_NOMEM;
-  return st;
-}
-

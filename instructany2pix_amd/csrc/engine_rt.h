@@ -1,0 +1,189 @@
+// Runtime shared by the three executors (conditional UNet: engine.hip, VAE: vae_engine.hip, CLIP text towers: clip_engine.hip):
+// weight arena + parameter table, workspace allocator, weight-prefetch plan, per-kernel event timing, and the operator wrappers that
+// plan and launch the HIP kernels. Definitions live in engine.hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/ia2p.h"
+#include "common.h"
+
+// ---- kernel launchers (gemm.hip, attention.hip, norm.hip, misc.hip) ------------------------------------------
+hipError_t ia2p_launch_gemm(const GemmArgs& a, bool conv, hipStream_t s, int* picked);
+hipError_t ia2p_launch_gemm_variant(const GemmArgs& a, bool conv, int variant, hipStream_t s, bool with_reduce = true);
+hipError_t ia2p_launch_splitk_reduce(const GemmArgs& a, hipStream_t s);
+void ia2p_gemm_candidates(int M, int N, int K, bool conv, bool geglu, size_t max_slab_bytes, double slack, std::vector<GemmPlan>* out);
+hipError_t ia2p_launch_attention(const AttnArgs& a, hipStream_t s);
+int ia2p_gn_chunks(int B, int HW);
+hipError_t ia2p_launch_groupnorm(const half_t* x, int ldx, half_t* y, int ldy, const half_t* gamma, const half_t* beta,
+                                 float* partial, int B, int HW, int C, int G, float eps, int silu, hipStream_t s);
+hipError_t ia2p_launch_layernorm(const half_t* x, int ldx, half_t* y, int ldy, const half_t* gamma, const half_t* beta,
+                                 int M, int C, float eps, hipStream_t s);
+hipError_t ia2p_launch_embed(float t, const half_t* text_embeds, const half_t* time_ids, half_t* tsin, half_t* addin,
+                             int B, int Tp, int P, int Ad, int nids, hipStream_t s);
+hipError_t ia2p_launch_linear_small(const half_t* X, int ldx, const half_t* W, const half_t* bias, const half_t* addend, int ldadd,
+                                    half_t* out, int ldo, int M, int N, int K, int silu_in, int silu_out, hipStream_t s);
+hipError_t ia2p_launch_conv_in(const half_t* x, const half_t* w, const half_t* bias, half_t* y, int B, int Cin, int H, int W, int Co, hipStream_t s);
+hipError_t ia2p_launch_conv_out(const half_t* x, int ldx, const half_t* w, const half_t* bias, half_t* y, int B, int C, int H, int W, int Co, hipStream_t s);
+hipError_t ia2p_launch_concat(const half_t* a, int lda, int Ca, const half_t* b, int ldb, int Cb, half_t* y, long M, hipStream_t s);
+hipError_t ia2p_launch_ddim_step(const half_t* x, const half_t* eps_u, const half_t* eps_c, float g, float c_x, float c_e,
+                                 half_t* out, half_t* out2, long n, hipStream_t s);
+hipError_t ia2p_launch_mask_blend(const half_t* x, const half_t* init, const half_t* noise, const half_t* mask, float c0, float c1,
+                                  half_t* out, half_t* out2, int B, int C, long HW, hipStream_t s);
+hipError_t ia2p_launch_fold_ln(const half_t* W, const half_t* gamma, const half_t* beta, const half_t* bias, half_t* Wf, float* cs, float* lb,
+                               int N, int K, hipStream_t s);
+hipError_t ia2p_launch_clip_embed(const int* ids, const half_t* tok, const half_t* pos, half_t* x, float* stats, int rows, int T, int H, int vocab, hipStream_t s);
+hipError_t ia2p_launch_causal_attention_small(const half_t* qkv, half_t* out, int B, int T, int heads, hipStream_t s);
+hipError_t ia2p_launch_clip_pool(const int* ids, const half_t* x, const half_t* gamma, const half_t* beta, half_t* out, int B, int T, int H, int eos_id,
+                                 float eps, hipStream_t s);
+hipError_t ia2p_launch_touch(const void* p, size_t bytes, unsigned* sink, hipStream_t s);
+hipError_t ia2p_launch_pack_conv(const half_t* src, half_t* dst, int Co, int Ci, hipStream_t s);
+hipError_t ia2p_launch_pack_geglu(const half_t* src, half_t* dst, int rows, int rowlen, hipStream_t s);
+hipError_t ia2p_launch_softmax_rows(half_t* x, long ld, int rows, int n, float scale, hipStream_t s);
+hipError_t ia2p_launch_conv1x1_nchw(const half_t* x, const half_t* w, const half_t* bias, half_t* y, int B, int Ci, int Co, long HW, hipStream_t s);
+
+extern thread_local std::string g_err;   // error of a failed ia2p_*_create / ctx-less entry point
+const half_t* zero_page();
+
+enum PKind { PK_COPY = 0, PK_CONV = 1, PK_GEGLU_W = 2, PK_GEGLU_B = 3 };
+
+struct Param {
+  size_t off;       // element offset in the arena
+  size_t elems;
+  int kind;
+  int d0, d1;       // conv: Co, Ci ; geglu: rows, rowlen
+  bool loaded;
+  bool optional;    // IP-Adapter tensors
+};
+
+struct Block { size_t off, size; bool free_; };
+
+struct Arena {            // deterministic first-fit allocator over [0, cap)
+  std::vector<Block> blocks;
+  size_t cap, high;
+  void reset(size_t c) { cap = c; high = 0; blocks.clear(); blocks.push_back({0, c, true}); }
+  size_t alloc(size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    for (size_t i = 0; i < blocks.size(); ++i)
+      if (blocks[i].free_ && blocks[i].size >= bytes) {
+        const size_t off = blocks[i].off;
+        if (blocks[i].size > bytes) {
+          Block rest{off + bytes, blocks[i].size - bytes, true};
+          blocks[i].size = bytes;
+          blocks.insert(blocks.begin() + i + 1, rest);
+        }
+        blocks[i].free_ = false;
+        if (off + bytes > high) high = off + bytes;
+        return off;
+      }
+    return (size_t)-1;
+  }
+  void release(size_t off) {
+    for (size_t i = 0; i < blocks.size(); ++i)
+      if (blocks[i].off == off && !blocks[i].free_) {
+        blocks[i].free_ = true;
+        if (i + 1 < blocks.size() && blocks[i + 1].free_) { blocks[i].size += blocks[i + 1].size; blocks.erase(blocks.begin() + i + 1); }
+        if (i > 0 && blocks[i - 1].free_) { blocks[i - 1].size += blocks[i].size; blocks.erase(blocks.begin() + i); }
+        return;
+      }
+  }
+};
+
+struct ProfRec { hipEvent_t e0, e1; int k; double flops, bytes; };
+// profile classes = device kernel names as rocprofv3 prints them (template arguments included)
+enum { PK_GEMM0 = 0, PK_CONV0 = 16, PK_ATTN = 32, PK_GN, PK_LN, PK_EMBED, PK_CONV_IN, PK_CONV_OUT, PK_CONCAT, PK_REDUCE, PK_NCLASS };
+const char* prof_name(int k);
+
+// state shared by the executors (conditional UNet, VAE): weights, workspace, prefetch plan, per-kernel timing
+struct RunCtx {
+  std::string err;
+  std::unordered_map<std::string, Param> params;
+  size_t arena_elems = 0;
+  half_t* arena = nullptr;
+  bool finalized = false;
+  int groups = 32;          // GroupNorm groups
+  // run state
+  Arena ws;
+  char* ws_base = nullptr;
+  bool dry = false;
+  hipStream_t stream = nullptr;
+  bool failed = false;
+  // weight prefetch plan: weights of every GEMM/conv launch of a pass, in launch order
+  std::vector<std::pair<const half_t*, size_t>> wseq;
+  size_t widx = 0;
+  bool record = false;
+  int wseq_key = -1;
+  bool prefetch = true;
+  const half_t* tail_pf = nullptr;   // what the LAST contraction of a pass prefetches: the first weights of the next pass (embedding MLPs)
+  size_t tail_pf_bytes = 0;
+  bool ln_fold = true;       // LayerNorms folded into their consumer GEMMs (IA2P_LN_FOLD=0: separate layernorm_kernel launches, for A/B runs)
+  bool prof = false;
+  // autotune pass (ia2p_autotune): every GEMM / conv site of an unmeasured shape times its candidate plans in place
+  bool tuning = false;
+  int tune_reps = 5, tune_sites = 0;
+  char* tune_scratch = nullptr;                 // [slab region | flush region]
+  size_t tune_slab_bytes = 0, tune_flush_bytes = 0;
+  std::vector<ProfRec> recs;
+  std::vector<hipEvent_t> evpool;
+  double p_ms[PK_NCLASS], p_fl[PK_NCLASS], p_by[PK_NCLASS];
+  int64_t p_n[PK_NCLASS];
+  RunCtx() {
+    if (const char* e = getenv("IA2P_PREFETCH")) prefetch = atoi(e) != 0;
+    if (const char* e = getenv("IA2P_LN_FOLD")) ln_fold = atoi(e) != 0;
+    for (int k = 0; k < PK_NCLASS; ++k) { p_ms[k] = p_fl[k] = p_by[k] = 0; p_n[k] = 0; }
+  }
+  ~RunCtx() {
+    for (auto& r : recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    for (auto e : evpool) (void)hipEventDestroy(e);
+  }
+};
+
+ia2p_status fail(RunCtx* c, ia2p_status st, const char* fmt, ...);
+
+struct T2 { size_t off; half_t* p; };   // workspace tensor
+T2 wsalloc(RunCtx* c, size_t elems);
+void wsfree(RunCtx* c, T2 t);
+hipEvent_t get_event(RunCtx* c);
+
+struct ProfScope {
+  RunCtx* c; int k; double fl, by; hipEvent_t e0, e1; bool on;
+  ProfScope(RunCtx* c_, int k_, double fl_, double by_) : c(c_), k(k_), fl(fl_), by(by_), on(c_ && c_->prof && !c_->dry) {
+    if (on) { e0 = get_event(c); e1 = get_event(c); (void)hipEventRecord(e0, c->stream); }
+  }
+  ~ProfScope() { if (on) { (void)hipEventRecord(e1, c->stream); c->recs.push_back(ProfRec{e0, e1, k, fl, by}); } }
+  void set_class(int kk) { k = kk; }
+};
+#define CHECK_LAUNCH(c, expr, what)                                                             \
+  do { if (!(c)->dry && !(c)->failed) { hipError_t e_ = (expr); if (e_ != hipSuccess) fail((c), IA2P_ERR_HIP, "%s: %s", what, hipGetErrorString(e_)); } } while (0)
+
+inline const half_t* W_(RunCtx* c, size_t off) { return c->arena + off; }
+
+#define RET_HIP(e, what) return (e) == hipSuccess ? IA2P_OK : fail(nullptr, IA2P_ERR_HIP, "%s: %s", what, hipGetErrorString(e))
+
+// LayerNorm folded into a GEMM: where the consumer finds the row statistics and the folded constants
+struct LnIn { const float* stats; int slots; const float* cs; const float* lb; float eps; };
+
+// ---- operator wrappers: plan (tile / K-split / autotune), slabs, weight prefetch, profiling class, launch
+void op_gemm(RunCtx* c, const half_t* A, int lda, const half_t* W, const half_t* bias, const half_t* residual, int ldr,
+             half_t* C, int ldc, int M, int N, int K, int geglu = 0, int rpb = 0, int bstride = 0, int roff = 0, int ldw = 0,
+             const LnIn* ln = nullptr, float* stats_out = nullptr, int* stat_slots = nullptr, int act = 0);
+void op_conv3(RunCtx* c, const half_t* X, int B, int Hs, int Ws, int Cin, const half_t* W, const half_t* bias, int Co,
+              int stride, int up, const half_t* rowvec, int rowvec_ld, const half_t* residual, half_t* Y, int pad_lo = 1);
+void op_gn(RunCtx* c, const half_t* x, half_t* y, size_t g, size_t b, int B, int HW, int C, float eps, int silu, float* partial);
+void op_ln(RunCtx* c, const half_t* x, half_t* y, size_t g, size_t b, int M, int C);
+
+// ---- weight arena plumbing shared by the three contexts
+ia2p_status rc_bind_arena(RunCtx* c, void* dev, size_t bytes);
+ia2p_status rc_load_tensor(RunCtx* c, const char* key, const void* src, const int64_t* shape, int ndim, void* stream);
+ia2p_status rc_finalize(RunCtx* c, const char* what);
+ia2p_status rc_adopt(RunCtx* c);
