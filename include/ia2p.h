@@ -217,7 +217,7 @@ typedef struct ia2p_clip ia2p_clip;
 typedef struct {
   int vocab_size, hidden_size, num_layers, num_heads, intermediate_size, max_positions;
   int projection_dim;     /* 0: no text_projection (CLIPTextModel) */
-  int hidden_act;         /* 1 = gelu, 2 = quick_gelu */
+  int hidden_act;         /* 1 = gelu, 2 = quick_gelu, 3 = gelu_new (tanh form; GPT-2) */
   int eos_token_id;
   float layer_norm_eps;
 } ia2p_clip_config;
@@ -235,6 +235,19 @@ size_t ia2p_clip_workspace_bytes(ia2p_clip* clip, int B, int T);
  * hidden_penultimate is requested. */
 ia2p_status ia2p_clip_encode(ia2p_clip* clip, void* stream, const int32_t* input_ids, int B, int T, void* hidden_penultimate,
                              void* last_hidden, void* pooled, void* workspace, size_t workspace_bytes);
+/* The same pre-LayerNorm causal transformer driven with `inputs_embeds` [B, T, hidden] fp16 instead of token ids (position embeddings
+ * are added inside): how the reference runs the GPT-2 sequence model of its embedding prior, `self.model(inputs_embeds=...,
+ * attention_mask=ones)["last_hidden_state"]` (instructany2pix/prior/model.py:493-495, :611-613; transformers GPT2Model with
+ * hidden_act 3, created with vocab_size 0 since the token table is never read). All-ones attention mask only. */
+ia2p_status ia2p_clip_encode_embeds(ia2p_clip* clip, void* stream, const void* inputs_embeds, int B, int T, void* hidden_penultimate,
+                                    void* last_hidden, void* workspace, size_t workspace_bytes);
+/* Sampler update of the embedding prior in fp32 (prior/model.py:208-240 `get_eps`, :627-637 guidance + diffusers DDPMScheduler.step):
+ *   eps_i = (sample - sqrt_a * o_i) / sqrt_b;  eps = eps_u + g * (eps_c - eps_u);  x0 = (sample - sqrt_b * eps) / sqrt_a;
+ *   out = k0 * x0 + k1 * sample + sigma * noise
+ * sample / noise / out: fp32 [n] device; out_cond / out_uncond: fp16 [n] outputs of the sequence model (out_cond NULL = no guidance;
+ * noise NULL = none). sqrt_a = sqrt(abar_t), sqrt_b = sqrt(1 - abar_t); k0, k1, sigma from the DDPM posterior (host: scheduler.py). */
+ia2p_status ia2p_prior_step(void* stream, const float* sample, const void* out_cond, const void* out_uncond, const float* noise, float g,
+                            float sqrt_a, float sqrt_b, float k0, float k1, float sigma, float* out, int64_t n);
 
 #ifdef __cplusplus
 }

@@ -5,7 +5,7 @@ Importing this package touches no GPU and no native code; the HIP library (libia
 """
 from .config import UNetConfig, sdxl_base, sdxl_refiner, tiny
 
-__all__ = ["HipCLIPTextModel", "SDXLTextEncoders", "UNetConfig", "sdxl_base", "sdxl_refiner", "tiny", "StableDiffusionXLImg2ImgPipeline", "EulerDiscreteScheduler", "InstructAny2PixPipeline", "HipUNet2DConditionModel", "DDIMScheduler",
+__all__ = ["InstructAny2PixPrior", "prior_config", "MODALITY", "HipGPT2Model", "DDPMScheduler", "HipCLIPTextModel", "SDXLTextEncoders", "UNetConfig", "sdxl_base", "sdxl_refiner", "tiny", "StableDiffusionXLImg2ImgPipeline", "EulerDiscreteScheduler", "InstructAny2PixPipeline", "HipUNet2DConditionModel", "DDIMScheduler",
            "SDXLDDIMPipeline", "StableDiffusionXLPipeline", "IPAdapterXL", "ImageProjModel", "HipAutoencoderKL"]
 
 
@@ -14,7 +14,10 @@ def __getattr__(name):          # lazy: keep `import instructany2pix_amd` free o
         from .pipeline import InstructAny2PixPipeline as v
     elif name == "HipUNet2DConditionModel":
         from .unet import HipUNet2DConditionModel as v
-    elif name in ("DDIMScheduler", "EulerDiscreteScheduler"):
+    elif name in ("InstructAny2PixPrior", "prior_config", "MODALITY", "HipGPT2Model"):
+        from . import prior
+        v = getattr(prior, name)
+    elif name in ("DDIMScheduler", "EulerDiscreteScheduler", "DDPMScheduler"):
         from . import scheduler
         v = getattr(scheduler, name)
     elif name == "StableDiffusionXLImg2ImgPipeline":

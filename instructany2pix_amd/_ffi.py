@@ -90,6 +90,8 @@ SIGNATURES = {
     "ia2p_clip_finalize_weights": (_I, [_P]),
     "ia2p_clip_workspace_bytes": (_SZ, [_P, _I, _I]),
     "ia2p_clip_encode": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _SZ]),
+    "ia2p_clip_encode_embeds": (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _SZ]),
+    "ia2p_prior_step": (_I, [_P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _P, _I64]),
     "ia2p_vae_create": (_I, [C.POINTER(VAEConfigC), C.POINTER(_P)]),
     "ia2p_vae_destroy": (None, [_P]),
     "ia2p_vae_last_error": (C.c_char_p, [_P]),
@@ -185,7 +187,7 @@ def make_clip_config(cfg) -> CLIPConfigC:
     c = CLIPConfigC()
     c.vocab_size, c.hidden_size, c.num_layers, c.num_heads = cfg.vocab_size, cfg.hidden_size, cfg.num_hidden_layers, cfg.num_attention_heads
     c.intermediate_size, c.max_positions, c.projection_dim = cfg.intermediate_size, cfg.max_position_embeddings, cfg.projection_dim
-    c.hidden_act = {"gelu": 1, "quick_gelu": 2}[cfg.hidden_act]
+    c.hidden_act = {"gelu": 1, "quick_gelu": 2, "gelu_new": 3}[cfg.hidden_act]
     c.eos_token_id, c.layer_norm_eps = cfg.eos_token_id, cfg.layer_norm_eps
     return c
 

@@ -5,7 +5,7 @@ through `unet.config` (reference: instructany2pix/ddim/pnp_pipeline.py:44-47,
 instructany2pix/diffusion/ip_adapter/ip_adapter.py:114,124-132) and SURVEY.md Appendix A.1.
 """
 from dataclasses import dataclass, field, asdict
-from typing import List, Tuple
+from typing import List, Optional, Tuple
 
 
 @dataclass
@@ -147,7 +147,7 @@ class CLIPTextConfig:
 
     def validate(self):
         assert self.hidden_size == 64 * self.num_attention_heads and self.intermediate_size % 64 == 0
-        assert self.hidden_act in ("gelu", "quick_gelu") and self.max_position_embeddings <= 128 and self.projection_dim % 8 == 0
+        assert self.hidden_act in ("gelu", "quick_gelu", "gelu_new") and self.max_position_embeddings <= 128 and self.projection_dim % 8 == 0
         return self
 
 
@@ -158,6 +158,45 @@ def sdxl_text_encoder() -> CLIPTextConfig:
 def sdxl_text_encoder_2() -> CLIPTextConfig:
     return CLIPTextConfig(hidden_size=1280, num_hidden_layers=32, num_attention_heads=20, intermediate_size=5120, hidden_act="gelu",
                           projection_dim=1280).validate()
+
+
+def laion_clip_h_text() -> CLIPTextConfig:
+    """Text tower of laion/CLIP-ViT-H-14-laion2B-s32B-b79K: the conditioning encoder inside the embedding prior
+    (`CLIPTextModelHiddenState`, reference instructany2pix/prior/model.py:28-34)."""
+    return CLIPTextConfig(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096, hidden_act="gelu").validate()
+
+
+@dataclass
+class GPT2Config:
+    """transformers `GPT2Config` fields the prior's sequence model reads (`GPT2Model(GPT2Config.from_pretrained('gpt2-medium'))`,
+    reference instructany2pix/prior/model.py:185 with prior/__init__.py `pretrained_name`)."""
+    vocab_size: int = 50257
+    n_positions: int = 1024
+    n_embd: int = 1024
+    n_layer: int = 24
+    n_head: int = 16
+    n_inner: Optional[int] = None          # None = 4 * n_embd
+    activation_function: str = "gelu_new"
+    layer_norm_epsilon: float = 1e-5
+
+    def __getitem__(self, k):
+        return getattr(self, k)
+
+    @property
+    def inner(self) -> int:
+        return self.n_inner or 4 * self.n_embd
+
+    def validate(self):
+        assert self.n_embd == 64 * self.n_head and self.inner % 64 == 0 and self.activation_function in ("gelu_new", "gelu")
+        return self
+
+
+def gpt2_medium() -> GPT2Config:
+    return GPT2Config().validate()
+
+
+def tiny_gpt2() -> GPT2Config:
+    return GPT2Config(vocab_size=100, n_positions=64, n_embd=128, n_layer=3, n_head=2).validate()
 
 
 def tiny_clip(projection_dim: int = 0, hidden_act: str = "quick_gelu") -> CLIPTextConfig:

@@ -17,16 +17,16 @@ struct ia2p_clip : RunCtx {
 static ia2p_status clip_plan(ia2p_clip* c) {
   const ia2p_clip_config& g = c->cfg;
   const int H = g.hidden_size, I = g.intermediate_size;
-  if (g.num_layers < 1 || H % 64 || g.num_heads * 64 != H || I % 64 || g.vocab_size < 1 || g.max_positions < 1 || g.max_positions > 128)
+  if (g.num_layers < 1 || H % 64 || g.num_heads * 64 != H || I % 64 || g.vocab_size < 0 || g.max_positions < 1 || g.max_positions > 128)
     return fail(c, IA2P_ERR_SHAPE, "clip: hidden %d must be heads*64, intermediate %d a multiple of 64, 1..128 positions", H, I);
-  if (g.hidden_act != 1 && g.hidden_act != 2) return fail(c, IA2P_ERR_INVALID, "clip: hidden_act must be 1 (gelu) or 2 (quick_gelu)");
+  if (g.hidden_act < 1 || g.hidden_act > 3) return fail(c, IA2P_ERR_INVALID, "clip: hidden_act must be 1 (gelu), 2 (quick_gelu) or 3 (gelu_new)");
   if (g.projection_dim < 0 || g.projection_dim % 8) return fail(c, IA2P_ERR_SHAPE, "clip: projection_dim %d", g.projection_dim);
   size_t cur = 0;
   auto take = [&](size_t e) { size_t o = cur; cur += (e + 127) & ~(size_t)127; return o; };
   auto reg = [&](const std::string& k, size_t off, size_t n) { c->params[k] = Param{off, n, PK_COPY, 0, 0, false, false}; };
   auto par = [&](const std::string& k, size_t n) { size_t o = take(n); reg(k, o, n); return o; };
   const std::string tm = "text_model.";
-  c->tok = par(tm + "embeddings.token_embedding.weight", (size_t)g.vocab_size * H);
+  c->tok = g.vocab_size ? par(tm + "embeddings.token_embedding.weight", (size_t)g.vocab_size * H) : 0;   // 0: inputs_embeds only (the GPT-2 prior)
   c->pos = par(tm + "embeddings.position_embedding.weight", (size_t)g.max_positions * H);
   for (int i = 0; i < g.num_layers; ++i) {
     const std::string p = tm + "encoder.layers." + std::to_string(i) + ".";
@@ -65,7 +65,7 @@ static ia2p_status clip_fold(ia2p_clip* c) {
   return e == hipSuccess ? IA2P_OK : fail(c, IA2P_ERR_HIP, "clip LayerNorm folding: %s", hipGetErrorString(e));
 }
 
-static ia2p_status clip_run(ia2p_clip* c, const int* ids, int B, int T, half_t* hid2, half_t* last, half_t* pooled) {
+static ia2p_status clip_run(ia2p_clip* c, const int* ids, const half_t* embeds, int B, int T, half_t* hid2, half_t* last, half_t* pooled) {
   const ia2p_clip_config& g = c->cfg;
   const int H = g.hidden_size, I = g.intermediate_size, M = B * T, L = g.num_layers;
   auto Fp = [&](size_t off) { return (const float*)(c->arena + off); };
@@ -73,7 +73,7 @@ static ia2p_status clip_run(ia2p_clip* c, const int* ids, int B, int T, half_t* 
   T2 stt = wsalloc(c, (size_t)M * ((H + 63) / 64) * 2 * 2);
   float* st = (float*)stt.p;
   int slots = 1;
-  CHECK_LAUNCH(c, ia2p_launch_clip_embed(ids, W_(c, c->tok), W_(c, c->pos), x.p, st, M, T, H, g.vocab_size, c->stream), "clip embeddings");
+  CHECK_LAUNCH(c, ia2p_launch_clip_embed(ids, W_(c, c->tok), embeds, W_(c, c->pos), x.p, st, M, T, H, g.vocab_size, c->stream), "clip embeddings");
   const bool need_last = last || pooled;
   const int run_layers = need_last ? L : L - 1;
   for (int i = 0; i < run_layers; ++i) {
@@ -146,12 +146,12 @@ size_t ia2p_clip_workspace_bytes(ia2p_clip* c, int B, int T) {
   if (!c || clip_check(c, B, T) != IA2P_OK) return 0;
   c->dry = true; c->failed = false; c->record = false;
   c->ws.reset((size_t)1 << 46); c->ws_base = nullptr;
-  (void)clip_run(c, nullptr, B, T, nullptr, (half_t*)1, (half_t*)1);
+  (void)clip_run(c, nullptr, nullptr, B, T, nullptr, (half_t*)1, c->cfg.vocab_size ? (half_t*)1 : nullptr);
   c->dry = false;
   return c->failed ? 0 : c->ws.high + 256;
 }
-ia2p_status ia2p_clip_encode(ia2p_clip* c, void* stream, const int32_t* ids, int B, int T, void* hid2, void* last, void* pooled, void* ws, size_t ws_bytes) {
-  if (!c || !ids || !ws || (!hid2 && !last && !pooled)) return fail(c, IA2P_ERR_INVALID, "clip_encode: null argument");
+static ia2p_status clip_encode_impl(ia2p_clip* c, void* stream, const int32_t* ids, const half_t* embeds, int B, int T, void* hid2, void* last, void* pooled,
+                                    void* ws, size_t ws_bytes) {
   if (!c->finalized) return fail(c, IA2P_ERR_STATE, "clip_encode before weights were finalized");
   ia2p_status st = clip_check(c, B, T);
   if (st != IA2P_OK) return st;
@@ -163,13 +163,22 @@ ia2p_status ia2p_clip_encode(ia2p_clip* c, void* stream, const int32_t* ids, int
     c->wseq.clear();
     c->dry = true; c->record = true; c->failed = false;
     c->ws.reset((size_t)1 << 46); c->ws_base = nullptr;
-    (void)clip_run(c, nullptr, B, T, nullptr, key == 1 ? (half_t*)1 : nullptr, nullptr);
+    (void)clip_run(c, nullptr, nullptr, B, T, nullptr, key == 1 ? (half_t*)1 : nullptr, nullptr);
     c->dry = false; c->record = false; c->wseq_key = key;
   }
   c->widx = 0; c->dry = false; c->failed = false; c->stream = (hipStream_t)stream;
   c->ws.reset(usable); c->ws_base = (char*)base;
-  st = clip_run(c, ids, B, T, (half_t*)hid2, (half_t*)last, (half_t*)pooled);
+  st = clip_run(c, ids, embeds, B, T, (half_t*)hid2, (half_t*)last, (half_t*)pooled);
   if (c->failed && st == IA2P_OK) st = IA2P_ERR_HIP;
   if (c->failed && c->err == "workspace too small") st = IA2P_ERR_NOMEM;
   return st;
+}
+ia2p_status ia2p_clip_encode(ia2p_clip* c, void* stream, const int32_t* ids, int B, int T, void* hid2, void* last, void* pooled, void* ws, size_t ws_bytes) {
+  if (!c || !ids || !ws || (!hid2 && !last && !pooled)) return fail(c, IA2P_ERR_INVALID, "clip_encode: null argument");
+  if (!c->cfg.vocab_size) return fail(c, IA2P_ERR_STATE, "clip_encode: this model was created without a token embedding (vocab_size 0); use ia2p_clip_encode_embeds");
+  return clip_encode_impl(c, stream, ids, nullptr, B, T, hid2, last, pooled, ws, ws_bytes);
+}
+ia2p_status ia2p_clip_encode_embeds(ia2p_clip* c, void* stream, const void* inputs_embeds, int B, int T, void* hid2, void* last, void* ws, size_t ws_bytes) {
+  if (!c || !inputs_embeds || !ws || (!hid2 && !last)) return fail(c, IA2P_ERR_INVALID, "clip_encode_embeds: null argument");
+  return clip_encode_impl(c, stream, nullptr, (const half_t*)inputs_embeds, B, T, hid2, last, nullptr, ws, ws_bytes);
 }

@@ -29,7 +29,8 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }
-__device__ __forceinline__ float act_f(float x, int act) { return act == 1 ? gelu_erf_f(x) : act == 2 ? quick_gelu_f(x) : x; }
+__device__ __forceinline__ float gelu_tanh_f(float x) { return 0.5f * x * (1.0f + tanhf(0.79788456080286535588f * (x + 0.044715f * x * x * x))); }   // "gelu_new" (GPT-2)
+__device__ __forceinline__ float act_f(float x, int act) { return act == 1 ? gelu_erf_f(x) : act == 2 ? quick_gelu_f(x) : act == 3 ? gelu_tanh_f(x) : x; }
 
 // ---- launch descriptors shared by kernels and the host executor --------------------------------------
 

@@ -920,6 +920,13 @@ ia2p_status ia2p_mask_blend(void* stream, const void* x, const void* init, const
   return e == hipSuccess ? IA2P_OK : fail(nullptr, IA2P_ERR_HIP, "mask_blend: %s", hipGetErrorString(e));
 }
 
+ia2p_status ia2p_prior_step(void* stream, const float* sample, const void* out_cond, const void* out_uncond, const float* noise, float g, float sqrt_a,
+                            float sqrt_b, float k0, float k1, float sigma, float* out, int64_t n) {
+  if (!sample || !out_uncond || !out || n < 0 || !(sqrt_a > 0.f) || !(sqrt_b > 0.f)) return fail(nullptr, IA2P_ERR_INVALID, "prior_step: bad argument");
+  hipError_t e = ia2p_launch_prior_step(sample, (const half_t*)out_cond, (const half_t*)out_uncond, noise, g, sqrt_a, sqrt_b, k0, k1, sigma, out, (long)n, (hipStream_t)stream);
+  return e == hipSuccess ? IA2P_OK : fail(nullptr, IA2P_ERR_HIP, "prior_step: %s", hipGetErrorString(e));
+}
+
 // ---- per-operator entry points ---------------------------------------------------------------------------------------
 
 ia2p_status ia2p_groupnorm_silu(void* stream, const void* x, void* y, const void* gamma, const void* beta, int B, int HW, int C, int groups, float eps, int silu, float* partial) {

@@ -42,7 +42,10 @@ hipError_t ia2p_launch_mask_blend(const half_t* x, const half_t* init, const hal
                                   half_t* out, half_t* out2, int B, int C, long HW, hipStream_t s);
 hipError_t ia2p_launch_fold_ln(const half_t* W, const half_t* gamma, const half_t* beta, const half_t* bias, half_t* Wf, float* cs, float* lb,
                                int N, int K, hipStream_t s);
-hipError_t ia2p_launch_clip_embed(const int* ids, const half_t* tok, const half_t* pos, half_t* x, float* stats, int rows, int T, int H, int vocab, hipStream_t s);
+hipError_t ia2p_launch_clip_embed(const int* ids, const half_t* tok, const half_t* embeds, const half_t* pos, half_t* x, float* stats, int rows, int T, int H,
+                                  int vocab, hipStream_t s);
+hipError_t ia2p_launch_prior_step(const float* smp, const half_t* o_c, const half_t* o_u, const float* noise, float g, float sqrt_a, float sqrt_b, float k0, float k1,
+                                  float sigma, float* out, long n, hipStream_t s);
 hipError_t ia2p_launch_causal_attention_small(const half_t* qkv, half_t* out, int B, int T, int heads, hipStream_t s);
 hipError_t ia2p_launch_clip_pool(const int* ids, const half_t* x, const half_t* gamma, const half_t* beta, half_t* out, int B, int T, int H, int eos_id,
                                  float eps, hipStream_t s);

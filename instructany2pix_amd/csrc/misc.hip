@@ -194,6 +194,23 @@ __global__ void ddim_step_kernel(const half_t* x, const half_t* eps_u, const hal
   }
 }
 
+// Sampler update of the embedding prior (reference prior/model.py:208-240 get_eps, :627-637 guidance + DDPMScheduler.step), fp32:
+//   eps_i = (s - sqrt_a * o_i) / sqrt_b ; eps = eps_u + g (eps_c - eps_u) ; x0 = (s - sqrt_b * eps) / sqrt_a
+//   out = k0 * x0 + k1 * s + sigma * noise
+// o_c / o_u: fp16 outputs of the sequence model for the conditioned / unconditioned half (o_c NULL = no guidance).
+__global__ void prior_step_kernel(const float* s, const half_t* o_c, const half_t* o_u, const float* noise, float g, float sqrt_a, float sqrt_b,
+                                  float k0, float k1, float sigma, float* out, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float x = s[i];
+    float e = (x - sqrt_a * (float)o_u[i]) / sqrt_b;
+    if (o_c) { const float ec = (x - sqrt_a * (float)o_c[i]) / sqrt_b; e = e + g * (ec - e); }
+    const float x0 = (x - sqrt_b * e) / sqrt_a;
+    float o = k0 * x0 + k1 * x;
+    if (noise) o += sigma * noise[i];
+    out[i] = o;
+  }
+}
+
 // out = (1 - m) * (c0 * init + c1 * noise) + m * x, m = mask[b, 0, y, x] shared by the C channels: the per-step latent blend of
 // the inpainting loop (diffusers StableDiffusionXLInpaintPipeline, 4-channel UNet branch: known region re-noised to the next
 // timestep with DDIM add_noise, c0 = sqrt(abar), c1 = sqrt(1 - abar); c0 = 1, c1 = 0 after the last step). out2 optional.
@@ -237,14 +254,17 @@ __global__ __launch_bounds__(256) void fold_ln_kernel(const half_t* W, const hal
 // ---- CLIP text encoders (conditioning side of the path; reference encode_prompt, ddim/sdxl_pipeline.py:202-395) -----------------
 // x[row] = token_embedding[ids[row]] + position_embedding[row % T]; also the {sum, sum^2} of the fp16 row for the folded LayerNorm
 // of the first layer (slot 0). One wave per token row.
-__global__ __launch_bounds__(256) void clip_embed_kernel(const int* ids, const half_t* tok, const half_t* pos, half_t* x, float* stats,
+__global__ __launch_bounds__(256) void clip_embed_kernel(const int* ids, const half_t* tok, const half_t* embeds, const half_t* pos, half_t* x, float* stats,
                                                          int rows, int T, int H, int vocab) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  int id = ids[row];
-  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
-  const half_t* a = tok + (size_t)id * H;
+  const half_t* a = embeds + (size_t)row * H;            // inputs_embeds form (GPT2Model(inputs_embeds=...))
+  if (!embeds) {
+    int id = ids[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    a = tok + (size_t)id * H;
+  }
   const half_t* b = pos + (size_t)(row % T) * H;
   float s1 = 0.f, s2 = 0.f;
   for (int k = lane * 8; k < H; k += 512) {
@@ -474,14 +494,20 @@ hipError_t ia2p_launch_mask_blend(const half_t* x, const half_t* init, const hal
   hipLaunchKernelGGL(mask_blend_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, x, init, noise, mask, c0, c1, out, out2, C, HW, n);
   return hipGetLastError();
 }
+hipError_t ia2p_launch_prior_step(const float* smp, const half_t* o_c, const half_t* o_u, const float* noise, float g, float sqrt_a, float sqrt_b, float k0, float k1,
+                                  float sigma, float* out, long n, hipStream_t s) {
+  hipLaunchKernelGGL(prior_step_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, smp, o_c, o_u, noise, g, sqrt_a, sqrt_b, k0, k1, sigma, out, n);
+  return hipGetLastError();
+}
 hipError_t ia2p_launch_fold_ln(const half_t* W, const half_t* gamma, const half_t* beta, const half_t* bias, half_t* Wf, float* cs, float* lb,
                                int N, int K, hipStream_t s) {
   hipLaunchKernelGGL(fold_ln_kernel, dim3(N), dim3(256), 0, s, W, gamma, beta, bias, Wf, cs, lb, K);
   return hipGetLastError();
 }
-hipError_t ia2p_launch_clip_embed(const int* ids, const half_t* tok, const half_t* pos, half_t* x, float* stats, int rows, int T, int H, int vocab, hipStream_t s) {
+hipError_t ia2p_launch_clip_embed(const int* ids, const half_t* tok, const half_t* embeds, const half_t* pos, half_t* x, float* stats, int rows, int T, int H,
+                                  int vocab, hipStream_t s) {
   if (H % 8) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(clip_embed_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, ids, tok, pos, x, stats, rows, T, H, vocab);
+  hipLaunchKernelGGL(clip_embed_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, ids, tok, embeds, pos, x, stats, rows, T, H, vocab);
   return hipGetLastError();
 }
 hipError_t ia2p_launch_causal_attention_small(const half_t* qkv, half_t* out, int B, int T, int heads, hipStream_t s) {

@@ -27,6 +27,7 @@ from .ddim import SDXLDDIMPipeline, StableDiffusionXLPipeline
 from .img2img import StableDiffusionXLImg2ImgPipeline
 from .inpaint import StableDiffusionXLInpaintPipeline, subject_consistency
 from .ip_adapter import IPAdapterXL
+from .prior import MODALITY
 from .scheduler import DDIMScheduler
 from .unet import HipUNet2DConditionModel
 
@@ -52,7 +53,10 @@ class InstructAny2PixPipeline:
                  unet_config: Optional[UNetConfig] = None, unet_state_dict=None, ip_ckpt=None, device: str = "cuda:0",
                  conditioner: Optional[Callable] = None, text_encoder: Optional[Callable] = None,
                  vae_encode: Optional[Callable] = None, vae_decode: Optional[Callable] = None, clip_embeddings_dim: int = 1024,
-                 refiner_unet: Optional[HipUNet2DConditionModel] = None, refiner_text_encoder: Optional[Callable] = None):
+                 refiner_unet: Optional[HipUNet2DConditionModel] = None, refiner_text_encoder: Optional[Callable] = None, prior=None):
+        # the embedding prior (reference :97-98,:120-122 `self.model`): prior.py::InstructAny2PixPrior on the HIP kernels, or None when
+        # the conditioner supplies `y` itself
+        self.model = prior
         if unet is None:
             unet = HipUNet2DConditionModel(unet_config or sdxl_base(), device)
             if unet_state_dict is not None:
@@ -110,7 +114,16 @@ class InstructAny2PixPipeline:
         self.cache = c
         if llm_only:
             return None, None, c["caption"]
-        latent_la = fuse_instruction_embedding(c["base_embed"], c["image_embeds"], c["y"], h, norm)
+        y0 = c.get("y")
+        if y0 is None:                                                                         # :313-317, the prior's one live call
+            if self.model is None:
+                raise NotImplementedError("the conditioner returned no `y` and no prior= was attached")
+            ie = c["image_embeds"]
+            y = self.model.generate_diffusion(MODALITY.VIDEO, MODALITY.IMAGE, ie / ie.norm() * 100, device="cpu", no_diffusion=True,
+                                              num_inference_steps=25, image_bind_overwrite=None, dtype=torch.float32, guidance_scale=10,
+                                              force_guidence_t0=True, do_classifier_free_guidance=True, score=6.5)
+            y0 = y[0].to(device=c["base_embed"].device, dtype=c["base_embed"].dtype)
+        latent_la = fuse_instruction_embedding(c["base_embed"], c["image_embeds"], y0, h, norm)
         images, latent_inv = self.denoise(c["base_latents"], latent_la.reshape(1, -1)[0], prompt_embeds=c["prompt_embeds"],
                                           pooled_prompt_embeds=c["pooled_prompt_embeds"], negative_prompt_embeds=c["negative_prompt_embeds"],
                                           negative_pooled_prompt_embeds=c["negative_pooled_prompt_embeds"],

@@ -205,3 +205,93 @@ class EulerDiscreteScheduler:
         fused_update(sample, model_output, None, 1.0, c_x, c_e, out)
         self._step_index += 1
         return (out,) if not return_dict else SimpleNamespace(prev_sample=out)
+
+
+def prior_update(sample, out_cond, out_uncond, noise, guidance, sqrt_a, sqrt_b, k0, k1, sigma, out):
+    """fp32 sampler update of the embedding prior (`ia2p_prior_step`): per element
+    eps_i = (sample - sqrt_a o_i) / sqrt_b, guidance on eps, x0 = (sample - sqrt_b eps) / sqrt_a, out = k0 x0 + k1 sample + sigma noise."""
+    for t in (sample, noise, out):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.is_cuda)
+    for t in (out_cond, out_uncond):
+        assert t is None or (t.dtype == torch.float16 and t.is_contiguous() and t.is_cuda)
+    _ffi.check(_ffi.lib().ia2p_prior_step(_ffi.current_stream(), _ffi.ptr(sample), _ffi.ptr(out_cond), _ffi.ptr(out_uncond), _ffi.ptr(noise),
+                                          float(guidance), float(sqrt_a), float(sqrt_b), float(k0), float(k1), float(sigma), _ffi.ptr(out),
+                                          sample.numel()), None)
+    return out
+
+
+class DDPMScheduler:
+    """diffusers 0.26.3 `DDPMScheduler` as the reference's embedding prior configures and calls it: built from the SDXL-base
+    `scheduler_config.json` (`DDPMScheduler.from_pretrained("stabilityai/stable-diffusion-xl-base-1.0", subfolder="scheduler")`,
+    instructany2pix/prior/model.py:131), then `.set_timesteps`, `.timesteps`, `.alphas_cumprod`, `.one`, `.num_inference_steps`,
+    `.config.num_train_timesteps`, `.order` (:208-219, :588-589, :622) and `.step(noise_pred, t, sample, generator=)` (:635).
+    Fields DDPM keeps from that config: scaled-linear betas 0.00085..0.012, 1000 steps, "leading" spacing with steps_offset 1,
+    epsilon prediction, no clipping; DDPM defaults for the rest (variance_type "fixed_small", no thresholding)."""
+    order = 1
+    init_noise_sigma = 1.0
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", steps_offset=1,
+                 timestep_spacing="leading", prediction_type="epsilon", clip_sample=False, variance_type="fixed_small", **unused):
+        if (beta_schedule != "scaled_linear" or timestep_spacing != "leading" or prediction_type != "epsilon" or clip_sample
+                or variance_type != "fixed_small"):
+            raise NotImplementedError("only the SDXL-base scheduler configuration is implemented")
+        self.config = SimpleNamespace(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end, beta_schedule=beta_schedule,
+                                      steps_offset=steps_offset, timestep_spacing=timestep_spacing, prediction_type=prediction_type,
+                                      clip_sample=clip_sample, variance_type=variance_type)
+        self.betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        self.alphas = 1.0 - self.betas
+        self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
+        self.one = torch.tensor(1.0)
+        self.custom_timesteps = False
+        self.num_inference_steps: Optional[int] = None
+        self.timesteps = torch.from_numpy(np.arange(0, num_train_timesteps)[::-1].copy().astype(np.int64))
+
+    @classmethod
+    def from_config(cls, config, **kw):
+        d = dict(vars(config)) if not isinstance(config, dict) else dict(config)
+        d.update(kw)
+        return cls(**d)
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        if num_inference_steps > self.config.num_train_timesteps:
+            raise ValueError(f"`num_inference_steps`: {num_inference_steps} cannot be larger than `self.config.train_timesteps`: "
+                             f"{self.config.num_train_timesteps} as the unet model trained with this scheduler can only handle maximal "
+                             f"{self.config.num_train_timesteps} timesteps.")
+        self.num_inference_steps = num_inference_steps
+        ratio = self.config.num_train_timesteps // num_inference_steps
+        ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64) + self.config.steps_offset
+        self.timesteps = torch.from_numpy(ts)
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def previous_timestep(self, timestep):
+        n = self.num_inference_steps if self.num_inference_steps else self.config.num_train_timesteps
+        return timestep - self.config.num_train_timesteps // n
+
+    def posterior_coeffs(self, t: int):
+        """(sqrt(abar_t), sqrt(1 - abar_t), k0, k1, sigma): x_{t-1} = k0 x0 + k1 x_t + sigma z with the fixed_small variance
+        (clamped at 1e-20, as diffusers does), sigma = 0 at t = 0. Float32 arithmetic on the float32 table, as in diffusers."""
+        t = int(t)
+        prev = int(self.previous_timestep(t))
+        a_t = self.alphas_cumprod[t]
+        a_p = self.alphas_cumprod[prev] if prev >= 0 else self.one
+        b_t, b_p = 1 - a_t, 1 - a_p
+        cur_a = a_t / a_p
+        cur_b = 1 - cur_a
+        k0 = (a_p ** 0.5 * cur_b) / b_t
+        k1 = cur_a ** 0.5 * b_p / b_t
+        var = torch.clamp((1 - a_p) / (1 - a_t) * cur_b, min=1e-20)
+        sigma = float(var ** 0.5) if t > 0 else 0.0
+        return float(a_t ** 0.5), float(b_t ** 0.5), float(k0), float(k1), sigma
+
+    def step(self, model_output, timestep, sample, generator=None, return_dict: bool = False, **kw):
+        """Generic form (epsilon in, x_{t-1} out) in torch; the prior's loop uses the fused `prior_update` instead."""
+        sa, sb, k0, k1, sigma = self.posterior_coeffs(int(timestep))
+        x0 = (sample - sb * model_output) / sa
+        prev = k0 * x0 + k1 * sample
+        if int(timestep) > 0:
+            z = torch.randn(model_output.shape, generator=generator, device=generator.device if generator is not None else "cpu",
+                            dtype=model_output.dtype).to(model_output.device)
+            prev = prev + sigma * z
+        return (prev,) if not return_dict else SimpleNamespace(prev_sample=prev, pred_original_sample=x0)

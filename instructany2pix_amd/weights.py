@@ -180,6 +180,10 @@ def _make(key: str, shape, kind: str, seed: int, device, dtype) -> torch.Tensor:
         r.mul_(0.3 * _fan_in(shape) ** -0.5)
     elif kind == "w_out":        # conv_out: input is ~N(0,1) after GroupNorm+SiLU (rms ~0.6)
         r.mul_(1.6 * _fan_in(shape) ** -0.5)
+    elif kind == "wt":           # transformers Conv1D layout [in, out]
+        r.mul_(shape[0] ** -0.5)
+    elif kind == "wt_res":
+        r.mul_(0.3 * shape[0] ** -0.5)
     elif kind == "emb":          # embedding tables: unit-scale rows would swamp nothing; CLIP uses ~0.02, use 0.5 to keep LayerNorm honest
         r.mul_(0.5)
     elif kind == "b":
@@ -289,4 +293,37 @@ def clip_param_specs(cfg) -> List[Tuple[str, Tuple[int, ...], str]]:
     s += [("text_model.final_layer_norm.weight", (H,), "gamma"), ("text_model.final_layer_norm.bias", (H,), "beta")]
     if cfg.projection_dim:
         s += [("text_projection.weight", (cfg.projection_dim, H), "w")]
+    return s
+
+
+# ---- embedding prior (reference instructany2pix/prior/model.py) --------------------------------------------------------------
+def gpt2_param_specs(cfg, prefix: str = "") -> List[Spec]:
+    """transformers `GPT2Model.state_dict()` keys and shapes (Conv1D weights are [in, out])."""
+    E, I = cfg.n_embd, cfg.inner
+    s: List[Spec] = [(prefix + "wte.weight", (cfg.vocab_size, E), "emb"), (prefix + "wpe.weight", (cfg.n_positions, E), "emb")]
+    for i in range(cfg.n_layer):
+        p = f"{prefix}h.{i}."
+        s += [(p + "ln_1.weight", (E,), "gamma"), (p + "ln_1.bias", (E,), "beta"),
+              (p + "attn.c_attn.weight", (E, 3 * E), "wt"), (p + "attn.c_attn.bias", (3 * E,), "b"),
+              (p + "attn.c_proj.weight", (E, E), "wt_res"), (p + "attn.c_proj.bias", (E,), "b"),
+              (p + "ln_2.weight", (E,), "gamma"), (p + "ln_2.bias", (E,), "beta"),
+              (p + "mlp.c_fc.weight", (E, I), "wt"), (p + "mlp.c_fc.bias", (I,), "b"),
+              (p + "mlp.c_proj.weight", (I, E), "wt_res"), (p + "mlp.c_proj.bias", (E,), "b")]
+    s += [(prefix + "ln_f.weight", (E,), "gamma"), (prefix + "ln_f.bias", (E,), "beta")]
+    return s
+
+
+def prior_param_specs(gpt_cfg, clip_cfg, sequence_input_embed_dim=(0, 1024, 1024, 512, 0, 0, 0), output_dim=None) -> List[Spec]:
+    """`InstructAny2PixPrior.state_dict()` (prior/model.py:159-185): sos/eos tables, one Linear per sequence slot with a non-zero
+    input width, the modality table, the CLIP text tower of the conditioning stage and the GPT-2 sequence model."""
+    E = gpt_cfg.n_embd
+    s: List[Spec] = [("start_of_sequence_tokens.weight", (32, E), "emb"), ("end_of_sequence_tokens.weight", (32, E), "emb")]
+    for i, d in enumerate(sequence_input_embed_dim):
+        if d:
+            s += [(f"input_sequence_embed_linear.{i}.weight", (E, d), "w"), (f"input_sequence_embed_linear.{i}.bias", (E,), "b")]
+    s += [("modality_embedding.weight", (10, E), "emb")]
+    if output_dim is not None and output_dim != E:
+        s += [("output_proj.weight", (output_dim, E), "w"), ("output_proj.bias", (output_dim,), "b")]
+    s += [("cond_stage_models.0.model." + k, shp, kind) for k, shp, kind in clip_param_specs(clip_cfg)]
+    s += gpt2_param_specs(gpt_cfg, "model.")
     return s

@@ -66,3 +66,4 @@ def build_unet(cfg, state_dict, ip_state=None, ip_scale=1.0, num_tokens=4, dtype
     if dtype is not None:
         m = m.to(dtype)
     return m.eval()
+from .prior_ref import GPT2ModelRef, build_gpt2, DDPMSchedulerRef, PriorRef, timestep_embedding_ref  # noqa: E402,F401

@@ -28,6 +28,11 @@ Fixtures:
   G13 sample_loop.npz   the vendored SDXL `__call__` text (ddim/sdxl_pipeline.py:544-886, with its own prepare_latents / _get_add_time_ids /
                        check_inputs / prepare_extra_step_kwargs) driven by the reference's `IPAdapterXL.generate` (ip_adapter.py:289-356) and its
                        AST-extracted `ImageProjModel`, over the oracle UNet + oracle DDIM tables (`python gen_goldens.py sample`)
+  G14 prior.npz         the reference's own embedding-prior inference text (`InstructAny2PixPrior.generate_diffusion`, `get_input_sequence_and_mask`,
+                       `add_sos_eos_tokens`, `get_eps`, `get_input`, ...; `CLIPTextModelHiddenState.forward / encode_text`; prior/model.py) and its
+                       `prior_config` literal (prior/__init__.py), on transformers' real GPT2Model (tiny config, seeded weights), the oracle CLIP tower,
+                       the reference's ldm `timestep_embedding` for diffusers' `get_timestep_embedding`, and the oracle's DDPM restatement as the
+                       scheduler object (diffusers is not installed) (`python gen_goldens.py prior`)
   G11 encode_prompt.npz the reference's vendored `encode_prompt` (ddim/sdxl_pipeline.py:202-395) driven with stand-in tokenizers and the
                        oracle's CLIP towers on seeded weights (`python gen_goldens.py encode_prompt`)
 """
@@ -406,6 +411,96 @@ def gen_encode_prompt():
     print({k: (v.shape if hasattr(v, "shape") else v) for k, v in d.items()})
 
 
+def gen_prior():
+    """G14: the reference prior's inference methods, compiled from their own AST, run on stand-ins"""
+    import inspect
+    import logging
+    import transformers
+    import oracle
+    from oracle.prior_ref import DDPMSchedulerRef
+    sys.path.insert(0, os.path.dirname(HERE))
+    from stub_tokenizer import StubTokenizer
+    from instructany2pix_amd.config import tiny_clip, tiny_gpt2
+    from instructany2pix_amd.weights import prior_param_specs, synthetic_state_dict
+    _, _, _, util = import_reference_modules()
+    tree = ast.parse(open(os.path.join(REF, "instructany2pix/prior/__init__.py")).read())
+    prior_config = next(ast.literal_eval(n.value) for n in tree.body if isinstance(n, ast.Assign) and n.targets[0].id == "prior_config")
+
+    class Bar:                      # tqdm(total=) context manager
+        def __init__(self, *a, **k): pass
+        def __enter__(self): return self
+        def __exit__(self, *a): return False
+        def update(self, *a): pass
+    glb = {"torch": torch, "nn": torch.nn, "inspect": inspect, "logging": logging, "tqdm": Bar,
+           "MODALITY": types.SimpleNamespace(IMAGE=0, AUDIO=1, TEXT=2, VIDEO=3),
+           "get_timestep_embedding": lambda timesteps, embedding_dim, flip_sin_to_cos, downscale_freq_shift: util.timestep_embedding(timesteps, embedding_dim)}
+    rel = "instructany2pix/prior/model.py"
+    P = type("P", (torch.nn.Module,), ast_extract_method(rel, "InstructAny2PixPrior", [
+        "get_eps", "add_sos_eos_tokens", "truncate_sequence_and_mask", "get_input_sequence_and_mask", "prepare_extra_step_kwargs", "generate_diffusion",
+        "get_input_item", "get_input", "get_learned_conditioning"], glb))
+    Hs = type("Hs", (torch.nn.Module,), ast_extract_method(rel, "CLIPTextModelHiddenState", ["forward", "encode_text"], glb))
+
+    gcfg, ccfg = tiny_gpt2(), tiny_clip(0, "gelu")
+    E = gcfg.n_embd
+    dims = (0, 1024, ccfg.hidden_size, 512, 0, 0, 0)
+    sd = synthetic_state_dict(prior_param_specs(gcfg, ccfg, dims), seed=41, dtype=torch.float32)
+    sub = lambda pre: {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+
+    clip = oracle.build_clip(ccfg, sub("cond_stage_models.0.model."))
+
+    class ClipShim(torch.nn.Module):          # transformers call form on the (transformers-pinned) oracle tower
+        def __init__(self):
+            super().__init__()
+            self.m = clip
+            self.device = torch.device("cpu")
+
+        def forward(self, input_ids=None, attention_mask=None):
+            assert bool(attention_mask.all())
+            return (self.m(input_ids)[1],)
+    hs = Hs()
+    hs.freeze_text_encoder, hs.tokenizer, hs.model, hs.device = True, StubTokenizer(5, ccfg.vocab_size), ClipShim(), None
+    for p_ in hs.model.parameters():
+        p_.requires_grad = False
+
+    gpt = transformers.GPT2Model(transformers.GPT2Config(vocab_size=gcfg.vocab_size, n_positions=gcfg.n_positions, n_embd=E, n_layer=gcfg.n_layer,
+                                                         n_head=gcfg.n_head, activation_function=gcfg.activation_function)).eval()
+    missing, unexpected = gpt.load_state_dict(sub("model."), strict=False)
+    assert not unexpected and all(k.endswith((".attn.bias", ".attn.masked_bias")) for k in missing), (missing, unexpected)
+
+    m = P()
+    m.noise_scheduler = DDPMSchedulerRef()
+    m.mae_token_num = prior_config["sequence_gen_length"]
+    m.sequence_input_key = prior_config["sequence_input_key"]
+    m.embed_dim = E
+    m.device = "cpu"
+    m.start_of_sequence_tokens, m.end_of_sequence_tokens = torch.nn.Embedding(32, E), torch.nn.Embedding(32, E)
+    m.modality_embedding = torch.nn.Embedding(10, E)
+    m.input_sequence_embed_linear = torch.nn.ModuleList([torch.nn.Linear(d_, E) if d_ else torch.nn.Identity() for d_ in dims])
+    m.cond_stage_models = torch.nn.ModuleList([hs])
+    m.cond_stage_model_metadata = {"crossattn_clip": {"model_idx": 0, "cond_stage_key": "text", "conditioning_key": "crossattn"}}
+    m.model = gpt
+    missing, unexpected = m.load_state_dict({k: v for k, v in sd.items() if not k.startswith("cond_stage_models.")}, strict=False)
+    assert not unexpected and all(k.startswith("cond_stage_models.") or k.endswith((".attn.bias", ".attn.masked_bias")) for k in missing), (missing, unexpected)
+    m.eval()
+
+    seen = []
+    gpt.register_forward_pre_hook(lambda mod, a, kw: seen.append(kw["inputs_embeds"].clone()), with_kwargs=True)
+    g = torch.Generator().manual_seed(77)
+    emb = torch.randn(1, 1024, generator=g)
+    src = emb / emb.norm() * 100
+    d = dict(src=npf(src), sequence_input_key=np.array(prior_config["sequence_input_key"]))
+    # the live call (reference pipeline.py:313-317), then the iterative form and the unguided form of the same method
+    for tag, kw in (("live", dict(no_diffusion=True, num_inference_steps=25, guidance_scale=10, force_guidence_t0=True, do_classifier_free_guidance=True, score=6.5)),
+                    ("steps3", dict(no_diffusion=False, num_inference_steps=3, guidance_scale=4, do_classifier_free_guidance=True, score=6.5)),
+                    ("nocfg", dict(no_diffusion=True, num_inference_steps=25, do_classifier_free_guidance=False, score=6.8))):
+        torch.manual_seed(1234)
+        seen.clear()
+        y, cond = m.generate_diffusion(3, 0, src, device="cpu", image_bind_overwrite=None, dtype=torch.float32, **kw)
+        d[tag + "_y"], d[tag + "_seq0"], d[tag + "_ncalls"] = npf(y), npf(seen[0]), len(seen)
+    np.savez_compressed(os.path.join(HERE, "prior.npz"), **d)
+    print({k: (v.shape if hasattr(v, "shape") else v) for k, v in d.items()})
+
+
 def gen_inverse():
     """G12: the reference's inversion loop itself (method text compiled from its AST) over the oracle UNet"""
     from typing import Any, Callable, Dict, List, Optional, Tuple, Union
@@ -545,6 +640,9 @@ if __name__ == "__main__":
     elif len(sys.argv) > 1 and sys.argv[1] == "encode_prompt":
         with torch.no_grad():
             gen_encode_prompt()
+    elif len(sys.argv) > 1 and sys.argv[1] == "prior":
+        with torch.no_grad():
+            gen_prior()
     elif len(sys.argv) > 1 and sys.argv[1] == "refiner":
         with torch.no_grad():
             gen_refiner()

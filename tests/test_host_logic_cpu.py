@@ -260,3 +260,36 @@ def test_encode_prompt_host_logic_matches_reference_golden(golden):
         mk(True).encode_prompt("a cat", negative_prompt=["x"])
     with pytest.raises(ValueError):
         mk(True).encode_prompt(["a", "b"], negative_prompt=["x"])
+
+
+def test_prior_host_side_tables_and_inventory():
+    """DDPM tables / posterior coefficients vs the oracle, the sinusoid vs the oracle's (G6-pinned) form, parameter inventory of the
+    released prior (gpt2-medium 354.8 M + CLIP ViT-H text tower 353.0 M + slot tables), the constructor's key list."""
+    import oracle
+    from instructany2pix_amd.config import gpt2_medium, laion_clip_h_text
+    from instructany2pix_amd.prior import MODALITY, get_timestep_embedding, prior_config
+    from instructany2pix_amd.scheduler import DDPMScheduler
+    from instructany2pix_amd.weights import gpt2_param_specs, clip_param_specs, prior_param_specs, param_count
+    sch, ref = DDPMScheduler(), oracle.DDPMSchedulerRef()
+    assert torch.equal(sch.alphas_cumprod, ref.alphas_cumprod)
+    for n in (1, 3, 25, 50):
+        sch.set_timesteps(n); ref.set_timesteps(n)
+        assert sch.timesteps.tolist() == ref.timesteps.tolist() and sch.timesteps[-1] == 1
+        for t in sch.timesteps.tolist():
+            sa, sb, k0, k1, sigma = sch.posterior_coeffs(t)
+            x, e = torch.full((1,), 0.7), torch.full((1,), -0.3)
+            want = ref.step(e, t, x, generator=torch.Generator().manual_seed(1))[0]
+            z = torch.randn(1, generator=torch.Generator().manual_seed(1))
+            got = k0 * ((x - sb * e) / sa) + k1 * x + sigma * z
+            assert abs(float(got - want)) < 2e-6
+    with pytest.raises(ValueError):
+        sch.set_timesteps(1001)
+    t = torch.tensor([6.5, 981.0])
+    assert torch.equal(get_timestep_embedding(t, 512), oracle.timestep_embedding_ref(t, 512))
+    with pytest.raises(NotImplementedError):
+        get_timestep_embedding(t, 512, flip_sin_to_cos=False)
+    assert param_count(gpt2_param_specs(gpt2_medium())) == 354_823_168
+    assert param_count(clip_param_specs(laion_clip_h_text())) == 352_984_064
+    assert param_count(prior_param_specs(gpt2_medium(), laion_clip_h_text())) == 710_507_520
+    assert (MODALITY.IMAGE, MODALITY.AUDIO, MODALITY.TEXT, MODALITY.VIDEO) == (0, 1, 2, 3)
+    assert prior_config["sequence_input_key"] == oracle.PriorRef.sequence_input_key and prior_config["sequence_input_embed_dim"] == [0, 1024, 1024, 512, 0, 0, 0]

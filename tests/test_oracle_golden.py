@@ -339,3 +339,62 @@ def test_g13_sampling_loop_matches_reference_methods(golden):
         out = oracle.sample_loop(unet, oracle.DDIMSchedulerRef(), xT.clone(), torch.cat([ctx, p], 1), dict(text_embeds=pooled, time_ids=tid), 6, g,
                                  torch.cat([nctx, n], 1), dict(text_embeds=npooled, time_ids=tid))
         assert np.abs(out.numpy() - d[tag]).max() < 2e-5 * np.abs(d[tag]).max(), tag
+
+
+# ---- embedding prior (second half) ------------------------------------------------------------------------
+@pytest.mark.parametrize("act", ["gelu_new", "gelu"])
+def test_gpt2_restatement_matches_transformers(act):
+    """The oracle's GPT-2 against the real transformers `GPT2Model` the reference's prior holds (prior/model.py:185), driven the way the
+    prior drives it (`inputs_embeds` + all-ones mask), same random weights; and the key inventory of the product's weight specs."""
+    tf = pytest.importorskip("transformers")
+    from instructany2pix_amd.config import tiny_gpt2
+    from instructany2pix_amd.weights import gpt2_param_specs
+    cfg = tiny_gpt2()
+    cfg.activation_function = act
+    torch.manual_seed(8)
+    hf = tf.GPT2Model(tf.GPT2Config(vocab_size=cfg.vocab_size, n_positions=cfg.n_positions, n_embd=cfg.n_embd, n_layer=cfg.n_layer, n_head=cfg.n_head,
+                                    activation_function=act, bos_token_id=0, eos_token_id=0, attn_implementation="eager")).eval()
+    sd = {k: v for k, v in hf.state_dict().items() if not k.endswith((".attn.bias", ".attn.masked_bias"))}
+    for k in sd:                                   # transformers initialises biases / LayerNorms trivially: make them count
+        if k.endswith(".bias") or ".ln_" in k or k.startswith("ln_f"):
+            sd[k] = sd[k] + 0.1 * torch.randn(sd[k].shape)
+    hf.load_state_dict(sd, strict=False)
+    ref = oracle.build_gpt2(cfg, sd)
+    x = torch.randn(2, 11, cfg.n_embd, generator=torch.Generator().manual_seed(9))
+    with torch.no_grad():
+        want = hf(inputs_embeds=x, attention_mask=torch.ones(2, 11))["last_hidden_state"]
+    got = ref(x, torch.ones(2, 11))["last_hidden_state"]
+    assert (got - want).abs().max() < 2e-5
+    assert {k: tuple(v.shape) for k, v in sd.items()} == {k: s for k, s, _ in gpt2_param_specs(cfg)}
+
+
+def test_prior_restatement_matches_reference_method_text():
+    """G14: `InstructAny2PixPrior.generate_diffusion` and the methods under it, compiled from the reference's own file and run on
+    transformers' GPT2Model, vs oracle.PriorRef on the same seeded weights: the live call of pipeline.py:313-317, a 3-step guided run
+    (sample in the sequence, DDPM posterior with k1 != 0, per-step noise) and an unguided run."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from stub_tokenizer import StubTokenizer
+    from instructany2pix_amd.config import tiny_clip, tiny_gpt2
+    from instructany2pix_amd.weights import prior_param_specs, synthetic_state_dict
+    G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "prior.npz"))
+    gcfg, ccfg = tiny_gpt2(), tiny_clip(0, "gelu")
+    sd = synthetic_state_dict(prior_param_specs(gcfg, ccfg, (0, 1024, ccfg.hidden_size, 512, 0, 0, 0)), seed=41, dtype=torch.float32)
+    clip = oracle.build_clip(ccfg, {k[len("cond_stage_models.0.model."):]: v for k, v in sd.items() if k.startswith("cond_stage_models.0.model.")})
+    tok = StubTokenizer(5, ccfg.vocab_size)
+
+    def text_hidden(prompts):
+        b = tok(prompts, max_length=77, padding=True, truncation=True)
+        return [clip(b.input_ids)[1], b.attention_mask.float()]
+    p = oracle.PriorRef(gcfg, sd, text_hidden)
+    assert list(G["sequence_input_key"]) == p.sequence_input_key and len(p.sequence_input_key) == 6      # the missing-comma key list
+    src = torch.from_numpy(G["src"])
+    for tag, kw, T in (("live", dict(no_diffusion=True, num_inference_steps=25, guidance_scale=10, force_guidence_t0=True, do_classifier_free_guidance=True, score=6.5), 11),
+                       ("steps3", dict(no_diffusion=False, num_inference_steps=3, guidance_scale=4, do_classifier_free_guidance=True, score=6.5), 14),
+                       ("nocfg", dict(no_diffusion=True, num_inference_steps=25, do_classifier_free_guidance=False, score=6.8), 11)):
+        torch.manual_seed(1234)
+        y, cond = p.generate_diffusion(3, 0, src, **kw)
+        want = torch.from_numpy(G[tag + "_y"])
+        assert float((y - want).abs().max()) <= 5e-5 * float(want.abs().max()), tag
+        assert G[tag + "_seq0"].shape[1] == T and int(G[tag + "_ncalls"]) == (1 if kw["no_diffusion"] else 3)
