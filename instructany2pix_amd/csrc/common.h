@@ -85,9 +85,10 @@ struct GemmArgs {
 struct GemmPlan { int variant; int splitk; };
 // tile variants of gemm_f16_kernel (id = index): {BM, BN, LDS ring stages}; 4 waves (2 x 2), BK = 64
 struct GemmTile { int bm, bn, stages; };
-constexpr int IA2P_GEMM_NVARIANT = 12;
+constexpr int IA2P_GEMM_NVARIANT = 13;
 constexpr GemmTile IA2P_GEMM_TILES[IA2P_GEMM_NVARIANT] = {{128, 128, 2}, {128, 128, 3}, {128, 64, 2}, {128, 64, 3}, {64, 64, 2}, {64, 64, 3},
-                                                          {64, 160, 2}, {64, 160, 3}, {128, 160, 2}, {128, 160, 3}, {160, 128, 2}, {160, 160, 2}};
+                                                          {64, 160, 2}, {64, 160, 3}, {128, 160, 2}, {128, 160, 3}, {160, 128, 2}, {160, 160, 2},
+                                                          {256, 128, 3}};
 GemmPlan ia2p_gemm_plan(int M, int N, int K, bool conv, bool geglu);
 bool ia2p_plan_lookup(int M, int N, int K, bool conv, bool geglu, GemmPlan* out);     // measured plan table (ia2p_autotune)
 void ia2p_plan_set(int M, int N, int K, bool conv, bool geglu, GemmPlan pl);

@@ -40,8 +40,14 @@ template <int N> __device__ __forceinline__ void wait_vm_barrier() {
 //   BK = 64 (8 chunks/row):  chunk ^ ((row >> 1) & 7)        BK = 32 (4 chunks/row):  chunk ^ ((-(row >> 2)) & 3)
 template <int BK> __device__ __forceinline__ int lds_swz(int row) { return BK == 64 ? (row >> 1) & 7 : (-(row >> 2)) & 3; }
 
-template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int BK = 64>
+// PP = 1 ("ping-pong", 8 waves = WGM 4, 3-stage ring, ONE workgroup per CU): waves 0-3 own the upper half of the tile rows, waves 4-7 the
+// lower half, and the two groups run half a k-step apart -- while one group reads its fragments from LDS the other issues its MFMAs, with a
+// workgroup barrier between the half-steps. Eight waves behind one barrier per k-step would all read, then all multiply (the LDS and the
+// MFMA phases add up); two independent workgroups per CU de-phase by themselves but need twice the LDS fill per flop
+// (profiles/r01g_gemm_loop_ablation.txt: the fill is the largest term of the 128x128 kernel).
+template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int BK = 64, int PP = 0>
 __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const GemmArgs p) {   // >= 2 waves/SIMD: big tiles must fit 256 registers
+  static_assert(!PP || (WGM == 4 && NSTAGE == 3), "ping-pong schedule: 8 waves, 3-stage ring");
   constexpr int NWAVE = WGM * 2;
   constexpr int WM = BM / WGM, WN = BN / 2;      // wave tile (waves arranged WGM x 2)
   constexpr int MR = WM / 16, NR = WN / 16;
@@ -180,16 +186,12 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const GemmArgs p
 #pragma unroll
     for (int j = 0; j < NR; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
 
-  const int nk = kt1 - kt0;
-  constexpr int LPS = A_PW + B_PW;   // LDS-DMA pieces this wave issues per k-tile
-  // NSTAGE-deep LDS ring: tiles kt+1 .. kt+NSTAGE-2 stay in flight across the barrier of step kt (counted vmcnt,
-  // raw s_barrier -- cdna_hip_programming.md §5 "Pipelining across barriers"); ONE barrier per k-step.
-#pragma unroll
-  for (int s = 0; s < NSTAGE - 1; ++s)
-    if (s < nk) stage(s, s);
   // ---- folded LayerNorm (consumer): thread r < BM collects the {sum, sum of squares} partials of tile row r. Issued behind the
   //      first tile loads, all slots in flight at once (slot order kept in the sums); turned into mean / rstd after the k-loop.
+  //      Ping-pong tile: loaded AHEAD of the first tiles and folded at once (48 registers carried through the loop would spill, and a spill
+  //      reload in the loop waits for vmcnt, i.e. drains the DMA queue); the prologue DMA stays in flight behind them.
   float ln_s1 = 0.f, ln_s2 = 0.f;
+  auto load_ln = [&]() {
   if (p.ln_stats && tid < BM && bm0 + tid < p.M) {
     const float2* st = (const float2*)p.ln_stats + (bm0 + tid);
     constexpr int MAXS = 24;
@@ -204,6 +206,83 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const GemmArgs p
       for (int sl = 0; sl < p.ln_slots; ++sl) { const float2 v = st[(size_t)sl * p.M]; ln_s1 += v.x; ln_s2 += v.y; }
     }
   }
+  };
+  if (PP) load_ln();
+  const int nk = kt1 - kt0;
+  constexpr int LPS = A_PW + B_PW;   // LDS-DMA pieces this wave issues per k-tile
+  // NSTAGE-deep LDS ring: tiles kt+1 .. kt+NSTAGE-2 stay in flight across the barrier of step kt (counted vmcnt,
+  // raw s_barrier -- cdna_hip_programming.md §5 "Pipelining across barriers"); ONE barrier per k-step.
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < nk) stage(s, s);
+  if (!PP) load_ln();
+  else asm volatile("" : "+v"(ln_s1), "+v"(ln_s2));     // folds now; the counted wait leaves the prologue DMA in flight
+  if constexpr (PP) {
+    // Barrier sequence b0, b1, ...; interval I_n lies between b_n and b_n+1. Group 0 reads tile t in I_2t and multiplies it in I_2t+1; group 1
+    // reads it in I_2t+1 and multiplies it in I_2t+2. Every wave waits for its DMA pieces of tile t before b_2t; the slot of tile t-1 is free
+    // after b_2t (group 1 finished reading it in I_2t-1), so tile t+2 is issued into it in I_2t: two tiles stay in flight.
+    static_assert(MR * NR <= 16, "ping-pong keeps the fragments of a whole k-tile in registers across a barrier");
+    const int grp = wave >> 2;
+    h8 af[KSUB][MR], wf[KSUB][NR];
+    auto rd = [&](int slot) {
+      const char* base = smem + slot * STAGE;
+#pragma unroll
+      for (int kk = 0; kk < KSUB; ++kk) {
+        const int coff = ((kk * 4 + fq) ^ fswz) << 4;
+#pragma unroll
+        for (int i = 0; i < MR; ++i) af[kk][i] = *(const h8*)(base + a_off + i * 16 * ROWB + coff);
+#pragma unroll
+        for (int j = 0; j < NR; ++j) wf[kk][j] = *(const h8*)(base + w_off + j * 16 * ROWB + coff);
+      }
+    };
+    auto mm = [&]() {
+#pragma unroll
+      for (int kk = 0; kk < KSUB; ++kk)
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+          for (int j = 0; j < NR; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
+    };
+    // One loop per group (straight-line bodies: a shared loop with per-group arms makes the compiler shuffle the 128 fragment / accumulator
+    // registers between the arms every iteration). Both loops pass exactly two barriers per k-tile.
+    auto top = [&](int t) {      // b_2t: tile t has landed for every wave (tile t+1 may still be in flight)
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 1 < nk) wait_vm_barrier<LPS>();
+      else wait_vm_barrier<0>();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mid = [&]() {           // b_2t+1
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    int slot_r = 0, slot_s = NSTAGE - 1;
+    auto adv = [&]() { slot_r = slot_r + 1 == NSTAGE ? 0 : slot_r + 1; slot_s = slot_s + 1 == NSTAGE ? 0 : slot_s + 1; };
+    // a group issues its DMA pieces of tile t+2 behind the fragment reads of its READ half-step
+    if (grp == 0) {
+      for (int t = 0; t < nk; ++t) {
+        top(t);
+        rd(slot_r);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + NSTAGE - 1 < nk) stage(t + NSTAGE - 1, slot_s);
+        mid();
+        mm();
+        adv();
+      }
+    } else {
+      for (int t = 0; t < nk; ++t) {
+        top(t);
+        if (t > 0) mm();
+        mid();
+        rd(slot_r);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + NSTAGE - 1 < nk) stage(t + NSTAGE - 1, slot_s);
+        adv();
+      }
+      mm();
+    }
+  } else {
   int cur = 0, nxt = NSTAGE - 1;      // ring slots: `cur` is consumed this step, `nxt` is refilled
   for (int kt = 0; kt < nk; ++kt) {
     const int ahead = nk - 1 - kt;    // tiles issued after tile kt that may remain in flight
@@ -252,6 +331,7 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const GemmArgs p
     nxt = nxt + 1 == NSTAGE ? 0 : nxt + 1;
   }
 
+  }
   float* ln_rows = (float*)smem;      // [0, BM): mean, [BM, 2 BM): rstd, then BN column sums and BN folded biases of this tile
   float* ln_cs = ln_rows + 2 * BM;
   float* ln_lb = ln_cs + BN;
@@ -368,18 +448,18 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const GemmArgs p
   }
 }
 
-template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int BK = 64>
+template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int BK = 64, int PP = 0>
 static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
   constexpr int smem = NSTAGE * (BM + BN) * 2 * BK;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_f16_kernel<BM, BN, NSTAGE, CONV, WGM, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_f16_kernel<BM, BN, NSTAGE, CONV, WGM, BK, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   const int extra = (a.pf && a.pf_bytes >= 4096) ? a.pf_blocks : 0;
-  hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, NSTAGE, CONV, WGM, BK>), dim3(tiles * (a.splitk > 1 ? a.splitk : 1) + extra), dim3(WGM * 128), smem, s, a);
+  hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, NSTAGE, CONV, WGM, BK, PP>), dim3(tiles * (a.splitk > 1 ? a.splitk : 1) + extra), dim3(WGM * 128), smem, s, a);
   return hipGetLastError();
 }
 
@@ -489,9 +569,10 @@ static double plan_cost_us(int M, int N, int K, bool conv, const GemmTile& t, in
   const int conc = (int)std::min<long>(occ, worst);         // co-resident workgroups there
   const long batches = (worst + conc - 1) / conc;
   const double per_cu = std::max(1.0, 0.6 * tiles / 256.0 + 0.4 * worst);
-  const double t_mfma = per_cu * (2.0 * t.bm * t.bn * 64) / (MFMA_EFF * (conc == 1 ? LONE_EFF : 1.0) * CU_FLOPS_PER_US);
+  const bool pingpong = t.bm == 256;    // 8 waves in two half-step-shifted groups: one workgroup behaves like two co-resident ones
+  const double t_mfma = per_cu * (2.0 * t.bm * t.bn * 64) / (MFMA_EFF * (conc == 1 && !pingpong ? LONE_EFF : 1.0) * CU_FLOPS_PER_US);
   const double t_fill = per_cu * ((t.bm + t.bn) * 128.0) / FILL_B_PER_US;
-  const double t_lat = batches * LAT_US / (t.stages - 1);
+  const double t_lat = batches * LAT_US / (t.stages - 1) * (pingpong ? 0.5 : 1.0);
   double total = BASE_US + nk * std::max({t_mfma, t_fill, t_lat}) + RAMP_US * batches;
   if (sk > 1) total += REDUCE_US + 2.0 * sk * (double)M * N * 4 / REDUCE_B_PER_US;
   return total;
@@ -556,9 +637,16 @@ void ia2p_gemm_candidates(int M, int N, int K, bool conv, bool geglu, size_t max
   static const int splits[] = {1, 2, 3, 4, 6, 8};
   const int nk = K / 64;
   std::vector<std::pair<double, GemmPlan>> all;
+  static const unsigned excluded = [] {          // IA2P_TUNE_EXCLUDE="12,7": variants the tuner must not consider (A/B runs)
+    unsigned m = 0;
+    if (const char* e = getenv("IA2P_TUNE_EXCLUDE"))
+      for (const char* q = e; *q; ++q)
+        if (*q >= '0' && *q <= '9') { const int v = atoi(q); if (v >= 0 && v < 32) m |= 1u << v; while (q[1] >= '0' && q[1] <= '9') ++q; }
+    return m;
+  }();
   for (int v = 0; v < IA2P_GEMM_NVARIANT; ++v) {
     const GemmTile& t = IA2P_GEMM_TILES[v];
-    if (geglu && (t.bn / 32) % 2) continue;
+    if ((geglu && (t.bn / 32) % 2) || (excluded >> v & 1)) continue;
     for (int sk : splits) {
       if (sk > 1 && (geglu || nk / sk < 4 || (size_t)sk * M * N * 4 > max_slab_bytes)) break;
       all.push_back({plan_cost_us(M, N, K, conv, t, sk), GemmPlan{v, sk}});
@@ -637,6 +725,10 @@ static hipError_t launch_any(const GemmArgs& a, int v, hipStream_t s, bool with_
     IA2P_TILE_CASE(10, 160, 128, 2)
     IA2P_TILE_CASE(11, 160, 160, 2)
 #undef IA2P_TILE_CASE
+    case 12:
+      static_assert(IA2P_GEMM_TILES[12].bm == 256 && IA2P_GEMM_TILES[12].bn == 128 && IA2P_GEMM_TILES[12].stages == 3, "tile table");
+      e = launch_cfg<256, 128, 3, CONV, 4, 64, 1>(a, s);
+      break;
     // Measured and dropped in round 1 (tools/gemm_bench.py): 8-wave 256x128 (2- and 3-stage) and 256x320 at one
     // workgroup per CU; BK = 32 rings (64-byte rows halve the request efficiency). The template still takes WGM and BK.
     default: return hipErrorInvalidValue;

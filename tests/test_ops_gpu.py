@@ -41,7 +41,7 @@ def run(L, name, *args):
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("tile", [-1] + list(range(12)))        # every entry of IA2P_GEMM_TILES (csrc/common.h)
+@pytest.mark.parametrize("tile", [-1] + list(range(13)))        # every entry of IA2P_GEMM_TILES (csrc/common.h)
 @pytest.mark.parametrize("M,N,K", [(256, 320, 320), (2048, 1280, 1280), (616, 2560, 2048), (100, 64, 64), (37, 132, 128), (8192, 640, 2560)])
 def test_gemm_bias_residual(L, M, N, K, tile):
     f = _ffi()
@@ -68,7 +68,7 @@ def test_gemm_tile_choice_never_changes_the_bits(L, M, N, K):
     A, W, b, R = rnd(M, K, seed=51), rnd(N, K, seed=52, scale=K ** -0.5), rnd(N, seed=53), rnd(M, N, seed=54)
     outs = []
     try:
-        for tile in range(12):
+        for tile in range(13):
             out = torch.empty(M, N, dtype=torch.half, device="cuda")
             L.ia2p_debug_set_gemm_tile(tile)
             run(L, "ia2p_gemm", f.ptr(A), f.ptr(W), f.ptr(b), f.ptr(R), f.ptr(out), M, N, K, 0)
@@ -103,7 +103,7 @@ def test_gemm_no_bias_inplace_residual(L):
     assert rel_l2(X, ref) < 1e-3
 
 
-@pytest.mark.parametrize("tile", [-1, 0, 2, 4, 10])
+@pytest.mark.parametrize("tile", [-1, 0, 2, 4, 10, 12])
 @pytest.mark.parametrize("M,C", [(256, 128), (2048, 1280), (130, 640)])
 def test_gemm_geglu(L, M, C, tile):
     f = _ffi()
@@ -139,7 +139,7 @@ def _ln_fold_setup(L, M, C_, N, seed, bias=True):
     return f, X, Wp, R, gamma, beta, W, b, Wf, cs, fb
 
 
-@pytest.mark.parametrize("tile", [-1, 0, 4, 6, 8, 11])
+@pytest.mark.parametrize("tile", [-1, 0, 4, 6, 8, 11, 12])
 @pytest.mark.parametrize("M,C_,N,psplit,csplit", [(2048, 1280, 3840, 1, 1), (300, 256, 768, 1, 1), (256, 1280, 1280, 3, 2), (77, 128, 132, 2, 1)])
 def test_layernorm_folded_into_gemm(L, M, C_, N, psplit, csplit, tile):
     """producer GEMM emits row statistics, consumer GEMM reads the raw rows against gamma-folded weights: equals
@@ -224,7 +224,7 @@ def test_conv3x3(L, B, H, W, Cin, Co, stride, up):
     assert rel_l2(y, ref) < 1e-3, rel_l2(y, ref)
 
 
-@pytest.mark.parametrize("tile", list(range(12)))
+@pytest.mark.parametrize("tile", list(range(13)))
 @pytest.mark.parametrize("B,H,W,Cin,Co,stride,up", [(1, 32, 32, 320, 320, 1, 0), (2, 12, 20, 128, 192, 2, 0), (1, 10, 14, 64, 320, 1, 1)])
 def test_conv3x3_every_tile(L, tile, B, H, W, Cin, Co, stride, up):
     L.ia2p_debug_set_gemm_tile(tile)

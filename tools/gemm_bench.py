@@ -10,7 +10,7 @@ from instructany2pix_amd import _ffi
 L = _ffi.lib()
 VARS = [int(v) for v in os.environ.get("VARIANTS", "0,2,4").split(",")]
 TILES = [(128, 128, 2), (128, 128, 3), (128, 64, 2), (128, 64, 3), (64, 64, 2), (64, 64, 3), (64, 160, 2), (64, 160, 3), (128, 160, 2), (128, 160, 3),
-         (160, 128, 2), (160, 160, 2)]      # = IA2P_GEMM_TILES (csrc/common.h)
+         (160, 128, 2), (160, 160, 2), (256, 128, 3)]      # = IA2P_GEMM_TILES (csrc/common.h); the last one is the 8-wave ping-pong tile
 NAMES = {v: "%dx%ds%d" % t for v, t in enumerate(TILES)}
 LIN = [  # (M, N, K, count/step, label)
     (2048, 3840, 1280, 60, "L2 qkv"), (2048, 1280, 1280, 192, "L2 proj"), (2048, 10240, 1280, 60, "L2 ff-in(geglu)"),
