@@ -332,6 +332,24 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const GemmArgs p
   }
 
   }
+  // Ping-pong tile: no separate prefetch workgroups (a workgroup holds a whole CU's LDS, so they would queue up behind the tiles): every
+  // tile workgroup touches its slice of the next contraction's weights here; the loads fly during the epilogue.
+  unsigned pfacc = 0;
+  if (PP && p.pf) {
+    const long nwg = (long)tiles_m * tiles_n * nsplit;
+    const long per = ((p.pf_bytes + nwg - 1) / nwg + 255) & ~255L;
+    const long lo = (long)blockIdx.x * per, hi = min(lo + per, p.pf_bytes & ~15L);
+    const char* src = (const char*)p.pf;
+    constexpr long SW = NWAVE * 64 * 16;
+    if (lo < hi)
+      for (long o = lo + tid * 16; o < hi; o += 8 * SW) {      // 8 independent loads in flight per thread (clamped, never branched around)
+        unsigned v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *(const unsigned*)(src + min(o + u * SW, hi - 16));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pfacc ^= v[u];
+      }
+  }
   float* ln_rows = (float*)smem;      // [0, BM): mean, [BM, 2 BM): rstd, then BN column sums and BN folded biases of this tile
   float* ln_cs = ln_rows + 2 * BM;
   float* ln_lb = ln_cs + BN;
@@ -364,6 +382,7 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const GemmArgs p
         if (n < p.N) *(f4*)(slab + (size_t)m * p.N + n) = acc[i][j];
       }
     }
+    if (PP) asm volatile("" ::"v"(pfacc));
     return;
   }
   float2 row_st[MR];
@@ -446,6 +465,7 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const GemmArgs p
       }
     }
   }
+  if (PP) asm volatile("" ::"v"(pfacc));
 }
 
 template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int BK = 64, int PP = 0>
@@ -458,7 +478,7 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
     attr_set = true;
   }
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-  const int extra = (a.pf && a.pf_bytes >= 4096) ? a.pf_blocks : 0;
+  const int extra = (!PP && a.pf && a.pf_bytes >= 4096) ? a.pf_blocks : 0;
   hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, NSTAGE, CONV, WGM, BK, PP>), dim3(tiles * (a.splitk > 1 ? a.splitk : 1) + extra), dim3(WGM * 128), smem, s, a);
   return hipGetLastError();
 }
