@@ -15,6 +15,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -90,8 +91,15 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const GemmArgs p
     bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
   }
   int tm, tn;
-  if (p.m_fastest) { tn = bid / tiles_m; tm = bid - tn * tiles_m; }
-  else             { tm = bid / tiles_n; tn = bid - tm * tiles_n; }
+  if (p.group_w > 0) {
+    // grouped order: column panels of group_w tiles, row-major inside a panel, so that the contiguous range an XCD works on (and the
+    // workgroups co-resident on it) cover a compact rows x cols block: the operand panels its L2 has to fetch shrink with the perimeter
+    const int per = tiles_m * p.group_w;
+    const int panel = bid / per, r = bid - panel * per;
+    const int w = min(p.group_w, tiles_n - panel * p.group_w);
+    tm = r / w; tn = panel * p.group_w + (r - tm * w);
+  } else if (p.m_fastest) { tn = bid / tiles_m; tm = bid - tn * tiles_m; }
+  else                    { tm = bid / tiles_n; tn = bid - tm * tiles_n; }
   const int bm0 = tm * BM, bn0 = tn * BN;
 
   // ---- staging addresses. Piece `pi` covers tile rows pi*8 .. pi*8+7; lane -> (row pi*8 + lane/8, LDS chunk lane%8),
@@ -478,8 +486,18 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
     attr_set = true;
   }
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+  GemmArgs b = a;
+  static const int group_mode = getenv("IA2P_TILE_GROUP") ? atoi(getenv("IA2P_TILE_GROUP")) : 1;
+  if (group_mode) {
+    const int tiles_n = (a.N + BN - 1) / BN;
+    const int smem_per_cu = 160 * 1024 / smem;                                   // co-resident workgroups per CU by LDS
+    const double resident = std::min<double>(tiles / 8.0, 32.0 * std::max(1, std::min(smem_per_cu, 2)));   // tiles an XCD holds at once
+    static const double gscale = getenv("IA2P_TILE_GROUP_SCALE") ? atof(getenv("IA2P_TILE_GROUP_SCALE")) : 1.0;
+    int w = (int)(gscale * std::sqrt(resident * BM / BN) + 0.5);
+    b.group_w = std::max(1, std::min(w, tiles_n));
+  }
   const int extra = (!PP && a.pf && a.pf_bytes >= 4096) ? a.pf_blocks : 0;
-  hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, NSTAGE, CONV, WGM, BK, PP>), dim3(tiles * (a.splitk > 1 ? a.splitk : 1) + extra), dim3(WGM * 128), smem, s, a);
+  hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, NSTAGE, CONV, WGM, BK, PP>), dim3(tiles * (a.splitk > 1 ? a.splitk : 1) + extra), dim3(WGM * 128), smem, s, b);
   return hipGetLastError();
 }
 
