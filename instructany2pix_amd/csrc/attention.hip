@@ -14,6 +14,8 @@
 // touches LDS and the per-query rescale factors stay lane-local.
 #include "common.h"
 
+#include <cstdlib>
+
 #define MASKED (-1.0e30f)
 
 __device__ __forceinline__ fp16x4 lds_tr16(const char* p) {
@@ -75,8 +77,19 @@ __global__ __launch_bounds__(256) void attention_f16_kernel(const AttnArgs p) {
   char* sV = smem + 32768;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.z, hd = blockIdx.y;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  // Workgroups b, b+8, ... share an XCD (its L2, cold at kernel start): give each XCD a contiguous range of the (batch, head, query block)
+  // sequence, query block fastest, so that the query blocks of one (batch, head) read their K / V through ONE L2 instead of eight.
+  int b, hd, qb;
+  {
+    const int nq = (p.Nq + 127) >> 7, nwg = nq * p.heads * p.B;
+    int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7, i = bid >> 3;
+    if (p.xcd_map) bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    qb = bid % nq;
+    const int bh = bid / nq;
+    hd = bh % p.heads; b = bh / p.heads;
+  }
+  const int q0 = qb * 128 + wave * 32;
   const int r31 = lane & 31, hh = lane >> 5;
 
   // Q^T as the B operand of S^T = K . Q^T : lane holds Q[q0 + lane%32][16*s + 8*(lane/32) + 0..7]
@@ -256,13 +269,16 @@ __global__ __launch_bounds__(256) void attention_f16_kernel(const AttnArgs p) {
 }
 
 hipError_t ia2p_launch_attention(const AttnArgs& a, hipStream_t s) {
-  dim3 grid((a.Nq + 127) / 128, a.heads, a.B);
+  dim3 grid(((a.Nq + 127) / 128) * a.heads * a.B);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)attention_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(attention_f16_kernel, grid, dim3(256), 65536, s, a);
+  static const int xcd_map = getenv("IA2P_ATTN_XCD") ? atoi(getenv("IA2P_ATTN_XCD")) : 1;     // A/B switch
+  AttnArgs b = a;
+  b.xcd_map = xcd_map;
+  hipLaunchKernelGGL(attention_f16_kernel, grid, dim3(256), 65536, s, b);
   return hipGetLastError();
 }

@@ -106,5 +106,6 @@ struct AttnArgs {
   half_t* O;             // same indexing with ldo
   int ldq, ldo, B, heads, Nq, nseg;
   float scale_log2e;     // (1/sqrt(64)) * log2(e)
+  int xcd_map;           // 1: contiguous (batch, head, query block) range per XCD (set by the launcher)
   AttnSeg seg[2];
 };
