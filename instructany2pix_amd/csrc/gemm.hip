@@ -534,10 +534,10 @@ static const std::vector<ShapeRule>& shape_rules() {
 // launch (ln_stats; every wave derives them itself), {sum, sum of squares} of the fp16 output row for a producer launch
 // (stats_out, slot 0; wave partials combined through LDS in wave order). No GEGLU here.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
-  __shared__ float2 wsum[4];
+  // one WAVE per output row (4 rows per workgroup): every load of a row is independent, the row statistics need no workgroup barrier
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nq = p.N >> 2;
-  for (int m = blockIdx.x; m < p.M; m += gridDim.x) {
+  for (int m = blockIdx.x * 4 + wave; m < p.M; m += gridDim.x * 4) {
     float mu = 0.f, rs = 1.f;
     if (p.ln_stats) {
       float s1 = 0.f, s2 = 0.f;
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
       rs = rsqrtf(fmaxf(s2 * inv - mu * mu, 0.f) + p.ln_eps);
     }
     float st1 = 0.f, st2 = 0.f;
-    for (int q = threadIdx.x; q < nq; q += 256) {
+    for (int q = lane; q < nq; q += 64) {
       const int n = q * 4;
       f4 v = *(const f4*)(p.partial + (size_t)m * p.N + n);
       for (int s = 1; s < p.splitk; ++s) {
@@ -574,11 +574,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
     if (p.stats_out) {
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) { st1 += __shfl_xor(st1, o); st2 += __shfl_xor(st2, o); }
-      __syncthreads();                 // (previous row's wsum has been read)
-      if (lane == 0) wsum[wave] = make_float2(st1, st2);
-      __syncthreads();
-      if (threadIdx.x == 0)
-        ((float2*)p.stats_out)[m] = make_float2((wsum[0].x + wsum[1].x) + (wsum[2].x + wsum[3].x), (wsum[0].y + wsum[1].y) + (wsum[2].y + wsum[3].y));
+      if (lane == 0) ((float2*)p.stats_out)[m] = make_float2(st1, st2);
     }
   }
 }
@@ -734,7 +730,7 @@ extern "C" void ia2p_debug_gemm_plan(int M, int N, int K, int conv, int geglu, i
 }
 
 hipError_t ia2p_launch_splitk_reduce(const GemmArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(std::min(16384, a.M)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(std::min(16384, (a.M + 3) / 4)), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 
