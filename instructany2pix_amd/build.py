@@ -16,7 +16,9 @@ SOURCES = ["gemm.hip", "attention.hip", "norm.hip", "misc.hip", "engine.hip", "v
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"]
 # attention: MFMA results feed VALU softmax directly; the VGPR form avoids ~250 v_accvgpr_read/write per key tile
-FILE_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+# kernarg preload: the first 16 dwords of a kernel's (scalar) arguments arrive in SGPRs instead of through a cold read of the argument block
+PRELOAD = ["-mllvm", "-amdgpu-kernarg-preload-count=16"]
+FILE_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "gemm.hip": PRELOAD}
 
 
 def _stamp():

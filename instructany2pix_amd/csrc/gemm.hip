@@ -47,7 +47,11 @@ template <int BK> __device__ __forceinline__ int lds_swz(int row) { return BK ==
 // MFMA phases add up); two independent workgroups per CU de-phase by themselves but need twice the LDS fill per flop
 // (profiles/r01g_gemm_loop_ablation.txt: the fill is the largest term of the 128x128 kernel).
 template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int BK = 64, int PP = 0>
-__global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const GemmArgs p) {   // >= 2 waves/SIMD: big tiles must fit 256 registers
+__global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const half_t* hA, const half_t* hW, const half_t* hzero, int hM, int hN, int hK, int hlda, int hldw, int hrpb, int hbstride,
+                                                                         int hroff, int hsplitk, int hgroup_w, const GemmArgs p) {
+  // The leading 16 dwords of the argument list are what the prologue needs; built with -amdgpu-kernarg-preload-count=16 the command processor
+  // hands them over in SGPRs, so the first tile loads go out without waiting for a cold read of the argument block (which costs every launch
+  // ~1 us: tools/micro/launch_floor2.hip). The rest of GemmArgs (epilogue, conv geometry) arrives while those loads fly.   // >= 2 waves/SIMD: big tiles must fit 256 registers
   static_assert(!PP || (WGM == 4 && NSTAGE == 3), "ping-pong schedule: 8 waves, 3-stage ring");
   constexpr int NWAVE = WGM * 2;
   constexpr int WM = BM / WGM, WN = BN / 2;      // wave tile (waves arranged WGM x 2)
@@ -63,9 +67,9 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const GemmArgs p
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
   // ---- tile of this workgroup; blocks b, b+8, ... share an XCD (its L2): give each XCD a contiguous tile range
-  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  const int tiles_m = (hM + BM - 1) / BM, tiles_n = (hN + BN - 1) / BN;
   int bid = blockIdx.x;
-  const int nsplit = p.splitk > 1 ? p.splitk : 1;
+  const int nsplit = hsplitk > 1 ? hsplitk : 1;
   const int split = bid / (tiles_m * tiles_n);          // >= nsplit: prefetch workgroup
   if (split < nsplit) bid -= split * tiles_m * tiles_n;
   if (split >= nsplit) {   // prefetch workgroup: touch its slice of the next kernel's weights and leave
@@ -91,13 +95,13 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const GemmArgs p
     bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
   }
   int tm, tn;
-  if (p.group_w > 0) {
+  if (hgroup_w > 0) {
     // grouped order: column panels of group_w tiles, row-major inside a panel, so that the contiguous range an XCD works on (and the
     // workgroups co-resident on it) cover a compact rows x cols block: the operand panels its L2 has to fetch shrink with the perimeter
-    const int per = tiles_m * p.group_w;
+    const int per = tiles_m * hgroup_w;
     const int panel = bid / per, r = bid - panel * per;
-    const int w = min(p.group_w, tiles_n - panel * p.group_w);
-    tm = r / w; tn = panel * p.group_w + (r - tm * w);
+    const int w = min(hgroup_w, tiles_n - panel * hgroup_w);
+    tm = r / w; tn = panel * hgroup_w + (r - tm * w);
   } else if (p.m_fastest) { tn = bid / tiles_m; tm = bid - tn * tiles_m; }
   else                    { tm = bid / tiles_n; tn = bid - tm * tiles_n; }
   const int bm0 = tm * BM, bn0 = tn * BN;
@@ -114,15 +118,15 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const GemmArgs p
     const int m = bm0 + pi * RPP + srow;
     const int gch = cpos ^ lds_swz<BK>(pi * RPP + srow);
     if (!CONV) {
-      if (m < p.M) {
+      if (m < hM) {
         int src = m;
-        if (p.rpb) { const int b = m / p.rpb; src = b * p.bstride + (m - b * p.rpb) + p.roff; }
-        a_ptr[i] = p.A + (size_t)src * p.lda + gch * 8;
+        if (hrpb) { const int b = m / hrpb; src = b * hbstride + (m - b * hrpb) + hroff; }
+        a_ptr[i] = hA + (size_t)src * hlda + gch * 8;
         a_inc[i] = BK;
-      } else { a_ptr[i] = p.zero; a_inc[i] = 0; }
+      } else { a_ptr[i] = hzero; a_inc[i] = 0; }
     } else {
       a_ch[i] = gch * 8;
-      if (m < p.M) {
+      if (m < hM) {
         const int hw = p.Ho * p.Wo;
         const int b = m / hw, rem = m - b * hw;
         const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
@@ -137,12 +141,12 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const GemmArgs p
     const int pi = wave * B_PW + i;
     const int n = bn0 + pi * RPP + srow;
     const int gch = cpos ^ lds_swz<BK>(pi * RPP + srow);
-    if (n < p.N) { w_ptr[i] = p.W + (size_t)n * p.ldw + gch * 8; w_inc[i] = BK; }
-    else         { w_ptr[i] = p.zero; w_inc[i] = 0; }
+    if (n < hN) { w_ptr[i] = hW + (size_t)n * hldw + gch * 8; w_inc[i] = BK; }
+    else         { w_ptr[i] = hzero; w_inc[i] = 0; }
   }
 
   const int Hv = p.Hs << p.up, Wv = p.Ws << p.up;
-  const int nk_all = p.K / BK;
+  const int nk_all = hK / BK;
   const int kt0 = (int)((long)split * nk_all / nsplit), kt1 = (int)((long)(split + 1) * nk_all / nsplit);   // this workgroup's k-tiles
   int tap = (kt0 * BK) / (CONV ? p.Cin : BK), ci0 = CONV ? (kt0 * BK) % p.Cin : 0;  // conv: position of the k-tile being staged
   bool tap_fresh = true;
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const GemmArgs p
         for (int i = 0; i < A_PW; ++i) {
           const int iy = a_y[i] + ky, ix = a_x[i] + kx;
           const bool ok = (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
-          a_ptr[i] = ok ? p.A + (size_t)(a_pix[i] + (iy >> p.up) * p.Ws + (ix >> p.up)) * p.lda + ci0 + a_ch[i] : p.zero;
+          a_ptr[i] = ok ? hA + (size_t)(a_pix[i] + (iy >> p.up) * p.Ws + (ix >> p.up)) * hlda + ci0 + a_ch[i] : hzero;
           a_inc[i] = ok ? BK : 0;
         }
         tap_fresh = false;
@@ -200,18 +204,18 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const GemmArgs p
   //      reload in the loop waits for vmcnt, i.e. drains the DMA queue); the prologue DMA stays in flight behind them.
   float ln_s1 = 0.f, ln_s2 = 0.f;
   auto load_ln = [&]() {
-  if (p.ln_stats && tid < BM && bm0 + tid < p.M) {
+  if (p.ln_stats && tid < BM && bm0 + tid < hM) {
     const float2* st = (const float2*)p.ln_stats + (bm0 + tid);
     constexpr int MAXS = 24;
     if (p.ln_slots <= MAXS) {
       float2 v[MAXS];
 #pragma unroll
-      for (int u = 0; u < MAXS; ++u) v[u] = st[(size_t)min(u, p.ln_slots - 1) * p.M];
+      for (int u = 0; u < MAXS; ++u) v[u] = st[(size_t)min(u, p.ln_slots - 1) * hM];
 #pragma unroll
       for (int u = 0; u < MAXS; ++u)
         if (u < p.ln_slots) { ln_s1 += v[u].x; ln_s2 += v[u].y; }
     } else {
-      for (int sl = 0; sl < p.ln_slots; ++sl) { const float2 v = st[(size_t)sl * p.M]; ln_s1 += v.x; ln_s2 += v.y; }
+      for (int sl = 0; sl < p.ln_slots; ++sl) { const float2 v = st[(size_t)sl * hM]; ln_s1 += v.x; ln_s2 += v.y; }
     }
   }
   };
@@ -364,13 +368,13 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const GemmArgs p
   if (p.ln_stats) {
     __syncthreads();                  // every wave has finished reading the stage buffers
     if (tid < BM) {
-      const float inv = 1.f / (float)p.K;
+      const float inv = 1.f / (float)hK;
       const float mean = ln_s1 * inv;
       const float var = fmaxf(ln_s2 * inv - mean * mean, 0.f);
       ln_rows[tid] = mean;
       ln_rows[BM + tid] = rsqrtf(var + p.ln_eps);
     }
-    if (tid < BN / 4 && bn0 + tid * 4 < p.N) {
+    if (tid < BN / 4 && bn0 + tid * 4 < hN) {
       *(f4*)(ln_cs + tid * 4) = *(const f4*)(p.ln_cs + bn0 + tid * 4);
       *(f4*)(ln_lb + tid * 4) = *(const f4*)(p.ln_bias + bn0 + tid * 4);
     }
@@ -379,15 +383,15 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const GemmArgs p
 
   // ---- epilogue: acc[i][j][r] = C[m = bm0+wm0+16i+(lane&15)][n = bn0+wn0+16j+4*(lane>>4)+r]
   if (nsplit > 1) {      // raw fp32 slab of this K range; splitk_reduce_kernel finishes
-    float* slab = p.partial + (size_t)split * p.M * p.N;
+    float* slab = p.partial + (size_t)split * hM * hN;
 #pragma unroll
     for (int i = 0; i < MR; ++i) {
       const int m = bm0 + wm0 + i * 16 + frow;
-      if (m >= p.M) continue;
+      if (m >= hM) continue;
 #pragma unroll
       for (int j = 0; j < NR; ++j) {
         const int n = bn0 + wn0 + j * 16 + fq * 4;
-        if (n < p.N) *(f4*)(slab + (size_t)m * p.N + n) = acc[i][j];
+        if (n < hN) *(f4*)(slab + (size_t)m * hN + n) = acc[i][j];
       }
     }
     if (PP) asm volatile("" ::"v"(pfacc));
@@ -399,7 +403,7 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const GemmArgs p
 #pragma unroll
   for (int i = 0; i < MR; ++i) {
     const int m = bm0 + wm0 + i * 16 + frow;
-    if (m >= p.M) continue;
+    if (m >= hM) continue;
     const half_t* rv = nullptr;
     if (p.rowvec) rv = p.rowvec + (size_t)(m / p.rows_per_batch) * p.rowvec_ld;
     float mu = 0.f, rs = 1.f;
@@ -409,7 +413,7 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const GemmArgs p
 #pragma unroll
       for (int j = 0; j < NR; ++j) {
         const int n = bn0 + wn0 + j * 16 + fq * 4;
-        if (n >= p.N) continue;
+        if (n >= hN) continue;
         f4 v = acc[i][j];
         if (p.ln_stats) {
           const f4 cs = *(const f4*)(ln_cs + n - bn0), lb = *(const f4*)(ln_lb + n - bn0);
@@ -436,7 +440,7 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const GemmArgs p
 #pragma unroll
       for (int j = 0; j < NR; j += 2) {
         const int n = bn0 + wn0 + j * 16 + fq * 4;     // packed row of the `a` half; gate rows sit 16 further
-        if (n >= p.N) continue;
+        if (n >= hN) continue;
         h4 o;
         if (p.ln_stats) {
           const f4 ca = *(const f4*)(ln_cs + n - bn0), cg = *(const f4*)(ln_cs + n - bn0 + 16), la = *(const f4*)(ln_lb + n - bn0), lg = *(const f4*)(ln_lb + n - bn0 + 16);
@@ -467,9 +471,9 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const GemmArgs p
 #pragma unroll
       for (int i = 0; i < MR; ++i) {
         const int m = bm0 + wm0 + i * 16 + frow;
-        if (m >= p.M) continue;
+        if (m >= hM) continue;
         const float2 o = xch[wm0 + i * 16 + frow];
-        ((float2*)p.stats_out)[(size_t)tn * p.M + m] = make_float2(row_st[i].x + o.x, row_st[i].y + o.y);
+        ((float2*)p.stats_out)[(size_t)tn * hM + m] = make_float2(row_st[i].x + o.x, row_st[i].y + o.y);
       }
     }
   }
@@ -497,7 +501,8 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
     b.group_w = std::max(1, std::min(w, tiles_n));
   }
   const int extra = (!PP && a.pf && a.pf_bytes >= 4096) ? a.pf_blocks : 0;
-  hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, NSTAGE, CONV, WGM, BK, PP>), dim3(tiles * (a.splitk > 1 ? a.splitk : 1) + extra), dim3(WGM * 128), smem, s, b);
+  hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, NSTAGE, CONV, WGM, BK, PP>), dim3(tiles * (a.splitk > 1 ? a.splitk : 1) + extra), dim3(WGM * 128), smem, s,
+                     b.A, b.W, b.zero, b.M, b.N, b.K, b.lda, b.ldw, b.rpb, b.bstride, b.roff, b.splitk, b.group_w, b);
   return hipGetLastError();
 }
 
