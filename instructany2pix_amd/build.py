@@ -18,7 +18,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-res
 # attention: MFMA results feed VALU softmax directly; the VGPR form avoids ~250 v_accvgpr_read/write per key tile
 # kernarg preload: the first 16 dwords of a kernel's (scalar) arguments arrive in SGPRs instead of through a cold read of the argument block
 PRELOAD = ["-mllvm", "-amdgpu-kernarg-preload-count=16"]
-FILE_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "gemm.hip": PRELOAD}
+FILE_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"] + PRELOAD, "gemm.hip": PRELOAD, "norm.hip": PRELOAD}
 
 
 def _stamp():

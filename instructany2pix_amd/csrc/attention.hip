@@ -70,7 +70,14 @@ __device__ __forceinline__ void stage_kv2(const half_t* K0, const half_t* V0, in
   }
 }
 
-__global__ __launch_bounds__(256) void attention_f16_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(256) void attention_f16_kernel(const half_t* aQ, half_t* aO, int aldq, int aldo, int aB, int aheads, int aNq, int anseg, float ascale,
+                                                            int axcd, const half_t* aK0, const half_t* aV0, int an0, int ald0, int arpb0, float aw0,
+                                                            const half_t* aK1, const half_t* aV1, int an1, int ald1, int arpb1, float aw1) {
+  // scalar arguments (the first 16 dwords are preloaded into SGPRs: build.py PRELOAD), re-assembled into the descriptor the body uses
+  AttnArgs p;
+  p.Q = aQ; p.O = aO; p.ldq = aldq; p.ldo = aldo; p.B = aB; p.heads = aheads; p.Nq = aNq; p.nseg = anseg; p.scale_log2e = ascale; p.xcd_map = axcd;
+  p.seg[0].K = aK0; p.seg[0].V = aV0; p.seg[0].nkeys = an0; p.seg[0].ld = ald0; p.seg[0].rows_per_batch = arpb0; p.seg[0].weight = aw0;
+  p.seg[1].K = aK1; p.seg[1].V = aV1; p.seg[1].nkeys = an1; p.seg[1].ld = ald1; p.seg[1].rows_per_batch = arpb1; p.seg[1].weight = aw1;
   // up to 4 key tiles (256 keys) of K and of V resident at once: one load phase + one barrier per 256 keys
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   char* sK = smem;
@@ -279,6 +286,8 @@ hipError_t ia2p_launch_attention(const AttnArgs& a, hipStream_t s) {
   static const int xcd_map = getenv("IA2P_ATTN_XCD") ? atoi(getenv("IA2P_ATTN_XCD")) : 1;     // A/B switch
   AttnArgs b = a;
   b.xcd_map = xcd_map;
-  hipLaunchKernelGGL(attention_f16_kernel, grid, dim3(256), 65536, s, b);
+  hipLaunchKernelGGL(attention_f16_kernel, grid, dim3(256), 65536, s, b.Q, b.O, b.ldq, b.ldo, b.B, b.heads, b.Nq, b.nseg, b.scale_log2e, b.xcd_map,
+                     b.seg[0].K, b.seg[0].V, b.seg[0].nkeys, b.seg[0].ld, b.seg[0].rows_per_batch, b.seg[0].weight,
+                     b.seg[1].K, b.seg[1].V, b.seg[1].nkeys, b.seg[1].ld, b.seg[1].rows_per_batch, b.seg[1].weight);
   return hipGetLastError();
 }

@@ -538,15 +538,17 @@ static const std::vector<ShapeRule>& shape_rules() {
 // pass), so the row-wise extras of the folded LayerNorm are reductions inside the workgroup: mean / rstd of the row for a consumer
 // launch (ln_stats; every wave derives them itself), {sum, sum of squares} of the fp16 output row for a producer launch
 // (stats_out, slot 0; wave partials combined through LDS in wave order). No GEGLU here.
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* hpartial, half_t* hC, const half_t* hresidual, float* hstats_out, int hM, int hN, int hsplitk,
+                                                            int hldc, int hldr, const GemmArgs p) {
+  // leading scalars = what the streaming loop needs first (preloaded into SGPRs: build.py PRELOAD); the rest of the epilogue description follows
   // one WAVE per output row (4 rows per workgroup): every load of a row is independent, the row statistics need no workgroup barrier
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nq = p.N >> 2;
-  for (int m = blockIdx.x * 4 + wave; m < p.M; m += gridDim.x * 4) {
+  const int nq = hN >> 2;
+  for (int m = blockIdx.x * 4 + wave; m < hM; m += gridDim.x * 4) {
     float mu = 0.f, rs = 1.f;
     if (p.ln_stats) {
       float s1 = 0.f, s2 = 0.f;
-      for (int sl = lane; sl < p.ln_slots; sl += 64) { const float2 v = ((const float2*)p.ln_stats)[(size_t)sl * p.M + m]; s1 += v.x; s2 += v.y; }
+      for (int sl = lane; sl < p.ln_slots; sl += 64) { const float2 v = ((const float2*)p.ln_stats)[(size_t)sl * hM + m]; s1 += v.x; s2 += v.y; }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
       const float inv = 1.f / (float)p.K;
@@ -556,9 +558,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
     float st1 = 0.f, st2 = 0.f;
     for (int q = lane; q < nq; q += 64) {
       const int n = q * 4;
-      f4 v = *(const f4*)(p.partial + (size_t)m * p.N + n);
-      for (int s = 1; s < p.splitk; ++s) {
-        const f4 w = *(const f4*)(p.partial + ((size_t)s * p.M + m) * p.N + n);
+      f4 v = *(const f4*)(hpartial + (size_t)m * hN + n);
+      for (int s = 1; s < hsplitk; ++s) {
+        const f4 w = *(const f4*)(hpartial + ((size_t)s * hM + m) * hN + n);
         v[0] += w[0]; v[1] += w[1]; v[2] += w[2]; v[3] += w[3];
       }
       if (p.ln_stats) {
@@ -568,18 +570,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
       } else if (p.bias) { const h4 b = *(const h4*)(p.bias + n); v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3]; }
       if (p.act) { v[0] = act_f(v[0], p.act); v[1] = act_f(v[1], p.act); v[2] = act_f(v[2], p.act); v[3] = act_f(v[3], p.act); }
       if (p.rowvec) { const h4 b = *(const h4*)(p.rowvec + (size_t)(m / p.rows_per_batch) * p.rowvec_ld + n); v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3]; }
-      if (p.residual) { const h4 b = *(const h4*)(p.residual + (size_t)m * p.ldr + n); v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3]; }
+      if (hresidual) { const h4 b = *(const h4*)(hresidual + (size_t)m * hldr + n); v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3]; }
       h4 o; o[0] = (half_t)v[0]; o[1] = (half_t)v[1]; o[2] = (half_t)v[2]; o[3] = (half_t)v[3];
-      *(h4*)(p.C + (size_t)m * p.ldc + n) = o;
-      if (p.stats_out) {
+      *(h4*)(hC + (size_t)m * hldc + n) = o;
+      if (hstats_out) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { const float f = (float)o[r]; st1 += f; st2 += f * f; }
       }
     }
-    if (p.stats_out) {
+    if (hstats_out) {
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) { st1 += __shfl_xor(st1, o); st2 += __shfl_xor(st2, o); }
-      if (lane == 0) ((float2*)p.stats_out)[m] = make_float2(st1, st2);
+      if (lane == 0) ((float2*)hstats_out)[m] = make_float2(st1, st2);
     }
   }
 }
@@ -735,7 +737,8 @@ extern "C" void ia2p_debug_gemm_plan(int M, int N, int K, int conv, int geglu, i
 }
 
 hipError_t ia2p_launch_splitk_reduce(const GemmArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(std::min(16384, (a.M + 3) / 4)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(std::min(16384, (a.M + 3) / 4)), dim3(256), 0, s, (const float*)a.partial, a.C, a.residual, a.stats_out, a.M, a.N, a.splitk,
+                     a.ldc, a.ldr, a);
   return hipGetLastError();
 }
 
