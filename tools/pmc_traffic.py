@@ -23,6 +23,17 @@ def fold(d, cname):
 
 
 def short(name):
+    """kernel name without the argument list; Itanium-mangled template kernels (rocprofv3 does not demangle signatures that contain
+    _Float16) are rewritten to the form the executor's own tables use: gemm_f16_kernel<128, 128, 2, false, 2, 64, 0>"""
+    m = re.match(r"_Z(\d+)", name)
+    if m and not name.startswith("_ZN"):
+        n = int(m.group(1))
+        base, rest = name[m.end():m.end() + n], name[m.end() + n:]
+        t = re.match(r"I((?:L[ib]\d+E)+)E", rest)
+        if t:
+            args = [("true" if v == "1" else "false") if k == "b" else v for k, v in re.findall(r"L([ib])(\d+)E", t.group(1))]
+            return f"{base}<{', '.join(args)}>"
+        return base
     m = re.match(r"(?:void )?([A-Za-z0-9_]+(?:<[^>]*>)?)", name)
     return m.group(1) if m else name
 

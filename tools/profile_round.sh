@@ -16,7 +16,7 @@ cp profiles/${TAG}_pmc_traffic.json gpurun_out/
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG} --output-format csv -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-roofline --plans $R/gpurun_out/${TAG}_plans_cfg3.txt > $R/gpurun_out/prof_${TAG}.log 2>&1
 cd $R
-find gpurun_out/prof_${TAG} -name "*kernel_stats.csv" -exec cp {} gpurun_out/${TAG}_kernel_stats_bench_cfg3.csv \;
+find gpurun_out/prof_${TAG} -name "*kernel_stats.csv" -exec python3 tools/demangle_stats.py {} gpurun_out/${TAG}_kernel_stats_bench_cfg3.csv \;
 python3 bench.py --steps 50 --warmup 3 --plans gpurun_out/${TAG}_plans_cfg3.txt --kernel-table gpurun_out/${TAG}_kernel_table.json > gpurun_out/${TAG}_bench_cfg3.json 2> gpurun_out/${TAG}_bench_cfg3.err
 tail -1 gpurun_out/${TAG}_bench_cfg3.json | cut -c1-1800
 grep -E "launches/step" gpurun_out/${TAG}_bench_cfg3.err | head -20
