@@ -79,8 +79,14 @@ ia2p_status ia2p_bind_arena(ia2p_ctx* ctx, void* dev_arena, size_t bytes);   /* 
  * or IP-Adapter key ("ip_adapter.<idx>.to_k_ip.weight", idx = position in unet.attn_processors; ip_adapter.py:168-169).
  * `dev_src` is fp16 in the checkpoint's own layout; it is re-laid-out into the arena on `stream`. */
 ia2p_status ia2p_load_tensor(ia2p_ctx* ctx, const char* key, const void* dev_src, const int64_t* shape, int ndim, void* stream);
-ia2p_status ia2p_finalize_weights(ia2p_ctx* ctx);      /* verifies every UNet parameter was loaded */
-ia2p_status ia2p_adopt_arena(ia2p_ctx* ctx);           /* arena was filled elsewhere (broadcast): mark as finalized */
+ia2p_status ia2p_finalize_weights(ia2p_ctx* ctx);      /* verifies every UNet parameter was loaded; derives the LayerNorm-folded copies */
+/* A tensor (re)loaded after finalize marks the derived data stale; the next forward re-derives it on its stream before running.
+ * The arena is [head | tail]: head = the parameters as loaded (ia2p_arena_raw_bytes; what a data-parallel rank must RECEIVE), tail = data
+ * derived from them at finalize (LayerNorm-folded weight copies, +43 %). ia2p_adopt_arena: the head was filled elsewhere (RCCL broadcast
+ * from the rank that read the checkpoint) -- marks the UNet parameters (and, with_ip_adapter != 0, the IP-Adapter
+ * tensors) present and derives the tail locally. */
+size_t ia2p_arena_raw_bytes(ia2p_ctx* ctx);
+ia2p_status ia2p_adopt_arena(ia2p_ctx* ctx, int with_ip_adapter);
 /* IP-Adapter plugin state: set_ip_adapter (ip_adapter.py:120-142) / set_scale (:211-214) / disable (:153-154). */
 ia2p_status ia2p_set_ip_adapter(ia2p_ctx* ctx, int enabled, int num_tokens, float scale);
 
@@ -167,6 +173,11 @@ ia2p_status ia2p_pack_geglu(void* stream, const void* src, void* dst, int rows, 
 ia2p_status ia2p_attention(void* stream, const void* Q, int ldq, void* O, int ldo, int B, int heads, int Nq, int nseg,
                            const void* K0, const void* V0, int ld0, int nkeys0, float w0,
                            const void* K1, const void* V1, int ld1, int nkeys1, float w1);
+/* The `attn_map` side effect of IPAttnProcessor2_0 (reference attention_processor.py:390-391; stored on the processor, read only by the
+ * attention-map hooks of diffusion/ip_adapter/utils.py:15-20):  out[b,h,q,t] = sum_d Q[b,q,h*64+d] * softmax_t(Kip[b,t,h*64+d]) -- the
+ * softmax binds to ip_key^T, i.e. runs over the TOKEN axis, unscaled, before the matmul. Q rows stride ldq, Kip [B*ntok, ldk], out fp16
+ * [B, heads, Nq, ntok], ntok <= 16. */
+ia2p_status ia2p_ip_attn_map(void* stream, const void* Q, int ldq, const void* Kip, int ldk, void* out, int B, int heads, int Nq, int ntok);
 ia2p_status ia2p_linear_small(void* stream, const void* X, const void* W, const void* bias, void* out, int M, int N, int K,
                               int silu_in, int silu_out);
 
@@ -181,6 +192,9 @@ ia2p_status ia2p_profile_enable(ia2p_ctx* ctx, int on);   /* also clears the sum
 int ia2p_profile_classes(void);
 /* sums since enable for class k: launches, milliseconds, algorithmic flops and bytes */
 ia2p_status ia2p_profile_read(ia2p_ctx* ctx, int k, char* name, int name_len, int64_t* launches, double* ms, double* flops, double* bytes);
+/* the same sums by REGION of the UNet evaluation: 0 = other (embeddings), 1 = conv blocks (conv_in / conv_out, the ResnetBlock2Ds with their
+ * GroupNorm+SiLU and 1x1 shortcuts, resample convolutions, skip concatenation -- SURVEY.md §8d "conv blocks"), 2 = transformer blocks */
+ia2p_status ia2p_profile_read_region(ia2p_ctx* ctx, int region, int64_t* launches, double* ms, double* flops, double* bytes);
 
 /* ---- VAE (diffusers AutoencoderKL): pipe.vae.encode / pipe.vae.decode ----------------------------
  * reference call sites: ddim/pnp_pipeline.py:190-204 (prepare_latents of the img2img base class), ddim/sdxl_pipeline.py:859-871.

@@ -53,7 +53,8 @@ SIGNATURES = {
     "ia2p_bind_arena": (_I, [_P, _P, _SZ]),
     "ia2p_load_tensor": (_I, [_P, C.c_char_p, _P, C.POINTER(_I64), _I, _P]),
     "ia2p_finalize_weights": (_I, [_P]),
-    "ia2p_adopt_arena": (_I, [_P]),
+    "ia2p_adopt_arena": (_I, [_P, _I]),
+    "ia2p_arena_raw_bytes": (_SZ, [_P]),
     "ia2p_set_ip_adapter": (_I, [_P, _I, _I, _F]),
     "ia2p_workspace_bytes": (_SZ, [_P, _I, _I, _I, _I]),
     "ia2p_unet_forward": (_I, [_P, _P, _P, _F, _P, _I, _P, _P, _P, _I, _I, _I, _P, _SZ]),
@@ -79,6 +80,7 @@ SIGNATURES = {
     "ia2p_pack_geglu": (_I, [_P, _P, _P, _I, _I]),
     "ia2p_attention": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _F, _P, _P, _I, _I, _F]),
     "ia2p_linear_small": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I]),
+    "ia2p_ip_attn_map": (_I, [_P, _P, _I, _P, _I, _P, _I, _I, _I, _I]),
     "ia2p_debug_set_gemm_tile": (None, [_I]),
     "ia2p_debug_gemm_plan": (None, [_I, _I, _I, _I, _I, _P, _P]),
     "ia2p_clip_create": (_I, [C.POINTER(CLIPConfigC), C.POINTER(_P)]),
@@ -104,6 +106,7 @@ SIGNATURES = {
     "ia2p_vae_encode": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _SZ]),
     "ia2p_profile_enable": (_I, [_P, _I]),
     "ia2p_profile_classes": (_I, []),
+    "ia2p_profile_read_region": (_I, [_P, _I, C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ia2p_profile_read": (_I, [_P, _I, C.c_char_p, _I, C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 

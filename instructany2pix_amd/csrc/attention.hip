@@ -277,11 +277,13 @@ __global__ __launch_bounds__(256) void attention_f16_kernel(const half_t* aQ, ha
 
 hipError_t ia2p_launch_attention(const AttnArgs& a, hipStream_t s) {
   dim3 grid(((a.Nq + 127) / 128) * a.heads * a.B);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[64] = {false};     // per device (the attribute is)
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
     hipError_t e = hipFuncSetAttribute((const void*)attention_f16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
   static const int xcd_map = getenv("IA2P_ATTN_XCD") ? atoi(getenv("IA2P_ATTN_XCD")) : 1;     // A/B switch
   AttnArgs b = a;

@@ -52,17 +52,19 @@ static ia2p_status clip_plan(ia2p_clip* c) {
   return IA2P_OK;
 }
 
-static ia2p_status clip_fold(ia2p_clip* c) {
+static ia2p_status clip_fold(ia2p_clip* c, hipStream_t stream = nullptr, bool sync = true) {
   const int H = c->cfg.hidden_size, I = c->cfg.intermediate_size;
   hipError_t e = hipSuccess;
   auto Hp = [&](size_t off) { return c->arena + off; };
   auto Fp = [&](size_t off) { return (float*)(c->arena + off); };
   for (const CLayer& l : c->layers) {
-    if (e == hipSuccess) e = ia2p_launch_fold_ln(Hp(l.wqkv), Hp(l.ln1g), Hp(l.ln1b), Hp(l.bqkv), Hp(l.fqkv), Fp(l.cs1), Fp(l.lb1), 3 * H, H, nullptr);
-    if (e == hipSuccess) e = ia2p_launch_fold_ln(Hp(l.w1), Hp(l.ln2g), Hp(l.ln2b), Hp(l.b1), Hp(l.f1), Fp(l.cs2), Fp(l.lb2), I, H, nullptr);
+    if (e == hipSuccess) e = ia2p_launch_fold_ln(Hp(l.wqkv), Hp(l.ln1g), Hp(l.ln1b), Hp(l.bqkv), Hp(l.fqkv), Fp(l.cs1), Fp(l.lb1), 3 * H, H, stream);
+    if (e == hipSuccess) e = ia2p_launch_fold_ln(Hp(l.w1), Hp(l.ln2g), Hp(l.ln2b), Hp(l.b1), Hp(l.f1), Fp(l.cs2), Fp(l.lb2), I, H, stream);
   }
-  if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
-  return e == hipSuccess ? IA2P_OK : fail(c, IA2P_ERR_HIP, "clip LayerNorm folding: %s", hipGetErrorString(e));
+  if (e == hipSuccess && sync) e = hipStreamSynchronize(stream);
+  if (e != hipSuccess) return fail(c, IA2P_ERR_HIP, "clip LayerNorm folding: %s", hipGetErrorString(e));
+  c->fold_dirty = false;
+  return IA2P_OK;
 }
 
 static ia2p_status clip_run(ia2p_clip* c, const int* ids, const half_t* embeds, int B, int T, half_t* hid2, half_t* last, half_t* pooled) {
@@ -156,6 +158,10 @@ static ia2p_status clip_encode_impl(ia2p_clip* c, void* stream, const int32_t* i
   ia2p_status st = clip_check(c, B, T);
   if (st != IA2P_OK) return st;
   if (!zero_page()) return fail(c, IA2P_ERR_HIP, "cannot allocate zero page");
+  if (c->fold_dirty) {            // a tensor was reloaded after finalize: re-derive the folded LayerNorm copies, stream-ordered
+    st = clip_fold(c, (hipStream_t)stream, false);
+    if (st != IA2P_OK) return st;
+  }
   const uintptr_t base = ((uintptr_t)ws + 255) & ~(uintptr_t)255;
   const size_t usable = ws_bytes - (base - (uintptr_t)ws);
   const int key = (last || pooled) ? 1 : 2;

@@ -75,6 +75,7 @@ struct ia2p_ctx : RunCtx {
   Resnet mid_r0, mid_r1;
   Transformer mid_t;
   int n_attn2 = 0;
+  size_t arena_raw_elems = 0;   // head of the arena: everything a checkpoint provides; [arena_raw_elems, arena_elems) is derived at finalize
 };
 
 ia2p_status fail(RunCtx* c, ia2p_status st, const char* fmt, ...) {
@@ -95,7 +96,11 @@ struct Planner {
   ia2p_ctx* c;
   size_t cur = 0;
   int kv_cursor = 0;
+  // derived data (LayerNorm-folded weight copies, fp32 column sums / biases) goes to a TAIL region [fold_base, fold_base + fold_cur): the
+  // head [0, fold_base) then holds exactly what a checkpoint provides, and a rank that receives only the head re-derives the tail itself
+  size_t fold_base = 0, fold_cur = 0;
   size_t take(size_t elems) { size_t o = cur; cur += (elems + 127) & ~(size_t)127; return o; }
+  size_t take_fold(size_t elems) { size_t o = fold_base + fold_cur; fold_cur += (elems + 127) & ~(size_t)127; return o; }
   void reg(const std::string& key, size_t off, size_t elems, int kind = PK_COPY, int d0 = 0, int d1 = 0, bool optional = false) {
     c->params[key] = Param{off, elems, kind, d0, d1, false, optional};
   }
@@ -146,10 +151,10 @@ struct Planner {
       b.wff1 = take((size_t)8 * ch * ch); reg(q + ".ff.net.0.proj.weight", b.wff1, (size_t)8 * ch * ch, PK_GEGLU_W, 8 * ch, ch);
       b.bff1 = take((size_t)8 * ch); reg(q + ".ff.net.0.proj.bias", b.bff1, (size_t)8 * ch, PK_GEGLU_B, 8 * ch, 1);
       b.wff2 = mat(q + ".ff.net.2.weight", ch, 4 * ch); b.bff2 = vec(q + ".ff.net.2.bias", ch);
-      b.fqkv = take((size_t)3 * ch * ch); b.fq2 = take((size_t)ch * ch); b.fff1 = take((size_t)8 * ch * ch);
-      b.cs1 = take((size_t)2 * 3 * ch); b.lb1 = take((size_t)2 * 3 * ch);         // fp32 arrays: 2 half-slots per value
-      b.cs2 = take((size_t)2 * ch); b.lb2 = take((size_t)2 * ch);
-      b.cs3 = take((size_t)2 * 8 * ch); b.lb3 = take((size_t)2 * 8 * ch);
+      b.fqkv = take_fold((size_t)3 * ch * ch); b.fq2 = take_fold((size_t)ch * ch); b.fff1 = take_fold((size_t)8 * ch * ch);
+      b.cs1 = take_fold((size_t)2 * 3 * ch); b.lb1 = take_fold((size_t)2 * 3 * ch);         // fp32 arrays: 2 half-slots per value
+      b.cs2 = take_fold((size_t)2 * ch); b.lb2 = take_fold((size_t)2 * ch);
+      b.cs3 = take_fold((size_t)2 * 8 * ch); b.lb3 = take_fold((size_t)2 * 8 * ch);
       t.blocks.push_back(b);
     }
     t.wout = mat(p + ".proj_out.weight", ch, ch); t.bout = vec(p + ".proj_out.bias", ch);
@@ -157,7 +162,8 @@ struct Planner {
   }
 };
 
-static ia2p_status build_plan(ia2p_ctx* c) {
+static ia2p_status plan_pass(ia2p_ctx* c, size_t fold_base, size_t* raw_elems, size_t* fold_elems) {
+  c->params.clear(); c->down.clear(); c->up.clear();
   const ia2p_unet_config& g = c->cfg;
   const int n = g.n_blocks;
   if (n < 1 || n > IA2P_MAX_BLOCKS) return fail(c, IA2P_ERR_INVALID, "n_blocks %d out of range", n);
@@ -179,6 +185,7 @@ static ia2p_status build_plan(ia2p_ctx* c) {
   if (pooled <= 0) return fail(c, IA2P_ERR_SHAPE, "projection_class_embeddings_input_dim smaller than the time ids");
 
   Planner P{c};
+  P.fold_base = fold_base;
   const int T = g.time_embed_dim, ctx = g.cross_attention_dim;
   const int* ch = g.block_out_channels;
   c->conv_in_w = P.take((size_t)ch[0] * g.in_channels * 9); P.reg("conv_in.weight", c->conv_in_w, (size_t)ch[0] * g.in_channels * 9);
@@ -273,7 +280,18 @@ static ia2p_status build_plan(ia2p_ctx* c) {
   };
   add_ip(ipslots_down); add_ip(ipslots_up); add_ip(ipslots_mid);
   c->n_attn2 = idx;
-  c->arena_elems = P.cur;
+  *raw_elems = P.cur; *fold_elems = P.fold_cur;
+  return IA2P_OK;
+}
+// two passes of the same deterministic walk: the first measures the head (checkpoint data), the second places the derived tail behind it
+static ia2p_status build_plan(ia2p_ctx* c) {
+  size_t raw = 0, fold = 0;
+  ia2p_status st = plan_pass(c, 0, &raw, &fold);
+  if (st != IA2P_OK) return st;
+  st = plan_pass(c, raw, &raw, &fold);
+  if (st != IA2P_OK) return st;
+  c->arena_raw_elems = raw;
+  c->arena_elems = raw + fold;
   return IA2P_OK;
 }
 
@@ -359,6 +377,11 @@ static void run_gemm(RunCtx* c, GemmArgs& a, bool conv, const char* what, double
   if (c->tuning && !c->dry && !c->failed) tune_site(c, a, conv);
   const GemmPlan pl = ia2p_gemm_plan(a.M, a.N, a.K, conv, a.geglu != 0);
   if (pl.variant < 0 || pl.variant >= IA2P_GEMM_NVARIANT) { fail(c, IA2P_ERR_INVALID, "%s: tile variant %d out of range", what, pl.variant); return; }
+  if (c->tuning && !c->dry && pl.splitk > 1 && (size_t)pl.splitk * a.M * a.N * sizeof(float) > c->tune_slab_bytes) {
+    fail(c, IA2P_ERR_NOMEM, "%s: plan (variant %d, K split %d) needs %zu bytes of slabs, the autotune scratch holds %zu", what, pl.variant, pl.splitk,
+         (size_t)pl.splitk * a.M * a.N * sizeof(float), c->tune_slab_bytes);
+    return;
+  }
   if (stat_slots) *stat_slots = pl.splitk > 1 ? 1 : (a.N + IA2P_GEMM_TILES[pl.variant].bn - 1) / IA2P_GEMM_TILES[pl.variant].bn;
   T2 slab{(size_t)-1, nullptr};
   if (pl.splitk > 1) {
@@ -425,8 +448,11 @@ struct Fwd {
   T2 kv_text, kv_ip;   // [B*Lt, kv_rows], [B*Li, kv_rows]
 };
 
+struct RegionScope { RunCtx* c; int prev; RegionScope(RunCtx* c_, int r) : c(c_), prev(c_->region) { c->region = r; } ~RegionScope() { c->region = prev; } };
+
 static T2 run_resnet(Fwd& f, const Resnet& r, T2 x, int H, int Wd) {
   ia2p_ctx* c = f.c;
+  RegionScope rs(c, PR_CONV_BLOCK);
   const int HW = H * Wd, M = f.B * HW;
   T2 n1 = wsalloc(c, (size_t)M * r.cin);
   op_gn(c, x.p, n1.p, r.n1g, r.n1b, f.B, HW, r.cin, c->cfg.norm_eps, 1, f.gn_partial);
@@ -459,6 +485,7 @@ static void op_attn(RunCtx* c, const AttnArgs& a) {
 
 static T2 run_transformer(Fwd& f, const Transformer& t, T2 x, int H, int Wd) {
   ia2p_ctx* c = f.c;
+  RegionScope rs(c, PR_TRANSFORMER);
   const int HW = H * Wd, M = f.B * HW, C = t.c;
   const int ctxd = c->cfg.cross_attention_dim;
   const int Lt = c->ip_enabled ? f.L - c->ip_tokens : f.L;
@@ -541,6 +568,7 @@ static T2 run_transformer(Fwd& f, const Transformer& t, T2 x, int H, int Wd) {
 // context K/V of every cross-attention layer in one GEMM each (text rows / image-token rows of ctx); per layer: reference
 // attention_processor.py:358-359 (to_k/to_v) and :379-380 (to_k_ip/to_v_ip). kv_text: [B*Lt, kv_rows], kv_ip: [B*Li, kv_rows].
 static void project_context(ia2p_ctx* c, const half_t* context, int L, int B, half_t* kv_text, half_t* kv_ip) {
+  RegionScope rs(c, PR_TRANSFORMER);
   const int ctxd = c->cfg.cross_attention_dim;
   const int Lt = c->ip_enabled ? L - c->ip_tokens : L, Li = c->ip_enabled ? c->ip_tokens : 0;
   op_gemm(c, context, ctxd, W_(c, c->kv_text_base), nullptr, nullptr, 0, kv_text, c->kv_rows, B * Lt, c->kv_rows, ctxd, 0, Lt, L, 0);
@@ -598,6 +626,7 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
   }
 
   // ---- down path
+  RegionScope rs_conv(c, PR_CONV_BLOCK);      // from here on everything outside run_transformer belongs to the conv blocks
   int H = h, Wd = w;
   std::vector<T2> skips;
   std::vector<int> skip_c;
@@ -702,6 +731,7 @@ ia2p_status rc_load_tensor(RunCtx* c, const char* key, const void* src, const in
   }
   if (e != hipSuccess) return fail(c, IA2P_ERR_HIP, "load '%s': %s", key, hipGetErrorString(e));
   p.loaded = true;
+  c->fold_dirty = true;     // data derived from the parameters at finalize (LayerNorm folds) is stale until the owner re-derives it
   return IA2P_OK;
 }
 ia2p_status rc_finalize(RunCtx* c, const char* what) {
@@ -715,9 +745,10 @@ ia2p_status rc_finalize(RunCtx* c, const char* what) {
   c->finalized = true;
   return IA2P_OK;
 }
-ia2p_status rc_adopt(RunCtx* c) {
+ia2p_status rc_adopt(RunCtx* c, bool with_optional) {
   if (!c || !c->arena) return fail(c, IA2P_ERR_STATE, "adopt_arena before bind_arena");
-  for (auto& kv : c->params) kv.second.loaded = true;
+  for (auto& kv : c->params)
+    if (with_optional || !kv.second.optional) kv.second.loaded = true;
   c->finalized = true;
   return IA2P_OK;
 }
@@ -754,7 +785,7 @@ ia2p_status ia2p_load_tensor(ia2p_ctx* c, const char* key, const void* src, cons
   return rc_load_tensor(c, key, src, shape, ndim, stream);
 }
 // LayerNorm folding pass over every transformer block (idempotent: reads the raw tensors, writes the folded copies)
-static ia2p_status fold_all(ia2p_ctx* c) {
+static ia2p_status fold_all(ia2p_ctx* c, hipStream_t stream, bool sync) {
   std::vector<const Transformer*> ts;
   for (const Stage& s : c->down) for (const Transformer& t : s.att) ts.push_back(&t);
   ts.push_back(&c->mid_t);
@@ -765,18 +796,26 @@ static ia2p_status fold_all(ia2p_ctx* c) {
   for (const Transformer* t : ts)
     for (const TBlock& b : t->blocks) {
       const int C = t->c;
-      if (e == hipSuccess) e = ia2p_launch_fold_ln(H(b.wqkv), H(b.ln1g), H(b.ln1b), nullptr, H(b.fqkv), F(b.cs1), F(b.lb1), 3 * C, C, nullptr);
-      if (e == hipSuccess) e = ia2p_launch_fold_ln(H(b.wq2), H(b.ln2g), H(b.ln2b), nullptr, H(b.fq2), F(b.cs2), F(b.lb2), C, C, nullptr);
-      if (e == hipSuccess) e = ia2p_launch_fold_ln(H(b.wff1), H(b.ln3g), H(b.ln3b), H(b.bff1), H(b.fff1), F(b.cs3), F(b.lb3), 8 * C, C, nullptr);
+      if (e == hipSuccess) e = ia2p_launch_fold_ln(H(b.wqkv), H(b.ln1g), H(b.ln1b), nullptr, H(b.fqkv), F(b.cs1), F(b.lb1), 3 * C, C, stream);
+      if (e == hipSuccess) e = ia2p_launch_fold_ln(H(b.wq2), H(b.ln2g), H(b.ln2b), nullptr, H(b.fq2), F(b.cs2), F(b.lb2), C, C, stream);
+      if (e == hipSuccess) e = ia2p_launch_fold_ln(H(b.wff1), H(b.ln3g), H(b.ln3b), H(b.bff1), H(b.fff1), F(b.cs3), F(b.lb3), 8 * C, C, stream);
     }
-  if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
-  return e == hipSuccess ? IA2P_OK : fail(c, IA2P_ERR_HIP, "LayerNorm folding: %s", hipGetErrorString(e));
+  if (e == hipSuccess && sync) e = hipStreamSynchronize(stream);
+  if (e != hipSuccess) return fail(c, IA2P_ERR_HIP, "LayerNorm folding: %s", hipGetErrorString(e));
+  c->fold_dirty = false;
+  return IA2P_OK;
 }
 ia2p_status ia2p_finalize_weights(ia2p_ctx* c) {
   const ia2p_status st = rc_finalize(c, "UNet");
-  return st == IA2P_OK ? fold_all(c) : st;
+  return st == IA2P_OK ? fold_all(c, nullptr, true) : st;
 }
-ia2p_status ia2p_adopt_arena(ia2p_ctx* c) { return rc_adopt(c); }
+size_t ia2p_arena_raw_bytes(ia2p_ctx* c) { return c ? c->arena_raw_elems * sizeof(half_t) : 0; }
+// The head of the arena ([0, ia2p_arena_raw_bytes): parameters as loaded) was filled elsewhere -- an RCCL broadcast from the rank that read the
+// checkpoint; the derived tail (LayerNorm folds) is recomputed here from it, so 2.5 GB of it never cross xGMI.
+ia2p_status ia2p_adopt_arena(ia2p_ctx* c, int with_ip_adapter) {
+  const ia2p_status st = rc_adopt(c, with_ip_adapter != 0);
+  return st == IA2P_OK ? fold_all(c, nullptr, true) : st;
+}
 
 ia2p_status ia2p_set_ip_adapter(ia2p_ctx* c, int enabled, int num_tokens, float scale) {
   if (!c) return IA2P_ERR_INVALID;
@@ -815,6 +854,10 @@ static ia2p_status unet_forward_impl(ia2p_ctx* c, void* stream, const void* samp
   ia2p_status st = check_fwd_shape(c, B, h, w, L);
   if (st != IA2P_OK) return st;
   if (!zero_page()) return fail(c, IA2P_ERR_HIP, "cannot allocate zero page");
+  if (c->fold_dirty) {            // a tensor was reloaded after finalize (hot swap, strict=False load): re-derive the folds, stream-ordered
+    st = fold_all(c, (hipStream_t)stream, false);
+    if (st != IA2P_OK) return st;
+  }
   const uintptr_t base = ((uintptr_t)ws + 255) & ~(uintptr_t)255;
   const size_t usable = ws_bytes - (base - (uintptr_t)ws);
   const int key = (c->ip_enabled ? 1 + c->ip_tokens : 0) + (kv ? 1000 : 0);
@@ -855,6 +898,10 @@ ia2p_status ia2p_project_context(ia2p_ctx* c, void* stream, const void* context,
   if (!need) return fail(c, IA2P_ERR_SHAPE, "project_context: B=%d L=%d", B, L);
   if (kv_bytes < need) return fail(c, IA2P_ERR_NOMEM, "project_context: kv buffer holds %zu bytes, needs %zu", kv_bytes, need);
   if (!zero_page()) return fail(c, IA2P_ERR_HIP, "cannot allocate zero page");
+  if (c->fold_dirty) {
+    const ia2p_status fs = fold_all(c, (hipStream_t)stream, false);
+    if (fs != IA2P_OK) return fs;
+  }
   const uintptr_t base = ((uintptr_t)ws + 255) & ~(uintptr_t)255;
   const bool pf = c->prefetch;
   c->prefetch = false;               // a stand-alone call: no "next launch" to stream weights for
@@ -1034,6 +1081,12 @@ ia2p_status ia2p_attention(void* stream, const void* Q, int ldq, void* O, int ld
   hipError_t e = ia2p_launch_attention(a, (hipStream_t)stream);
   RET_HIP(e, "attention");
 }
+ia2p_status ia2p_ip_attn_map(void* stream, const void* Q, int ldq, const void* Kip, int ldk, void* out, int B, int heads, int Nq, int ntok) {
+  if (!Q || !Kip || !out || B < 1 || heads < 1 || Nq < 1) return fail(nullptr, IA2P_ERR_INVALID, "ip_attn_map: bad argument");
+  if (ntok < 1 || ntok > 16 || ldq % 8 || ldq < heads * 64 || ldk < heads * 64) return fail(nullptr, IA2P_ERR_SHAPE, "ip_attn_map: ntok=%d (1..16), ldq=%d (mult of 8), ldk=%d", ntok, ldq, ldk);
+  hipError_t e = ia2p_launch_ip_attn_map((const half_t*)Q, ldq, (const half_t*)Kip, ldk, (half_t*)out, B, heads, Nq, ntok, (hipStream_t)stream);
+  RET_HIP(e, "ip_attn_map");
+}
 ia2p_status ia2p_linear_small(void* stream, const void* X, const void* W, const void* bias, void* out, int M, int N, int K, int silu_in, int silu_out) {
   if (!X || !W || !out) return fail(nullptr, IA2P_ERR_INVALID, "linear_small: null argument");
   if (M > 16 || K % 8) return fail(nullptr, IA2P_ERR_SHAPE, "linear_small: M=%d (<=16) K=%d (mult of 8)", M, K);
@@ -1046,20 +1099,35 @@ ia2p_status ia2p_profile_enable(ia2p_ctx* c, int on) {
   for (auto& r : c->recs) { c->evpool.push_back(r.e0); c->evpool.push_back(r.e1); }
   c->recs.clear();
   for (int k = 0; k < PK_NCLASS; ++k) { c->p_ms[k] = c->p_fl[k] = c->p_by[k] = 0; c->p_n[k] = 0; }
+  for (int k = 0; k < PR_NREGION; ++k) { c->r_ms[k] = c->r_fl[k] = c->r_by[k] = 0; c->r_n[k] = 0; }
   c->prof = on != 0;
   return IA2P_OK;
 }
 int ia2p_profile_classes(void) { return PK_NCLASS; }
-ia2p_status ia2p_profile_read(ia2p_ctx* c, int k, char* name, int name_len, int64_t* launches, double* ms, double* flops, double* bytes) {
-  if (!c || k < 0 || k >= PK_NCLASS) return IA2P_ERR_INVALID;
+static void prof_fold(ia2p_ctx* c) {
   for (auto& r : c->recs) {     // fold finished records (synchronises on their stop events)
     float t = 0.f;
     (void)hipEventSynchronize(r.e1);
     (void)hipEventElapsedTime(&t, r.e0, r.e1);
     c->p_ms[r.k] += t; c->p_fl[r.k] += r.flops; c->p_by[r.k] += r.bytes; c->p_n[r.k] += 1;
+    const int g = r.region >= 0 && r.region < PR_NREGION ? r.region : PR_OTHER;
+    c->r_ms[g] += t; c->r_fl[g] += r.flops; c->r_by[g] += r.bytes; c->r_n[g] += 1;
     c->evpool.push_back(r.e0); c->evpool.push_back(r.e1);
   }
   c->recs.clear();
+}
+ia2p_status ia2p_profile_read_region(ia2p_ctx* c, int region, int64_t* launches, double* ms, double* flops, double* bytes) {
+  if (!c || region < 0 || region >= PR_NREGION) return IA2P_ERR_INVALID;
+  prof_fold(c);
+  if (launches) *launches = c->r_n[region];
+  if (ms) *ms = c->r_ms[region];
+  if (flops) *flops = c->r_fl[region];
+  if (bytes) *bytes = c->r_by[region];
+  return IA2P_OK;
+}
+ia2p_status ia2p_profile_read(ia2p_ctx* c, int k, char* name, int name_len, int64_t* launches, double* ms, double* flops, double* bytes) {
+  if (!c || k < 0 || k >= PK_NCLASS) return IA2P_ERR_INVALID;
+  prof_fold(c);
   if (name && name_len > 0) { strncpy(name, prof_name(k), name_len - 1); name[name_len - 1] = 0; }
   if (launches) *launches = c->p_n[k];
   if (ms) *ms = c->p_ms[k];

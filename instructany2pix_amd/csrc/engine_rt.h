@@ -49,6 +49,7 @@ hipError_t ia2p_launch_prior_step(const float* smp, const half_t* o_c, const hal
 hipError_t ia2p_launch_causal_attention_small(const half_t* qkv, half_t* out, int B, int T, int heads, hipStream_t s);
 hipError_t ia2p_launch_clip_pool(const int* ids, const half_t* x, const half_t* gamma, const half_t* beta, half_t* out, int B, int T, int H, int eos_id,
                                  float eps, hipStream_t s);
+hipError_t ia2p_launch_ip_attn_map(const half_t* Q, int ldq, const half_t* Kip, int ldk, half_t* out, int B, int heads, int Nq, int ntok, hipStream_t s);
 hipError_t ia2p_launch_touch(const void* p, size_t bytes, unsigned* sink, hipStream_t s);
 hipError_t ia2p_launch_pack_conv(const half_t* src, half_t* dst, int Co, int Ci, hipStream_t s);
 hipError_t ia2p_launch_pack_geglu(const half_t* src, half_t* dst, int rows, int rowlen, hipStream_t s);
@@ -102,7 +103,9 @@ struct Arena {            // deterministic first-fit allocator over [0, cap)
   }
 };
 
-struct ProfRec { hipEvent_t e0, e1; int k; double flops, bytes; };
+struct ProfRec { hipEvent_t e0, e1; int k; double flops, bytes; int region; };
+// profile regions of a UNet evaluation: what part of the network a launch belongs to (bench.py: conv-block roofline)
+enum { PR_OTHER = 0, PR_CONV_BLOCK = 1, PR_TRANSFORMER = 2, PR_NREGION };
 // profile classes = device kernel names as rocprofv3 prints them (template arguments included)
 enum { PK_GEMM0 = 0, PK_CONV0 = 16, PK_ATTN = 32, PK_GN, PK_LN, PK_EMBED, PK_CONV_IN, PK_CONV_OUT, PK_CONCAT, PK_REDUCE, PK_NCLASS };
 const char* prof_name(int k);
@@ -140,10 +143,15 @@ struct RunCtx {
   std::vector<hipEvent_t> evpool;
   double p_ms[PK_NCLASS], p_fl[PK_NCLASS], p_by[PK_NCLASS];
   int64_t p_n[PK_NCLASS];
+  int region = PR_OTHER;     // region the executor is in (tags the profile records)
+  double r_ms[PR_NREGION], r_fl[PR_NREGION], r_by[PR_NREGION];
+  int64_t r_n[PR_NREGION];
+  bool fold_dirty = false;   // a LayerNorm-fold source tensor was (re)loaded after the last fold: re-fold before the next forward
   RunCtx() {
     if (const char* e = getenv("IA2P_PREFETCH")) prefetch = atoi(e) != 0;
     if (const char* e = getenv("IA2P_LN_FOLD")) ln_fold = atoi(e) != 0;
     for (int k = 0; k < PK_NCLASS; ++k) { p_ms[k] = p_fl[k] = p_by[k] = 0; p_n[k] = 0; }
+    for (int k = 0; k < PR_NREGION; ++k) { r_ms[k] = r_fl[k] = r_by[k] = 0; r_n[k] = 0; }
   }
   ~RunCtx() {
     for (auto& r : recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
@@ -163,7 +171,7 @@ struct ProfScope {
   ProfScope(RunCtx* c_, int k_, double fl_, double by_) : c(c_), k(k_), fl(fl_), by(by_), on(c_ && c_->prof && !c_->dry) {
     if (on) { e0 = get_event(c); e1 = get_event(c); (void)hipEventRecord(e0, c->stream); }
   }
-  ~ProfScope() { if (on) { (void)hipEventRecord(e1, c->stream); c->recs.push_back(ProfRec{e0, e1, k, fl, by}); } }
+  ~ProfScope() { if (on) { (void)hipEventRecord(e1, c->stream); c->recs.push_back(ProfRec{e0, e1, k, fl, by, c->region}); } }
   void set_class(int kk) { k = kk; }
 };
 #define CHECK_LAUNCH(c, expr, what)                                                             \
@@ -189,4 +197,4 @@ void op_ln(RunCtx* c, const half_t* x, half_t* y, size_t g, size_t b, int M, int
 ia2p_status rc_bind_arena(RunCtx* c, void* dev, size_t bytes);
 ia2p_status rc_load_tensor(RunCtx* c, const char* key, const void* src, const int64_t* shape, int ndim, void* stream);
 ia2p_status rc_finalize(RunCtx* c, const char* what);
-ia2p_status rc_adopt(RunCtx* c);
+ia2p_status rc_adopt(RunCtx* c, bool with_optional = true);

@@ -483,11 +483,14 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const half_t* hA
 template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int BK = 64, int PP = 0>
 static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
   constexpr int smem = NSTAGE * (BM + BN) * 2 * BK;
-  static bool attr_set = false;
-  if (!attr_set) {
+  // the attribute is per DEVICE: one flag per device id (several contexts on several GPUs in one process)
+  static bool attr_set[64] = {false};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
     hipError_t e = hipFuncSetAttribute((const void*)gemm_f16_kernel<BM, BN, NSTAGE, CONV, WGM, BK, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   GemmArgs b = a;

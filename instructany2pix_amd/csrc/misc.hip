@@ -452,6 +452,42 @@ __global__ void conv1x1_nchw_kernel(const half_t* x, const half_t* w /*[Co][Ci]*
   }
 }
 
+
+// ---- IPAttnProcessor2_0's `attn_map` side effect (reference attention_processor.py:390-391):
+//      attn_map[b,h,q,t] = sum_d Q[b,q,h*64+d] * softmax_t(K_ip[b,t,h*64+d])  -- the softmax binds to ip_key^T (over the TOKEN axis, no 1/sqrt(d))
+//      before the matmul. HBM-bound: Q once in (128 B per row and head), ntok halves out. One thread per (b, head, query).
+__global__ __launch_bounds__(256) void ip_attn_map_kernel(const half_t* Q, int ldq, const half_t* Kip, int ldk, half_t* out, int heads, int Nq, int ntok) {
+  __shared__ float S[64 * 16];           // [d][t]
+  const int b = blockIdx.z, hd = blockIdx.y;
+  if (threadIdx.x < 64) {
+    const int d = threadIdx.x;
+    float v[16] = {}, mx = -3.0e38f, sum = 0.f;
+    for (int t = 0; t < ntok; ++t) { v[t] = (float)Kip[((size_t)b * ntok + t) * ldk + hd * 64 + d]; mx = fmaxf(mx, v[t]); }
+    for (int t = 0; t < ntok; ++t) { v[t] = __expf(v[t] - mx); sum += v[t]; }
+    const float inv = 1.f / sum;
+    for (int t = 0; t < 16; ++t) S[d * 16 + t] = t < ntok ? v[t] * inv : 0.f;
+  }
+  __syncthreads();
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= Nq) return;
+  const half_t* qp = Q + ((size_t)b * Nq + q) * ldq + hd * 64;
+  float acc[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) acc[t] = 0.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const h8 v = *(const h8*)(qp + c * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float x = (float)v[j];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) acc[t] = fmaf(x, S[(c * 8 + j) * 16 + t], acc[t]);     // columns t >= ntok of S are zero
+    }
+  }
+  half_t* op = out + (((size_t)b * heads + hd) * Nq + q) * ntok;
+  for (int t = 0; t < ntok; ++t) op[t] = (half_t)acc[t];
+}
+
 // ---- host launchers -------------------------------------------------------------------------------------------------------
 static inline int grid_for(long n, int block) { long g = (n + block - 1) / block; return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
 
@@ -548,5 +584,10 @@ hipError_t ia2p_launch_softmax_rows(half_t* x, long ld, int rows, int n, float s
 hipError_t ia2p_launch_conv1x1_nchw(const half_t* x, const half_t* w, const half_t* bias, half_t* y, int B, int Ci, int Co, long HW, hipStream_t s) {
   if (Ci > 8 || Co > 8) return hipErrorInvalidValue;
   hipLaunchKernelGGL(conv1x1_nchw_kernel, dim3(grid_for((long)B * HW, 256)), dim3(256), 0, s, x, w, bias, y, B, Ci, Co, HW);
+  return hipGetLastError();
+}
+hipError_t ia2p_launch_ip_attn_map(const half_t* Q, int ldq, const half_t* Kip, int ldk, half_t* out, int B, int heads, int Nq, int ntok, hipStream_t s) {
+  if (ntok < 1 || ntok > 16 || ldq % 8) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(ip_attn_map_kernel, dim3((Nq + 255) / 256, heads, B), dim3(256), 0, s, Q, ldq, Kip, ldk, out, heads, Nq, ntok);
   return hipGetLastError();
 }

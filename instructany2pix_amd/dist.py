@@ -4,7 +4,8 @@ The reference is single-process, single-GPU (instructany2pix/pipeline.py:124,131
 addition. One process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm, "gloo" in
 CPU tests). The path has NO per-step exchange: every request's trajectory depends only on its own latents and
 conditioning (GroupNorm / LayerNorm / attention are per-sample, CFG pairs stay on one GPU). The only collective
-is the one-time broadcast of the flat weight arena (UNet + IP-Adapter with the LayerNorm-folded weight copies, ~8.3 GB fp16) from rank 0 over xGMI,
+is the one-time broadcast of the head of the flat weight arena (UNet + IP-Adapter parameters as loaded, ~5.8 GB fp16; the LayerNorm-folded
+copies behind it are re-derived on every rank) from rank 0 over xGMI,
 plus an optional all-gather of the final latents (64 KB per rank at cfg 4).
 """
 from __future__ import annotations
@@ -54,11 +55,12 @@ def broadcast_flat(buf: torch.Tensor, src: int = 0, chunk_bytes: int = 1 << 30) 
     return buf
 
 
-def broadcast_weights(unet, src: int = 0):
-    """Rank `src` holds loaded weights; everyone else receives the arena bytes and adopts them."""
-    broadcast_flat(unet.arena, src)
+def broadcast_weights(unet, src: int = 0, with_ip_adapter: bool = True):
+    """Rank `src` holds loaded weights; everyone else receives the HEAD of the arena (the parameters as loaded: 5.8 GB for SDXL-base +
+    IP-Adapter, six messages) and derives the LayerNorm-folded tail locally (`ia2p_adopt_arena`), which keeps 2.5 GB off xGMI."""
+    broadcast_flat(unet.arena_raw, src)
     if dist.is_initialized() and dist.get_rank() != src:
-        unet.adopt_arena()
+        unet.adopt_arena(with_ip_adapter)
 
 
 def barrier():

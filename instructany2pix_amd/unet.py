@@ -89,9 +89,16 @@ class HipUNet2DConditionModel:
         _ffi.check(self._lib.ia2p_load_tensor(self._ctx, key.encode(), _ffi.ptr(t), shape, t.ndim, _ffi.current_stream()), self._ctx)
         torch.cuda.current_stream().synchronize()      # `t` may be a temporary
 
-    def adopt_arena(self):
-        """Arena bytes were produced elsewhere (RCCL broadcast from rank 0): mark parameters present."""
-        _ffi.check(self._lib.ia2p_adopt_arena(self._ctx), self._ctx)
+    @property
+    def arena_raw(self) -> torch.Tensor:
+        """Head of the arena: the parameters as loaded (5.8 GB for SDXL-base + IP-Adapter). The tail behind it holds data derived at
+        finalize (LayerNorm-folded weight copies, 2.5 GB) that every rank can recompute: only this view needs to travel."""
+        return self.arena[: self._lib.ia2p_arena_raw_bytes(self._ctx)]
+
+    def adopt_arena(self, with_ip_adapter: bool = True):
+        """The arena HEAD was produced elsewhere (RCCL broadcast of `arena_raw` from rank 0): mark parameters present and derive the
+        tail (LayerNorm folds) locally with the same kernel rank 0 used, so ranks hold bit-identical arenas."""
+        _ffi.check(self._lib.ia2p_adopt_arena(self._ctx, int(with_ip_adapter)), self._ctx)
         self._weights_gen += 1
 
     # ---- operator-plugin API (reference ip_adapter.py:120-154) ----------------------------------------------------
@@ -235,6 +242,16 @@ class HipUNet2DConditionModel:
     # ---- per-kernel-class timing for the roofline leg of bench.py ------------------------------------------------
     def profile(self, on: bool):
         _ffi.check(self._lib.ia2p_profile_enable(self._ctx, int(on)), self._ctx)
+
+    def profile_read_regions(self):
+        """{"other" | "conv_blocks" | "transformer": dict(launches, ms, flops, bytes)} summed since profile(True): which part of the network
+        the launches belonged to (conv blocks = conv_in/out, ResnetBlock2D incl. GroupNorm+SiLU and shortcuts, resample convs, concat)."""
+        res = {}
+        for r, name in enumerate(("other", "conv_blocks", "transformer")):
+            n, ms, fl, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
+            _ffi.check(self._lib.ia2p_profile_read_region(self._ctx, r, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)), self._ctx)
+            res[name] = dict(launches=n.value, ms=ms.value, flops=fl.value, bytes=by.value)
+        return res
 
     def profile_read(self):
         """{kernel name: dict(launches, ms, flops, bytes)} summed since profile(True)."""

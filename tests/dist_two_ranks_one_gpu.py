@@ -1,4 +1,5 @@
-"""Two ranks sharing ONE GPU (gloo transport): rank 0 loads weights, the flat arena is broadcast, rank 1 adopts it;
+"""Two ranks sharing ONE GPU (gloo transport): rank 0 loads weights, the HEAD of the flat arena (parameters as loaded) is broadcast, rank 1
+adopts it and derives the LayerNorm-folded tail locally -- its whole arena must then equal rank 0's bit for bit;
 rank 0 measures kernel plans and broadcasts the table;
 both evaluate their own shard of a request batch and the gathered result must equal the single-process result
 bit for bit. Launched by tests/test_unet_gpu.py::test_two_ranks_broadcast_and_shard through torch.distributed.run."""
@@ -22,12 +23,19 @@ ipsd = synthetic_state_dict(ip_adapter_specs(cfg, 64)["ip_adapter"], seed=7)
 if rank == 0:
     unet.load_state_dict(synthetic_state_dict(unet_param_specs(cfg), seed=7))
     unet.load_ip_adapter_weights(ipsd, scale=0.9, num_tokens=4)
-host = unet.arena.cpu()                      # gloo moves host memory; RCCL would broadcast unet.arena itself
+raw = unet.arena_raw
+assert 0 < raw.numel() < unet.arena.numel()   # the derived tail (LayerNorm folds) is not part of what travels
+host = raw.cpu()                             # gloo moves host memory; RCCL broadcasts unet.arena_raw itself (tests/dist_nccl_ranks.py)
 D.broadcast_flat(host, src=0, chunk_bytes=16 << 20)
 if rank != 0:
-    unet.arena.copy_(host)
-    unet.adopt_arena()
+    assert not unet.arena[raw.numel():].any()
+    raw.copy_(host)
+    unet.adopt_arena(with_ip_adapter=True)   # marks the parameters present and runs the fold kernels on this rank
     unet.load_ip_adapter_weights([], scale=0.9, num_tokens=4)
+torch.cuda.synchronize()
+v = unet.arena.view(torch.int16).to(torch.int64)
+sums = D.gather_batches(torch.stack([v.sum(), (v * (torch.arange(v.numel(), device=dev) % 65521)).sum()]).cpu()[None])
+assert torch.equal(sums[0], sums[1]), "rank 1's locally folded arena differs from rank 0's"
 g = torch.Generator().manual_seed(3)
 B = 4
 x = torch.randn(B, 4, 16, 16, generator=g).half().to(dev)

@@ -1,0 +1,149 @@
+"""Full-size parity at every single-GPU BASELINE configuration: the HIP path (through the C ABI) against the CPU oracle with the full
+SDXL-base architecture (2.567 G parameters) + IP-Adapter, same seeded fp16-representable weights, same seeded inputs
+(bench.make_inputs: SURVEY.md §8d seeds).
+
+  cfg 3  (configs[2])  latent [8,4,64,64], 81-token context (77 text + 4 image tokens)  -> every one of the 8 requests vs the oracle
+  cfg 2  (configs[1])  latent [1,4,64,64], 77-token text-only context                    -> one evaluation + a 20-step DDIM trajectory
+  cfg 5  (configs[4])  latent [4,4,96,96] with CFG (B_eff = 8), 81-token contexts        -> 2 guided steps, 2 of the 4 requests
+Reference call sites: instructany2pix/ddim/pnp_pipeline.py:251-275 (inversion loop), ddim/sdxl_pipeline.py:824-857 (guided sampling
+loop), diffusion/ip_adapter/ip_adapter.py:289-356 (context assembly).
+
+Tolerances (fp16 activations against the fp32 oracle): one UNet evaluation rel-L2 <= 5e-3 and
+max|d| <= 2e-2 * max|ref|; trajectories rel-L2 <= 3e-2 and cosine >= 0.999.
+"""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def rel_l2(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / b.norm())
+
+
+def traj_metrics(a, b):
+    a, b = a.float().cpu().flatten(), b.float().cpu().flatten()
+    return float((a - b).norm() / b.norm()), float(torch.dot(a, b) / (a.norm() * b.norm()))
+
+
+@pytest.fixture(scope="module")
+def full():
+    """(cfg, HIP UNet, oracle UNet, the oracle's IP processors) -- built once: 8.3 GB arena on the GPU, 11.7 GB of fp32 weights on the host"""
+    import oracle
+    from instructany2pix_amd.config import sdxl_base
+    from instructany2pix_amd.unet import HipUNet2DConditionModel
+    from instructany2pix_amd.weights import unet_param_specs, ip_adapter_specs, iter_synthetic
+    cfg = sdxl_base()
+    us, ips = unet_param_specs(cfg), ip_adapter_specs(cfg)["ip_adapter"]
+    hip = HipUNet2DConditionModel(cfg, DEV)
+    hip.load_state_dict(iter_synthetic(us, 7, DEV, torch.float16))
+    hip.load_ip_adapter_weights(iter_synthetic(ips, 7, DEV, torch.float16), scale=1.0, num_tokens=4)
+    host = lambda it: ((k, v.cpu()) for k, v in it)
+    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    ref = oracle.build_unet_fast(cfg, host(iter_synthetic(us, 7, DEV, torch.float16)), host(iter_synthetic(ips, 7, DEV, torch.float16)), ip_scale=1.0)
+    ip_procs = dict(ref.attn_processors)
+    return cfg, hip, ref, ip_procs, oracle
+
+
+def _set_ip(hip, ref, ip_procs, scale):
+    hip.load_ip_adapter_weights([], scale=scale, num_tokens=4)          # descriptors only: the weights are in the arena
+    ref.set_attn_processor(ip_procs)
+    for p in ip_procs.values():
+        if hasattr(p, "scale"):
+            p.scale = scale
+
+
+def _set_text_only(hip, ref, oracle):
+    from instructany2pix_amd.attention_processor import AttnProcessor2_0
+    hip.set_attn_processor(AttnProcessor2_0())
+    ref.set_attn_processor(oracle.AttnProcessor2_0Ref())
+
+
+def test_cfg3_batch8_every_request_vs_oracle(full):
+    """BASELINE configs[2] at full size: each of the 8 requests of the bench workload against the oracle."""
+    from bench import make_inputs
+    cfg, hip, ref, ip_procs, oracle = full
+    _set_ip(hip, ref, ip_procs, 1.0)
+    lat, ctx, pooled, tid = make_inputs(cfg, 8, 64, 81, DEV, cfg_id=3)
+    t = 981                                                              # first step of the 50-step schedule
+    out = hip(lat, t, encoder_hidden_states=ctx, added_cond_kwargs=dict(text_embeds=pooled, time_ids=tid))[0]
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    with torch.no_grad():
+        want = ref(lat.float().cpu(), t, ctx.float().cpu(), added_cond_kwargs=dict(text_embeds=pooled.float().cpu(), time_ids=tid.float().cpu()))[0]
+    for r in range(8):
+        e = rel_l2(out[r], want[r])
+        assert e < 5e-3, (r, e)
+        assert float((out[r].float().cpu() - want[r]).abs().max()) < 2e-2 * float(want[r].abs().max()), r
+
+
+def test_cfg2_batch1_text_only_forward_and_20_step_trajectory(full):
+    """BASELINE configs[1]'s exact workload: B = 1, 64x64 latent, 77-token text-only context (AttnProcessor2_0 on every layer):
+    one evaluation, then 20 steps of the 50-step DDIM sampling schedule's loop (no guidance) against the oracle loop."""
+    from bench import make_inputs
+    from instructany2pix_amd.ddim import StableDiffusionXLPipeline
+    cfg, hip, ref, ip_procs, oracle = full
+    _set_text_only(hip, ref, oracle)
+    lat, ctx, pooled, tid = make_inputs(cfg, 1, 64, 77, DEV, cfg_id=2)
+    added_ref = dict(text_embeds=pooled.float().cpu(), time_ids=tid.float().cpu())
+    out = hip(lat, 981, encoder_hidden_states=ctx, added_cond_kwargs=dict(text_embeds=pooled, time_ids=tid))[0]
+    with torch.no_grad():
+        want = ref(lat.float().cpu(), 981, ctx.float().cpu(), added_cond_kwargs=added_ref)[0]
+    e = rel_l2(out, want)
+    assert e < 5e-3, e
+    assert float((out.float().cpu() - want).abs().max()) < 2e-2 * float(want.abs().max())
+    N = 20
+    got = StableDiffusionXLPipeline(hip)(prompt_embeds=ctx, pooled_prompt_embeds=pooled, num_inference_steps=N, latents=lat, guidance_scale=1.0,
+                                         height=512, width=512).images
+    ref_out = oracle.sample_loop(ref, oracle.DDIMSchedulerRef(), lat.float().cpu(), ctx.float().cpu(), added_ref, N)
+    r, c = traj_metrics(got, ref_out)
+    assert r < 3e-2 and c > 0.999, (r, c)
+
+
+def test_cfg5_768px_guided_two_steps_vs_oracle(full):
+    """BASELINE configs[4] shapes: four 768x768 requests (96x96 latents) with classifier-free guidance 10 -> B_eff = 8 per UNet
+    evaluation, 81-token conditional / unconditional contexts. Two steps of the 50-step loop on the HIP path for all four requests;
+    the oracle runs requests 0 and 3 (requests are independent: no cross-sample operator on the path)."""
+    from bench import make_inputs
+    from instructany2pix_amd.ddim import StableDiffusionXLPipeline
+    cfg, hip, ref, ip_procs, oracle = full
+    _set_ip(hip, ref, ip_procs, 1.0)
+    lat, ctx, pooled, tid = make_inputs(cfg, 4, 96, 81, DEV, cfg_id=5)
+    _, nctx, npooled, _ = make_inputs(cfg, 4, 96, 81, DEV, cfg_id=15)
+    steps = []
+    pipe = StableDiffusionXLPipeline(hip)
+    # run exactly two steps: a 50-step schedule cut after the second update (the callback records the latents after every step)
+    class _Stop(Exception):
+        pass
+
+    def cb(i, t, x):
+        steps.append(x.clone())
+        if i == 1:
+            raise _Stop
+    try:
+        pipe(prompt_embeds=ctx, negative_prompt_embeds=nctx, pooled_prompt_embeds=pooled, negative_pooled_prompt_embeds=npooled,
+             num_inference_steps=50, latents=lat, guidance_scale=10.0, height=768, width=768, callback=cb)
+    except _Stop:
+        pass
+    torch.cuda.synchronize()
+    assert len(steps) == 2 and torch.isfinite(steps[1]).all()
+    sel = [0, 3]
+    f = lambda t_: t_[sel].float().cpu()
+    sch = oracle.DDIMSchedulerRef()
+    sch.set_timesteps(50)
+    x = f(lat)
+    ctx2 = torch.cat([f(nctx), f(ctx)], 0)
+    added2 = dict(text_embeds=torch.cat([f(npooled), f(pooled)], 0), time_ids=torch.cat([f(tid), f(tid)], 0))
+    with torch.no_grad():
+        for i in range(2):
+            t = int(sch.timesteps[i])
+            eu, ec = ref(torch.cat([x, x], 0), t, ctx2, added_cond_kwargs=added2)[0].chunk(2)
+            x = sch.step(oracle.cfg_combine(eu, ec, 10.0), t, x)
+            r, c = traj_metrics(steps[i][sel], x)
+            # guidance 10 amplifies the fp16 difference of the two UNet outputs tenfold before it enters the update
+            assert r < 3e-2 and c > 0.999, (i, r, c)
