@@ -8,17 +8,29 @@ One "step" = one pass of the hot path over one batch: conditional-UNet evaluatio
 B_eff = 8 latents of 64x64x4, 81-token context = 77 text + 4 IP-Adapter image tokens) + the fused DDIM
 update, i.e. BASELINE.json configs[2]. Inputs and weights are synthetic (seeded) and resident
 in HBM before the timed region. With N > 1 every rank runs its own batch of 8 (weak scaling, no per-step
-communication; rank 0's weight arena is RCCL-broadcast once, outside the timed region).
+communication; the head of rank 0's weight arena is RCCL-broadcast once, outside the timed region, and every
+other rank derives the LayerNorm-folded tail itself).
+
+Timing: W untimed warm-up steps, then EXACTLY K steps bracketed by barrier + synchronize on
+both sides -> `value` (max over ranks, wall clock). The same region is also bracketed by HIP events on the
+launch stream, and `--repeats` (default 5) further K-step runs are timed the same way: `timing` carries every
+run and their median.
 
 Rank 0 prints ONE JSON line; besides the contract fields it carries
   "roofline":     the kernel with the largest share of step time, timed live with HIP events on the launch
-                  stream (ia2p_profile_*), algorithmic FLOPs (2*M*N*K) per launch / average launch duration
-  "cpu_baseline": the CPU oracle (oracle/, torch fp32 on the host cores) timed on a bounded sample.
+                  stream (ia2p_profile_*): algorithmic FLOPs (2*M*N*K) per launch / average launch duration;
+                  plus `whole_step`, `conv_blocks` (MFMA and HBM fractions of the conv-block region on the
+                  algorithmic bytes of SURVEY.md §8d) and `hbm_kernels` (GroupNorm+SiLU, concat, K-split
+                  reduce, CFG + DDIM update against 8.0 TB/s spec and 6.29 TB/s measured-copy peak)
+  "cpu_baseline": the CPU oracle (oracle/, torch fp32 on the host cores) timed on a bounded sample
+  "config.secondary": the other single-GPU BASELINE shapes (configs[1]: B=1, 77-token text-only; configs[4]:
+                  768x768 with guidance, B_eff = 8) measured in the same process, non-headline.
 """
 import argparse
 import glob
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -26,7 +38,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_PEAK_TFLOPS = 2500.0       # dense fp16/bf16, /opt/skills/guides/MI355X_MICROARCH.md
-HBM_PEAK_GBS = 8000.0
+HBM_PEAK_GBS = 8000.0           # spec
+HBM_COPY_GBS = 6290.0           # measured float4 copy (same guide)
+# algorithmic FLOPs per UNet evaluation and conv-block bytes / FLOPs (17 ResnetBlocks + 4 resample convs + conv_in/out;
+# input once, output once, weights once) at the BASELINE shapes, keyed by (B_eff, latent side, with IP-Adapter)
+STEP_TFLOP = {(1, 64, False): 1.591, (8, 64, True): 12.751, (8, 96, True): 29.195}
+CONV_BLOCK_GB = {(1, 64): 0.792, (8, 64): 1.423, (8, 96): 2.325}
+CONV_BLOCK_TFLOP = {(1, 64): 0.406, (8, 64): 3.247, (8, 96): 7.304}
 
 
 def log(*a):
@@ -58,9 +76,30 @@ def usable_cores():
     return n
 
 
+def conv_block_algorithmic(B, hw):
+    """(bytes, flops) of the conv-block region per UNet evaluation: SURVEY.md §8(d)'s figures at the BASELINE shapes, else the same
+    definition evaluated by formula (input once, output once, weights once per ResnetBlock / resample conv / boundary conv; SDXL-base)."""
+    if (B, hw) in CONV_BLOCK_GB:
+        return CONV_BLOCK_GB[(B, hw)] * 1e9, CONV_BLOCK_TFLOP[(B, hw)] * 1e12
+    h = hw
+    res = [(320, 320, h), (320, 320, h), (320, 640, h // 2), (640, 640, h // 2), (640, 1280, h // 4), (1280, 1280, h // 4), (1280, 1280, h // 4), (1280, 1280, h // 4),
+           (2560, 1280, h // 4), (2560, 1280, h // 4), (1920, 1280, h // 4), (1920, 640, h // 2), (1280, 640, h // 2), (960, 640, h // 2), (960, 320, h), (640, 320, h), (640, 320, h)]
+    by = fl = 0.0
+    for ci, co, s in res:
+        sc = ci * co if ci != co else 0
+        by += B * s * s * (ci + co) * 2 + (9 * ci * co + 9 * co * co + sc + 1280 * co) * 2
+        fl += 2.0 * B * s * s * (9 * ci * co + 9 * co * co + sc)
+    for c, si, so in [(320, h, h // 2), (640, h // 2, h // 4), (1280, h // 4, h // 2), (640, h // 2, h)]:
+        by += B * (si * si + so * so) * c * 2 + 9 * c * c * 2
+        fl += 2.0 * B * so * so * 9 * c * c
+    by += B * h * h * (4 + 320) * 2 * 2 + 9 * 4 * 320 * 2 * 2
+    fl += 2.0 * B * h * h * 9 * 4 * 320 * 2
+    return by, fl
+
+
 def cpu_baseline(cfg, unet_specs, ip_specs, seed, dev, inputs_cpu, L, sample_batch):
-    """Oracle UNet step on the host cores: 1 warm-up + 1 timed evaluation of `sample_batch` requests.
-    Weights are the very tensors the HIP path was loaded with (same device generator), copied to the host."""
+    """Oracle UNet + DDIM step on the host cores: 1 warm-up + 2 timed steps of `sample_batch` requests of the workload (every step of the
+    50-step schedule costs the same). Weights are the very tensors the HIP path was loaded with (same device generator), copied to the host."""
     import torch
     import oracle
     from instructany2pix_amd.weights import iter_synthetic
@@ -68,7 +107,7 @@ def cpu_baseline(cfg, unet_specs, ip_specs, seed, dev, inputs_cpu, L, sample_bat
     torch.set_num_threads(cores)
     t0 = time.time()
     host = lambda it: ((k, v.cpu()) for k, v in it)
-    net = oracle.build_unet_fast(cfg, host(iter_synthetic(unet_specs, seed, dev, torch.float16)), host(iter_synthetic(ip_specs, seed, dev, torch.float16)))
+    net = oracle.build_unet_fast(cfg, host(iter_synthetic(unet_specs, seed, dev, torch.float16)), host(iter_synthetic(ip_specs, seed, dev, torch.float16)) if L > 77 else None)
     log(f"[cpu_baseline] oracle built in {time.time() - t0:.1f}s, {cores} threads")
     lat, ctx, pooled, tid = [t[:sample_batch].float() for t in inputs_cpu]
     added = dict(text_embeds=pooled, time_ids=tid)
@@ -76,14 +115,132 @@ def cpu_baseline(cfg, unet_specs, ip_specs, seed, dev, inputs_cpu, L, sample_bat
     sch.set_timesteps(50)
     times = []
     with torch.no_grad():
-        for i in range(2):
+        for i in range(3):
             t = int(sch.timesteps[i])
             t0 = time.time()
             eps = net(lat, t, ctx, added_cond_kwargs=added)[0]
             lat = sch.step(eps, t, lat)
             times.append(time.time() - t0)
-    log(f"[cpu_baseline] step times {times}")
-    return times[-1], cores
+    log(f"[cpu_baseline] step times {times} (first = warm-up)")
+    return times[1:], cores
+
+
+class Workload:
+    """one denoise loop on resident inputs: UNet evaluation at B_eff + fused (CFG +) DDIM update, ping-ponging two latent buffers"""
+
+    def __init__(self, unet, cfg, B_eff, hw, L, guidance, dev, cfg_id):
+        import torch
+        from instructany2pix_amd.scheduler import DDIMScheduler
+        self.unet, self.B_eff, self.hw, self.L, self.guidance = unet, B_eff, hw, L, guidance
+        self.lat, self.ctx, pooled, tid = make_inputs(cfg, B_eff, hw, L, dev, cfg_id)
+        if guidance:        # cat([latents] * 2): both halves carry the same latents (sdxl_pipeline.py:826)
+            self.lat[B_eff // 2:] = self.lat[:B_eff // 2]
+        self.added = dict(text_embeds=pooled, time_ids=tid)
+        self.sch = DDIMScheduler()
+        self.sch.set_timesteps(50)
+        self.ts = [int(t) for t in self.sch.timesteps]
+        self.eps = torch.empty_like(self.lat)
+        self.x, self.y = self.lat.clone(), torch.empty_like(self.lat)
+        self.i = 0
+
+    def step(self):
+        from instructany2pix_amd.scheduler import fused_update
+        i, ts = self.i, self.ts
+        if i % len(ts) == 0:          # a new request every 50 steps: start again from the seeded latents (keeps any --steps finite)
+            self.x.copy_(self.lat)
+        t = ts[i % len(ts)]
+        self.unet(self.x, t, encoder_hidden_states=self.ctx, added_cond_kwargs=self.added, out=self.eps)
+        c_x, c_e = self.sch.step_coeffs(t)
+        if self.guidance:
+            h = self.B_eff // 2       # eps = eps_u + g (eps_c - eps_u), x_{t-1} written to both halves (sdxl_pipeline.py:842-851)
+            fused_update(self.x[:h], self.eps[:h], self.eps[h:], self.guidance, c_x, c_e, self.y[:h], self.y[h:])
+        else:
+            fused_update(self.x, self.eps, None, 1.0, c_x, c_e, self.y)
+        self.x, self.y = self.y, self.x
+        self.i += 1
+
+    def run(self, n):
+        for _ in range(n):
+            self.step()
+
+    def timed(self, n):
+        """(wall seconds, HIP-event milliseconds) of n steps; the caller brackets with barriers"""
+        import torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e0.record()
+        self.run(n)
+        e1.record()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, e0.elapsed_time(e1)
+
+    def profile(self, nprof=3):
+        """per-kernel-class and per-region HIP-event sums over nprof steps, plus the sampler update timed on its own"""
+        import torch
+        self.unet.profile(True)
+        self.run(nprof)
+        torch.cuda.synchronize()
+        table, regions = self.unet.profile_read(), self.unet.profile_read_regions()
+        self.unet.profile(False)
+        from instructany2pix_amd.scheduler import fused_update
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 50
+        e0.record()
+        for _ in range(reps):
+            fused_update(self.x, self.eps, None, 1.0, 0.9, 0.1, self.y)
+        e1.record()
+        torch.cuda.synchronize()
+        n = self.x.numel()
+        table["ddim_step_kernel"] = dict(launches=nprof, ms=e0.elapsed_time(e1) / reps * nprof, flops=0.0, bytes=3.0 * 2 * n * nprof)
+        return table, regions
+
+
+def roofline_block(table, regions, nprof, B_eff, hw, use_ip, ms_per_step):
+    tot_ms = sum(v["ms"] for k, v in table.items() if k != "ddim_step_kernel")
+    gemm = {k: v for k, v in table.items() if v["flops"] > 0 and (k.startswith("gemm_f16_kernel") or k.startswith("attention"))}
+    dom = max(gemm, key=lambda k: gemm[k]["ms"])
+    d = table[dom]
+    ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+    traffic, traffic_src = None, None
+    pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if pmc:                     # HBM-side bytes per launch of this kernel, from separate rocprofv3 --pmc passes (tools/pmc_traffic.py)
+        k = json.load(open(pmc[-1]))["kernels"].get(dom)
+        if k:
+            traffic, traffic_src = k["traffic_bytes_per_launch"], os.path.basename(pmc[-1])
+    out = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
+           "traffic": traffic, "traffic_unit": "bytes/launch (L2<->fabric, Infinity-Cache hits included)", "traffic_source": traffic_src,
+           "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
+           "launches_per_step": d["launches"] / nprof, "avg_launch_us": 1e3 * d["ms"] / d["launches"],
+           "flops_per_launch": d["flops"] / d["launches"], "share_of_step": d["ms"] / tot_ms}
+    step_tf = STEP_TFLOP.get((B_eff, hw, use_ip))
+    if step_tf is None:
+        step_tf = sum(v["flops"] for v in table.values()) / nprof / 1e12
+    out["whole_step"] = {"algorithmic_tflop": step_tf, "ms": ms_per_step, "tflops": step_tf / (ms_per_step * 1e-3), "mfma_frac": step_tf / (ms_per_step * 1e-3) / MFMA_PEAK_TFLOPS}
+    cb = regions["conv_blocks"]
+    cb_bytes, cb_flops = conv_block_algorithmic(B_eff, hw)
+    cb_ms = cb["ms"] / nprof
+    out["conv_blocks"] = {"ms": cb_ms, "launches_per_step": cb["launches"] / nprof, "algorithmic_bytes": cb_bytes, "algorithmic_flops": cb_flops,
+                          "tflops": cb_flops / (cb_ms * 1e-3) / 1e12, "mfma_frac": cb_flops / (cb_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
+                          "hbm_gbs": cb_bytes / (cb_ms * 1e-3) / 1e9, "hbm_frac": cb_bytes / (cb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "hbm_frac_of_measured_copy_peak": cb_bytes / (cb_ms * 1e-3) / 1e9 / HBM_COPY_GBS,
+                          "note": "region = conv_in/out, 17 ResnetBlock2D (GroupNorm+SiLU, 3x3 convs, 1x1 shortcuts), 4 resample convs, skip concats; "
+                                  "HIP events around every launch of the region (adds ~2 us per launch)"}
+    hbm = {}
+    for name in ("gn_stats_kernel+gn_apply_kernel", "concat_kernel", "splitk_reduce_kernel", "ddim_step_kernel", "conv_in_kernel", "conv_out_kernel"):
+        v = table.get(name)
+        if v and v["ms"] > 0:
+            gbs = v["bytes"] / (v["ms"] * 1e-3) / 1e9
+            hbm[name] = {"ms_per_step": v["ms"] / nprof, "launches_per_step": v["launches"] / nprof, "avg_launch_us": 1e3 * v["ms"] / v["launches"],
+                         "algorithmic_gbs": gbs, "frac_of_8000": gbs / HBM_PEAK_GBS, "frac_of_6290": gbs / HBM_COPY_GBS}
+    out["hbm_kernels"] = hbm
+    return out
+
+
+def log_table(table, nprof):
+    for k, v in sorted(table.items(), key=lambda kv: -kv[1]["ms"]):
+        log(f"  {k:42s} {v['launches'] / nprof:7.1f} launches/step {v['ms'] / nprof:8.3f} ms/step "
+            f"{(v['flops'] / (v['ms'] * 1e-3) / 1e12) if v['ms'] else 0:8.1f} TFLOP/s {(v['bytes'] / (v['ms'] * 1e-3) / 1e9) if v['ms'] else 0:8.1f} GB/s(alg)")
 
 
 def main():
@@ -91,12 +248,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--repeats", type=int, default=5, help="K-step runs timed in all (the first one is `value`); their median goes to `timing`")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--latent", type=int, default=64, help="latent side (64 = 512x512 pixels)")
     ap.add_argument("--ctx", type=int, default=81, help="context tokens (77 text + 4 image tokens)")
+    ap.add_argument("--guidance", type=float, default=0.0, help="> 0: classifier-free guidance, the batch is cat([uncond, cond]) (B_eff = --batch)")
     ap.add_argument("--unet", choices=["base", "refiner"], default="base", help="refiner = the second engine config (non-headline; use --ctx 77)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the non-headline BASELINE shapes (configs[1], configs[4])")
     ap.add_argument("--no-autotune", action="store_true", help="use the built-in cost model instead of measured kernel plans")
     ap.add_argument("--plans", default=None, help="import this kernel plan table instead of measuring (profiler runs: keeps the tuning launches out of the trace)")
     ap.add_argument("--save-plans", default=None, help="write the kernel plan table in use to this file")
@@ -106,8 +266,8 @@ def main():
 
     import torch
     from instructany2pix_amd import dist as D
+    from instructany2pix_amd.attention_processor import AttnProcessor2_0
     from instructany2pix_amd.config import sdxl_base, sdxl_refiner
-    from instructany2pix_amd.scheduler import DDIMScheduler, fused_update
     from instructany2pix_amd.unet import HipUNet2DConditionModel, export_plans, import_plans
     from instructany2pix_amd.weights import unet_param_specs, ip_adapter_specs, iter_synthetic
 
@@ -120,56 +280,53 @@ def main():
     seed = 7
     unet_specs, ip_specs = unet_param_specs(cfg), ip_adapter_specs(cfg)["ip_adapter"]
     use_ip = args.ctx > 77
+    backend = torch.distributed.get_backend() if world > 1 else None
 
     t0 = time.time()
     unet = HipUNet2DConditionModel(cfg, dev)
     if rank == 0:   # weights are generated once (seeded, on the device for speed) and broadcast
         unet.load_state_dict(iter_synthetic(unet_specs, seed, dev, torch.float16))
-        if use_ip:
-            unet.load_ip_adapter_weights(iter_synthetic(ip_specs, seed, dev, torch.float16), scale=1.0, num_tokens=args.ctx - 77)
-    D.broadcast_weights(unet, src=0)
-    if rank != 0 and use_ip:
-        unet.load_ip_adapter_weights([], scale=1.0, num_tokens=args.ctx - 77)
+        if args.unet == "base":      # the IP-Adapter tensors travel with the arena whatever the headline context is (secondary shapes use them)
+            unet.load_ip_adapter_weights(iter_synthetic(ip_specs, seed, dev, torch.float16), scale=1.0, num_tokens=4)
+    t_b = time.time()
+    D.broadcast_weights(unet, src=0, with_ip_adapter=args.unet == "base")
     torch.cuda.synchronize()
-    log(f"[rank {rank}] weights ready in {time.time() - t0:.1f}s (arena {unet.arena.numel() / 1e9:.2f} GB)")
+    bcast_s = time.time() - t_b
+    if use_ip:
+        unet.load_ip_adapter_weights([], scale=1.0, num_tokens=args.ctx - 77)      # descriptors only: the weights are in the arena
+    else:
+        unet.set_attn_processor(AttnProcessor2_0())
+    torch.cuda.synchronize()
+    log(f"[rank {rank}] weights ready in {time.time() - t0:.1f}s (arena {unet.arena.numel() / 1e9:.2f} GB, of which {unet.arena_raw.numel() / 1e9:.2f} GB travel; "
+        f"{world} rank(s){', backend ' + backend if backend else ''})")
 
     B, hw, L = args.batch, args.latent, args.ctx
-    lat, ctx, pooled, tid = make_inputs(cfg, B, hw, L, dev)
-    added = dict(text_embeds=pooled, time_ids=tid)
-    sch = DDIMScheduler()
-    sch.set_timesteps(50)
-    ts = [int(t) for t in sch.timesteps]
-    eps, nxt = torch.empty_like(lat), torch.empty_like(lat)
-
-    def step(i, x, y):
-        if i % len(ts) == 0:          # a new request every 50 steps: start again from the seeded latents (keeps any --steps finite)
-            x.copy_(lat)
-        t = ts[i % len(ts)]
-        unet(x, t, encoder_hidden_states=ctx, added_cond_kwargs=added, out=eps)
-        c_x, c_e = sch.step_coeffs(t)
-        fused_update(x, eps, None, 1.0, c_x, c_e, y)
+    wl = Workload(unet, cfg, B, hw, L, args.guidance, dev, cfg_id=3)
 
     # set-up, outside the timed region: measure the candidate (tile, K-split) plans of every GEMM / conv shape once on
     # rank 0 (ia2p_autotune) and hand the table to the other ranks so that all ranks run identical kernels
-    plans = "cost model"
-    if args.plans:
-        text = open(args.plans).read().strip()
-        import_plans(text)
-        plans = f"imported from {os.path.basename(args.plans)} ({text.count(';')} shapes)"
-    elif not args.no_autotune:
+    def tune(w, what):
         t0 = time.time()
         table = [None]
         if rank == 0:
-            n = unet.autotune(lat, ts[0], ctx, added)
+            n = unet.autotune(w.lat, w.ts[0], w.ctx, w.added)
             table[0] = export_plans()
-            log(f"[rank 0] autotune: {n} GEMM/conv shapes measured in {time.time() - t0:.1f}s")
+            log(f"[rank 0] autotune ({what}): {n} GEMM/conv shapes measured in {time.time() - t0:.1f}s")
             if os.environ.get("IA2P_PRINT_PLANS"):
                 log("[rank 0] plans: " + table[0])
         if world > 1:
             torch.distributed.broadcast_object_list(table, src=0)
             if rank != 0:
                 import_plans(table[0])
-        plans = f"measured in place at start-up ({table[0].count(';')} shapes)"
+        return table[0]
+
+    plans = "cost model"
+    if args.plans:
+        text = open(args.plans).read().strip()
+        import_plans(text)
+        plans = f"imported from {os.path.basename(args.plans)} ({text.count(';')} shapes)"
+    elif not args.no_autotune:
+        plans = f"measured in place at start-up ({tune(wl, 'headline').count(';')} shapes)"
     if args.save_plans and rank == 0:
         with open(args.save_plans, "w") as f:
             f.write(export_plans() + "\n")
@@ -177,22 +334,20 @@ def main():
     # The headline loop evaluates the WHOLE UNet every step, as the reference does: the context K/V hoisting the pipelines use
     # (same bits, one GEMM less per step) is switched off here and reported separately below.
     unet.cache_context_kv = False
-    x, y = lat.clone(), nxt
-    for i in range(args.warmup):
-        step(i, x, y)
-        x, y = y, x
+    wl.run(args.warmup)
     D.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, x, y)
-        x, y = y, x
-    torch.cuda.synchronize()
+    wall, ev_ms = wl.timed(args.steps)
     D.barrier()
-    elapsed = D.max_over_ranks(time.perf_counter() - t0, device=dev if world > 1 else "cpu")
-    assert torch.isfinite(x).all(), "non-finite latents after the timed run"
+    elapsed = D.max_over_ranks(wall, device=dev if world > 1 else "cpu")
+    assert torch.isfinite(wl.x).all(), "non-finite latents after the timed run"
+    runs = [ev_ms / args.steps]
+    for _ in range(max(0, args.repeats - 1)):
+        D.barrier()
+        _, ms = wl.timed(args.steps)
+        runs.append(ms / args.steps)
+    D.barrier()
 
-    default_cfg = (args.batch, args.latent, args.ctx, args.unet) == (8, 64, 81, "base")
+    default_cfg = (args.batch, args.latent, args.ctx, args.unet, args.guidance) == (8, 64, 81, "base", 0.0)
     metric = "denoise-steps/sec (512x512, 50-step DDIM, batch 8)" if default_cfg else \
         f"denoise-steps/sec ({args.latent * 8}x{args.latent * 8}, 50-step DDIM, batch {args.batch}{', SDXL-refiner UNet' if args.unet == 'refiner' else ''}) [non-headline shape]"
     res = {
@@ -202,59 +357,67 @@ def main():
         "config": {"workload": f"{'BASELINE configs[2]' if default_cfg else 'custom'}: {hw * 8}x{hw * 8} px, latent [{B},4,{hw},{hw}], 50-step DDIM schedule, "
                                f"context {L} tokens ({'77 text + %d IP-Adapter image tokens' % (L - 77) if use_ip else 'text only'}), {'SDXL-base UNet (2.567 G params) + IP-Adapter' if args.unet == 'base' else 'SDXL-refiner UNet (2.260 G params)'}, "
                                f"synthetic seeded weights", "global_batch": B * world, "parallelism": f"dp{world}", "kernel_plans": plans,
-                   "image_steps_per_s": world * B * args.steps / elapsed},
+                   "image_steps_per_s": world * (B // 2 if args.guidance else B) * args.steps / elapsed,
+                   "ranks": world, "dist_backend": backend or "none (single process)",
+                   "weight_broadcast": {"bytes": int(unet.arena_raw.numel()), "seconds": bcast_s, "note": "head of the arena only; LayerNorm-folded tail derived per rank"} if world > 1 else None},
+        "timing": {"method": "rank 0: HIP events on the launch stream around each K-step run; run 0 is the region `value` is quoted on (wall clock, max over ranks)",
+                   "runs_ms_per_step": runs, "median_ms_per_step": statistics.median(runs), "steps_per_s_median": 1e3 / statistics.median(runs)},
     }
 
     if rank == 0:      # secondary number, not `value`: the same loop with the request's context K/V projected once (what the pipelines do)
         unet.cache_context_kv = True
-        step(0, x, y)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
+        wl.run(1)
         nk = min(20, args.steps)
-        for i in range(nk):
-            step(i, x, y)
-            x, y = y, x
-        torch.cuda.synchronize()
-        res["config"]["ms_per_step_with_context_kv_hoisted"] = 1e3 * (time.perf_counter() - t1) / nk
+        _, ms = wl.timed(nk)
+        res["config"]["ms_per_step_with_context_kv_hoisted"] = ms / nk
         unet.cache_context_kv = False
     if rank == 0 and not args.no_roofline:
-        unet.profile(True)
         nprof = 3
-        for i in range(nprof):
-            step(i, x, y)
-            x, y = y, x
-        torch.cuda.synchronize()
-        table = unet.profile_read()
-        unet.profile(False)
-        tot_ms = sum(v["ms"] for v in table.values())
-        dom = max(table, key=lambda k: table[k]["ms"])
-        d = table[dom]
-        ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-        traffic, traffic_src = None, None
-        pmc = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
-        if pmc:                     # HBM-side bytes per launch of this kernel, from separate rocprofv3 --pmc passes (tools/pmc_traffic.py)
-            k = json.load(open(pmc[-1]))["kernels"].get(dom)
-            if k:
-                traffic, traffic_src = k["traffic_bytes_per_launch"], os.path.basename(pmc[-1])
-        res["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
-                           "traffic": traffic, "traffic_unit": "bytes/launch (L2<->fabric, Infinity-Cache hits included)", "traffic_source": traffic_src,
-                           "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
-                           "launches_per_step": d["launches"] / nprof, "avg_launch_us": 1e3 * d["ms"] / d["launches"],
-                           "flops_per_launch": d["flops"] / d["launches"], "share_of_step": d["ms"] / tot_ms}
-        for k, v in sorted(table.items(), key=lambda kv: -kv[1]["ms"]):
-            log(f"  {k:42s} {v['launches'] / nprof:7.1f} launches/step {v['ms'] / nprof:8.3f} ms/step "
-                f"{(v['flops'] / (v['ms'] * 1e-3) / 1e12) if v['ms'] else 0:8.1f} TFLOP/s {(v['bytes'] / (v['ms'] * 1e-3) / 1e9) if v['ms'] else 0:8.1f} GB/s(alg)")
+        table, regions = wl.profile(nprof)
+        res["roofline"] = roofline_block(table, regions, nprof, B, hw, use_ip, statistics.median(runs))
+        log_table(table, nprof)
         if args.kernel_table:
             os.makedirs(os.path.dirname(os.path.abspath(args.kernel_table)), exist_ok=True)
-            json.dump({"steps_profiled": nprof, "kernels": table}, open(args.kernel_table, "w"), indent=1)
+            json.dump({"steps_profiled": nprof, "kernels": table, "regions": regions}, open(args.kernel_table, "w"), indent=1)
+
+    # ---- the other single-GPU BASELINE shapes, same process, non-headline ----------------------------------------------------
+    if rank == 0 and world == 1 and default_cfg and not args.no_secondary:
+        sec = {}
+        for name, (b2, hw2, L2, g2, cid) in {"configs[1]: 512x512, batch 1, 77-token text-only context": (1, 64, 77, 0.0, 2),
+                                              "configs[4]: 768x768, 4 requests with classifier-free guidance 10 (B_eff 8), 81-token contexts": (8, 96, 81, 10.0, 5)}.items():
+            if L2 > 77:
+                unet.load_ip_adapter_weights([], scale=1.0, num_tokens=L2 - 77)
+            else:
+                unet.set_attn_processor(AttnProcessor2_0())
+            w2 = Workload(unet, cfg, b2, hw2, L2, g2, dev, cfg_id=cid)
+            if not args.no_autotune and not args.plans:
+                tune(w2, name.split(":")[0])
+            w2.run(3)
+            n2 = 30 if b2 == 1 else 10
+            r2 = [w2.timed(n2)[1] / n2 for _ in range(3)]
+            ms2 = statistics.median(r2)
+            entry = {"ms_per_step": ms2, "steps_per_s": 1e3 / ms2, "runs_ms_per_step": r2, "B_eff": b2, "latent": hw2, "context_tokens": L2, "guidance": g2}
+            if not args.no_roofline:
+                t2, rg2 = w2.profile(3)
+                rb = roofline_block(t2, rg2, 3, b2, hw2, L2 > 77, ms2)
+                entry["roofline"] = {k: rb[k] for k in ("kernel", "achieved", "frac", "whole_step", "conv_blocks", "hbm_kernels")}
+                if b2 == 1:
+                    wbytes = 5.135e9           # compulsory weight bytes of a text-only evaluation
+                    entry["weight_streaming"] = {"bytes": wbytes, "bound_ms_at_6290": wbytes / HBM_COPY_GBS / 1e6, "frac_of_bound": wbytes / HBM_COPY_GBS / 1e6 / ms2}
+            sec[name] = entry
+            log(f"[secondary] {name}: {ms2:.2f} ms/step")
+        res["config"]["secondary"] = sec
+        unet.load_ip_adapter_weights([], scale=1.0, num_tokens=4)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sb = max(1, min(args.cpu_sample_batch, B))
-        inputs_cpu = [t.cpu() for t in (lat, ctx, pooled, tid)]
-        t_step, cores = cpu_baseline(cfg, unet_specs, ip_specs, seed, dev, inputs_cpu, L, sb)
+        inputs_cpu = [t.cpu() for t in (wl.lat, wl.ctx, wl.added["text_embeds"], wl.added["time_ids"])]
+        t_steps, cores = cpu_baseline(cfg, unet_specs, ip_specs, seed, dev, inputs_cpu, L, sb)
+        t_step = sum(t_steps) / len(t_steps)
         res["cpu_baseline"] = {"value": 1.0 / (t_step * B / sb), "unit": "steps/s", "cores": cores, "kind": "port",
-                               "sample": f"oracle (torch fp32, {cores} threads = usable cores of this box): 1 warm-up + 1 timed UNet+DDIM step on "
-                                         f"{sb} of the {B} requests of the same workload ({t_step:.2f} s), scaled x{B // sb} to the batch-{B} step"}
+                               "sample": f"oracle (torch fp32, {cores} threads = usable cores of this box): 1 warm-up + 2 timed UNet+DDIM steps "
+                                         f"({', '.join('%.2f s' % t for t in t_steps)}) on {sb} of the {B} requests of the same workload, "
+                                         f"mean scaled x{B // sb} to the batch-{B} step"}
 
     if rank == 0:
         print(json.dumps(res), flush=True)
