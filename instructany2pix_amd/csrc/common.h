@@ -67,6 +67,7 @@ struct GemmArgs {
   int ldr;
   int geglu;             // 1: W/bias rows interleaved in 16-row (a,g) pairs; out[m, n/2] = a * gelu(g)
   int m_fastest;         // tile order: 1 = consecutive blocks walk M (weights panel shared), 0 = walk N
+  int vec8;              // set by the launcher: strides / bases allow 16-byte epilogue accesses
   int group_w;           // > 0: grouped tile order in column panels of this many tiles (set by the launcher; overrides m_fastest)
   // weight prefetch: extra workgroups (launched after the tiles) stream the NEXT contraction's weights once,
   // sequentially, so they are in the Infinity Cache / L2 instead of HBM-cold when that kernel starts

@@ -41,6 +41,23 @@ template <int N> __device__ __forceinline__ void wait_vm_barrier() {
 //   BK = 64 (8 chunks/row):  chunk ^ ((row >> 1) & 7)        BK = 32 (4 chunks/row):  chunk ^ ((-(row >> 2)) & 3)
 template <int BK> __device__ __forceinline__ int lds_swz(int row) { return BK == 64 ? (row >> 1) & 7 : (-(row >> 2)) & 3; }
 
+
+// LDS budget of the staged epilogue: the fp32 tile is read out in NCHUNK row chunks so that chunk + row constants (+ statistics partials) stay
+// within what two co-resident workgroups can hold (<= 80 KiB each), or within the stage buffers when those are larger
+template <int BM, int BN, int NSTAGE, int WGM, int BK>
+struct EpiCfg {
+  static constexpr int STAGE_BYTES = NSTAGE * (BM + BN) * 2 * BK;
+  static constexpr bool POW2 = ((BN / 8) & (BN / 8 - 1)) == 0;
+  static constexpr int extra(int cr) { return (2 * BM + 2 * BN) * 4 + (POW2 ? 0 : cr * (BN / 8) * 8); }
+  static constexpr int LIMIT = STAGE_BYTES > 80 * 1024 ? STAGE_BYTES : 80 * 1024;
+  static constexpr int NCHUNK = (BM * BN * 4 + extra(BM) <= LIMIT) ? 1 : 2;
+  static_assert(WGM % NCHUNK == 0, "a chunk holds whole wave rows");
+  static constexpr int CR = BM / NCHUNK;
+  static constexpr int TILE_BYTES = CR * BN * 4;
+  static_assert(TILE_BYTES + extra(CR) <= LIMIT, "epilogue staging does not fit");
+  static constexpr int SMEM = STAGE_BYTES > TILE_BYTES + extra(CR) ? STAGE_BYTES : TILE_BYTES + extra(CR);
+};
+
 // PP = 1 ("ping-pong", 8 waves = WGM 4, 3-stage ring, ONE workgroup per CU): waves 0-3 own the upper half of the tile rows, waves 4-7 the
 // lower half, and the two groups run half a k-step apart -- while one group reads its fragments from LDS the other issues its MFMAs, with a
 // workgroup barrier between the half-steps. Eight waves behind one barrier per k-step would all read, then all multiply (the LDS and the
@@ -362,11 +379,21 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const half_t* hA
         for (int u = 0; u < 8; ++u) pfacc ^= v[u];
       }
   }
-  float* ln_rows = (float*)smem;      // [0, BM): mean, [BM, 2 BM): rstd, then BN column sums and BN folded biases of this tile
-  float* ln_cs = ln_rows + 2 * BM;
+  // ---- epilogue, staged through LDS. The MFMA layout gives a lane 4 consecutive columns of ONE row (acc[i][j][r] = C[bm0+wm0+16i+(lane&15)]
+  //      [bn0+wn0+16j+4(lane>>4)+r]): stored from there, a wave-instruction touches 16 rows x 32 B -- quarter cache lines, and so does every
+  //      residual read (profiles/r01g_gemm_loop_ablation.txt: 15 us of a 34 us launch at K -> 0). Instead the fp32 tile goes through the (now
+  //      free) stage buffers once: written in the MFMA layout (16-B chunks XOR-swizzled by row & 7: conflict-free ds_write_b128), read back
+  //      row-major, 8 columns per thread, so that bias / time-embedding row / folded-LayerNorm constants / residual are 16-B loads and C is
+  //      written in whole 128-B lines; everything is still applied to the fp32 accumulator and rounded once.
+  using EC = EpiCfg<BM, BN, NSTAGE, WGM, BK>;
+  constexpr int NT = NWAVE * 64, CR = EC::CR;                           // threads, tile rows per chunk
+  float* tile = (float*)smem;
+  float* ln_rows = (float*)(smem + EC::TILE_BYTES);                     // [0, BM): mean, [BM, 2 BM): rstd
+  float* ln_cs = ln_rows + 2 * BM;                                      // BN column sums and BN folded biases of this tile
   float* ln_lb = ln_cs + BN;
+  float2* part = (float2*)(ln_lb + BN);                                 // row-statistics partials (tile widths whose 8-column groups per row are not a power of two)
+  __syncthreads();                    // every wave has finished reading the stage buffers
   if (p.ln_stats) {
-    __syncthreads();                  // every wave has finished reading the stage buffers
     if (tid < BM) {
       const float inv = 1.f / (float)hK;
       const float mean = ln_s1 * inv;
@@ -378,102 +405,192 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const half_t* hA
       *(f4*)(ln_cs + tid * 4) = *(const f4*)(p.ln_cs + bn0 + tid * 4);
       *(f4*)(ln_lb + tid * 4) = *(const f4*)(p.ln_bias + bn0 + tid * 4);
     }
-    __syncthreads();
   }
-
-  // ---- epilogue: acc[i][j][r] = C[m = bm0+wm0+16i+(lane&15)][n = bn0+wn0+16j+4*(lane>>4)+r]
-  if (nsplit > 1) {      // raw fp32 slab of this K range; splitk_reduce_kernel finishes
-    float* slab = p.partial + (size_t)split * hM * hN;
-#pragma unroll
-    for (int i = 0; i < MR; ++i) {
-      const int m = bm0 + wm0 + i * 16 + frow;
-      if (m >= hM) continue;
-#pragma unroll
-      for (int j = 0; j < NR; ++j) {
-        const int n = bn0 + wn0 + j * 16 + fq * 4;
-        if (n < hN) *(f4*)(slab + (size_t)m * hN + n) = acc[i][j];
-      }
-    }
-    if (PP) asm volatile("" ::"v"(pfacc));
-    return;
-  }
-  float2 row_st[MR];
-#pragma unroll
-  for (int i = 0; i < MR; ++i) row_st[i] = make_float2(0.f, 0.f);
-#pragma unroll
-  for (int i = 0; i < MR; ++i) {
-    const int m = bm0 + wm0 + i * 16 + frow;
-    if (m >= hM) continue;
-    const half_t* rv = nullptr;
-    if (p.rowvec) rv = p.rowvec + (size_t)(m / p.rows_per_batch) * p.rowvec_ld;
-    float mu = 0.f, rs = 1.f;
-    if (p.ln_stats) { mu = ln_rows[wm0 + i * 16 + frow]; rs = ln_rows[BM + wm0 + i * 16 + frow]; }
-    float st1 = 0.f, st2 = 0.f;       // row statistics of the fp16 output (producer side of a folded LayerNorm)
-    if (!p.geglu) {
-#pragma unroll
-      for (int j = 0; j < NR; ++j) {
-        const int n = bn0 + wn0 + j * 16 + fq * 4;
-        if (n >= hN) continue;
-        f4 v = acc[i][j];
-        if (p.ln_stats) {
-          const f4 cs = *(const f4*)(ln_cs + n - bn0), lb = *(const f4*)(ln_lb + n - bn0);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = rs * (v[r] - mu * cs[r]) + lb[r];
-        } else
-        if (p.bias) { const h4 b = *(const h4*)(p.bias + n); v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3]; }
-        if (p.act) { v[0] = act_f(v[0], p.act); v[1] = act_f(v[1], p.act); v[2] = act_f(v[2], p.act); v[3] = act_f(v[3], p.act); }
-        if (rv) { const h4 b = *(const h4*)(rv + n); v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3]; }
-        if (p.residual) { const h4 b = *(const h4*)(p.residual + (size_t)m * p.ldr + n); v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3]; }
-        h4 o; o[0] = (half_t)v[0]; o[1] = (half_t)v[1]; o[2] = (half_t)v[2]; o[3] = (half_t)v[3];
-        *(h4*)(p.C + (size_t)m * p.ldc + n) = o;
-        if (p.stats_out) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) { const float f = (float)o[r]; st1 += f; st2 += f * f; }
-        }
-      }
-      if (p.stats_out) {               // the 4 lanes l, l+16, l+32, l+48 hold the same row: fold them
-        st1 += __shfl_xor(st1, 16); st2 += __shfl_xor(st2, 16);
-        st1 += __shfl_xor(st1, 32); st2 += __shfl_xor(st2, 32);
-        row_st[i] = make_float2(st1, st2);
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < NR; j += 2) {
-        const int n = bn0 + wn0 + j * 16 + fq * 4;     // packed row of the `a` half; gate rows sit 16 further
-        if (n >= hN) continue;
-        h4 o;
-        if (p.ln_stats) {
-          const f4 ca = *(const f4*)(ln_cs + n - bn0), cg = *(const f4*)(ln_cs + n - bn0 + 16), la = *(const f4*)(ln_lb + n - bn0), lg = *(const f4*)(ln_lb + n - bn0 + 16);
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            o[r] = (half_t)((rs * (acc[i][j][r] - mu * ca[r]) + la[r]) * gelu_erf_f(rs * (acc[i][j + 1][r] - mu * cg[r]) + lg[r]));
-        } else {
-        const h4 ba = *(const h4*)(p.bias + n), bg = *(const h4*)(p.bias + n + 16);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (half_t)((acc[i][j][r] + (float)ba[r]) * gelu_erf_f(acc[i][j + 1][r] + (float)bg[r]));
-        }
-        const int nout = ((bn0 + wn0 + j * 16) >> 1) + fq * 4;
-        *(h4*)(p.C + (size_t)m * p.ldc + nout) = o;
-      }
-    }
-  }
-  if (p.stats_out) {
-    // the two waves that share tile rows (N halves) add up through LDS, so a tile contributes ONE partial per row: slot = tile_n.
-    // (The stage buffers are free here; floats [0, 2 BM) may hold the consumer-side mean / rstd of this same launch.)
-    float2* xch = (float2*)(smem + (2 * BM + 2 * BN) * sizeof(float));
-    __syncthreads();
-    if ((wave & 1) && fq == 0) {
-#pragma unroll
-      for (int i = 0; i < MR; ++i) xch[wm0 + i * 16 + frow] = row_st[i];
-    }
-    __syncthreads();
-    if (!(wave & 1) && fq == 0) {
+  const bool fast = p.vec8 != 0 && (hN & 7) == 0;     // 16-byte accesses everywhere (every shape of the executors); else 8-byte pieces
+  auto tl = [&](int r, int c) -> f4 { return *(const f4*)(tile + (size_t)r * BN + ((c ^ (r & 7)) << 2)); };
+#pragma unroll 1
+  for (int ch = 0; ch < EC::NCHUNK; ++ch) {
+    if (ch) __syncthreads();          // the previous chunk has been read out
+    if (wm0 / CR == ch) {
 #pragma unroll
       for (int i = 0; i < MR; ++i) {
-        const int m = bm0 + wm0 + i * 16 + frow;
-        if (m >= hM) continue;
-        const float2 o = xch[wm0 + i * 16 + frow];
-        ((float2*)p.stats_out)[(size_t)tn * hM + m] = make_float2(row_st[i].x + o.x, row_st[i].y + o.y);
+        const int r = wm0 - ch * CR + i * 16 + frow;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+          const int c = (wn0 + j * 16) / 4 + fq;
+          *(f4*)(tile + (size_t)r * BN + ((c ^ (r & 7)) << 2)) = acc[i][j];
+        }
+      }
+    }
+    __syncthreads();
+    const int row0 = bm0 + ch * CR;
+    if (nsplit > 1) {                 // raw fp32 slab of this K range; splitk_reduce_kernel finishes
+      float* slab = p.partial + (size_t)split * hM * hN;
+      constexpr int GPR = BN / 4;
+      for (int idx = tid; idx < CR * GPR; idx += NT) {
+        const int r = idx / GPR, g = idx - r * GPR;
+        const int m = row0 + r, n = bn0 + g * 4;
+        if (m < hM && n < hN) *(f4*)(slab + (size_t)m * hN + n) = tl(r, g);
+      }
+    } else if (p.geglu) {             // packed columns: 32-wide blocks [16 values | 16 gates]; out[m][n/2] = a * gelu(g)
+      constexpr int GPR = BN / 16;    // groups of 8 OUTPUT columns per row
+      constexpr int TOTAL = CR * GPR, U = EC::NCHUNK == 1 ? 2 : 1, ITER = (TOTAL + NT * U - 1) / (NT * U);
+#pragma unroll 1
+      for (int k = 0; k < ITER; ++k) {
+        f4 a0[U], a1[U], g0[U], g1[U];
+        h8 ba[U], bg[U];
+        int rr[U], gg[U];
+        bool live[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {       // all loads of U groups in flight before any arithmetic
+          const int idx = tid + (k * U + u) * NT;
+          const int r = min(idx / GPR, CR - 1), g = idx - (idx / GPR) * GPR;
+          const int ca = (g >> 1) * 8 + (g & 1) * 2;                   // first 16-B chunk of the 8 value columns; the gates sit 4 chunks further
+          rr[u] = r; gg[u] = g;
+          live[u] = idx < TOTAL && row0 + r < hM && bn0 + ca * 4 < hN;
+          a0[u] = tl(r, ca); a1[u] = tl(r, ca + 1); g0[u] = tl(r, ca + 4); g1[u] = tl(r, ca + 5);
+          if (!p.ln_stats) {
+            const int n = min(bn0 + ca * 4, hN - 24);      // values n .. n+7, gates n+16 .. n+23
+            ba[u] = *(const h8*)(p.bias + n); bg[u] = *(const h8*)(p.bias + n + 16);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int r = rr[u], g = gg[u];
+          const int cl = ((g >> 1) * 8 + (g & 1) * 2) * 4;              // tile-local packed column of the first value
+          float va[8] = {a0[u][0], a0[u][1], a0[u][2], a0[u][3], a1[u][0], a1[u][1], a1[u][2], a1[u][3]};
+          float vg[8] = {g0[u][0], g0[u][1], g0[u][2], g0[u][3], g1[u][0], g1[u][1], g1[u][2], g1[u][3]};
+          if (p.ln_stats) {
+            const float mu = ln_rows[ch * CR + r], rs = ln_rows[BM + ch * CR + r];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              va[e] = rs * (va[e] - mu * ln_cs[cl + e]) + ln_lb[cl + e];
+              vg[e] = rs * (vg[e] - mu * ln_cs[cl + 16 + e]) + ln_lb[cl + 16 + e];
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { va[e] += (float)ba[u][e]; vg[e] += (float)bg[u][e]; }
+          }
+          h8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (half_t)(va[e] * gelu_erf_f(vg[e]));
+          if (live[u]) *(h8*)(p.C + (size_t)(row0 + r) * p.ldc + (bn0 >> 1) + (g >> 1) * 16 + (g & 1) * 8) = o;
+        }
+      }
+    } else {
+      constexpr int GPR = BN / 8;     // groups of 8 columns per row
+      constexpr bool POW2 = (GPR & (GPR - 1)) == 0;
+      constexpr int TOTAL = CR * GPR, U = EC::NCHUNK == 1 ? 4 : 1, ITER = (TOTAL + NT * U - 1) / (NT * U);   // (two chunks: the second chunk's accumulators are still live)
+      static_assert(!POW2 || NT % GPR == 0, "row groups must not straddle waves");
+#pragma unroll 1
+      for (int k = 0; k < ITER; ++k) {
+        f4 x0[U], x1[U];
+        h8 hb[U], hv[U], hr[U];
+        int rr[U], gg[U];
+        bool live[U];
+        float st1[U], st2[U];
+        if (fast) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) {     // all loads of U groups in flight before any arithmetic (clamped addresses, never branched around)
+            const int idx = tid + (k * U + u) * NT;
+            const int r = min(idx / GPR, CR - 1), g = idx - (idx / GPR) * GPR;
+            rr[u] = r; gg[u] = g;
+            const int m = row0 + r, n = bn0 + g * 8;
+            live[u] = idx < TOTAL && m < hM && n < hN;
+            const int mc = min(m, hM - 1), nc = min(n, hN - 8);
+            x0[u] = tl(r, 2 * g); x1[u] = tl(r, 2 * g + 1);
+            if (p.bias && !p.ln_stats) hb[u] = *(const h8*)(p.bias + nc);
+            if (p.rowvec) hv[u] = *(const h8*)(p.rowvec + (size_t)(mc / p.rows_per_batch) * p.rowvec_ld + nc);
+            if (p.residual) hr[u] = *(const h8*)(p.residual + (size_t)mc * p.ldr + nc);
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int r = rr[u], cl = gg[u] * 8;
+            float v[8] = {x0[u][0], x0[u][1], x0[u][2], x0[u][3], x1[u][0], x1[u][1], x1[u][2], x1[u][3]};
+            if (p.ln_stats) {
+              const float mu = ln_rows[ch * CR + r], rs = ln_rows[BM + ch * CR + r];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = rs * (v[e] - mu * ln_cs[cl + e]) + ln_lb[cl + e];
+            } else if (p.bias) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += (float)hb[u][e];
+            }
+            if (p.act) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = act_f(v[e], p.act);
+            }
+            if (p.rowvec) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += (float)hv[u][e];
+            }
+            if (p.residual) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += (float)hr[u][e];
+            }
+            h8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
+            if (live[u]) *(h8*)(p.C + (size_t)(row0 + r) * p.ldc + bn0 + cl) = o;
+            st1[u] = st2[u] = 0.f;
+            if (p.stats_out && live[u]) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) { const float f = (float)o[e]; st1[u] += f; st2[u] += f * f; }
+            }
+          }
+        } else {
+          // strides / widths that only allow 8-byte accesses (N % 8 == 4, odd leading dimensions): two 4-column halves per group
+#pragma unroll 1
+          for (int u = 0; u < U; ++u) {
+            const int idx = tid + (k * U + u) * NT;
+            const int r = min(idx / GPR, CR - 1), g = idx - (idx / GPR) * GPR;
+            rr[u] = r; gg[u] = g;
+            const int m = row0 + r;
+            live[u] = idx < TOTAL && m < hM && bn0 + g * 8 < hN;
+            st1[u] = st2[u] = 0.f;
+            if (!live[u]) continue;
+            for (int hf = 0; hf < 2; ++hf) {
+              const int n = bn0 + g * 8 + hf * 4, cl = g * 8 + hf * 4;
+              if (n >= hN) break;
+              f4 v = tl(r, 2 * g + hf);
+              if (p.ln_stats) {
+                const float mu = ln_rows[ch * CR + r], rs = ln_rows[BM + ch * CR + r];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = rs * (v[e] - mu * ln_cs[cl + e]) + ln_lb[cl + e];
+              } else if (p.bias) { const h4 b = *(const h4*)(p.bias + n); v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3]; }
+              if (p.act) { v[0] = act_f(v[0], p.act); v[1] = act_f(v[1], p.act); v[2] = act_f(v[2], p.act); v[3] = act_f(v[3], p.act); }
+              if (p.rowvec) { const h4 b = *(const h4*)(p.rowvec + (size_t)(m / p.rows_per_batch) * p.rowvec_ld + n); v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3]; }
+              if (p.residual) { const h4 b = *(const h4*)(p.residual + (size_t)m * p.ldr + n); v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3]; }
+              h4 o; o[0] = (half_t)v[0]; o[1] = (half_t)v[1]; o[2] = (half_t)v[2]; o[3] = (half_t)v[3];
+              *(h4*)(p.C + (size_t)m * p.ldc + n) = o;
+              if (p.stats_out) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float f = (float)o[e]; st1[u] += f; st2[u] += f * f; }
+              }
+            }
+          }
+        }
+        if (p.stats_out) {             // {sum, sum of squares} of the fp16 output row over this tile's columns: ONE partial per row and tile (slot = tile_n)
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int idx = tid + (k * U + u) * NT;
+            if constexpr (POW2) {
+              float a = st1[u], b = st2[u];
+#pragma unroll
+              for (int o = 1; o < GPR; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }      // fixed butterfly: deterministic
+              if (gg[u] == 0 && idx < TOTAL && row0 + rr[u] < hM) ((float2*)p.stats_out)[(size_t)tn * hM + row0 + rr[u]] = make_float2(a, b);
+            } else if (idx < TOTAL) part[idx] = make_float2(st1[u], st2[u]);
+          }
+        }
+      }
+      if constexpr (!POW2) {
+        if (p.stats_out) {
+          __syncthreads();
+          if (tid < CR && row0 + tid < hM) {
+            float s1 = 0.f, s2 = 0.f;
+            for (int g = 0; g < GPR; ++g) { const float2 v = part[tid * GPR + g]; s1 += v.x; s2 += v.y; }      // group order: deterministic
+            ((float2*)p.stats_out)[(size_t)tn * hM + row0 + tid] = make_float2(s1, s2);
+          }
+        }
       }
     }
   }
@@ -482,7 +599,7 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const half_t* hA
 
 template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int BK = 64, int PP = 0>
 static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
-  constexpr int smem = NSTAGE * (BM + BN) * 2 * BK;
+  constexpr int smem = EpiCfg<BM, BN, NSTAGE, WGM, BK>::SMEM;
   // the attribute is per DEVICE: one flag per device id (several contexts on several GPUs in one process)
   static bool attr_set[64] = {false};
   int dev = 0;
@@ -494,6 +611,11 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
   }
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   GemmArgs b = a;
+  // 16-byte epilogue accesses need 8-element row strides and 16-byte-aligned bases; otherwise the epilogue falls back to 8-byte pieces
+  auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+  b.vec8 = (a.ldc % 8 == 0 && al16(a.C) && (!a.bias || al16(a.bias)) && (!a.residual || (a.ldr % 8 == 0 && al16(a.residual))) &&
+            (!a.rowvec || (a.rowvec_ld % 8 == 0 && al16(a.rowvec)))) ? 1 : 0;
+  if (a.geglu && !b.vec8) return hipErrorInvalidValue;
   static const int group_mode = getenv("IA2P_TILE_GROUP") ? atoi(getenv("IA2P_TILE_GROUP")) : 1;
   if (group_mode) {
     const int tiles_n = (a.N + BN - 1) / BN;
@@ -665,7 +787,7 @@ extern "C" int ia2p_plan_import(const char* text) {   // returns the number of e
   for (const char* p = text; *p;) {
     int M, N, K, cv, gg, v, sk, n = 0;
     if (sscanf(p, "%d,%d,%d,%d,%d,%d,%d;%n", &M, &N, &K, &cv, &gg, &v, &sk, &n) != 7 || n == 0) return -1;
-    if (M < 1 || N < 1 || K < 64 || v < 0 || v >= IA2P_GEMM_NVARIANT || sk < 1 || sk > K / 64 || (gg && (sk > 1 || (IA2P_GEMM_TILES[v].bn / 32) % 2))) return -1;
+    if (M < 1 || N < 1 || K < 64 || v < 0 || v >= IA2P_GEMM_NVARIANT || sk < 1 || sk > K / 64 || (gg && (sk > 1 || IA2P_GEMM_TILES[v].bn % 32))) return -1;
     in.push_back({PlanKey{M, N, K, cv != 0, gg != 0}, GemmPlan{v, sk}});
     p += n;
   }
@@ -690,7 +812,7 @@ void ia2p_gemm_candidates(int M, int N, int K, bool conv, bool geglu, size_t max
   }();
   for (int v = 0; v < IA2P_GEMM_NVARIANT; ++v) {
     const GemmTile& t = IA2P_GEMM_TILES[v];
-    if ((geglu && (t.bn / 32) % 2) || (excluded >> v & 1)) continue;
+    if ((geglu && t.bn % 32) || (excluded >> v & 1)) continue;
     for (int sk : splits) {
       if (sk > 1 && (geglu || nk / sk < 4 || (size_t)sk * M * N * 4 > max_slab_bytes)) break;
       all.push_back({plan_cost_us(M, N, K, conv, t, sk), GemmPlan{v, sk}});
@@ -719,7 +841,7 @@ GemmPlan ia2p_gemm_plan(int M, int N, int K, bool conv, bool geglu) {
     double best = 1e30;
     for (int v = 0; v < IA2P_GEMM_NVARIANT; ++v) {
       const GemmTile& t = IA2P_GEMM_TILES[v];
-      if (geglu && (t.bn / 32) % 2) continue;              // (value, gate) column groups must pair up inside a wave
+      if (geglu && t.bn % 32) continue;              // a (value, gate) block of 32 packed columns must not straddle tiles
       for (int sk : splits) {
         if (sk > 1 && (geglu || nk / sk < 4)) break;
         const double c = plan_cost_us(M, N, K, conv, t, sk);
@@ -750,7 +872,7 @@ static hipError_t launch_any(const GemmArgs& a, int v, hipStream_t s, bool with_
   if (a.splitk > 1 && !a.partial) return hipErrorInvalidValue;
   hipError_t e;
   if (v < 0 || v >= IA2P_GEMM_NVARIANT) return hipErrorInvalidValue;
-  if (a.geglu && (IA2P_GEMM_TILES[v].bn / 32) % 2) return hipErrorInvalidValue;   // (value, gate) column groups must pair up inside a wave
+  if (a.geglu && IA2P_GEMM_TILES[v].bn % 32) return hipErrorInvalidValue;   // a (value, gate) block of 32 packed columns must not straddle tiles
   switch (v) {
 #define IA2P_TILE_CASE(ID, BM_, BN_, ST_)                                                                                    \
   case ID:                                                                                                                   \
