@@ -78,6 +78,7 @@ struct GemmArgs {
   // splitk_reduce_kernel then sums them in slab order (deterministic) and applies the epilogue
   int splitk;            // 0/1 = off
   float* partial;
+  int* sk_counters;      // set by the launcher: per-tile ticket counters of the in-launch combine (null: a separate splitk_reduce_kernel launch finishes)
   int act;               // activation on (acc + bias) before rowvec / residual: 0 none, 1 GELU (erf), 2 quick-GELU x*sigmoid(1.702x) (CLIP MLPs)
   // LayerNorm folded into this contraction (consumer side). A is the un-normalised residual stream [M, K], W was pre-scaled by
   // the norm's gamma when the weights were finalized (fold_ln_kernel), and the epilogue finishes the normalisation:
@@ -97,10 +98,10 @@ struct GemmArgs {
 struct GemmPlan { int variant; int splitk; };
 // tile variants of gemm_f16_kernel (id = index): {BM, BN, LDS ring stages}; 4 waves (2 x 2), BK = 64
 struct GemmTile { int bm, bn, stages; };
-constexpr int IA2P_GEMM_NVARIANT = 13;
+constexpr int IA2P_GEMM_NVARIANT = 16;
 constexpr GemmTile IA2P_GEMM_TILES[IA2P_GEMM_NVARIANT] = {{128, 128, 2}, {128, 128, 3}, {128, 64, 2}, {128, 64, 3}, {64, 64, 2}, {64, 64, 3},
                                                           {64, 160, 2}, {64, 160, 3}, {128, 160, 2}, {128, 160, 3}, {160, 128, 2}, {160, 160, 2},
-                                                          {256, 128, 3}};
+                                                          {256, 128, 3}, {64, 64, 4}, {64, 64, 6}, {128, 64, 4}};   // 13..15: deep rings for latency-bound launches (few workgroups, e.g. batch 1)
 GemmPlan ia2p_gemm_plan(int M, int N, int K, bool conv, bool geglu);
 bool ia2p_plan_lookup(int M, int N, int K, bool conv, bool geglu, GemmPlan* out);     // measured plan table (ia2p_autotune)
 void ia2p_plan_set(int M, int N, int K, bool conv, bool geglu, GemmPlan pl);

@@ -382,7 +382,7 @@ static void run_gemm(RunCtx* c, GemmArgs& a, bool conv, const char* what, double
          (size_t)pl.splitk * a.M * a.N * sizeof(float), c->tune_slab_bytes);
     return;
   }
-  if (stat_slots) *stat_slots = pl.splitk > 1 ? 1 : (a.N + IA2P_GEMM_TILES[pl.variant].bn - 1) / IA2P_GEMM_TILES[pl.variant].bn;
+  if (stat_slots) *stat_slots = (pl.splitk > 1 && !ia2p_splitk_inkernel(a.M, a.N, pl.splitk)) ? 1 : (a.N + IA2P_GEMM_TILES[pl.variant].bn - 1) / IA2P_GEMM_TILES[pl.variant].bn;
   T2 slab{(size_t)-1, nullptr};
   if (pl.splitk > 1) {
     a.splitk = pl.splitk;
@@ -394,7 +394,7 @@ static void run_gemm(RunCtx* c, GemmArgs& a, bool conv, const char* what, double
     ProfScope ps(c, (conv ? PK_CONV0 : PK_GEMM0) + pl.variant, flops, bytes);
     CHECK_LAUNCH(c, ia2p_launch_gemm_variant(a, conv, pl.variant, c->stream, false), what);
   }
-  if (pl.splitk > 1) {
+  if (pl.splitk > 1 && !ia2p_splitk_inkernel(a.M, a.N, pl.splitk)) {
     ProfScope ps(c, PK_REDUCE, 0, (double)pl.splitk * a.M * a.N * 4 + 2.0 * a.M * a.N);
     CHECK_LAUNCH(c, ia2p_launch_splitk_reduce(a, c->stream), what);
   }
@@ -1027,7 +1027,7 @@ ia2p_status ia2p_gemm_ex(void* stream, const void* A, const void* W, const void*
   if (splitk > 1) { a.splitk = splitk; a.partial = partial; }
   int pick = 0;
   hipError_t e = ia2p_launch_gemm(a, false, (hipStream_t)stream, &pick);
-  if (stats_slots && pick >= 0 && pick < IA2P_GEMM_NVARIANT) *stats_slots = splitk > 1 ? 1 : (N + IA2P_GEMM_TILES[pick].bn - 1) / IA2P_GEMM_TILES[pick].bn;
+  if (stats_slots && pick >= 0 && pick < IA2P_GEMM_NVARIANT) *stats_slots = (splitk > 1 && !ia2p_splitk_inkernel(M, N, splitk)) ? 1 : (N + IA2P_GEMM_TILES[pick].bn - 1) / IA2P_GEMM_TILES[pick].bn;
   RET_HIP(e, "gemm_ex");
 }
 ia2p_status ia2p_gemm_splitk(void* stream, const void* A, const void* W, const void* bias, const void* residual, void* C, int M, int N, int K,

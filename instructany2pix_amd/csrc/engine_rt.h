@@ -22,6 +22,7 @@
 hipError_t ia2p_launch_gemm(const GemmArgs& a, bool conv, hipStream_t s, int* picked);
 hipError_t ia2p_launch_gemm_variant(const GemmArgs& a, bool conv, int variant, hipStream_t s, bool with_reduce = true);
 hipError_t ia2p_launch_splitk_reduce(const GemmArgs& a, hipStream_t s);
+bool ia2p_splitk_inkernel(int M, int N, int splitk);
 void ia2p_gemm_candidates(int M, int N, int K, bool conv, bool geglu, size_t max_slab_bytes, double slack, std::vector<GemmPlan>* out);
 hipError_t ia2p_launch_attention(const AttnArgs& a, hipStream_t s);
 int ia2p_gn_chunks(int B, int HW);

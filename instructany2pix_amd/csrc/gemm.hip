@@ -25,6 +25,8 @@
 #include <tuple>
 #include <vector>
 
+bool ia2p_splitk_inkernel(int M, int N, int splitk);
+
 #define GLDS16(gptr, ldsptr)                                                                         \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),            \
                                    (__attribute__((address_space(3))) void*)(ldsptr), 16, 0, 0)
@@ -33,6 +35,16 @@ template <int N> __device__ __forceinline__ void wait_vm_barrier() {
   // counted wait for this wave's LDS-DMA pieces + workgroup barrier, as ONE opaque statement: the "memory" clobber
   // keeps the compiler from moving LDS reads / DMA issues across it
   asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// wait until all but `tiles` (0 .. MAXT, wave-uniform) k-tiles of LPS pieces each have landed, then the workgroup barrier
+template <int MAXT, int LPS> __device__ __forceinline__ void wait_ring(int tiles) {
+  static_assert(MAXT * LPS <= 63, "vmcnt immediate");
+  if constexpr (MAXT <= 0) wait_vm_barrier<0>();
+  else {
+    if (tiles >= MAXT) wait_vm_barrier<MAXT * LPS>();
+    else wait_ring<MAXT - 1, LPS>(tiles);
+  }
 }
 
 // BM x BN tile; WGM x 2 waves, each owning a (BM/WGM) x (BN/2) sub-tile
@@ -48,7 +60,7 @@ template <int BM, int BN, int NSTAGE, int WGM, int BK>
 struct EpiCfg {
   static constexpr int STAGE_BYTES = NSTAGE * (BM + BN) * 2 * BK;
   static constexpr bool POW2 = ((BN / 8) & (BN / 8 - 1)) == 0;
-  static constexpr int extra(int cr) { return (2 * BM + 2 * BN) * 4 + (POW2 ? 0 : cr * (BN / 8) * 8); }
+  static constexpr int extra(int cr) { return (2 * BM + 2 * BN + 4) * 4 + (POW2 ? 0 : cr * (BN / 8) * 8); }
   static constexpr int LIMIT = STAGE_BYTES > 80 * 1024 ? STAGE_BYTES : 80 * 1024;
   static constexpr int NCHUNK = (BM * BN * 4 + extra(BM) <= LIMIT) ? 1 : 2;
   static_assert(WGM % NCHUNK == 0, "a chunk holds whole wave rows");
@@ -315,8 +327,8 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const half_t* hA
   int cur = 0, nxt = NSTAGE - 1;      // ring slots: `cur` is consumed this step, `nxt` is refilled
   for (int kt = 0; kt < nk; ++kt) {
     const int ahead = nk - 1 - kt;    // tiles issued after tile kt that may remain in flight
-    if (NSTAGE >= 3 && ahead >= 1) wait_vm_barrier<LPS>();
-    else wait_vm_barrier<0>();
+    // tiles kt+1 .. kt+NSTAGE-2 were issued before this wait and may stay in flight (fewer at the tail): vmcnt counts this wave's pieces
+    wait_ring<NSTAGE - 2, LPS>(ahead < NSTAGE - 2 ? ahead : NSTAGE - 2);
     // every wave has passed the barrier => tile kt has landed for all, and slot `nxt` (read in step kt-1) is free
     if (kt + NSTAGE - 1 < nk) stage(kt + NSTAGE - 1, nxt);
     const char* base = smem + cur * STAGE;
@@ -391,7 +403,8 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const half_t* hA
   float* ln_rows = (float*)(smem + EC::TILE_BYTES);                     // [0, BM): mean, [BM, 2 BM): rstd
   float* ln_cs = ln_rows + 2 * BM;                                      // BN column sums and BN folded biases of this tile
   float* ln_lb = ln_cs + BN;
-  float2* part = (float2*)(ln_lb + BN);                                 // row-statistics partials (tile widths whose 8-column groups per row are not a power of two)
+  int* sk_flag = (int*)(ln_lb + BN);                                    // K-split: the ticket this workgroup drew, broadcast to its waves
+  float2* part = (float2*)(ln_lb + BN + 4);                             // row-statistics partials (tile widths whose 8-column groups per row are not a power of two)
   __syncthreads();                    // every wave has finished reading the stage buffers
   if (p.ln_stats) {
     if (tid < BM) {
@@ -408,9 +421,7 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const half_t* hA
   }
   const bool fast = p.vec8 != 0 && (hN & 7) == 0;     // 16-byte accesses everywhere (every shape of the executors); else 8-byte pieces
   auto tl = [&](int r, int c) -> f4 { return *(const f4*)(tile + (size_t)r * BN + ((c ^ (r & 7)) << 2)); };
-#pragma unroll 1
-  for (int ch = 0; ch < EC::NCHUNK; ++ch) {
-    if (ch) __syncthreads();          // the previous chunk has been read out
+  auto acc_to_tile = [&](int ch) {
     if (wm0 / CR == ch) {
 #pragma unroll
       for (int i = 0; i < MR; ++i) {
@@ -422,17 +433,63 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const half_t* hA
         }
       }
     }
-    __syncthreads();
-    const int row0 = bm0 + ch * CR;
-    if (nsplit > 1) {                 // raw fp32 slab of this K range; splitk_reduce_kernel finishes
-      float* slab = p.partial + (size_t)split * hM * hN;
-      constexpr int GPR = BN / 4;
+  };
+  bool from_slabs = false;
+  if (nsplit > 1) {
+    // ---- K-split: this workgroup holds the partial sums of ONE K range. Every K-slice writes its raw fp32 slab (write-through `sc1` stores:
+    //      the bytes are in memory-side coherence when the wave's vmcnt drains, no release fence -- cdna_hip_programming.md §5 "In-launch split-K
+    //      reduction"); the slice that arrives LAST at the tile's ticket counter adds the slabs up in slab order (deterministic whoever is last)
+    //      and runs the epilogue: no reduce launch, no spin (nobody waits for anybody).
+    constexpr int GPR = BN / 4;
+    const __amdgpu_buffer_rsrc_t slab = __builtin_amdgcn_make_buffer_rsrc((void*)(p.partial + (size_t)split * hM * hN), 0, (int)min((size_t)hM * hN * 4, (size_t)0x7ffffff0), 0x00020000);
+#pragma unroll 1
+    for (int ch = 0; ch < EC::NCHUNK; ++ch) {
+      if (ch) __syncthreads();
+      acc_to_tile(ch);
+      __syncthreads();
+      const int row0 = bm0 + ch * CR;
       for (int idx = tid; idx < CR * GPR; idx += NT) {
         const int r = idx / GPR, g = idx - r * GPR;
         const int m = row0 + r, n = bn0 + g * 4;
-        if (m < hM && n < hN) *(f4*)(slab + (size_t)m * hN + n) = tl(r, g);
+        if (m < hM && n < hN) {
+          const f4 v = tl(r, g);
+          typedef unsigned u4v __attribute__((__vector_size__(4 * sizeof(unsigned))));
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), slab, (int)(((size_t)m * hN + n) * 4), 0, 16);      // aux 16 = sc1 (write-through)
+        }
       }
-    } else if (p.geglu) {             // packed columns: 32-wide blocks [16 values | 16 gates]; out[m][n/2] = a * gelu(g)
+    }
+    if (!p.sk_counters) { if (PP) asm volatile("" ::"v"(pfacc)); return; }      // finished by a separate splitk_reduce_kernel launch (A/B switch)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // EVERY storing wave drains its write-through stores ...
+    __syncthreads();                                       // ... before ONE lane signals for the workgroup
+    if (tid == 0) *sk_flag = __hip_atomic_fetch_add(p.sk_counters + (tm * tiles_n + tn), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (*sk_flag != nsplit - 1) { if (PP) asm volatile("" ::"v"(pfacc)); return; }
+    if (tid == 0) {
+      __hip_atomic_store(p.sk_counters + (tm * tiles_n + tn), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch (launches are stream-ordered)
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // drop this CU's stale lines before the plain loads below
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    from_slabs = true;
+  }
+#pragma unroll 1
+  for (int ch = 0; ch < EC::NCHUNK; ++ch) {
+    if (ch || from_slabs) __syncthreads();          // the previous chunk has been read out
+    const int row0 = bm0 + ch * CR;
+    if (!from_slabs) acc_to_tile(ch);
+    else {                            // tile chunk = sum of the K-slice slabs, slab 0 first
+      constexpr int GPR = BN / 4;
+      for (int idx = tid; idx < CR * GPR; idx += NT) {
+        const int r = idx / GPR, g = idx - r * GPR;
+        const int m = min(row0 + r, hM - 1), n = min(bn0 + g * 4, hN - 4);
+        const float* src = p.partial + (size_t)m * hN + n;
+        f4 v = *(const f4*)src;
+        for (int sl = 1; sl < nsplit; ++sl) { const f4 w = *(const f4*)(src + (size_t)sl * hM * hN); v[0] += w[0]; v[1] += w[1]; v[2] += w[2]; v[3] += w[3]; }
+        *(f4*)(tile + (size_t)r * BN + ((g ^ (r & 7)) << 2)) = v;
+      }
+    }
+    __syncthreads();
+    if (p.geglu) {                    // packed columns: 32-wide blocks [16 values | 16 gates]; out[m][n/2] = a * gelu(g)
       constexpr int GPR = BN / 16;    // groups of 8 OUTPUT columns per row
       constexpr int TOTAL = CR * GPR, U = EC::NCHUNK == 1 ? 2 : 1, ITER = (TOTAL + NT * U - 1) / (NT * U);
 #pragma unroll 1
@@ -616,6 +673,20 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
   b.vec8 = (a.ldc % 8 == 0 && al16(a.C) && (!a.bias || al16(a.bias)) && (!a.residual || (a.ldr % 8 == 0 && al16(a.residual))) &&
             (!a.rowvec || (a.rowvec_ld % 8 == 0 && al16(a.rowvec)))) ? 1 : 0;
   if (a.geglu && !b.vec8) return hipErrorInvalidValue;
+  b.sk_counters = nullptr;
+  if (ia2p_splitk_inkernel(a.M, a.N, a.splitk)) {
+    // ticket counters of the in-launch K-split combine: one int per output tile, zero between launches (the last arriver resets its tile's)
+    constexpr int NCNT = 1 << 20;
+    static int* cnt[64] = {nullptr};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && tiles <= NCNT) {
+      if (!cnt[dev]) {
+        if (hipMalloc((void**)&cnt[dev], NCNT * sizeof(int)) != hipSuccess || hipMemset(cnt[dev], 0, NCNT * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); cnt[dev] = nullptr; }
+      }
+      b.sk_counters = cnt[dev];
+    }
+  }
   static const int group_mode = getenv("IA2P_TILE_GROUP") ? atoi(getenv("IA2P_TILE_GROUP")) : 1;
   if (group_mode) {
     const int tiles_n = (a.N + BN - 1) / BN;
@@ -711,6 +782,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* hpartia
   }
 }
 
+// K-split launches combine their slabs inside the GEMM launch (last-arriving slice of a tile); IA2P_SPLITK_INKERNEL=0: separate
+// splitk_reduce_kernel launches instead (A/B switch, read once)
+// Which K-split launches combine inside the launch: those whose slabs are small (latency-bound launches: batch 1, tiny contractions), where the
+// reduce launch costs more than the last arriver's serial slab read. Measured on one box (profiles/r02e_splitk_inkernel_ab.txt): every K-split
+// in-launch: batch 8 +0.6 ms / step, batch 1 -0.16 ms; large slabs are summed faster by a whole-chip reduce launch than by 160 lone workgroups.
+// IA2P_SPLITK_INKERNEL = byte threshold on splitk*M*N*4 (0: never, default 8 MiB).
+bool ia2p_splitk_inkernel(int M, int N, int splitk) {
+  static const size_t limit = getenv("IA2P_SPLITK_INKERNEL") ? (size_t)atoll(getenv("IA2P_SPLITK_INKERNEL")) : ((size_t)8 << 20);
+  return splitk > 1 && (size_t)splitk * M * N * sizeof(float) <= limit;
+}
 static int g_force_splitk = -1;    // test/tuning hook
 extern "C" void ia2p_debug_set_gemm_splitk(int s) { g_force_splitk = s; }
 
@@ -891,16 +972,19 @@ static hipError_t launch_any(const GemmArgs& a, int v, hipStream_t s, bool with_
     IA2P_TILE_CASE(9, 128, 160, 3)
     IA2P_TILE_CASE(10, 160, 128, 2)
     IA2P_TILE_CASE(11, 160, 160, 2)
-#undef IA2P_TILE_CASE
+    IA2P_TILE_CASE(13, 64, 64, 4)
+    IA2P_TILE_CASE(14, 64, 64, 6)
+    IA2P_TILE_CASE(15, 128, 64, 4)
     case 12:
       static_assert(IA2P_GEMM_TILES[12].bm == 256 && IA2P_GEMM_TILES[12].bn == 128 && IA2P_GEMM_TILES[12].stages == 3, "tile table");
       e = launch_cfg<256, 128, 3, CONV, 4, 64, 1>(a, s);
       break;
+#undef IA2P_TILE_CASE
     // Measured and dropped in round 1 (tools/gemm_bench.py): 8-wave 256x128 (2- and 3-stage) and 256x320 at one
     // workgroup per CU; BK = 32 rings (64-byte rows halve the request efficiency). The template still takes WGM and BK.
     default: return hipErrorInvalidValue;
   }
-  if (e != hipSuccess || a.splitk <= 1 || !with_reduce) return e;
+  if (e != hipSuccess || a.splitk <= 1 || !with_reduce || ia2p_splitk_inkernel(a.M, a.N, a.splitk)) return e;
   return ia2p_launch_splitk_reduce(a, s);
 }
 
