@@ -241,7 +241,7 @@ def _sdpa(q, k, v):
     return s.softmax(-1) @ v.float()
 
 
-@pytest.mark.parametrize("B,heads,N", [(2, 2, 256), (1, 10, 1024), (2, 4, 100), (1, 1, 576), (1, 2, 33)])
+@pytest.mark.parametrize("B,heads,N", [(2, 2, 256), (1, 10, 1024), (2, 4, 100), (1, 1, 576), (1, 2, 33), (1, 2, 2304), (1, 1, 4096), (2, 1, 192), (1, 3, 320)])
 def test_self_attention(L, B, heads, N):
     f = _ffi()
     C_ = heads * 64
@@ -271,7 +271,7 @@ def test_self_attention_online_softmax_rescale(L):
     assert (out.float() - ref).abs().max() < 6e-3
 
 
-@pytest.mark.parametrize("Lt,Li,scale", [(77, 4, 1.0), (73, 4, 0.5), (77, 0, 0.0), (128, 16, 0.7)])
+@pytest.mark.parametrize("Lt,Li,scale", [(77, 4, 1.0), (73, 4, 0.5), (77, 0, 0.0), (128, 16, 0.7), (77, 64, 1.3), (300, 4, 0.9), (300, 100, 0.5), (64, 65, 2.0)])
 def test_cross_attention_two_softmaxes(L, Lt, Li, scale):
     """text + image-token branches, each with its own softmax (reference attention_processor.py:371,387,397)."""
     f = _ffi()
