@@ -56,16 +56,18 @@ template <int BK> __device__ __forceinline__ int lds_swz(int row) { return BK ==
 
 // LDS budget of the staged epilogue: the fp32 tile is read out in NCHUNK row chunks so that chunk + row constants (+ statistics partials) stay
 // within what two co-resident workgroups can hold (<= 80 KiB each), or within the stage buffers when those are larger
-template <int BM, int BN, int NSTAGE, int WGM, int BK>
+template <int BM, int BN, int NSTAGE, int WGM, int BK, int WGN = 2>
 struct EpiCfg {
-  static constexpr int STAGE_BYTES = NSTAGE * (BM + BN) * 2 * BK;
+  static constexpr int BNL = ((BN / (1024 / (2 * BK)) + WGM * WGN - 1) / (WGM * WGN)) * (WGM * WGN) * (1024 / (2 * BK));   // weight rows staged (>= BN)
+  static constexpr int STAGE_BYTES = NSTAGE * (BM + BNL) * 2 * BK;
+  static constexpr int PITCH = ((BN / 4 + 7) & ~7) * 4;        // floats per fp32 tile row: whole groups of 8 chunks (the XOR swizzle stays inside a group)
   static constexpr bool POW2 = ((BN / 8) & (BN / 8 - 1)) == 0;
   static constexpr int extra(int cr) { return (2 * BM + 2 * BN + 4) * 4 + (POW2 ? 0 : cr * (BN / 8) * 8); }
   static constexpr int LIMIT = STAGE_BYTES > 80 * 1024 ? STAGE_BYTES : 80 * 1024;
-  static constexpr int NCHUNK = (BM * BN * 4 + extra(BM) <= LIMIT) ? 1 : 2;
+  static constexpr int NCHUNK = (BM * PITCH * 4 + extra(BM) <= LIMIT) ? 1 : 2;
   static_assert(WGM % NCHUNK == 0, "a chunk holds whole wave rows");
   static constexpr int CR = BM / NCHUNK;
-  static constexpr int TILE_BYTES = CR * BN * 4;
+  static constexpr int TILE_BYTES = CR * PITCH * 4;
   static_assert(TILE_BYTES + extra(CR) <= LIMIT, "epilogue staging does not fit");
   static constexpr int SMEM = STAGE_BYTES > TILE_BYTES + extra(CR) ? STAGE_BYTES : TILE_BYTES + extra(CR);
 };
@@ -75,19 +77,21 @@ struct EpiCfg {
 // workgroup barrier between the half-steps. Eight waves behind one barrier per k-step would all read, then all multiply (the LDS and the
 // MFMA phases add up); two independent workgroups per CU de-phase by themselves but need twice the LDS fill per flop
 // (profiles/r01g_gemm_loop_ablation.txt: the fill is the largest term of the 128x128 kernel).
-template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int BK = 64, int PP = 0>
-__global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const half_t* hA, const half_t* hW, const half_t* hzero, int hM, int hN, int hK, int hlda, int hldw, int hrpb, int hbstride,
+template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int BK = 64, int PP = 0, int WGN = 2>
+__global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_f16_kernel(const half_t* hA, const half_t* hW, const half_t* hzero, int hM, int hN, int hK, int hlda, int hldw, int hrpb, int hbstride,
                                                                          int hroff, int hsplitk, int hgroup_w, const GemmArgs p) {
   // The leading 16 dwords of the argument list are what the prologue needs; built with -amdgpu-kernarg-preload-count=16 the command processor
   // hands them over in SGPRs, so the first tile loads go out without waiting for a cold read of the argument block (which costs every launch
   // ~1 us: tools/micro/launch_floor2.hip). The rest of GemmArgs (epilogue, conv geometry) arrives while those loads fly.   // >= 2 waves/SIMD: big tiles must fit 256 registers
   static_assert(!PP || (WGM == 4 && NSTAGE == 3), "ping-pong schedule: 8 waves, 3-stage ring");
-  constexpr int NWAVE = WGM * 2;
-  constexpr int WM = BM / WGM, WN = BN / 2;      // wave tile (waves arranged WGM x 2)
+  constexpr int NWAVE = WGM * WGN;
+  constexpr int WM = BM / WGM, WN = BN / WGN;    // wave tile (waves arranged WGM x WGN; WGN = 1: narrow tiles, one wave per 128-byte column block)
   constexpr int MR = WM / 16, NR = WN / 16;
   constexpr int ROWB = 2 * BK, CPR = ROWB / 16, RPP = 1024 / ROWB;   // row bytes, chunks per row, rows per 1-KiB staging piece
-  constexpr int A_PW = BM / RPP / NWAVE, B_PW = BN / RPP / NWAVE;    // staging pieces per wave
-  constexpr int STAGE = (BM + BN) * ROWB;
+  constexpr int A_PW = BM / RPP / NWAVE, B_PW = (BN / RPP + NWAVE - 1) / NWAVE;    // staging pieces per wave (B rounded up: the surplus rows read the zero page)
+  constexpr int BNL = B_PW * NWAVE * RPP;                            // weight rows held in LDS (>= BN)
+  static_assert(BM % (RPP * NWAVE) == 0 && BN % 16 == 0 && WN % 16 == 0 && WM % 16 == 0, "tile / wave layout");
+  constexpr int STAGE = (BM + BNL) * ROWB;
   constexpr int KSUB = BK / 32;                                       // 32-deep MFMA sub-steps per k-tile
   extern __shared__ __attribute__((aligned(1024))) char smem[];
 
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const half_t* hA
     const int pi = wave * B_PW + i;
     const int n = bn0 + pi * RPP + srow;
     const int gch = cpos ^ lds_swz<BK>(pi * RPP + srow);
-    if (n < hN) { w_ptr[i] = hW + (size_t)n * hldw + gch * 8; w_inc[i] = BK; }
+    if (n < hN && pi * RPP + srow < BN) { w_ptr[i] = hW + (size_t)n * hldw + gch * 8; w_inc[i] = BK; }
     else         { w_ptr[i] = hzero; w_inc[i] = 0; }
   }
 
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const half_t* hA
   };
 
   // ---- fragment read offsets (wave tile origin is a multiple of 16, so swz(row) = (lane>>1)&7)
-  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;   // wave / 2 in [0, WGM)
+  const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
   const int frow = lane & 15, fq = lane >> 4;
   const int fswz = lds_swz<BK>(frow);
   const int a_off = (wm0 + frow) * ROWB, w_off = BM * ROWB + (wn0 + frow) * ROWB;
@@ -397,7 +401,8 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const half_t* hA
   //      free) stage buffers once: written in the MFMA layout (16-B chunks XOR-swizzled by row & 7: conflict-free ds_write_b128), read back
   //      row-major, 8 columns per thread, so that bias / time-embedding row / folded-LayerNorm constants / residual are 16-B loads and C is
   //      written in whole 128-B lines; everything is still applied to the fp32 accumulator and rounded once.
-  using EC = EpiCfg<BM, BN, NSTAGE, WGM, BK>;
+  using EC = EpiCfg<BM, BN, NSTAGE, WGM, BK, WGN>;
+  constexpr int PITCH = EC::PITCH;
   constexpr int NT = NWAVE * 64, CR = EC::CR;                           // threads, tile rows per chunk
   float* tile = (float*)smem;
   float* ln_rows = (float*)(smem + EC::TILE_BYTES);                     // [0, BM): mean, [BM, 2 BM): rstd
@@ -420,7 +425,7 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const half_t* hA
     }
   }
   const bool fast = p.vec8 != 0 && (hN & 7) == 0;     // 16-byte accesses everywhere (every shape of the executors); else 8-byte pieces
-  auto tl = [&](int r, int c) -> f4 { return *(const f4*)(tile + (size_t)r * BN + ((c ^ (r & 7)) << 2)); };
+  auto tl = [&](int r, int c) -> f4 { return *(const f4*)(tile + (size_t)r * PITCH + ((c ^ (r & 7)) << 2)); };
   auto acc_to_tile = [&](int ch) {
     if (wm0 / CR == ch) {
 #pragma unroll
@@ -429,7 +434,7 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const half_t* hA
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
           const int c = (wn0 + j * 16) / 4 + fq;
-          *(f4*)(tile + (size_t)r * BN + ((c ^ (r & 7)) << 2)) = acc[i][j];
+          *(f4*)(tile + (size_t)r * PITCH + ((c ^ (r & 7)) << 2)) = acc[i][j];
         }
       }
     }
@@ -485,7 +490,7 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const half_t* hA
         const float* src = p.partial + (size_t)m * hN + n;
         f4 v = *(const f4*)src;
         for (int sl = 1; sl < nsplit; ++sl) { const f4 w = *(const f4*)(src + (size_t)sl * hM * hN); v[0] += w[0]; v[1] += w[1]; v[2] += w[2]; v[3] += w[3]; }
-        *(f4*)(tile + (size_t)r * BN + ((g ^ (r & 7)) << 2)) = v;
+        *(f4*)(tile + (size_t)r * PITCH + ((g ^ (r & 7)) << 2)) = v;
       }
     }
     __syncthreads();
@@ -654,15 +659,15 @@ __global__ __launch_bounds__(WGM * 128, 2) void gemm_f16_kernel(const half_t* hA
   if (PP) asm volatile("" ::"v"(pfacc));
 }
 
-template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int BK = 64, int PP = 0>
+template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int BK = 64, int PP = 0, int WGN = 2>
 static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
-  constexpr int smem = EpiCfg<BM, BN, NSTAGE, WGM, BK>::SMEM;
+  constexpr int smem = EpiCfg<BM, BN, NSTAGE, WGM, BK, WGN>::SMEM;
   // the attribute is per DEVICE: one flag per device id (several contexts on several GPUs in one process)
   static bool attr_set[64] = {false};
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_f16_kernel<BM, BN, NSTAGE, CONV, WGM, BK, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_f16_kernel<BM, BN, NSTAGE, CONV, WGM, BK, PP, WGN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
@@ -697,7 +702,7 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
     b.group_w = std::max(1, std::min(w, tiles_n));
   }
   const int extra = (!PP && a.pf && a.pf_bytes >= 4096) ? a.pf_blocks : 0;
-  hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, NSTAGE, CONV, WGM, BK, PP>), dim3(tiles * (a.splitk > 1 ? a.splitk : 1) + extra), dim3(WGM * 128), smem, s,
+  hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, NSTAGE, CONV, WGM, BK, PP, WGN>), dim3(tiles * (a.splitk > 1 ? a.splitk : 1) + extra), dim3(WGM * WGN * 64), smem, s,
                      b.A, b.W, b.zero, b.M, b.N, b.K, b.lda, b.ldw, b.rpb, b.bstride, b.roff, b.splitk, b.group_w, b);
   return hipGetLastError();
 }
@@ -975,6 +980,14 @@ static hipError_t launch_any(const GemmArgs& a, int v, hipStream_t s, bool with_
     IA2P_TILE_CASE(13, 64, 64, 4)
     IA2P_TILE_CASE(14, 64, 64, 6)
     IA2P_TILE_CASE(15, 128, 64, 4)
+    case 16:
+      static_assert(IA2P_GEMM_TILES[16].bm == 128 && IA2P_GEMM_TILES[16].bn == 80 && IA2P_GEMM_TILES[16].stages == 2, "tile table");
+      e = launch_cfg<128, 80, 2, CONV, 4, 64, 0, 1>(a, s);
+      break;
+    case 17:
+      static_assert(IA2P_GEMM_TILES[17].bm == 128 && IA2P_GEMM_TILES[17].bn == 80 && IA2P_GEMM_TILES[17].stages == 4, "tile table");
+      e = launch_cfg<128, 80, 4, CONV, 4, 64, 0, 1>(a, s);
+      break;
     case 12:
       static_assert(IA2P_GEMM_TILES[12].bm == 256 && IA2P_GEMM_TILES[12].bn == 128 && IA2P_GEMM_TILES[12].stages == 3, "tile table");
       e = launch_cfg<256, 128, 3, CONV, 4, 64, 1>(a, s);

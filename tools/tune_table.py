@@ -5,7 +5,7 @@ import re
 import sys
 
 TILES = [(128, 128, 2), (128, 128, 3), (128, 64, 2), (128, 64, 3), (64, 64, 2), (64, 64, 3), (64, 160, 2), (64, 160, 3), (128, 160, 2), (128, 160, 3),
-         (160, 128, 2), (160, 160, 2), (256, 128, 3), (64, 64, 4), (64, 64, 6), (128, 64, 4)]
+         (160, 128, 2), (160, 160, 2), (256, 128, 3), (64, 64, 4), (64, 64, 6), (128, 64, 4), (128, 80, 2), (128, 80, 4)]
 NAMES = ["%dx%ds%d" % t for t in TILES]
 NAMES[12] += "pp"
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 8
