@@ -200,7 +200,8 @@ ia2p_status ia2p_profile_read_region(ia2p_ctx* ctx, int region, int64_t* launche
  * reference call sites: ddim/pnp_pipeline.py:190-204 (prepare_latents of the img2img base class), ddim/sdxl_pipeline.py:859-871.
  * NCHW fp16 at both ends; h, w are LATENT sizes in both directions (image side = latent side * 2^(n_blocks-1)).
  * encode returns the posterior moments [B, 2*latent_channels, h, w] (mean | logvar); sampling and the 0.13025 scaling
- * stay on the host. The reference upcasts this model to fp32; this build keeps fp16 storage with fp32 accumulation. */
+ * stay on the host. The reference upcasts this model to fp32 (its activations overflow fp16); this build keeps fp16 storage with fp32
+ * accumulation and extends the range of the residual stream by a power-of-two storage scale (ia2p_vae_config.stream_scale). */
 typedef struct ia2p_vae ia2p_vae;
 typedef struct {
   int in_channels, out_channels, latent_channels;
@@ -209,6 +210,8 @@ typedef struct {
   int layers_per_block;
   int norm_num_groups;
   float norm_eps;
+  float stream_scale;   /* range extension in place of the reference's fp32 upcast (sdxl_pipeline.py:860-865): the residual stream is stored
+                         * multiplied by this power of two in [2^-16, 1] (<= 0 means 1 = plain fp16 storage); 2^-7 covers +-8.4e6 */
 } ia2p_vae_config;
 ia2p_status ia2p_vae_create(const ia2p_vae_config* cfg, ia2p_vae** out);
 void ia2p_vae_destroy(ia2p_vae* vae);

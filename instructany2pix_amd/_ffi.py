@@ -39,7 +39,7 @@ class CLIPConfigC(C.Structure):
 class VAEConfigC(C.Structure):
     _fields_ = [("in_channels", C.c_int), ("out_channels", C.c_int), ("latent_channels", C.c_int), ("n_blocks", C.c_int),
                 ("block_out_channels", C.c_int * MAX_BLOCKS), ("layers_per_block", C.c_int), ("norm_num_groups", C.c_int),
-                ("norm_eps", C.c_float)]
+                ("norm_eps", C.c_float), ("stream_scale", C.c_float)]
 
 
 # every symbol include/ia2p.h declares: name -> (restype, argtypes)
@@ -204,4 +204,5 @@ def make_vae_config(cfg) -> VAEConfigC:
     for i in range(c.n_blocks):
         c.block_out_channels[i] = cfg.block_out_channels[i]
     c.layers_per_block, c.norm_num_groups, c.norm_eps = cfg.layers_per_block, cfg.norm_num_groups, cfg.norm_eps
+    c.stream_scale = float(getattr(cfg, "stream_scale", 1.0))
     return c

@@ -107,6 +107,9 @@ class VAEConfig:
     norm_eps: float = 1e-6
     scaling_factor: float = 0.13025
     force_upcast: bool = True        # the reference upcasts the VAE to fp32 (sdxl_pipeline.py:860-865); see vae.py
+    # range extension that replaces the upcast on the HIP path: the residual stream is stored multiplied by this power of two (vae_engine.hip);
+    # 2^-7 covers magnitudes up to 8.4e6 (the original SDXL VAE checkpoint passes the fp16 maximum of 65504); 1.0 = plain fp16 storage
+    stream_scale: float = 2.0 ** -7
 
     def __getitem__(self, k):
         return getattr(self, k)

@@ -79,6 +79,9 @@ struct GemmArgs {
   int splitk;            // 0/1 = off
   float* partial;
   int* sk_counters;      // set by the launcher: per-tile ticket counters of the in-launch combine (null: a separate splitk_reduce_kernel launch finishes)
+  // range extension (VAE executor): out = acc * acc_scale + (bias + rowvec) * bias_scale + residual; 0 = 1.0. The VAE keeps its residual
+  // stream multiplied by a power of two < 1 so that fp16 storage does not overflow where the reference upcasts to fp32 (vae_engine.hip)
+  float acc_scale, bias_scale;
   int act;               // activation on (acc + bias) before rowvec / residual: 0 none, 1 GELU (erf), 2 quick-GELU x*sigmoid(1.702x) (CLIP MLPs)
   // LayerNorm folded into this contraction (consumer side). A is the un-normalised residual stream [M, K], W was pre-scaled by
   // the norm's gamma when the weights were finalized (fold_ln_kernel), and the epilogue finishes the normalisation:

@@ -414,6 +414,7 @@ void op_gemm(RunCtx* c, const half_t* A, int lda, const half_t* W, const half_t*
   a.rpb = rpb; a.bstride = bstride; a.roff = roff; a.bias = bias; a.residual = residual; a.ldr = ldr; a.geglu = geglu;
   a.rows_per_batch = 1;
   a.m_fastest = (long)M * K <= (long)N * K ? 1 : 0;
+  a.acc_scale = c->ep_acc_scale; a.bias_scale = c->ep_bias_scale; c->ep_acc_scale = c->ep_bias_scale = 1.f;
   set_prefetch(c, a, W, (size_t)N * K * sizeof(half_t));
   run_gemm(c, a, false, "gemm", 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * (geglu ? N / 2 : N) + (residual ? (double)M * N : 0)), stat_slots);
 }
@@ -428,6 +429,7 @@ void op_conv3(RunCtx* c, const half_t* X, int B, int Hs, int Ws, int Cin, const 
   a.Hs = Hs; a.Ws = Ws; a.stride = stride; a.up = up; a.Cin = Cin;
   a.bias = bias; a.rowvec = rowvec; a.rowvec_ld = rowvec_ld; a.rows_per_batch = a.Ho * a.Wo; a.residual = residual; a.ldr = Co;
   a.m_fastest = 0;
+  a.acc_scale = c->ep_acc_scale; a.bias_scale = c->ep_bias_scale; c->ep_acc_scale = c->ep_bias_scale = 1.f;
   set_prefetch(c, a, W, (size_t)Co * a.K * sizeof(half_t));
   run_gemm(c, a, true, "conv3x3", 2.0 * a.M * (double)Co * a.K, 2.0 * ((double)B * Hs * Ws * Cin + (double)Co * a.K + (double)a.M * Co + (residual ? (double)a.M * Co : 0)));
 }

@@ -34,7 +34,7 @@ hipError_t ia2p_launch_embed(float t, const half_t* text_embeds, const half_t* t
                              int B, int Tp, int P, int Ad, int nids, hipStream_t s);
 hipError_t ia2p_launch_linear_small(const half_t* X, int ldx, const half_t* W, const half_t* bias, const half_t* addend, int ldadd,
                                     half_t* out, int ldo, int M, int N, int K, int silu_in, int silu_out, hipStream_t s);
-hipError_t ia2p_launch_conv_in(const half_t* x, const half_t* w, const half_t* bias, half_t* y, int B, int Cin, int H, int W, int Co, hipStream_t s);
+hipError_t ia2p_launch_conv_in(const half_t* x, const half_t* w, const half_t* bias, half_t* y, int B, int Cin, int H, int W, int Co, hipStream_t s, float out_scale = 1.0f);
 hipError_t ia2p_launch_conv_out(const half_t* x, int ldx, const half_t* w, const half_t* bias, half_t* y, int B, int C, int H, int W, int Co, hipStream_t s);
 hipError_t ia2p_launch_concat(const half_t* a, int lda, int Ca, const half_t* b, int ldb, int Cb, half_t* y, long M, hipStream_t s);
 hipError_t ia2p_launch_ddim_step(const half_t* x, const half_t* eps_u, const half_t* eps_c, float g, float c_x, float c_e,
@@ -147,6 +147,7 @@ struct RunCtx {
   int region = PR_OTHER;     // region the executor is in (tags the profile records)
   double r_ms[PR_NREGION], r_fl[PR_NREGION], r_by[PR_NREGION];
   int64_t r_n[PR_NREGION];
+  float ep_acc_scale = 1.f, ep_bias_scale = 1.f;   // epilogue scales of the NEXT op_gemm / op_conv3 call (reset by it): range extension, vae_engine.hip
   bool fold_dirty = false;   // a LayerNorm-fold source tensor was (re)loaded after the last fold: re-fold before the next forward
   RunCtx() {
     if (const char* e = getenv("IA2P_PREFETCH")) prefetch = atoi(e) != 0;

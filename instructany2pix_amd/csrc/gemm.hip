@@ -424,6 +424,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_f16_kernel(const half_
       *(f4*)(ln_lb + tid * 4) = *(const f4*)(p.ln_bias + bn0 + tid * 4);
     }
   }
+  const float e_as = p.acc_scale == 0.f ? 1.f : p.acc_scale, e_bs = p.bias_scale == 0.f ? 1.f : p.bias_scale;
   const bool fast = p.vec8 != 0 && (hN & 7) == 0;     // 16-byte accesses everywhere (every shape of the executors); else 8-byte pieces
   auto tl = [&](int r, int c) -> f4 { return *(const f4*)(tile + (size_t)r * PITCH + ((c ^ (r & 7)) << 2)); };
   auto acc_to_tile = [&](int ch) {
@@ -573,9 +574,13 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_f16_kernel(const half_
               const float mu = ln_rows[ch * CR + r], rs = ln_rows[BM + ch * CR + r];
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = rs * (v[e] - mu * ln_cs[cl + e]) + ln_lb[cl + e];
-            } else if (p.bias) {
+            } else {
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] += (float)hb[u][e];
+              for (int e = 0; e < 8; ++e) v[e] *= e_as;
+              if (p.bias) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaf((float)hb[u][e], e_bs, v[e]);
+              }
             }
             if (p.act) {
 #pragma unroll
@@ -583,7 +588,7 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_f16_kernel(const half_
             }
             if (p.rowvec) {
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] += (float)hv[u][e];
+              for (int e = 0; e < 8; ++e) v[e] = fmaf((float)hv[u][e], e_bs, v[e]);
             }
             if (p.residual) {
 #pragma unroll
@@ -618,9 +623,12 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_f16_kernel(const half_
                 const float mu = ln_rows[ch * CR + r], rs = ln_rows[BM + ch * CR + r];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = rs * (v[e] - mu * ln_cs[cl + e]) + ln_lb[cl + e];
-              } else if (p.bias) { const h4 b = *(const h4*)(p.bias + n); v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3]; }
+              } else {
+                v[0] *= e_as; v[1] *= e_as; v[2] *= e_as; v[3] *= e_as;
+                if (p.bias) { const h4 b = *(const h4*)(p.bias + n); v[0] = fmaf((float)b[0], e_bs, v[0]); v[1] = fmaf((float)b[1], e_bs, v[1]); v[2] = fmaf((float)b[2], e_bs, v[2]); v[3] = fmaf((float)b[3], e_bs, v[3]); }
+              }
               if (p.act) { v[0] = act_f(v[0], p.act); v[1] = act_f(v[1], p.act); v[2] = act_f(v[2], p.act); v[3] = act_f(v[3], p.act); }
-              if (p.rowvec) { const h4 b = *(const h4*)(p.rowvec + (size_t)(m / p.rows_per_batch) * p.rowvec_ld + n); v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3]; }
+              if (p.rowvec) { const h4 b = *(const h4*)(p.rowvec + (size_t)(m / p.rows_per_batch) * p.rowvec_ld + n); v[0] = fmaf((float)b[0], e_bs, v[0]); v[1] = fmaf((float)b[1], e_bs, v[1]); v[2] = fmaf((float)b[2], e_bs, v[2]); v[3] = fmaf((float)b[3], e_bs, v[3]); }
               if (p.residual) { const h4 b = *(const h4*)(p.residual + (size_t)m * p.ldr + n); v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3]; }
               h4 o; o[0] = (half_t)v[0]; o[1] = (half_t)v[1]; o[2] = (half_t)v[2]; o[3] = (half_t)v[3];
               *(h4*)(p.C + (size_t)m * p.ldc + n) = o;
@@ -768,9 +776,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* hpartia
         const f4 cs = *(const f4*)(p.ln_cs + n), lb = *(const f4*)(p.ln_bias + n);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = rs * (v[r] - mu * cs[r]) + lb[r];
-      } else if (p.bias) { const h4 b = *(const h4*)(p.bias + n); v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3]; }
+      } else {
+        const float e_as = p.acc_scale == 0.f ? 1.f : p.acc_scale, e_bs = p.bias_scale == 0.f ? 1.f : p.bias_scale;
+        v[0] *= e_as; v[1] *= e_as; v[2] *= e_as; v[3] *= e_as;
+        if (p.bias) { const h4 b = *(const h4*)(p.bias + n); v[0] = fmaf((float)b[0], e_bs, v[0]); v[1] = fmaf((float)b[1], e_bs, v[1]); v[2] = fmaf((float)b[2], e_bs, v[2]); v[3] = fmaf((float)b[3], e_bs, v[3]); }
+      }
       if (p.act) { v[0] = act_f(v[0], p.act); v[1] = act_f(v[1], p.act); v[2] = act_f(v[2], p.act); v[3] = act_f(v[3], p.act); }
-      if (p.rowvec) { const h4 b = *(const h4*)(p.rowvec + (size_t)(m / p.rows_per_batch) * p.rowvec_ld + n); v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3]; }
+      if (p.rowvec) { const float e_bs = p.bias_scale == 0.f ? 1.f : p.bias_scale; const h4 b = *(const h4*)(p.rowvec + (size_t)(m / p.rows_per_batch) * p.rowvec_ld + n); v[0] = fmaf((float)b[0], e_bs, v[0]); v[1] = fmaf((float)b[1], e_bs, v[1]); v[2] = fmaf((float)b[2], e_bs, v[2]); v[3] = fmaf((float)b[3], e_bs, v[3]); }
       if (hresidual) { const h4 b = *(const h4*)(hresidual + (size_t)m * hldr + n); v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3]; }
       h4 o; o[0] = (half_t)v[0]; o[1] = (half_t)v[1]; o[2] = (half_t)v[2]; o[3] = (half_t)v[3];
       *(h4*)(hC + (size_t)m * hldc + n) = o;

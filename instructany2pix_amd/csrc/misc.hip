@@ -96,7 +96,7 @@ __global__ __launch_bounds__(64) void linear_small_kernel(const half_t* X, int l
 
 // ---- conv_in: latent NCHW [B,Cin,H,W] -> channels-last [B*H*W, Co], 3x3 pad 1 (Cin*9 <= 64 taps) --------------------
 __global__ __launch_bounds__(256) void conv_in_kernel(const half_t* x, const half_t* w /*[Co][Cin][3][3]*/, const half_t* bias,
-                                                      half_t* y, int B, int Cin, int H, int W, int Co, int pix_per_block) {
+                                                      half_t* y, int B, int Cin, int H, int W, int Co, int pix_per_block, float out_scale) {
   extern __shared__ half_t wl[];   // [Cin*9][Co]
   const int KT = Cin * 9;
   for (int i = threadIdx.x; i < KT * Co; i += blockDim.x) {
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const half_t* x, const hal
         }
     h8 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (half_t)acc[e];
+    for (int e = 0; e < 8; ++e) o[e] = (half_t)(acc[e] * out_scale);
     *(h8*)(y + (size_t)pp * Co + tx * 8) = o;
   }
 }
@@ -502,11 +502,11 @@ hipError_t ia2p_launch_linear_small(const half_t* X, int ldx, const half_t* W, c
   hipLaunchKernelGGL(linear_small_kernel, dim3((N + 3) / 4), dim3(64), 0, s, X, ldx, W, bias, addend, ldadd, out, ldo, M, N, K, silu_in, silu_out);
   return hipGetLastError();
 }
-hipError_t ia2p_launch_conv_in(const half_t* x, const half_t* w, const half_t* bias, half_t* y, int B, int Cin, int H, int W, int Co, hipStream_t s) {
+hipError_t ia2p_launch_conv_in(const half_t* x, const half_t* w, const half_t* bias, half_t* y, int B, int Cin, int H, int W, int Co, hipStream_t s, float out_scale) {
   if (Co % 8 || Co / 8 > 256) return hipErrorInvalidValue;
   const int ppb = 64;
   const size_t sm = (size_t)Cin * 9 * Co * sizeof(half_t);
-  hipLaunchKernelGGL(conv_in_kernel, dim3((B * H * W + ppb - 1) / ppb), dim3(256), sm, s, x, w, bias, y, B, Cin, H, W, Co, ppb);
+  hipLaunchKernelGGL(conv_in_kernel, dim3((B * H * W + ppb - 1) / ppb), dim3(256), sm, s, x, w, bias, y, B, Cin, H, W, Co, ppb, out_scale);
   return hipGetLastError();
 }
 hipError_t ia2p_launch_conv_out(const half_t* x, int ldx, const half_t* w, const half_t* bias, half_t* y, int B, int C, int H, int W, int Co, hipStream_t s) {

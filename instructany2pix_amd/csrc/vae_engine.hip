@@ -8,6 +8,12 @@
 // pads only after the image: `pad = 0`), GroupNorm+SiLU, the GEMM kernel for the single-head mid-block attention
 // (head_dim = channels: scores are materialised per image, S = Q.K^T, row softmax, O = P.V with V^T produced directly
 // as W_v.X^T), direct kernels at the 3/4/8-channel boundaries.
+// Range extension instead of the reference's fp32 upcast (ddim/sdxl_pipeline.py:860-865 `upcast_vae`): the residual stream of the SDXL VAE
+// grows past the fp16 maximum with the original checkpoint. Every tensor that carries the stream (and each resnet's conv1 output) is STORED
+// multiplied by `ss` = cfg.stream_scale, a power of two <= 1 (2^-7 by default: range +-8.4e6): the producing epilogue multiplies its fp32
+// accumulator by ss before the single rounding, GroupNorm reads the scaled tensor with eps * ss^2 (exactly the unscaled normalisation),
+// linear consumers (shortcuts, resample convolutions) pass the scale through and scale only their bias. Powers of two: no rounding is
+// added anywhere; fp16 keeps its 11 significant bits at every magnitude above 6e-5 / ss.
 // =====================================================================================================================
 struct VRes { int cin, cout; bool shortcut; size_t n1g, n1b, w1, b1, n2g, n2b, w2, b2, wsc, bsc; };
 struct VMid { int c; VRes r0, r1; size_t gg, gb, wqk, bqk, wv, bv, wo, bo; };
@@ -18,6 +24,7 @@ struct ia2p_vae : RunCtx {
   size_t e_in_w, e_in_b, e_ng, e_nb, e_out_w, e_out_b, q_w, q_b, pq_w, pq_b, d_in_w, d_in_b, d_ng, d_nb, d_out_w, d_out_b;
   std::vector<VStage> enc, dec;
   VMid emid, dmid;
+  float ss = 1.f;        // stream scale (see the header comment)
 };
 
 struct VPlanner {
@@ -110,24 +117,28 @@ static ia2p_status vae_plan(ia2p_vae* c) {
 }
 
 static T2 vae_resnet(ia2p_vae* c, const VRes& r, T2 x, int B, int H, int Wd, float* gnp) {
+  const float ss = c->ss, eps = c->cfg.norm_eps * ss * ss;     // x holds ss * (stream)
   const int HW = H * Wd;
   const long M = (long)B * HW;
   T2 n1 = wsalloc(c, (size_t)M * r.cin);
-  op_gn(c, x.p, n1.p, r.n1g, r.n1b, B, HW, r.cin, c->cfg.norm_eps, 1, gnp);
+  op_gn(c, x.p, n1.p, r.n1g, r.n1b, B, HW, r.cin, eps, 1, gnp);
   T2 hh = wsalloc(c, (size_t)M * r.cout);
+  c->ep_acc_scale = ss; c->ep_bias_scale = ss;                 // hh = ss * conv1(...)
   op_conv3(c, n1.p, B, H, Wd, r.cin, W_(c, r.w1), W_(c, r.b1), r.cout, 1, 0, nullptr, 0, nullptr, hh.p);
   wsfree(c, n1);
   T2 n2 = wsalloc(c, (size_t)M * r.cout);
-  op_gn(c, hh.p, n2.p, r.n2g, r.n2b, B, HW, r.cout, c->cfg.norm_eps, 1, gnp);
+  op_gn(c, hh.p, n2.p, r.n2g, r.n2b, B, HW, r.cout, eps, 1, gnp);
   wsfree(c, hh);
   T2 xs{(size_t)-1, nullptr};
   const half_t* resid = x.p;
   if (r.shortcut) {
     xs = wsalloc(c, (size_t)M * r.cout);
+    c->ep_acc_scale = 1.f; c->ep_bias_scale = ss;               // linear in the (scaled) stream: only the bias is scaled
     op_gemm(c, x.p, r.cin, W_(c, r.wsc), W_(c, r.bsc), nullptr, 0, xs.p, r.cout, (int)M, r.cout, r.cin);
     resid = xs.p;
   }
   T2 out = wsalloc(c, (size_t)M * r.cout);
+  c->ep_acc_scale = ss; c->ep_bias_scale = ss;                 // ss * (conv2 + b) + (scaled) residual
   op_conv3(c, n2.p, B, H, Wd, r.cout, W_(c, r.w2), W_(c, r.b2), r.cout, 1, 0, nullptr, 0, c->dry ? nullptr : resid, out.p);
   wsfree(c, n2);
   if (r.shortcut) wsfree(c, xs);
@@ -140,19 +151,22 @@ static T2 vae_mid(ia2p_vae* c, const VMid& m, T2 x, int B, int H, int Wd, float*
   wsfree(c, x);
   // attention (ldm AttnBlock, blocks.py:179-203): x + to_out(softmax(QK^T / sqrt(C)) V), one head of width C
   T2 n = wsalloc(c, (size_t)B * HW * C);
-  op_gn(c, a.p, n.p, m.gg, m.gb, B, HW, C, c->cfg.norm_eps, 0, gnp);
+  const float ss = c->ss;
+  op_gn(c, a.p, n.p, m.gg, m.gb, B, HW, C, c->cfg.norm_eps * ss * ss, 0, gnp);
   T2 qk = wsalloc(c, (size_t)HW * 2 * C), vt = wsalloc(c, (size_t)C * HW), sc = wsalloc(c, (size_t)HW * HW), o = wsalloc(c, (size_t)HW * C);
   T2 out = wsalloc(c, (size_t)B * HW * C);
   for (int b = 0; b < B; ++b) {
     const half_t* nb = c->dry ? nullptr : n.p + (size_t)b * HW * C;
     op_gemm(c, nb, C, W_(c, m.wqk), W_(c, m.bqk), nullptr, 0, qk.p, 2 * C, HW, 2 * C, C);                  // [q | k]
     op_gemm(c, W_(c, m.wv), C, nb, nullptr, nullptr, 0, vt.p, HW, C, HW, C);                              // V^T = W_v . X^T (bias added after P.V: rows of P sum to 1)
-    op_gemm(c, qk.p, 2 * C, c->dry ? nullptr : qk.p + C, nullptr, nullptr, 0, sc.p, HW, HW, HW, C, 0, 0, 0, 0, 2 * C);   // S = Q . K^T
+    c->ep_acc_scale = 1.0f / sqrtf((float)C);                                                              // scores leave the accumulator already scaled: |q.k| can pass the fp16 maximum
+    op_gemm(c, qk.p, 2 * C, c->dry ? nullptr : qk.p + C, nullptr, nullptr, 0, sc.p, HW, HW, HW, C, 0, 0, 0, 0, 2 * C);   // S = Q . K^T / sqrt(C)
     {
       ProfScope ps(c, PK_ATTN, 0, 4.0 * HW * HW);
-      CHECK_LAUNCH(c, ia2p_launch_softmax_rows(sc.p, HW, HW, HW, 1.0f / sqrtf((float)C), c->stream), "vae softmax");
+      CHECK_LAUNCH(c, ia2p_launch_softmax_rows(sc.p, HW, HW, HW, 1.0f, c->stream), "vae softmax");
     }
     op_gemm(c, sc.p, HW, vt.p, W_(c, m.bv), nullptr, 0, o.p, C, HW, C, HW);                                // O = P . V + b_v
+    c->ep_acc_scale = ss; c->ep_bias_scale = ss;
     op_gemm(c, o.p, C, W_(c, m.wo), W_(c, m.bo), c->dry ? nullptr : a.p + (size_t)b * HW * C, C,
             c->dry ? nullptr : out.p + (size_t)b * HW * C, C, HW, C, C);                                  // + residual
   }
@@ -180,7 +194,7 @@ static ia2p_status vae_run_decode(ia2p_vae* c, const half_t* zin, half_t* img, i
   }
   T2 x = wsalloc(c, (size_t)B * h * w * cm);
   { ProfScope ps(c, PK_CONV_IN, 0, 0);
-    CHECK_LAUNCH(c, ia2p_launch_conv_in(zq.p, W_(c, c->d_in_w), W_(c, c->d_in_b), x.p, B, z, h, w, cm, c->stream), "decoder.conv_in");
+    CHECK_LAUNCH(c, ia2p_launch_conv_in(zq.p, W_(c, c->d_in_w), W_(c, c->d_in_b), x.p, B, z, h, w, cm, c->stream, c->ss), "decoder.conv_in");
   }
   wsfree(c, zq);
   x = vae_mid(c, c->dmid, x, B, h, w, gp);
@@ -190,13 +204,14 @@ static ia2p_status vae_run_decode(ia2p_vae* c, const half_t* zin, half_t* img, i
     for (const VRes& r : st.res) { T2 y = vae_resnet(c, r, x, B, H, Wd, gp); wsfree(c, x); x = y; }
     if (st.resample) {
       T2 u = wsalloc(c, (size_t)B * (2 * H) * (2 * Wd) * st.rc);
+      c->ep_acc_scale = 1.f; c->ep_bias_scale = c->ss;
       op_conv3(c, x.p, B, H, Wd, st.rc, W_(c, st.rw), W_(c, st.rb), st.rc, 1, 1, nullptr, 0, nullptr, u.p);
       wsfree(c, x); x = u; H *= 2; Wd *= 2;
     }
   }
   const int c0 = g.block_out_channels[0];
   T2 no = wsalloc(c, (size_t)B * H * Wd * c0);
-  op_gn(c, x.p, no.p, c->d_ng, c->d_nb, B, H * Wd, c0, g.norm_eps, 1, gp);
+  op_gn(c, x.p, no.p, c->d_ng, c->d_nb, B, H * Wd, c0, g.norm_eps * c->ss * c->ss, 1, gp);
   wsfree(c, x);
   { ProfScope ps(c, PK_CONV_OUT, 0, 0);
     CHECK_LAUNCH(c, ia2p_launch_conv_out(no.p, c0, W_(c, c->d_out_w), W_(c, c->d_out_b), img, B, c0, H, Wd, g.out_channels, c->stream), "decoder.conv_out");
@@ -214,13 +229,14 @@ static ia2p_status vae_run_encode(ia2p_vae* c, const half_t* img, half_t* moment
   int H = Hi, Wd = Wi;
   T2 x = wsalloc(c, (size_t)B * H * Wd * g.block_out_channels[0]);
   { ProfScope ps(c, PK_CONV_IN, 0, 0);
-    CHECK_LAUNCH(c, ia2p_launch_conv_in(img, W_(c, c->e_in_w), W_(c, c->e_in_b), x.p, B, g.in_channels, H, Wd, g.block_out_channels[0], c->stream), "encoder.conv_in");
+    CHECK_LAUNCH(c, ia2p_launch_conv_in(img, W_(c, c->e_in_w), W_(c, c->e_in_b), x.p, B, g.in_channels, H, Wd, g.block_out_channels[0], c->stream, c->ss), "encoder.conv_in");
   }
   for (int i = 0; i < n; ++i) {
     const VStage& st = c->enc[i];
     for (const VRes& r : st.res) { T2 y = vae_resnet(c, r, x, B, H, Wd, gp); wsfree(c, x); x = y; }
     if (st.resample) {       // F.pad(x, (0,1,0,1)) + conv stride 2 padding 0 (ldm Downsample, blocks.py:73-77)
       T2 d = wsalloc(c, (size_t)B * (H / 2) * (Wd / 2) * st.rc);
+      c->ep_acc_scale = 1.f; c->ep_bias_scale = c->ss;
       op_conv3(c, x.p, B, H, Wd, st.rc, W_(c, st.rw), W_(c, st.rb), st.rc, 2, 0, nullptr, 0, nullptr, d.p, 0);
       wsfree(c, x); x = d; H /= 2; Wd /= 2;
     }
@@ -228,7 +244,7 @@ static ia2p_status vae_run_encode(ia2p_vae* c, const half_t* img, half_t* moment
   x = vae_mid(c, c->emid, x, B, H, Wd, gp);
   const int cm = g.block_out_channels[n - 1];
   T2 no = wsalloc(c, (size_t)B * H * Wd * cm);
-  op_gn(c, x.p, no.p, c->e_ng, c->e_nb, B, H * Wd, cm, g.norm_eps, 1, gp);
+  op_gn(c, x.p, no.p, c->e_ng, c->e_nb, B, H * Wd, cm, g.norm_eps * c->ss * c->ss, 1, gp);
   wsfree(c, x);
   T2 m0 = wsalloc(c, (size_t)B * 2 * z * H * Wd);
   { ProfScope ps(c, PK_CONV_OUT, 0, 0);
@@ -246,6 +262,11 @@ ia2p_status ia2p_vae_create(const ia2p_vae_config* cfg, ia2p_vae** out) {
   ia2p_vae* c = new ia2p_vae();
   c->cfg = *cfg;
   c->groups = cfg->norm_num_groups;
+  c->ss = cfg->stream_scale > 0.f ? cfg->stream_scale : 1.f;
+  {
+    int ex = 0;
+    if (std::frexp(c->ss, &ex) != 0.5f || c->ss > 1.f || c->ss < 1.0f / 65536.f) { delete c; *out = nullptr; return fail(nullptr, IA2P_ERR_INVALID, "stream_scale must be a power of two in [2^-16, 1]"); }
+  }
   ia2p_status st = vae_plan(c);
   if (st != IA2P_OK) { g_err = c->err; delete c; *out = nullptr; return st; }
   c->failed = false;

@@ -6,9 +6,11 @@
   vae.config.{scaling_factor, force_upcast}, vae.dtype
 
 First "next" row of SURVEY.md §8f. All arithmetic runs in libia2p_hip.so (`ia2p_vae_encode` / `ia2p_vae_decode`).
-Precision note: the reference upcasts this model to fp32 (`force_upcast`, sdxl_pipeline.py:860-865) because the real SDXL
-VAE overflows fp16 activations; this build stores activations in fp16 with fp32 accumulation and fp32 norm statistics
-(parity against the fp32 oracle is stated in tests/test_vae_gpu.py), so `force_upcast` is reported False.
+Precision note: the reference upcasts this model to fp32 (`force_upcast`, sdxl_pipeline.py:860-865) because the residual stream of the
+original SDXL VAE checkpoint passes the fp16 maximum. The HIP executor keeps fp16 storage (fp32 accumulation and norm statistics) and
+extends its range instead: the stream is stored multiplied by `VAEConfig.stream_scale` (2^-7: magnitudes up to 8.4e6), exactly undone by
+the GroupNorms (csrc/vae_engine.hip). So `config.force_upcast` reads False (callers need not upcast anything), and every output is checked
+for non-finite values: an overflow raises instead of producing black images (tests/test_vae_gpu.py drives both).
 """
 from __future__ import annotations
 
@@ -103,6 +105,7 @@ class HipAutoencoderKL:
         ws = self._workspace(B, h, w, False)
         mom = torch.empty(B, 2 * self._cfg.latent_channels, h, w, dtype=torch.float16, device=self.device)
         _ffi.check(self._lib.ia2p_vae_encode(self._h, _ffi.current_stream(), _ffi.ptr(x), _ffi.ptr(mom), B, h, w, _ffi.ptr(ws), ws.numel()), self._h, vae=True)
+        self._check_finite(mom, "encode")
         dist = DiagonalGaussianDistribution(mom)
         return SimpleNamespace(latent_dist=dist) if return_dict else (dist,)
 
@@ -116,7 +119,13 @@ class HipAutoencoderKL:
         ws = self._workspace(B, h, w, True)
         img = torch.empty(B, self._cfg.out_channels, h * f, w * f, dtype=torch.float16, device=self.device)
         _ffi.check(self._lib.ia2p_vae_decode(self._h, _ffi.current_stream(), _ffi.ptr(x), _ffi.ptr(img), B, h, w, _ffi.ptr(ws), ws.numel()), self._h, vae=True)
+        self._check_finite(img, "decode")
         return SimpleNamespace(sample=img) if return_dict else (img,)
+
+    def _check_finite(self, t, what):
+        if not bool(torch.isfinite(t).all()):
+            raise _ffi.IA2PError(f"HipAutoencoderKL.{what}: non-finite output -- the activations left the range of fp16 storage at stream_scale="
+                                 f"{self._cfg.stream_scale:g} (the reference runs this model in fp32); lower VAEConfig.stream_scale (a power of two)")
 
     # hooks with the signatures the loops in ddim.py accept (vae_encode= / vae_decode=)
     def encode_to_latents(self, image, generator=None):

@@ -158,3 +158,48 @@ def test_image_to_image_hot_segment_with_vae():
     assert float((a - b).norm() / b.norm()) < 4e-2 and float(torch.dot(a, b) / (a.norm() * b.norm())) > 0.998
     a, b = out.float().cpu().flatten(), rout.flatten()
     assert float(torch.dot(a, b) / (a.norm() * b.norm())) > 0.995, float(torch.dot(a, b) / (a.norm() * b.norm()))
+
+
+def test_vae_range_extension_replaces_the_fp32_upcast():
+    """Weights scaled so that the residual stream passes the fp16 maximum (what the original SDXL VAE checkpoint does; the reference
+    upcasts the model to fp32 for it, ddim/sdxl_pipeline.py:860-865): plain fp16 storage (stream_scale 1) overflows and RAISES,
+    the default stream scale reproduces the fp32 oracle. With ordinary weights the scale changes nothing beyond fp16 rounding."""
+    import dataclasses
+    import oracle
+    from instructany2pix_amd import _ffi
+    from instructany2pix_amd.config import tiny_vae
+    from instructany2pix_amd.vae import HipAutoencoderKL
+    from instructany2pix_amd.weights import vae_param_specs, synthetic_state_dict
+    cfg = tiny_vae()
+    assert cfg.stream_scale == 2.0 ** -7
+    sd = synthetic_state_dict(vae_param_specs(cfg), seed=7)
+    big = dict(sd)
+    for k in ("decoder.conv_in.weight", "decoder.conv_in.bias", "encoder.conv_in.weight", "encoder.conv_in.bias"):
+        big[k] = (sd[k].float() * min(4.0e4, 5.0e4 / float(sd[k].float().abs().max()))).half()       # still fp16-representable weights
+    ref = oracle.build_vae(cfg, big)
+    g = torch.Generator().manual_seed(3)
+    z = torch.randn(2, 4, 8, 8, generator=g).half()
+    x = torch.randn(2, 3, 32, 32, generator=g).half()
+    with torch.no_grad():
+        rimg, rmom = ref.decode(z.float()), ref.encode_moments(x.float())
+    with torch.no_grad():
+        assert float(ref.decoder.conv_in(ref.post_quant_conv(z.float())).abs().max()) > 65504.0           # the stream really leaves the fp16 range
+    ext = HipAutoencoderKL(cfg, DEV)
+    ext.load_state_dict(big)
+    assert ext.config.force_upcast is False
+    img = ext.decode(z.to(DEV), return_dict=False)[0]
+    assert rel_l2(img, rimg) < 1e-2, rel_l2(img, rimg)
+    assert rel_l2(ext.encode(x.to(DEV)).latent_dist.parameters, rmom) < 1e-2
+    plain = HipAutoencoderKL(dataclasses.replace(cfg, stream_scale=1.0), DEV)
+    plain.load_state_dict(big)
+    with pytest.raises(_ffi.IA2PError):
+        plain.decode(z.to(DEV))
+    # ordinary weights: both storage scales agree with the oracle and with each other to fp16 accuracy
+    a, b = HipAutoencoderKL(cfg, DEV), HipAutoencoderKL(dataclasses.replace(cfg, stream_scale=1.0), DEV)
+    a.load_state_dict(sd); b.load_state_dict(sd)
+    ia, ib = a.decode(z.to(DEV), return_dict=False)[0], b.decode(z.to(DEV), return_dict=False)[0]
+    with torch.no_grad():
+        r0 = oracle.build_vae(cfg, sd).decode(z.float())
+    assert rel_l2(ia, r0) < 1e-2 and rel_l2(ib, r0) < 1e-2 and rel_l2(ia, ib) < 5e-3
+    with pytest.raises(ValueError):
+        HipAutoencoderKL(dataclasses.replace(cfg, stream_scale=0.3), DEV)
