@@ -7,7 +7,8 @@ The reference's `__call__` (:303-386) does, in order: LLM + ImageBind (`forward_
     :330      latent_inv = pipe_inversion.inverse(num_inference_steps=N, prompt='', image=img_base)
     :331-337  polar interpolation with fresh noise (CPU, fp16, global torch RNG)
     :342-354  ip_adapter_xl.generate(prompt=..., clip_image_embeds=latent_la[0], latents=latent_inv, guidance_scale=cfg, scale=scale)
-followed by the refiner pass (:358-361; `self.piperf`, img2img.py — SURVEY.md §8f rank 2, built) and the subject-consistency
+followed by the refiner pass (:358-361; `self.piperf`, img2img.py — SURVEY.md §8f rank 2, built; with a VAE attached the base result
+reaches it the reference's way: decoded, quantised to 8 bits, re-encoded) and the subject-consistency
 pass (:363-368; `self.pipe_inpainting` / `ip_adapter_xl_inpaint`, inpaint.py — rank 3, built; its masks come from SAM / GroundingDINO,
 which stay outside).
 
@@ -41,6 +42,19 @@ def polar_intrtpolate(x, y, alpha):
     return ll / ll.norm() * n
 
 
+def to_8bit_image(image):
+    """What the reference's hand-over between its pipelines does to an image tensor in [-1, 1]: `postprocess(output_type="pil")`
+    (`(x / 2 + 0.5).clamp(0, 1)`, `* 255`, round, uint8) followed by the img2img pipeline's `preprocess` (`/ 255`, `2 x - 1`)."""
+    q = ((image.float() / 2 + 0.5).clamp(0, 1) * 255.0).round()
+    return (q / 255.0 * 2.0 - 1.0).to(image.dtype)
+
+
+def _need(c, keys, stage):
+    missing = [k for k in keys if k not in c]
+    if missing:
+        raise KeyError(f"the conditioner returned no {missing} (needed by the {stage}; pass refinement=0 / subject_strength=0 to skip that stage)")
+
+
 def fuse_instruction_embedding(base_embed, image_embeds, y0, h, norm):
     """reference pipeline.py:322-324"""
     latent_la = base_embed * h[0] + image_embeds * h[1] + y0 / y0.norm() * 20.0 * h[2]
@@ -53,7 +67,14 @@ class InstructAny2PixPipeline:
                  unet_config: Optional[UNetConfig] = None, unet_state_dict=None, ip_ckpt=None, device: str = "cuda:0",
                  conditioner: Optional[Callable] = None, text_encoder: Optional[Callable] = None,
                  vae_encode: Optional[Callable] = None, vae_decode: Optional[Callable] = None, clip_embeddings_dim: int = 1024,
-                 refiner_unet: Optional[HipUNet2DConditionModel] = None, refiner_text_encoder: Optional[Callable] = None, prior=None):
+                 refiner_unet: Optional[HipUNet2DConditionModel] = None, refiner_text_encoder: Optional[Callable] = None, prior=None,
+                 refiner_handoff: str = "image"):
+        # how the base result reaches the refiner: "image" = the reference's route (decode, 8-bit image, VAE re-encode with a posterior
+        # sample; needs vae_encode and vae_decode), "latent" = the sampled latents go in directly (no VAE round trip; the only route
+        # when no VAE is attached)
+        if refiner_handoff not in ("image", "latent"):
+            raise ValueError("refiner_handoff must be 'image' or 'latent'")
+        self.refiner_handoff = refiner_handoff
         # the embedding prior (reference :97-98,:120-122 `self.model`): prior.py::InstructAny2PixPrior on the HIP kernels, or None when
         # the conditioner supplies `y` itself
         self.model = prior
@@ -132,15 +153,23 @@ class InstructAny2PixPipeline:
         non_refined = images
         oo = images
         if refinement > 0 and self.piperf is not None:                                         # :358-361
-            # the reference hands the decoded PIL image over and the refiner re-encodes it with the shared VAE; in latent space
-            # that round trip is the identity up to VAE error, so the base latents go in directly. Conditioning = text encoder 2
-            # on caption + ',high quality,well-formed,award-winning' (out of scope: the conditioner supplies its embeddings).
-            oo = self.piperf(latents=images, strength=refinement, prompt_embeds=c["refiner_prompt_embeds"],
-                             pooled_prompt_embeds=c["refiner_pooled_prompt_embeds"], negative_prompt_embeds=c["refiner_negative_prompt_embeds"],
-                             negative_pooled_prompt_embeds=c["refiner_negative_pooled_prompt_embeds"], noise=c.get("refiner_noise"),
-                             output_type="latent").images
+            _need(c, ("refiner_prompt_embeds", "refiner_pooled_prompt_embeds", "refiner_negative_prompt_embeds", "refiner_negative_pooled_prompt_embeds"),
+                  "refiner pass")
+            # Conditioning = text encoder 2 on caption + ',high quality,well-formed,award-winning' (the conditioner supplies its embeddings).
+            kw = dict(strength=refinement, prompt_embeds=c["refiner_prompt_embeds"], pooled_prompt_embeds=c["refiner_pooled_prompt_embeds"],
+                      negative_prompt_embeds=c["refiner_negative_prompt_embeds"], negative_pooled_prompt_embeds=c["refiner_negative_pooled_prompt_embeds"],
+                      noise=c.get("refiner_noise"), output_type="latent")
+            vae_route = self.refiner_handoff == "image" and self.pipe._vae_decode is not None and self.piperf._vae_encode is not None
+            if vae_route:
+                # the reference hands a decoded 8-bit image over and the refiner pipeline re-encodes it with the shared VAE
+                # (`retrieve_latents(vae.encode(image)) * scaling_factor`: a posterior SAMPLE, global RNG)
+                oo = self.piperf(image=to_8bit_image(self.pipe._vae_decode(images)), **kw).images
+            else:
+                oo = self.piperf(latents=images, **kw).images
         subject_data = c.get("subject_data") or []
         if subject_strength > 0 and len(subject_data) > 0:                                     # :363-368 (masks: SAM / GroundingDINO, off-path)
+            _need(c, ("subject_prompt_embeds", "subject_pooled_prompt_embeds", "subject_negative_prompt_embeds", "subject_negative_pooled_prompt_embeds"),
+                  "subject-consistency pass")
             oo = subject_consistency(subject_data, oo, self.ip_adapter_xl_inpaint, subject_strength, output_type="latent",
                                      prompt_embeds=c["subject_prompt_embeds"], pooled_prompt_embeds=c["subject_pooled_prompt_embeds"],
                                      negative_prompt_embeds=c["subject_negative_prompt_embeds"],

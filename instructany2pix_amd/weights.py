@@ -208,6 +208,60 @@ def iter_synthetic(specs: List[Spec], seed: int = 7, device="cpu", dtype=torch.f
         yield k, _make(k, shp, kind, seed, device, dtype)
 
 
+def iter_safetensors(path: str, specs: "List[Spec] | None" = None, prefix: str = "") -> Iterator[Tuple[str, torch.Tensor]]:
+    """Stream a checkpoint tensor by tensor: `path` is a `.safetensors` file, a directory holding `diffusion_pytorch_model*.safetensors`
+    (diffusers' layout of `unet/`, sharded or not, `.fp16` variant included), or a `*.safetensors.index.json`. Yields (key, tensor) with
+    `prefix` stripped, for `load_state_dict(...)` of the HIP modules: 5 GB of UNet weights are never resident twice on the host.
+    With `specs` (e.g. `unet_param_specs(cfg)`) the key set and every shape are checked against the architecture first -- the loader of
+    SURVEY.md §7.1's `IA2P_UNET_WEIGHTS`; the reference gets the same tensors through `from_pretrained` (pipeline.py:101,128)."""
+    import glob
+    import json
+    import os
+    from safetensors import safe_open
+    if os.path.isdir(path):
+        idx = sorted(glob.glob(os.path.join(path, "*.safetensors.index.json")))
+        files = [idx[0]] if idx else sorted(glob.glob(os.path.join(path, "diffusion_pytorch_model*.safetensors"))) or sorted(glob.glob(os.path.join(path, "*.safetensors")))
+        if not files:
+            raise FileNotFoundError(f"no .safetensors checkpoint under {path}")
+        if len(files) > 1 and not idx:
+            plain = [f for f in files if os.path.basename(f) == "diffusion_pytorch_model.safetensors"]
+            files = plain or files[:1]
+        path = files[0]
+    if path.endswith(".index.json"):
+        shards = sorted(set(json.load(open(path))["weight_map"].values()))
+        files = [os.path.join(os.path.dirname(path), f) for f in shards]
+    else:
+        files = [path]
+    handles = [safe_open(f, framework="pt", device="cpu") for f in files]
+    where = {}
+    for h in handles:
+        for k in h.keys():
+            if k.startswith(prefix):
+                where[k[len(prefix):]] = (h, k)
+    if specs is not None:
+        want = {k: tuple(shp) for k, shp, _ in specs}
+        missing, extra = sorted(set(want) - set(where)), sorted(set(where) - set(want))
+        if missing or extra:
+            raise KeyError(f"checkpoint does not match the architecture: {len(missing)} missing (e.g. {missing[:3]}), {len(extra)} unexpected (e.g. {extra[:3]})")
+        for k, shp in want.items():
+            h, full = where[k]
+            got = tuple(h.get_slice(full).get_shape())
+            if got != shp:
+                raise ValueError(f"checkpoint tensor '{k}' has shape {got}, the architecture expects {shp}")
+        order = [k for k, _, _ in specs]
+    else:
+        order = list(where)
+    for k in order:
+        h, full = where[k]
+        yield k, h.get_tensor(full)
+
+
+def load_unet_safetensors(unet, path: str, strict: bool = True):
+    """`unet.load_state_dict` from a diffusers UNet checkpoint on disk (see iter_safetensors); returns the UNet."""
+    unet.load_state_dict(iter_safetensors(path, unet_param_specs(unet.config) if strict else None), strict=strict)
+    return unet
+
+
 def param_count(specs: List[Spec]) -> int:
     t = 0
     for _, shp, _ in specs:

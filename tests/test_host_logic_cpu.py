@@ -293,3 +293,44 @@ def test_prior_host_side_tables_and_inventory():
     assert param_count(prior_param_specs(gpt2_medium(), laion_clip_h_text())) == 710_507_520
     assert (MODALITY.IMAGE, MODALITY.AUDIO, MODALITY.TEXT, MODALITY.VIDEO) == (0, 1, 2, 3)
     assert prior_config["sequence_input_key"] == oracle.PriorRef.sequence_input_key and prior_config["sequence_input_embed_dim"] == [0, 1024, 1024, 512, 0, 0, 0]
+
+
+def test_iter_safetensors_streams_and_validates_a_checkpoint(tmp_path):
+    """`weights.iter_safetensors` (the IA2P_UNET_WEIGHTS loader): single file, diffusers directory layout, sharded index; key-set and
+    shape validation against the architecture."""
+    import json
+    from safetensors.torch import save_file
+    from instructany2pix_amd.config import tiny
+    from instructany2pix_amd.weights import iter_safetensors, synthetic_state_dict, unet_param_specs
+    cfg = tiny()
+    specs = unet_param_specs(cfg)
+    sd = synthetic_state_dict(specs, seed=7)
+    d = tmp_path / "unet"
+    d.mkdir()
+    one = str(d / "diffusion_pytorch_model.safetensors")
+    save_file(dict(sd), one)
+    for src in (one, str(d)):
+        got = dict(iter_safetensors(src, specs))
+        assert list(got) == [k for k, _, _ in specs] and all(torch.equal(got[k], sd[k]) for k in sd)
+    # sharded: two files + index, keys with a prefix
+    keys = list(sd)
+    sh = tmp_path / "sharded"
+    sh.mkdir()
+    a, b = {("unet." + k): sd[k] for k in keys[::2]}, {("unet." + k): sd[k] for k in keys[1::2]}
+    save_file(a, str(sh / "m-00001-of-00002.safetensors")); save_file(b, str(sh / "m-00002-of-00002.safetensors"))
+    json.dump({"weight_map": {**{k: "m-00001-of-00002.safetensors" for k in a}, **{k: "m-00002-of-00002.safetensors" for k in b}}},
+              open(sh / "m.safetensors.index.json", "w"))
+    got = dict(iter_safetensors(str(sh), specs, prefix="unet."))
+    assert all(torch.equal(got[k], sd[k]) for k in sd)
+    # validation
+    bad = dict(sd)
+    bad.pop(keys[3])
+    save_file(bad, str(tmp_path / "missing.safetensors"))
+    with pytest.raises(KeyError):
+        next(iter_safetensors(str(tmp_path / "missing.safetensors"), specs))
+    bad = dict(sd)
+    bad[keys[3]] = torch.zeros(3, dtype=torch.float16)
+    save_file(bad, str(tmp_path / "shape.safetensors"))
+    with pytest.raises(ValueError):
+        next(iter_safetensors(str(tmp_path / "shape.safetensors"), specs))
+    assert len(dict(iter_safetensors(str(tmp_path / "missing.safetensors")))) == len(sd) - 1           # without specs: whatever is there

@@ -196,3 +196,60 @@ def test_pipeline_call_runs_refinement_through_piperf():
     torch.manual_seed(3)
     a, b, _ = pipe("make it blue", [], num_inference_steps=6, cfg=4.0, refinement=0.0)
     assert torch.equal(a, b) and torch.equal(a, non_refined)
+
+
+def test_pipeline_refiner_handoff_through_the_vae_like_the_reference():
+    """With a VAE attached the base result reaches the refiner the reference's way (pipeline.py:358-361): decoded, quantised to an
+    8-bit image, re-encoded by the refiner pipeline (posterior sample, global RNG), then noised and denoised. Equals the same steps
+    by hand; the latent shortcut stays available (`refiner_handoff="latent"`) and differs from it; missing conditioner keys are
+    reported up front."""
+    from instructany2pix_amd.config import tiny, tiny_refiner, tiny_vae
+    from instructany2pix_amd.pipeline import InstructAny2PixPipeline, to_8bit_image
+    from instructany2pix_amd.unet import HipUNet2DConditionModel
+    from instructany2pix_amd.vae import HipAutoencoderKL
+    from instructany2pix_amd.weights import unet_param_specs, ip_adapter_specs, vae_param_specs, synthetic_state_dict
+    bcfg, rcfg, vcfg = tiny(), tiny_refiner(), tiny_vae()
+    base = HipUNet2DConditionModel(bcfg, DEV)
+    base.load_state_dict(synthetic_state_dict(unet_param_specs(bcfg), seed=7))
+    ref = HipUNet2DConditionModel(rcfg, DEV)
+    ref.load_state_dict(synthetic_state_dict(unet_param_specs(rcfg), seed=11))
+    vae = HipAutoencoderKL(vcfg, DEV)
+    vae.load_state_dict(synthetic_state_dict(vae_param_specs(vcfg), seed=7))
+    specs = ip_adapter_specs(bcfg, 64)
+    ck = {"image_proj": synthetic_state_dict(specs["image_proj"], seed=7), "ip_adapter": synthetic_state_dict(specs["ip_adapter"], seed=7)}
+    g = torch.Generator().manual_seed(5)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    cond = dict(image_embeds=rn(1, 64), base_embed=rn(1, 64), y=rn(1, 64), caption="a photo", base_latents=rn(1, 4, 16, 16).half(),
+                prompt_embeds=rn(1, 77, bcfg.cross_attention_dim).half(), pooled_prompt_embeds=rn(1, bcfg.pooled_dim).half(),
+                negative_prompt_embeds=rn(1, 77, bcfg.cross_attention_dim).half(), negative_pooled_prompt_embeds=rn(1, bcfg.pooled_dim).half(),
+                refiner_prompt_embeds=rn(1, 77, rcfg.cross_attention_dim).half(), refiner_pooled_prompt_embeds=rn(1, rcfg.pooled_dim).half(),
+                refiner_negative_prompt_embeds=rn(1, 77, rcfg.cross_attention_dim).half(), refiner_negative_pooled_prompt_embeds=rn(1, rcfg.pooled_dim).half(),
+                refiner_noise=rn(1, 4, 16, 16).half())
+    mk = lambda **kw: InstructAny2PixPipeline(unet=base, ip_ckpt=ck, device=DEV, clip_embeddings_dim=64, conditioner=lambda inst, mm, use_cache=False: cond,
+                                              refiner_unet=ref, vae_encode=vae.encode_to_latents, vae_decode=vae.decode_from_latents, **kw)
+    pipe = mk()
+    assert pipe.refiner_handoff == "image"
+    torch.manual_seed(3)
+    non_refined, refined, _ = pipe("make it blue", [], num_inference_steps=6, cfg=4.0, refinement=0.5)
+    # the same hand-over step by step (the base sampler drew one polar-mixing noise from the global RNG before the posterior sample)
+    torch.manual_seed(3)
+    again, _, _ = pipe("make it blue", [], num_inference_steps=6, cfg=4.0, refinement=0.0)
+    assert torch.equal(again, non_refined)
+    img8 = to_8bit_image(vae.decode_from_latents(non_refined))
+    q = (img8.float() / 2 + 0.5) * 255
+    assert float((q - q.round()).abs().max()) < 0.1 and float(img8.min()) >= -1 and float(img8.max()) <= 1        # an 8-bit image in [-1, 1] (held in fp16: ulp 5e-4 * 127.5)
+    by_hand = pipe.piperf(image=img8, strength=0.5, prompt_embeds=cond["refiner_prompt_embeds"], pooled_prompt_embeds=cond["refiner_pooled_prompt_embeds"],
+                          negative_prompt_embeds=cond["refiner_negative_prompt_embeds"], negative_pooled_prompt_embeds=cond["refiner_negative_pooled_prompt_embeds"],
+                          noise=cond["refiner_noise"], output_type="latent").images
+    assert torch.equal(by_hand, refined)
+    short = mk(refiner_handoff="latent")
+    torch.manual_seed(3)
+    nr2, refined2, _ = short("make it blue", [], num_inference_steps=6, cfg=4.0, refinement=0.5)
+    assert torch.equal(nr2, non_refined) and not torch.equal(refined2, refined)
+    with pytest.raises(ValueError):
+        mk(refiner_handoff="pil")
+    bad = dict(cond)
+    del bad["refiner_pooled_prompt_embeds"]
+    pipe.conditioner = lambda inst, mm, use_cache=False: bad
+    with pytest.raises(KeyError, match="refiner_pooled_prompt_embeds"):
+        pipe("make it blue", [], num_inference_steps=2, cfg=4.0, refinement=0.5)

@@ -363,3 +363,28 @@ def test_context_kv_hoisting_is_bit_identical_and_invalidates(tiny_models):
         assert hip._kv[3] == hip._weights_gen and torch.equal(e, d)
     finally:
         hip.cache_context_kv = True
+
+
+def test_load_unet_safetensors_gives_the_same_bits(tiny_models, tmp_path):
+    """a diffusers-layout checkpoint streamed from disk (`weights.load_unet_safetensors`) == the same tensors loaded from a dict"""
+    from safetensors.torch import save_file
+    from instructany2pix_amd.attention_processor import AttnProcessor2_0
+    from instructany2pix_amd.unet import HipUNet2DConditionModel
+    from instructany2pix_amd.weights import load_unet_safetensors
+    cfg, sd, ipsd, hip, _ = tiny_models
+    (tmp_path / "unet").mkdir()
+    save_file(dict(sd), str(tmp_path / "unet" / "diffusion_pytorch_model.fp16.safetensors"))
+    disk = load_unet_safetensors(HipUNet2DConditionModel(cfg, DEV), str(tmp_path / "unet"))
+    hip.set_attn_processor(AttnProcessor2_0())
+    x, ctx, te, tid = (t.to(DEV) for t in _inputs(cfg, 2, 16, 16, 77, seed=8))
+    kw = dict(encoder_hidden_states=ctx, added_cond_kwargs=dict(text_embeds=te, time_ids=tid))
+    assert torch.equal(disk(x, 401, **kw)[0], hip(x, 401, **kw)[0])
+    # a tensor reloaded after finalize (LoRA-merged hot swap): the LayerNorm-folded copies are re-derived before the next forward
+    key = next(k for k in sd if k.endswith("transformer_blocks.0.norm1.weight"))
+    before = disk(x, 401, **kw)[0].clone()
+    disk.load_state_dict({key: sd[key] * 1.5}, strict=False)
+    moved = disk(x, 401, **kw)[0].clone()
+    assert not torch.equal(moved, before)
+    fresh = HipUNet2DConditionModel(cfg, DEV)
+    fresh.load_state_dict({**sd, key: sd[key] * 1.5})
+    assert torch.equal(fresh(x, 401, **kw)[0], moved)
