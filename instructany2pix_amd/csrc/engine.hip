@@ -54,9 +54,9 @@ const char* prof_name(int k) {
                                       "embed_kernel+linear_small_kernel", "conv_in_kernel", "conv_out_kernel", "concat_kernel", "splitk_reduce_kernel"};
   if (k >= PK_ATTN) return other[k - PK_ATTN];
   const GemmTile t = IA2P_GEMM_TILES[(k % PK_CONV0) % IA2P_GEMM_NVARIANT];
-  if (t.bm == 256) snprintf(buf[k], sizeof buf[k], "gemm_f16_kernel<%d, %d, %d, %s, 4, 64, 1>", t.bm, t.bn, t.stages, k >= PK_CONV0 ? "true" : "false");
+  if (t.bm == 256) snprintf(buf[k], sizeof buf[k], "gemm_f16_kernel<%d, %d, %d, %s, 4, 64, 1, 2>", t.bm, t.bn, t.stages, k >= PK_CONV0 ? "true" : "false");
   else if (t.bn == 80) snprintf(buf[k], sizeof buf[k], "gemm_f16_kernel<%d, %d, %d, %s, 4, 64, 0, 1>", t.bm, t.bn, t.stages, k >= PK_CONV0 ? "true" : "false");
-  else snprintf(buf[k], sizeof buf[k], "gemm_f16_kernel<%d, %d, %d, %s, 2, 64, 0>", t.bm, t.bn, t.stages, k >= PK_CONV0 ? "true" : "false");
+  else snprintf(buf[k], sizeof buf[k], "gemm_f16_kernel<%d, %d, %d, %s, 2, 64, 0, 2>", t.bm, t.bn, t.stages, k >= PK_CONV0 ? "true" : "false");
   return buf[k];
 }
 
@@ -189,7 +189,7 @@ static ia2p_status plan_pass(ia2p_ctx* c, size_t fold_base, size_t* raw_elems, s
   P.fold_base = fold_base;
   const int T = g.time_embed_dim, ctx = g.cross_attention_dim;
   const int* ch = g.block_out_channels;
-  c->conv_in_w = P.take((size_t)ch[0] * g.in_channels * 9); P.reg("conv_in.weight", c->conv_in_w, (size_t)ch[0] * g.in_channels * 9);
+  c->conv_in_w = P.take((size_t)ch[0] * 64); P.reg("conv_in.weight", c->conv_in_w, (size_t)ch[0] * g.in_channels * 9, PK_PAD_CONV_IN, ch[0], g.in_channels * 9);
   c->conv_in_b = P.vec("conv_in.bias", ch[0]);
   c->te1w = P.mat("time_embedding.linear_1.weight", T, g.time_proj_dim); c->te1b = P.vec("time_embedding.linear_1.bias", T);
   c->te2w = P.mat("time_embedding.linear_2.weight", T, T); c->te2b = P.vec("time_embedding.linear_2.bias", T);
@@ -731,6 +731,7 @@ ia2p_status rc_load_tensor(RunCtx* c, const char* key, const void* src, const in
     case PK_COPY: e = hipMemcpyAsync(dst, src, n * sizeof(half_t), hipMemcpyDeviceToDevice, s); break;
     case PK_CONV: e = ia2p_launch_pack_conv((const half_t*)src, dst, p.d0, p.d1, s); break;
     case PK_GEGLU_W: case PK_GEGLU_B: e = ia2p_launch_pack_geglu((const half_t*)src, dst, p.d0, p.d1, s); break;
+    case PK_PAD_CONV_IN: e = ia2p_launch_pack_conv_in((const half_t*)src, dst, p.d0, p.d1, s); break;
   }
   if (e != hipSuccess) return fail(c, IA2P_ERR_HIP, "load '%s': %s", key, hipGetErrorString(e));
   p.loaded = true;

@@ -95,76 +95,128 @@ __global__ __launch_bounds__(64) void linear_small_kernel(const half_t* X, int l
 }
 
 // ---- conv_in: latent NCHW [B,Cin,H,W] -> channels-last [B*H*W, Co], 3x3 pad 1 (Cin*9 <= 64 taps) --------------------
-__global__ __launch_bounds__(256) void conv_in_kernel(const half_t* x, const half_t* w /*[Co][Cin][3][3]*/, const half_t* bias,
+// MFMA form: a wave owns 16 consecutive pixels. K = Cin*9 <= 64 (two 32-deep MFMA steps, zero padded); the weights are staged once per
+// workgroup as a zero-padded [Co][64] LDS image (first operand: a lane ends up with 4 consecutive output channels of one pixel), the
+// im2col fragment of the 16 pixels is gathered straight from the NCHW input into registers, and the 16 x Co output block goes through LDS
+// so that every pixel row leaves as whole 16-byte pieces. HBM-bound on the output write (B*H*W*Co*2 bytes).
+__global__ __launch_bounds__(256) void conv_in_kernel(const half_t* x, const half_t* w /*[Co][64]: k = ci*9 + tap, zero padded (ia2p_launch_pack_conv_in)*/, const half_t* bias,
                                                       half_t* y, int B, int Cin, int H, int W, int Co, int pix_per_block, float out_scale) {
-  extern __shared__ half_t wl[];   // [Cin*9][Co]
+  extern __shared__ __attribute__((aligned(16))) char cin_smem[];
+  half_t* wl = (half_t*)cin_smem;                       // [Co][64], k = ci*9 + tap, zero beyond Cin*9
+  half_t* ol = wl + (size_t)Co * 64;                    // [4 waves][16 pixels][Co] output staging
   const int KT = Cin * 9;
-  for (int i = threadIdx.x; i < KT * Co; i += blockDim.x) {
-    const int co = i / KT, k = i - co * KT;
-    wl[k * Co + co] = w[i];
-  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < Co * 8; i += 256) *(h8*)(wl + (size_t)i * 8) = *(const h8*)(w + (size_t)i * 8);
   __syncthreads();
-  const int TX = Co >> 3, TY = blockDim.x / TX;
-  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
-  if (ty >= TY) return;
   const int npix = B * H * W;
-  const int p0 = blockIdx.x * pix_per_block;
-  float bs[8];
-  { const h8 d = *(const h8*)(bias + tx * 8);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) bs[e] = (float)d[e]; }
-  for (int pp = p0 + ty; pp < min(p0 + pix_per_block, npix); pp += TY) {
+  const int p0 = (blockIdx.x * 4 + wave) * 16;
+  const int pl = lane & 15, kq = lane >> 4;
+  // im2col fragment: lane holds X[k = 32*s + 8*kq + j][pixel pl]
+  h8 xf[2];
+  {
+    const int pp = min(p0 + pl, npix - 1);
     const int b = pp / (H * W), rem = pp - b * H * W, oy = rem / W, ox = rem - oy * W;
-    float acc[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = bs[e];
-    for (int ci = 0; ci < Cin; ++ci)
-      for (int ky = 0; ky < 3; ++ky)
-        for (int kx = 0; kx < 3; ++kx) {
-          const int iy = oy + ky - 1, ix = ox + kx - 1;
-          if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) continue;
-          const float xv = (float)x[(((size_t)b * Cin + ci) * H + iy) * W + ix];
-          const h8 d = *(const h8*)(wl + (ci * 9 + ky * 3 + kx) * Co + tx * 8);
+    for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-          for (int e = 0; e < 8; ++e) acc[e] += xv * (float)d[e];
-        }
-    h8 o;
+      for (int j = 0; j < 8; ++j) {
+        const int k = s2 * 32 + kq * 8 + j;
+        const int ci = k / 9, tap = k - ci * 9, ky = tap / 3, kx = tap - ky * 3;
+        const int iy = oy + ky - 1, ix = ox + kx - 1;
+        const bool ok = k < KT && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        const half_t v = x[(((size_t)b * Cin + min(ci, Cin - 1)) * H + min(max(iy, 0), H - 1)) * W + min(max(ix, 0), W - 1)];
+        xf[s2][j] = ok ? v : (half_t)0.f;
+      }
+  }
+  half_t* ow = ol + (size_t)wave * 16 * Co;
+  for (int n0 = 0; n0 < Co; n0 += 16) {
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int nrow = min(n0 + pl, Co - 1);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (half_t)(acc[e] * out_scale);
-    *(h8*)(y + (size_t)pp * Co + tx * 8) = o;
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const h8 wf = *(const h8*)(wl + (size_t)nrow * 64 + s2 * 32 + kq * 8);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[s2], acc, 0, 0, 0);      // D[row = channel n0 + 4*kq + i][col = pixel pl]
+    }
+    const int n = n0 + kq * 4;
+    if (n < Co) {
+      const h4 bv = *(const h4*)(bias + n);
+      h4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = (half_t)((acc[i] + (float)bv[i]) * out_scale);
+      *(h4*)(ow + (size_t)pl * Co + n) = o;
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0): this wave's staging writes are visible to itself
+  __builtin_amdgcn_wave_barrier();
+  const int vec = Co >> 3;                    // 16-byte pieces per pixel row
+  for (int i = lane; i < 16 * vec; i += 64) {
+    const int r = i / vec, c8 = i - r * vec;
+    if (p0 + r < npix) *(h8*)(y + (size_t)(p0 + r) * Co + c8 * 8) = *(const h8*)(ow + (size_t)r * Co + c8 * 8);
   }
 }
 
-// ---- conv_out: channels-last [B*H*W, C] -> NCHW [B,Co<=8,H,W], 3x3 pad 1; one wave per output pixel ------------------
+// ---- conv_out: channels-last [B*H*W, C] -> NCHW [B,Co<=8,H,W], 3x3 pad 1 ---------------------------------------------------------
+// MFMA form: a wave owns 16 consecutive pixels and accumulates a 16 x 16 output block of which Co <= 8 columns are real (lanes of the
+// other columns feed zeros). Per tap and 32-channel chunk a lane loads 8 channels of its pixel's neighbour (16 B, zero outside the
+// image) and the matching 8 weights from the LDS image of [Co][9][C]; the 3 x 3 neighbourhoods of adjacent pixels overlap, so the 9-fold
+// re-read of the input is served by L1 / L2. Reads x once from HBM (B*H*W*C*2 bytes), writes 2*Co bytes per pixel.
+template <int NC>        // 32-channel chunks per tap (C = 32 NC): all NC loads of a tap are in flight before its MFMAs; 0 = any C
 __global__ __launch_bounds__(256) void conv_out_kernel(const half_t* x, int ldx, const half_t* w /*[Co][9][C]*/, const half_t* bias,
                                                        half_t* y, int B, int C, int H, int W, int Co) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int pp = blockIdx.x * 4 + wave;
-  if (pp >= B * H * W) return;
+  extern __shared__ __attribute__((aligned(16))) char cout_smem[];
+  half_t* wl = (half_t*)cout_smem;                      // [Co][9][C]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < (Co * 9 * C) >> 3; i += 256) *(h8*)(wl + (size_t)i * 8) = *(const h8*)(w + (size_t)i * 8);
+  __syncthreads();
+  const int npix = B * H * W;
+  const int p0 = (blockIdx.x * 4 + wave) * 16;
+  if (p0 >= npix) return;
+  const int pl = lane & 15, kq = lane >> 4;
+  const int pp = min(p0 + pl, npix - 1);
   const int b = pp / (H * W), rem = pp - b * H * W, oy = rem / W, ox = rem - oy * W;
-  const int cv = C >> 3, nvec = 9 * cv;
-  float acc[8];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) acc[c] = 0.f;
-  for (int v = lane; v < nvec; v += 64) {
-    const int tap = v / cv, c8 = v - tap * cv, ky = tap / 3, kx = tap - ky * 3;
+  const int ncol = min(pl, Co - 1);
+  const bool wreal = pl < Co;
+  f4 acc = {0.f, 0.f, 0.f, 0.f};
+  const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 1
+  for (int tap = 0; tap < 9; ++tap) {
+    const int ky = tap / 3, kx = tap - ky * 3;
     const int iy = oy + ky - 1, ix = ox + kx - 1;
-    if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W) continue;
-    const h8 d = *(const h8*)(x + ((size_t)(b * H + iy) * W + ix) * ldx + c8 * 8);
+    const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+    const half_t* xp = x + ((size_t)(b * H + min(max(iy, 0), H - 1)) * W + min(max(ix, 0), W - 1)) * ldx + kq * 8;
+    const half_t* wp = wl + ((size_t)ncol * 9 + tap) * C + kq * 8;
+    if constexpr (NC > 0) {
+      h8 a[NC], wv[NC];
 #pragma unroll
-    for (int c = 0; c < 8; ++c)
-      if (c < Co) {
-        const h8 wv = *(const h8*)(w + ((size_t)c * 9 + tap) * C + c8 * 8);
+      for (int u = 0; u < NC; ++u) { a[u] = *(const h8*)(xp + u * 32); wv[u] = *(const h8*)(wp + u * 32); }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[c] += (float)d[e] * (float)wv[e];
+      for (int u = 0; u < NC; ++u) {
+        if (!ok) a[u] = zero8;
+        if (!wreal) wv[u] = zero8;
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u], wv[u], acc, 0, 0, 0);      // D[row = pixel 4*kq + i][col = output channel pl]
       }
-  }
-#pragma unroll
-  for (int c = 0; c < 8; ++c)
-    if (c < Co) {
-      const float s = wave_sum(acc[c]);
-      if (lane == c) y[(((size_t)b * Co + c) * H + oy) * W + ox] = (half_t)(s + (float)bias[c]);
+    } else {
+#pragma unroll 4
+      for (int c0 = 0; c0 < C; c0 += 32) {
+        h8 a = *(const h8*)(xp + c0);
+        h8 wv = *(const h8*)(wp + c0);
+        if (!ok) a = zero8;
+        if (!wreal) wv = zero8;
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, wv, acc, 0, 0, 0);
+      }
     }
+  }
+  if (wreal) {
+    const float bs = (float)bias[pl];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = p0 + kq * 4 + i;
+      if (q < npix) {
+        const int qb = q / (H * W), qr = q - qb * H * W;
+        y[((size_t)qb * Co + pl) * H * W + qr] = (half_t)(acc[i] + bs);
+      }
+    }
+  }
 }
 
 // ---- channel concat of two channels-last tensors (torch.cat([h, skip], dim=1) of the up path) --------------------------
@@ -380,6 +432,13 @@ __global__ void pack_conv_kernel(const half_t* src, half_t* dst, int Co, int Ci)
   }
 }
 // GEGLU pairing: packed row p (block t = p/32): p%32 < 16 -> value row 16t + p%32 ; else gate row half + 16t + p%32 - 16
+// conv_in weights [Co][Cin*9] -> [Co][64] (k = ci*9 + tap, zero padded): the first-operand image of conv_in_kernel's two MFMA steps
+__global__ void pack_conv_in_kernel(const half_t* src, half_t* dst, int Co, int KT) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < (long)Co * 64; i += (long)gridDim.x * blockDim.x) {
+    const int co = (int)(i >> 6), k = (int)(i & 63);
+    dst[i] = k < KT ? src[(size_t)co * KT + k] : (half_t)0.f;
+  }
+}
 __global__ void pack_geglu_kernel(const half_t* src, half_t* dst, int rows, int rowlen) {
   const long total = (long)rows * rowlen;
   const int half_ = rows / 2;
@@ -503,15 +562,42 @@ hipError_t ia2p_launch_linear_small(const half_t* X, int ldx, const half_t* W, c
   return hipGetLastError();
 }
 hipError_t ia2p_launch_conv_in(const half_t* x, const half_t* w, const half_t* bias, half_t* y, int B, int Cin, int H, int W, int Co, hipStream_t s, float out_scale) {
-  if (Co % 8 || Co / 8 > 256) return hipErrorInvalidValue;
+  if (Co % 8 || Cin * 9 > 64) return hipErrorInvalidValue;
   const int ppb = 64;
-  const size_t sm = (size_t)Cin * 9 * Co * sizeof(half_t);
+  const size_t sm = (size_t)Co * 64 * sizeof(half_t) + (size_t)64 * Co * sizeof(half_t);      // padded weights + 4 x 16 pixel rows of output
+  if (sm > 160 * 1024) return hipErrorInvalidValue;
+  static bool attr[64] = {false};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (sm > 65536 && (dev < 0 || dev >= 64 || !attr[dev])) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_in_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64) attr[dev] = true;
+  }
   hipLaunchKernelGGL(conv_in_kernel, dim3((B * H * W + ppb - 1) / ppb), dim3(256), sm, s, x, w, bias, y, B, Cin, H, W, Co, ppb, out_scale);
   return hipGetLastError();
 }
 hipError_t ia2p_launch_conv_out(const half_t* x, int ldx, const half_t* w, const half_t* bias, half_t* y, int B, int C, int H, int W, int Co, hipStream_t s) {
-  if (Co > 8 || C % 8) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(conv_out_kernel, dim3((B * H * W + 3) / 4), dim3(256), 0, s, x, ldx, w, bias, y, B, C, H, W, Co);
+  if (Co > 8 || C % 32) return hipErrorInvalidValue;
+  const size_t sm = (size_t)Co * 9 * C * sizeof(half_t);
+  if (sm > 160 * 1024) return hipErrorInvalidValue;
+  static bool attr[64] = {false};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (sm > 65536 && (dev < 0 || dev >= 64 || !attr[dev])) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_out_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_out_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64) attr[dev] = true;
+  }
+  const dim3 grid((B * H * W + 63) / 64);
+  switch (C) {
+    case 128: hipLaunchKernelGGL(conv_out_kernel<4>, grid, dim3(256), sm, s, x, ldx, w, bias, y, B, C, H, W, Co); break;
+    case 320: hipLaunchKernelGGL(conv_out_kernel<10>, grid, dim3(256), sm, s, x, ldx, w, bias, y, B, C, H, W, Co); break;
+    case 384: hipLaunchKernelGGL(conv_out_kernel<12>, grid, dim3(256), sm, s, x, ldx, w, bias, y, B, C, H, W, Co); break;
+    case 512: hipLaunchKernelGGL(conv_out_kernel<16>, grid, dim3(256), sm, s, x, ldx, w, bias, y, B, C, H, W, Co); break;
+    default: hipLaunchKernelGGL(conv_out_kernel<0>, grid, dim3(256), sm, s, x, ldx, w, bias, y, B, C, H, W, Co); break;
+  }
   return hipGetLastError();
 }
 hipError_t ia2p_launch_concat(const half_t* a, int lda, int Ca, const half_t* b, int ldb, int Cb, half_t* y, long M, hipStream_t s) {
@@ -564,6 +650,11 @@ hipError_t ia2p_launch_touch(const void* p, size_t bytes, unsigned* sink, hipStr
 }
 hipError_t ia2p_launch_pack_conv(const half_t* src, half_t* dst, int Co, int Ci, hipStream_t s) {
   hipLaunchKernelGGL(pack_conv_kernel, dim3(grid_for((long)Co * Ci * 9, 256)), dim3(256), 0, s, src, dst, Co, Ci);
+  return hipGetLastError();
+}
+hipError_t ia2p_launch_pack_conv_in(const half_t* src, half_t* dst, int Co, int KT, hipStream_t s) {
+  if (KT > 64) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pack_conv_in_kernel, dim3(grid_for((long)Co * 64, 256)), dim3(256), 0, s, src, dst, Co, KT);
   return hipGetLastError();
 }
 hipError_t ia2p_launch_pack_geglu(const half_t* src, half_t* dst, int rows, int rowlen, hipStream_t s) {

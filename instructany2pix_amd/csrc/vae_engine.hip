@@ -34,6 +34,7 @@ struct VPlanner {
   size_t vec(const std::string& k, int n) { size_t o = take(n); c->params[k] = Param{o, (size_t)n, PK_COPY, 0, 0, false, false}; return o; }
   size_t mat(const std::string& k, int r, int cc) { size_t o = take((size_t)r * cc); c->params[k] = Param{o, (size_t)r * cc, PK_COPY, 0, 0, false, false}; return o; }
   size_t conv3(const std::string& k, int co, int ci) { size_t o = take((size_t)co * ci * 9); c->params[k] = Param{o, (size_t)co * ci * 9, PK_CONV, co, ci, false, false}; return o; }
+  size_t conv_in(const std::string& k, int co, int kt) { size_t o = take((size_t)co * 64); c->params[k] = Param{o, (size_t)co * kt, PK_PAD_CONV_IN, co, kt, false, false}; return o; }
   VRes resnet(const std::string& p, int cin, int cout) {
     VRes r;
     r.cin = cin; r.cout = cout; r.shortcut = cin != cout;
@@ -75,7 +76,7 @@ static ia2p_status vae_plan(ia2p_vae* c) {
   const int* ch = g.block_out_channels;
   const int z = g.latent_channels;
   VPlanner P{c};
-  c->e_in_w = P.mat("encoder.conv_in.weight", ch[0], g.in_channels * 9); c->e_in_b = P.vec("encoder.conv_in.bias", ch[0]);
+  c->e_in_w = P.conv_in("encoder.conv_in.weight", ch[0], g.in_channels * 9); c->e_in_b = P.vec("encoder.conv_in.bias", ch[0]);
   int cprev = ch[0];
   for (int i = 0; i < n; ++i) {
     VStage st;
@@ -94,7 +95,7 @@ static ia2p_status vae_plan(ia2p_vae* c) {
   c->e_out_w = P.conv3("encoder.conv_out.weight", 2 * z, ch[n - 1]); c->e_out_b = P.vec("encoder.conv_out.bias", 2 * z);
   c->q_w = P.mat("quant_conv.weight", 2 * z, 2 * z); c->q_b = P.vec("quant_conv.bias", 2 * z);
   c->pq_w = P.mat("post_quant_conv.weight", z, z); c->pq_b = P.vec("post_quant_conv.bias", z);
-  c->d_in_w = P.mat("decoder.conv_in.weight", ch[n - 1], z * 9); c->d_in_b = P.vec("decoder.conv_in.bias", ch[n - 1]);
+  c->d_in_w = P.conv_in("decoder.conv_in.weight", ch[n - 1], z * 9); c->d_in_b = P.vec("decoder.conv_in.bias", ch[n - 1]);
   c->dmid = P.mid("decoder.mid_block", ch[n - 1]);
   cprev = ch[n - 1];
   for (int i = 0; i < n; ++i) {
