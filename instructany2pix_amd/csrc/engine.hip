@@ -635,7 +635,8 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
   std::vector<int> skip_c;
   T2 x = wsalloc(c, (size_t)B * H * Wd * g.block_out_channels[0]);
   {
-    ProfScope ps(c, PK_CONV_IN, 0, 0);
+    ProfScope ps(c, PK_CONV_IN, 2.0 * B * H * Wd * 9.0 * g.in_channels * g.block_out_channels[0],
+                 2.0 * ((double)B * H * Wd * (g.in_channels + g.block_out_channels[0]) + 64.0 * g.block_out_channels[0]));
     CHECK_LAUNCH(c, ia2p_launch_conv_in(sample, W_(c, c->conv_in_w), W_(c, c->conv_in_b), x.p, B, g.in_channels, H, Wd, g.block_out_channels[0], c->stream), "conv_in");
   }
   skips.push_back(x); skip_c.push_back(g.block_out_channels[0]);
@@ -695,7 +696,7 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
   op_gn(c, x.p, no.p, c->ngo, c->nbo, B, H * Wd, c0, g.norm_eps, 1, f.gn_partial);
   wsfree(c, x);
   {
-    ProfScope ps(c, PK_CONV_OUT, 0, 0);
+    ProfScope ps(c, PK_CONV_OUT, 2.0 * B * H * Wd * 9.0 * c0 * g.out_channels, 2.0 * ((double)B * H * Wd * (c0 + g.out_channels) + 9.0 * c0 * g.out_channels));
     CHECK_LAUNCH(c, ia2p_launch_conv_out(no.p, c0, W_(c, c->conv_out_w), W_(c, c->conv_out_b), out, B, c0, H, Wd, g.out_channels, c->stream), "conv_out");
   }
   wsfree(c, no); wsfree(c, f.temb_all); wsfree(c, gnp); wsfree(c, f.kv_text); wsfree(c, f.kv_ip);
