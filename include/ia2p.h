@@ -173,6 +173,14 @@ ia2p_status ia2p_pack_geglu(void* stream, const void* src, void* dst, int rows, 
 ia2p_status ia2p_attention(void* stream, const void* Q, int ldq, void* O, int ldo, int B, int heads, int Nq, int nseg,
                            const void* K0, const void* V0, int ld0, int nkeys0, float w0,
                            const void* K1, const void* V1, int ld1, int nkeys1, float w1);
+/* `to_q` fused with the cross-attention that consumes it (reference attention_processor.py:344 + :371 / :387 / :397; AttnProcessor2_0 :239 + :259):
+ *   O = ia2p_attention(Q = epilogue(X . Wq^T), ...)  in ONE launch, Q never written -- bit-identical to ia2p_gemm_ex on a 128 x 64 tile followed
+ *   by ia2p_attention. X [B*Nq, K], Wq [heads*64, K] (gamma-folded when ln != NULL, as ia2p_gemm_ex), bias [heads*64] or NULL (ignored with ln).
+ *   Nq must be a multiple of 128 (one tile = 128 queries of one batch element x one head), K of 64. */
+ia2p_status ia2p_qproj_attention(void* stream, const void* X, const void* Wq, const void* bias, const ia2p_ln_fold* ln, void* O, int ldo,
+                                 int B, int heads, int Nq, int K, int nseg,
+                                 const void* K0, const void* V0, int ld0, int nkeys0, float w0,
+                                 const void* K1, const void* V1, int ld1, int nkeys1, float w1);
 /* The `attn_map` side effect of IPAttnProcessor2_0 (reference attention_processor.py:390-391; stored on the processor, read only by the
  * attention-map hooks of diffusion/ip_adapter/utils.py:15-20):  out[b,h,q,t] = sum_d Q[b,q,h*64+d] * softmax_t(Kip[b,t,h*64+d]) -- the
  * softmax binds to ip_key^T, i.e. runs over the TOKEN axis, unscaled, before the matmul. Q rows stride ldq, Kip [B*ntok, ldk], out fp16

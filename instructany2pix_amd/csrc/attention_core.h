@@ -1,0 +1,319 @@
+// Attention core shared by attention_f16_kernel (attention.hip) and the fused to_q + cross-attention tile (qxattn.hip):
+// K/V staging, the key-tile loop with its softmax(es) and the P.V accumulation for ONE wave's 32 queries of one (batch, head).
+// See attention.hip for the structure and the reference call sites.
+#pragma once
+#include "common.h"
+
+#define MASKED (-1.0e30f)
+
+__device__ __forceinline__ fp16x4 lds_tr16(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4f16((fp16x4 __attribute__((address_space(3)))*)p);
+}
+
+// Stage NT key tiles (64 keys each) of K and V into their swizzled LDS images. All 4*NT loads of a thread are
+// issued before the first LDS write (clamped row index: never a per-lane branch around a load -- hipcc would
+// wait vmcnt(0) per element); padding rows are zeroed by select.
+template <int NT>
+__device__ __forceinline__ void stage_kv(const half_t* Kb, const half_t* Vb, int ld, int s0, int nsk, int tid, char* sK, char* sV) {
+  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+  u4 kreg[2 * NT], vreg[2 * NT];
+#pragma unroll
+  for (int u = 0; u < 2 * NT; ++u) {
+    const int c = tid + 256 * u, row = c >> 3, pos = c & 7;
+    const size_t off = (size_t)(s0 + min(row, nsk - 1)) * ld + pos * 8;
+    kreg[u] = *(const u4*)(Kb + off);
+    vreg[u] = *(const u4*)(Vb + off);
+  }
+#pragma unroll
+  for (int u = 0; u < 2 * NT; ++u) {
+    const int c = tid + 256 * u, row = c >> 3, pos = c & 7;
+    const unsigned keep = row < nsk ? 0xFFFFFFFFu : 0u;     // bit mask, not a pointer select (that went through scratch)
+    *(u4*)(sK + row * 128 + ((pos ^ ((row >> 1) & 7)) << 4)) = kreg[u] & keep;
+    *(u4*)(sV + row * 128 + ((pos ^ (((row >> 1) & 1) << 2)) << 4)) = vreg[u] & keep;
+  }
+}
+
+// Both key segments of a short-context cross-attention (e.g. 77 text + 4 image-token keys = 2 + 1 tiles) staged in ONE
+// load phase: tiles [0, nt0) hold segment 0, tiles [nt0, NT) segment 1.
+template <int NT>
+__device__ __forceinline__ void stage_kv2(const half_t* K0, const half_t* V0, int ld0, int n0, const half_t* K1, const half_t* V1,
+                                          int ld1, int n1, int nt0, int tid, char* sK, char* sV) {
+  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+  u4 kreg[2 * NT], vreg[2 * NT];
+#pragma unroll
+  for (int u = 0; u < 2 * NT; ++u) {
+    const bool s1 = (u >> 1) >= nt0;                       // wave-uniform
+    const int c = tid + 256 * u, row = (c >> 3) - (s1 ? nt0 * 64 : 0), pos = c & 7;
+    const size_t off = (size_t)min(row, (s1 ? n1 : n0) - 1) * (s1 ? ld1 : ld0) + pos * 8;
+    kreg[u] = *(const u4*)((s1 ? K1 : K0) + off);
+    vreg[u] = *(const u4*)((s1 ? V1 : V0) + off);
+  }
+#pragma unroll
+  for (int u = 0; u < 2 * NT; ++u) {
+    const bool s1 = (u >> 1) >= nt0;
+    const int c = tid + 256 * u, lrow = c >> 3, row = lrow - (s1 ? nt0 * 64 : 0), pos = c & 7;
+    const unsigned keep = row < (s1 ? n1 : n0) ? 0xFFFFFFFFu : 0u;
+    *(u4*)(sK + lrow * 128 + ((pos ^ ((lrow >> 1) & 7)) << 4)) = kreg[u] & keep;
+    *(u4*)(sV + lrow * 128 + ((pos ^ (((lrow >> 1) & 1) << 2)) << 4)) = vreg[u] & keep;
+  }
+}
+
+// Two-phase form of the resident staging (the fused to_q + cross-attention tile issues the loads ahead of its GEMM loop, so the context K / V
+// are in registers when the projection is through): all ATTN_PRE_TILES tile slots are loaded (rows clamped into the segment: slots past the last tile re-read
+// its lines), only the live ones are written. Same LDS image as stage_kv2.
+typedef unsigned int attn_u4 __attribute__((ext_vector_type(4)));
+constexpr int ATTN_PRE_TILES = 3;       // 77 text + 4 image-token keys = 2 + 1 tiles
+struct AttnKvRegs { attn_u4 k[2 * ATTN_PRE_TILES], v[2 * ATTN_PRE_TILES]; };
+__device__ __host__ __forceinline__ bool attn_kv_resident(const AttnArgs& p) {
+  return ((p.seg[0].nkeys + 63) >> 6) + (p.nseg == 2 ? (p.seg[1].nkeys + 63) >> 6 : 0) <= ATTN_PRE_TILES;
+}
+__device__ __forceinline__ void attn_kv_load(const AttnArgs& p, int b, int hd, int tid, AttnKvRegs& rg) {
+  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+  const int nt0 = (p.seg[0].nkeys + 63) >> 6;
+  const bool two = p.nseg == 2;                            // one segment: the unused slots re-read segment 0
+  const AttnSeg sg1 = two ? p.seg[1] : p.seg[0];
+  const half_t* K0 = p.seg[0].K + (size_t)b * p.seg[0].rows_per_batch * p.seg[0].ld + hd * 64;
+  const half_t* V0 = p.seg[0].V + (size_t)b * p.seg[0].rows_per_batch * p.seg[0].ld + hd * 64;
+  const half_t* K1 = sg1.K + (size_t)b * sg1.rows_per_batch * sg1.ld + hd * 64;
+  const half_t* V1 = sg1.V + (size_t)b * sg1.rows_per_batch * sg1.ld + hd * 64;
+#pragma unroll
+  for (int u = 0; u < 2 * ATTN_PRE_TILES; ++u) {
+    const bool s1 = (u >> 1) >= nt0;                       // wave-uniform
+    const int c = tid + 256 * u, row = (c >> 3) - (s1 ? nt0 * 64 : 0), pos = c & 7;
+    const size_t off = (size_t)min(row, (s1 ? sg1.nkeys : p.seg[0].nkeys) - 1) * (s1 ? sg1.ld : p.seg[0].ld) + pos * 8;
+    rg.k[u] = *(const u4*)((s1 ? K1 : K0) + off);
+    rg.v[u] = *(const u4*)((s1 ? V1 : V0) + off);
+  }
+}
+__device__ __forceinline__ void attn_kv_store(const AttnArgs& p, int tid, const AttnKvRegs& rg, char* sK, char* sV) {
+  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+  const int n1 = p.nseg == 2 ? p.seg[1].nkeys : 0;
+  const int nt0 = (p.seg[0].nkeys + 63) >> 6, nt = nt0 + ((n1 + 63) >> 6);
+#pragma unroll
+  for (int u = 0; u < 2 * ATTN_PRE_TILES; ++u) {
+    if ((u >> 1) >= nt) break;                             // wave-uniform
+    const bool s1 = (u >> 1) >= nt0;
+    const int c = tid + 256 * u, lrow = c >> 3, row = lrow - (s1 ? nt0 * 64 : 0), pos = c & 7;
+    const unsigned keep = row < (s1 ? n1 : p.seg[0].nkeys) ? 0xFFFFFFFFu : 0u;
+    *(u4*)(sK + lrow * 128 + ((pos ^ ((lrow >> 1) & 7)) << 4)) = rg.k[u] & keep;
+    *(u4*)(sV + lrow * 128 + ((pos ^ (((lrow >> 1) & 1) << 2)) << 4)) = rg.v[u] & keep;
+  }
+}
+
+// qf: Q^T as the B operand of S^T = K . Q^T -- lane holds Q[q0 + lane%32][16*s + 8*(lane/32) + 0..7] (fp16, already rounded).
+// Result: otot[d][r] <-> channel 32d + (r&3) + 8(r>>2) + 4*(lane/32) of query q0 + lane%32. All 256 threads of the workgroup must call
+// (the staging and its barriers are workgroup-wide); sK / sV: 32 KiB each.
+// PRE: the caller has already put a resident context into sK / sV (attn_kv_load / attn_kv_store + barrier).
+template <int MODE, bool PRE = false>      // 0: one key segment; 1: two segments, the second <= 64 keys (IP-Adapter image tokens), merged accumulator; 2: generic two segments
+__device__ __forceinline__ void attn_core(const AttnArgs& p, int b, int hd, const h8 (&qf)[4], char* sK, char* sV, int tid, f16v (&otot)[2]) {
+  const int lane = tid & 63;
+  const int r31 = lane & 31, hh = lane >> 5;
+  (void)r31;
+  // Accumulators. MODE 0 / 1 keep ONE output accumulator `o` for the whole launch (MODE 1 scales the image-token probabilities so that both
+  // segments share the final 1 / l_text); MODE 2 (generic second segment) sums weight_s * o_s / l_s per segment into `otot`.
+  f16v o[2];
+  float mrun = MASKED, lrun = 0.f;
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[d][r] = 0.f; if (MODE == 2) otot[d][r] = 0.f; }
+
+  // short two-segment contexts: everything resident after one load phase and one barrier
+  const int nt0 = (p.seg[0].nkeys + 63) >> 6, nt1 = p.nseg == 2 ? (p.seg[1].nkeys + 63) >> 6 : 0;
+  const bool resident = PRE || (MODE != 0 && nt0 + nt1 <= 4);
+  if (resident && !PRE) {
+    const half_t* K0 = p.seg[0].K + (size_t)b * p.seg[0].rows_per_batch * p.seg[0].ld + hd * 64;
+    const half_t* V0 = p.seg[0].V + (size_t)b * p.seg[0].rows_per_batch * p.seg[0].ld + hd * 64;
+    const half_t* K1 = p.seg[1].K + (size_t)b * p.seg[1].rows_per_batch * p.seg[1].ld + hd * 64;
+    const half_t* V1 = p.seg[1].V + (size_t)b * p.seg[1].rows_per_batch * p.seg[1].ld + hd * 64;
+    switch (nt0 + nt1) {
+      case 2: stage_kv2<2>(K0, V0, p.seg[0].ld, p.seg[0].nkeys, K1, V1, p.seg[1].ld, p.seg[1].nkeys, nt0, tid, sK, sV); break;
+      case 3: stage_kv2<3>(K0, V0, p.seg[0].ld, p.seg[0].nkeys, K1, V1, p.seg[1].ld, p.seg[1].nkeys, nt0, tid, sK, sV); break;
+      default: stage_kv2<4>(K0, V0, p.seg[0].ld, p.seg[0].nkeys, K1, V1, p.seg[1].ld, p.seg[1].nkeys, nt0, tid, sK, sV); break;
+    }
+    __syncthreads();
+  }
+  float lt = 1.f;                          // MODE 1: softmax denominator of the text segment, final once segment 0 is through
+  constexpr int NSEG = MODE == 0 ? 1 : 2;
+#pragma unroll 1
+  for (int sg = 0; sg < NSEG; ++sg) {
+    const AttnSeg seg = sg == 0 ? p.seg[0] : p.seg[1];   // (a runtime index into the by-value argument would push it to scratch)
+    const half_t* Kb = seg.K + (size_t)b * seg.rows_per_batch * seg.ld + hd * 64;
+    const half_t* Vb = seg.V + (size_t)b * seg.rows_per_batch * seg.ld + hd * 64;
+    const bool ip_tile = MODE == 1 && sg == 1;           // one tile of <= 64 keys with its own softmax, merged into `o`
+    if (MODE == 2 || ip_tile) { mrun = MASKED; lrun = 0.f; }
+    if (MODE == 2) {
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    }
+
+    for (int s0 = 0; s0 < seg.nkeys; s0 += 256) {
+      const int nsk = min(256, seg.nkeys - s0);          // keys in this super-tile
+      const int ntile = (nsk + 63) >> 6;
+      if (!resident) {
+        __syncthreads();  // previous super-tile fully consumed
+        switch (ntile) {   // wave-uniform; each arm is fully unrolled so the staging registers never go to scratch
+          case 1: stage_kv<1>(Kb, Vb, seg.ld, s0, nsk, tid, sK, sV); break;
+          case 2: stage_kv<2>(Kb, Vb, seg.ld, s0, nsk, tid, sK, sV); break;
+          case 3: stage_kv<3>(Kb, Vb, seg.ld, s0, nsk, tid, sK, sV); break;
+          default: stage_kv<4>(Kb, Vb, seg.ld, s0, nsk, tid, sK, sV); break;
+        }
+        __syncthreads();
+      }
+      const int tbase = resident && sg == 1 ? nt0 : 0;
+      // Software pipeline over the tiles of the super-tile (cdna_hip_programming.md T15): S^T of tile t+1 is ISSUED ahead of the softmax
+      // arithmetic of tile t, so the matrix pipe works through it (and through the P.V of tile t-1 queued before it) while the VALU runs the
+      // exponentials -- a wave's in-order stream otherwise leaves the MFMA pipe idle for the whole softmax (PMC r01i: 13.5 VALU per MFMA).
+      // Two named score sets (A / B), swapped by a two-step body: a runtime-indexed set would live in scratch.
+      auto qk = [&](int tl, f16v (&st)[2]) {       // S^T[key][q] for the two 32-key halves of tile tl; K fragments read ahead of the MFMAs
+        const char* sKt = sK + (tbase + tl) * 8192;
+        h8 kf[2][4];
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+          const int row = kh * 32 + r31;
+          const char* kp = sKt + row * 128;
+          const int sw = (row >> 1) & 7;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) kf[kh][s] = *(const h8*)(kp + (((2 * s + hh) ^ sw) << 4));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) st[kh][r] = 0.f;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) st[kh] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kh][s], qf[s], st[kh], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      auto soft_pv = [&](int tl, f16v (&st)[2]) {
+        const int k0 = s0 + tl * 64;
+        const char* sVt = sV + (tbase + tl) * 8192;
+        // V^T fragments of the whole tile: issued now, their latency hides under the softmax arithmetic below
+        const int gi = (lane >> 4) & 1, li = lane & 15;
+        h8 vf[2][2][2];
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const int kb0 = kh * 32 + s2 * 16 + 4 * hh + (li >> 2);   // row this lane addresses for j<4
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+              const int col = d * 32 + gi * 16 + 4 * (li & 3);          // first of 4 contiguous d this lane addresses
+              const int pos = col >> 3, sub = (col & 7) * 2;
+              const int r0 = kb0, r1 = kb0 + 8;
+              const fp16x4 lo = lds_tr16(sVt + r0 * 128 + ((pos ^ (((r0 >> 1) & 1) << 2)) << 4) + sub);
+              const fp16x4 hi = lds_tr16(sVt + r1 * 128 + ((pos ^ (((r1 >> 1) & 1) << 2)) << 4) + sub);
+              vf[kh][s2][d][0] = lo[0]; vf[kh][s2][d][1] = lo[1]; vf[kh][s2][d][2] = lo[2]; vf[kh][s2][d][3] = lo[3];
+              vf[kh][s2][d][4] = hi[0]; vf[kh][s2][d][5] = hi[1]; vf[kh][s2][d][6] = hi[2]; vf[kh][s2][d][7] = hi[3];
+            }
+          }
+        __builtin_amdgcn_sched_barrier(0);
+        // st[kh][r] <-> key = k0 + 32kh + (r&3) + 8(r>>2) + 4*hh, query = q0 + lane%32
+        // softmax on RAW scores: max commutes with the positive scale, and exp2(c*s - c*m) is one FMA + one v_exp_f32
+        if (k0 + 64 > seg.nkeys) {        // only the last, partial tile of a segment needs masking (wave-uniform)
+#pragma unroll
+          for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int key = k0 + kh * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+              if (key >= seg.nkeys) st[kh][r] = MASKED;
+            }
+        }
+        float mx = st[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[0][r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[1][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(mrun, mx);
+        const float mc = mnew * p.scale_log2e;
+        float psum = 0.f;
+        h8 pf[2][2];
+        typedef float f2v __attribute__((ext_vector_type(2)));
+        if (!ip_tile) {
+#pragma unroll
+          for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+              const float e0 = __builtin_amdgcn_exp2f(fmaf(st[kh][r], p.scale_log2e, -mc));
+              const float e1 = __builtin_amdgcn_exp2f(fmaf(st[kh][r + 1], p.scale_log2e, -mc));
+              psum += e0;
+              psum += e1;
+              const h2 pr = __builtin_convertvector((f2v){e0, e1}, h2);      // ONE v_cvt_pk_f16_f32 per pair
+              pf[kh][r >> 3][r & 7] = pr[0]; pf[kh][r >> 3][(r & 7) + 1] = pr[1];
+            }
+          if (__any(mnew != mrun)) {        // running max moved for some query of this wave: rescale (rare after the first tiles)
+            const float alpha = __builtin_amdgcn_exp2f((mrun - mnew) * p.scale_log2e);
+            lrun *= alpha;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+            mrun = mnew;
+          }
+          lrun += psum;
+        } else {
+          // image-token tile (MODE 1): its own softmax over its <= 64 keys, all of them in this tile. `o` already holds sum_t e^(s_t - m_t) v_t
+          // of the text keys, to be divided by l_t at the end: scale these probabilities by (w_ip / w_text) * l_t / l_ip so that the common
+          // division leaves  w_text * text / l_t + w_ip * ip / l_ip  (reference attention_processor.py:371,387,397: two softmaxes, text + scale * ip)
+#pragma unroll
+          for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { st[kh][r] = __builtin_amdgcn_exp2f(fmaf(st[kh][r], p.scale_log2e, -mc)); psum += st[kh][r]; }
+          const float li = psum + __shfl_xor(psum, 32, 64);
+          const float c = seg.weight / p.seg[0].weight * lt / li;
+#pragma unroll
+          for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+              const h2 pr = __builtin_convertvector((f2v){st[kh][r] * c, st[kh][r + 1] * c}, h2);
+              pf[kh][r >> 3][r & 7] = pr[0]; pf[kh][r >> 3][(r & 7) + 1] = pr[1];
+            }
+        }
+
+        // ---- O^T[d][q] += V^T[d][key] . P^T[key][q]; k-step (kh,s2): slot (hh, j) <-> key 32kh + 16s2 + 8(j>>2) + 4hh + (j&3)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+              o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[kh][s2][d], pf[kh][s2], o[d], 0, 0, 0);
+      };
+      f16v sA[2];
+      if constexpr (MODE != 0) {           // two-segment launches (short contexts, both segments staged at once): no room for a second score set
+        for (int tl = 0; tl < ntile; ++tl) { qk(tl, sA); soft_pv(tl, sA); }
+      } else {
+        f16v sB[2];
+        qk(0, sA);
+        for (int tl = 0; tl < ntile; tl += 2) {
+          if (tl + 1 < ntile) qk(tl + 1, sB);
+          soft_pv(tl, sA);
+          if (tl + 1 < ntile) {
+            if (tl + 2 < ntile) qk(tl + 2, sA);
+            soft_pv(tl + 1, sB);
+          }
+        }
+      }
+    }
+    if (MODE == 2) {
+      const float l = lrun + __shfl_xor(lrun, 32, 64);
+      const float w = seg.weight / l;
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) otot[d][r] += o[d][r] * w;
+    } else if (sg == 0) lt = lrun + __shfl_xor(lrun, 32, 64);
+  }
+  if (MODE != 2) {
+    const float w = p.seg[0].weight / lt;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) otot[d][r] = o[d][r] * w;
+  }
+}

@@ -51,7 +51,7 @@ struct Stage {            // one down/up block
 const char* prof_name(int k) {
   static char buf[PK_NCLASS][64];
   static const char* const other[] = {"attention_f16_kernel", "gn_stats_kernel+gn_apply_kernel", "layernorm_kernel",
-                                      "embed_kernel+linear_small_kernel", "conv_in_kernel", "conv_out_kernel", "concat_kernel", "splitk_reduce_kernel"};
+                                      "embed_kernel+linear_small_kernel", "conv_in_kernel", "conv_out_kernel", "concat_kernel", "splitk_reduce_kernel", "qproj_xattn_kernel"};
   if (k >= PK_ATTN) return other[k - PK_ATTN];
   const GemmTile t = IA2P_GEMM_TILES[(k % PK_CONV0) % IA2P_GEMM_NVARIANT];
   if (t.bm == 256) snprintf(buf[k], sizeof buf[k], "gemm_f16_kernel<%d, %d, %d, %s, 4, 64, 1, 2>", t.bm, t.bn, t.stages, k >= PK_CONV0 ? "true" : "false");
@@ -486,6 +486,24 @@ static void op_attn(RunCtx* c, const AttnArgs& a) {
   CHECK_LAUNCH(c, ia2p_launch_attention(a, c->stream), "attention");
 }
 
+// to_q projection + the cross-attention that consumes it in ONE launch (qxattn.hip); Q never leaves the CU
+static void op_qxattn(RunCtx* c, const half_t* A, int lda, const half_t* W, const LnIn* ln, int M, int N, int K, const AttnArgs& x) {
+  GemmArgs a;
+  memset(&a, 0, sizeof a);
+  a.pad = 1;
+  if (ln) { a.ln_stats = ln->stats; a.ln_slots = ln->slots; a.ln_cs = ln->cs; a.ln_bias = ln->lb; a.ln_eps = ln->eps; }
+  a.A = A; a.W = W; a.zero = zero_page(); a.M = M; a.N = N; a.K = K; a.ldw = K; a.lda = lda; a.ldc = N;
+  a.rows_per_batch = 1;
+  a.m_fastest = M <= N ? 1 : 0;
+  a.acc_scale = a.bias_scale = 1.f;
+  set_prefetch(c, a, W, (size_t)N * K * sizeof(half_t));
+  double keys = 0;
+  for (int s = 0; s < x.nseg; ++s) keys += x.seg[s].nkeys;
+  ProfScope ps(c, PK_QXATTN, 2.0 * M * N * K + 4.0 * x.B * x.heads * (double)x.Nq * keys * 64,
+               2.0 * ((double)M * K + (double)N * K + (double)M * N + 2.0 * x.B * keys * x.heads * 64));
+  CHECK_LAUNCH(c, ia2p_launch_qproj_xattn(a, x, c->stream), "to_q + cross-attention");
+}
+
 static T2 run_transformer(Fwd& f, const Transformer& t, T2 x, int H, int Wd) {
   ia2p_ctx* c = f.c;
   RegionScope rs(c, PR_TRANSFORMER);
@@ -532,13 +550,6 @@ static T2 run_transformer(Fwd& f, const Transformer& t, T2 x, int H, int Wd) {
     }
     op_gemm(c, att.p, C, W_(c, b.wo1), W_(c, b.bo1), tk.p, C, tk.p, C, M, C, C, 0, 0, 0, 0, 0, nullptr, st, &slots);
     // cross-attention (IPAttnProcessor2_0 :310-412 when the adapter is installed, else AttnProcessor2_0)
-    if (fold) {
-      const LnIn ln{st, slots, F_(b.cs2), F_(b.lb2), eps};
-      op_gemm(c, tk.p, C, W_(c, b.fq2), nullptr, nullptr, 0, qkv.p, C, M, C, C, 0, 0, 0, 0, 0, &ln);
-    } else {
-      op_ln(c, tk.p, lnb.p, b.ln2g, b.ln2b, M, C);
-      op_gemm(c, lnb.p, C, W_(c, b.wq2), nullptr, nullptr, 0, qkv.p, C, M, C, C);
-    }
     {
       AttnArgs a;
       memset(&a, 0, sizeof a);
@@ -547,7 +558,19 @@ static T2 run_transformer(Fwd& f, const Transformer& t, T2 x, int H, int Wd) {
       const half_t* ki = (c->dry || !Li) ? nullptr : f.kv_ip.p + b.kv_col;
       a.seg[0].K = kt; a.seg[0].V = c->dry ? nullptr : kt + C; a.seg[0].nkeys = Lt; a.seg[0].ld = ldkv; a.seg[0].rows_per_batch = Lt; a.seg[0].weight = 1.f;
       a.seg[1].K = ki; a.seg[1].V = ki ? ki + C : nullptr; a.seg[1].nkeys = Li; a.seg[1].ld = ldkv; a.seg[1].rows_per_batch = Li; a.seg[1].weight = c->ip_scale;
-      op_attn(c, a);
+      // a 128 x 64 tile of to_q is 128 queries x one head: projection and attention run as one launch when tiles do not straddle batch elements
+      // (and the context fits 3 key tiles: its K / V ride in registers through the projection loop); small problems keep the finer 64 x 64 split
+      const bool fuse = c->xattn_fuse && HW % 128 == 0 && C == t.heads * 64 && (Lt + 63) / 64 + (Li + 63) / 64 <= 3 && (long)(M / 128) * t.heads >= c->xattn_min_tiles;
+      if (fold) {
+        const LnIn ln{st, slots, F_(b.cs2), F_(b.lb2), eps};
+        if (fuse) op_qxattn(c, tk.p, C, W_(c, b.fq2), &ln, M, C, C, a);
+        else op_gemm(c, tk.p, C, W_(c, b.fq2), nullptr, nullptr, 0, qkv.p, C, M, C, C, 0, 0, 0, 0, 0, &ln);
+      } else {
+        op_ln(c, tk.p, lnb.p, b.ln2g, b.ln2b, M, C);
+        if (fuse) op_qxattn(c, lnb.p, C, W_(c, b.wq2), nullptr, M, C, C, a);
+        else op_gemm(c, lnb.p, C, W_(c, b.wq2), nullptr, nullptr, 0, qkv.p, C, M, C, C);
+      }
+      if (!fuse) op_attn(c, a);
     }
     op_gemm(c, att.p, C, W_(c, b.wo2), W_(c, b.bo2), tk.p, C, tk.p, C, M, C, C, 0, 0, 0, 0, 0, nullptr, st, &slots);
     // GEGLU feed-forward
@@ -1085,6 +1108,29 @@ ia2p_status ia2p_attention(void* stream, const void* Q, int ldq, void* O, int ld
   a.seg[1] = AttnSeg{(const half_t*)K1, (const half_t*)V1, nkeys1, ld1, nkeys1, w1};
   hipError_t e = ia2p_launch_attention(a, (hipStream_t)stream);
   RET_HIP(e, "attention");
+}
+ia2p_status ia2p_qproj_attention(void* stream, const void* X, const void* Wq, const void* bias, const ia2p_ln_fold* ln, void* O, int ldo, int B, int heads,
+                                 int Nq, int K, int nseg, const void* K0, const void* V0, int ld0, int nkeys0, float w0,
+                                 const void* K1, const void* V1, int ld1, int nkeys1, float w1) {
+  if (!X || !Wq || !O || !K0 || !V0 || nseg < 1 || nseg > 2 || (nseg == 2 && (!K1 || !V1))) return fail(nullptr, IA2P_ERR_INVALID, "qproj_attention: bad argument");
+  if (ln && (!ln->stats || !ln->colsum || !ln->fbias || ln->slots < 1)) return fail(nullptr, IA2P_ERR_INVALID, "qproj_attention: incomplete ia2p_ln_fold");
+  if (B < 1 || heads < 1 || Nq < 128 || Nq % 128 || K < 64 || K % 64 || nkeys0 < 1 || (nseg == 2 && nkeys1 < 1) || ldo % 4 || ld0 % 8 || (nseg == 2 && ld1 % 8))
+    return fail(nullptr, IA2P_ERR_SHAPE, "qproj_attention: Nq=%d must be a multiple of 128, K=%d of 64, key counts >= 1, key strides multiples of 8, ldo of 4", Nq, K);
+  GemmArgs a;
+  memset(&a, 0, sizeof a);
+  a.pad = 1;
+  a.A = (const half_t*)X; a.W = (const half_t*)Wq; a.zero = zero_page(); a.M = B * Nq; a.N = heads * 64; a.K = K; a.ldw = K; a.lda = K; a.ldc = a.N;
+  a.bias = (const half_t*)bias; a.rows_per_batch = 1; a.m_fastest = a.M <= a.N;
+  if (ln) { a.ln_stats = ln->stats; a.ln_slots = ln->slots; a.ln_cs = ln->colsum; a.ln_bias = ln->fbias; a.ln_eps = ln->eps; }
+  AttnArgs x;
+  memset(&x, 0, sizeof x);
+  x.O = (half_t*)O; x.ldo = ldo; x.B = B; x.heads = heads; x.Nq = Nq; x.nseg = nseg;
+  x.scale_log2e = 0.125f * 1.4426950408889634f;
+  x.seg[0] = AttnSeg{(const half_t*)K0, (const half_t*)V0, nkeys0, ld0, nkeys0, w0};
+  x.seg[1] = AttnSeg{(const half_t*)K1, (const half_t*)V1, nkeys1, ld1, nkeys1, w1};
+  if (!ia2p_qproj_xattn_ok(a, x)) return fail(nullptr, IA2P_ERR_SHAPE, "qproj_attention: shape not supported by the fused tile (bias must be 16-byte aligned)");
+  hipError_t e = ia2p_launch_qproj_xattn(a, x, (hipStream_t)stream);
+  RET_HIP(e, "qproj_attention");
 }
 ia2p_status ia2p_ip_attn_map(void* stream, const void* Q, int ldq, const void* Kip, int ldk, void* out, int B, int heads, int Nq, int ntok) {
   if (!Q || !Kip || !out || B < 1 || heads < 1 || Nq < 1) return fail(nullptr, IA2P_ERR_INVALID, "ip_attn_map: bad argument");

@@ -25,6 +25,8 @@ hipError_t ia2p_launch_splitk_reduce(const GemmArgs& a, hipStream_t s);
 bool ia2p_splitk_inkernel(int M, int N, int splitk);
 void ia2p_gemm_candidates(int M, int N, int K, bool conv, bool geglu, size_t max_slab_bytes, double slack, std::vector<GemmPlan>* out);
 hipError_t ia2p_launch_attention(const AttnArgs& a, hipStream_t s);
+bool ia2p_qproj_xattn_ok(const GemmArgs& a, const AttnArgs& x);
+hipError_t ia2p_launch_qproj_xattn(const GemmArgs& a, const AttnArgs& x, hipStream_t s);   // qxattn.hip: to_q tile -> attention core, one launch
 int ia2p_gn_chunks(int B, int HW);
 hipError_t ia2p_launch_groupnorm(const half_t* x, int ldx, half_t* y, int ldy, const half_t* gamma, const half_t* beta,
                                  float* partial, int B, int HW, int C, int G, float eps, int silu, hipStream_t s);
@@ -109,7 +111,7 @@ struct ProfRec { hipEvent_t e0, e1; int k; double flops, bytes; int region; };
 // profile regions of a UNet evaluation: what part of the network a launch belongs to (bench.py: conv-block roofline)
 enum { PR_OTHER = 0, PR_CONV_BLOCK = 1, PR_TRANSFORMER = 2, PR_NREGION };
 // profile classes = device kernel names as rocprofv3 prints them (template arguments included)
-enum { PK_GEMM0 = 0, PK_CONV0 = 24, PK_ATTN = 48, PK_GN, PK_LN, PK_EMBED, PK_CONV_IN, PK_CONV_OUT, PK_CONCAT, PK_REDUCE, PK_NCLASS };
+enum { PK_GEMM0 = 0, PK_CONV0 = 24, PK_ATTN = 48, PK_GN, PK_LN, PK_EMBED, PK_CONV_IN, PK_CONV_OUT, PK_CONCAT, PK_REDUCE, PK_QXATTN, PK_NCLASS };
 const char* prof_name(int k);
 
 // state shared by the executors (conditional UNet, VAE): weights, workspace, prefetch plan, per-kernel timing
@@ -134,6 +136,8 @@ struct RunCtx {
   bool prefetch = true;
   const half_t* tail_pf = nullptr;   // what the LAST contraction of a pass prefetches: the first weights of the next pass (embedding MLPs)
   size_t tail_pf_bytes = 0;
+  int xattn_min_tiles = 256; // ... and only when the fused launch has at least this many 128-query x head tiles (IA2P_XATTN_MIN_TILES)
+  bool xattn_fuse = true;    // to_q + cross-attention as one launch where the shape allows (IA2P_XATTN_FUSE=0: two launches, for A/B runs)
   bool ln_fold = true;       // LayerNorms folded into their consumer GEMMs (IA2P_LN_FOLD=0: separate layernorm_kernel launches, for A/B runs)
   bool prof = false;
   // autotune pass (ia2p_autotune): every GEMM / conv site of an unmeasured shape times its candidate plans in place
@@ -153,6 +157,8 @@ struct RunCtx {
   RunCtx() {
     if (const char* e = getenv("IA2P_PREFETCH")) prefetch = atoi(e) != 0;
     if (const char* e = getenv("IA2P_LN_FOLD")) ln_fold = atoi(e) != 0;
+    if (const char* e = getenv("IA2P_XATTN_FUSE")) xattn_fuse = atoi(e) != 0;
+    if (const char* e = getenv("IA2P_XATTN_MIN_TILES")) xattn_min_tiles = atoi(e);
     for (int k = 0; k < PK_NCLASS; ++k) { p_ms[k] = p_fl[k] = p_by[k] = 0; p_n[k] = 0; }
     for (int k = 0; k < PR_NREGION; ++k) { r_ms[k] = r_fl[k] = r_by[k] = 0; r_n[k] = 0; }
   }

@@ -1,0 +1,60 @@
+// Fused `to_q` projection + cross-attention for gfx950.
+//
+// Reference: attention_processor.py:344 (`query = attn.to_q(hidden_states)`), :358-359 / :379-380 (context K / V, projected once per step by the
+// executor), :371 and :387 (the two scaled_dot_product_attention calls of IPAttnProcessor2_0) and :397 (`hidden_states + scale * ip_hidden_states`);
+// AttnProcessor2_0 :239 / :259 when no adapter is installed.
+//
+// A 128 x 64 tile of the to_q GEMM is exactly 128 queries x ONE head, and a cross-attention head needs nothing else from Q: the tile goes from
+// the MFMA accumulators through LDS into the Q^T fragments of the attention core (attention_core.h) and the workgroup walks the 77 (+4) context
+// keys right there. One launch instead of two per layer (70 per UNet evaluation), and Q never travels to HBM and back. Same arithmetic in the
+// same order as the two stand-alone kernels (projection epilogue in fp32, ONE rounding to fp16, the attention core unchanged): bit-identical
+// to running `gemm_f16_kernel<128, 64, ...>` + `attention_f16_kernel` (tests/test_ops_gpu.py).
+#include "gemm_kernel.h"
+
+template <int MODE>      // attention core mode: 0 one key segment; 1 text + <= 64 image-token keys; 2 generic two segments
+__global__ __launch_bounds__(256, 2) void qproj_xattn_kernel(const half_t* hA, const half_t* hW, const half_t* hzero, int hM, int hN, int hK, int hlda, int hldw, int hrpb,
+                                                             int hbstride, int hroff, int hsplitk, int hgroup_w, const GemmArgs p, const AttnArgs xa) {
+  gemm_tile_body<128, 64, 2, false, 2, 64, 0, 2, MODE + 1>(hA, hW, hzero, hM, hN, hK, hlda, hldw, hrpb, hbstride, hroff, hsplitk, hgroup_w, p, &xa);
+}
+
+// Q = epilogue(A . W^T) is [B * Nq, heads * 64]; x.Q / x.ldq are ignored (Q stays on chip). Requires Nq % 128 == 0 (a tile must not straddle
+// two batch elements), N = heads * 64, no K-split, no GEGLU / residual / row vector / statistics output; the context must fit
+// ATTN_PRE_TILES key tiles of 64 (77 text + 4 image tokens: 2 + 1).
+bool ia2p_qproj_xattn_ok(const GemmArgs& a, const AttnArgs& x) {
+  return x.Nq > 0 && x.Nq % 128 == 0 && a.M == x.B * x.Nq && a.N == x.heads * 64 && a.K >= 64 && a.K % 64 == 0 && a.splitk <= 1 && !a.geglu && !a.residual && !a.rowvec &&
+         !a.stats_out && !a.act && x.nseg >= 1 && x.nseg <= 2 && x.seg[0].nkeys > 0 && (x.nseg == 1 || x.seg[1].nkeys > 0) &&
+         (!a.bias || ((((uintptr_t)a.bias) & 15) == 0 && a.N % 8 == 0)) && x.ldo % 4 == 0 &&
+         attn_kv_resident(x);      // short contexts only: their K / V ride in registers through the projection loop
+}
+
+hipError_t ia2p_launch_qproj_xattn(const GemmArgs& a, const AttnArgs& x, hipStream_t s) {
+  if (!ia2p_qproj_xattn_ok(a, x)) return hipErrorInvalidValue;
+  constexpr int BM = 128, BN = 64, SMEM = 65536;       // K / V images of the attention core: 2 x 32 KiB (the GEMM ring needs 48 KiB)
+  static_assert(EpiCfg<BM, BN, 2, 2, 64, 2>::SMEM <= SMEM, "LDS budget");
+  static bool attr_set[64] = {false};                  // per device (the attribute is)
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+    hipError_t e = hipFuncSetAttribute((const void*)qproj_xattn_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)qproj_xattn_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)qproj_xattn_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
+  }
+  const int tiles_n = a.N / BN, tiles = (a.M / BM) * tiles_n;
+  GemmArgs b = a;
+  b.vec8 = 1; b.splitk = 0; b.sk_counters = nullptr; b.partial = nullptr;
+  b.group_w = ia2p_tile_group_w(tiles, tiles_n, SMEM, BM, BN);
+  AttnArgs y = x;
+  y.xcd_map = 0;
+  const int extra = (a.pf && a.pf_bytes >= 4096) ? a.pf_blocks : 0;
+  const int mode = y.nseg == 1 ? 0 : (y.seg[1].nkeys <= 64 && y.seg[0].weight != 0.f) ? 1 : 2;     // as ia2p_launch_attention
+#define IA2P_QX_LAUNCH(MODE)                                                                                                                   \
+  hipLaunchKernelGGL(qproj_xattn_kernel<MODE>, dim3(tiles + extra), dim3(256), SMEM, s, b.A, b.W, b.zero, b.M, b.N, b.K, b.lda, b.ldw, b.rpb, \
+                     b.bstride, b.roff, b.splitk, b.group_w, b, y)
+  if (mode == 0) IA2P_QX_LAUNCH(0);
+  else if (mode == 1) IA2P_QX_LAUNCH(1);
+  else IA2P_QX_LAUNCH(2);
+#undef IA2P_QX_LAUNCH
+  return hipGetLastError();
+}

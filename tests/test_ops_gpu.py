@@ -291,6 +291,70 @@ def test_cross_attention_two_softmaxes(L, Lt, Li, scale):
     assert rel_l2(out, ref) < 2e-3, rel_l2(out, ref)
 
 
+@pytest.mark.parametrize("folded", [True, False])
+@pytest.mark.parametrize("B,heads,Nq,Lt,Li,scale", [(2, 4, 256, 77, 4, 1.0), (1, 20, 256, 77, 4, 0.6), (1, 10, 1024, 77, 0, 0.0), (2, 2, 128, 128, 4, 0.9),
+                                                    (1, 3, 384, 64, 65, 2.0), (1, 2, 256, 77, 64, 1.3), (1, 2, 256, 13, 0, 0.0), (1, 1, 128, 192, 0, 0.0)])
+def test_qproj_fused_with_cross_attention(L, B, heads, Nq, Lt, Li, scale, folded):
+    """ia2p_qproj_attention = to_q (optionally behind a folded LayerNorm) + the two-softmax cross-attention in ONE launch
+    (reference attention_processor.py:344, :371, :387, :397): same BITS as ia2p_gemm_ex on the 128 x 64 tile followed by
+    ia2p_attention, and within the attention tolerance of torch fp32."""
+    f = _ffi()
+    C_ = heads * 64
+    M = B * Nq
+    kv, kvi = rnd(B, Lt, 2 * C_, seed=31), rnd(B, max(Li, 1), 2 * C_, seed=32)
+    att = lambda q_ptr, out: run(L, "ia2p_attention", q_ptr, C_, f.ptr(out), C_, B, heads, Nq, 2 if Li else 1,
+                                 f.ptr(kv), C.c_void_p(kv.data_ptr() + 2 * C_), 2 * C_, Lt, 1.0,
+                                 f.ptr(kvi), C.c_void_p(kvi.data_ptr() + 2 * C_), 2 * C_, Li, scale)
+    segs = (2 if Li else 1, f.ptr(kv), C.c_void_p(kv.data_ptr() + 2 * C_), 2 * C_, Lt, 1.0,
+            f.ptr(kvi), C.c_void_p(kvi.data_ptr() + 2 * C_), 2 * C_, Li, scale)
+    q = torch.empty(M, C_, dtype=torch.half, device="cuda")
+    two, one = torch.empty(B, Nq, C_, dtype=torch.half, device="cuda"), torch.full((B, Nq, C_), float("nan"), dtype=torch.half, device="cuda")
+    L.ia2p_debug_set_gemm_tile(2)                      # 128 x 64 x 2 stages: the tile the fused kernel is built on
+    try:
+        if folded:
+            _, X, Wp, R, gamma, beta, W, b, Wf, cs, fb = _ln_fold_setup(L, M, C_, C_, seed=70 + heads, bias=False)
+            t = torch.empty(M, C_, dtype=torch.half, device="cuda")
+            stats = torch.zeros((C_ // 64 + 1) * M * 2, dtype=torch.float32, device="cuda")
+            slots = C.c_int(0)
+            run(L, "ia2p_gemm_ex", f.ptr(X), f.ptr(Wp), None, f.ptr(R), f.ptr(t), M, C_, C_, 0, None, f.ptr(stats), C.addressof(slots), 1, None)
+            ln = f.LnFoldC(stats.data_ptr(), slots.value, cs.data_ptr(), fb.data_ptr(), 1e-5)
+            run(L, "ia2p_gemm_ex", f.ptr(t), f.ptr(Wf), None, None, f.ptr(q), M, C_, C_, 0, C.addressof(ln), None, None, 1, None)
+            att(f.ptr(q), two)
+            run(L, "ia2p_qproj_attention", f.ptr(t), f.ptr(Wf), None, C.addressof(ln), f.ptr(one), C_, B, heads, Nq, C_, *segs)
+            qref = F.layer_norm(t.float(), (C_,), gamma.float(), beta.float(), 1e-5) @ W.float().t()
+        else:
+            X, W, b = rnd(M, C_, seed=33), rnd(C_, C_, seed=34, scale=C_ ** -0.5), rnd(C_, seed=35, scale=0.3)
+            run(L, "ia2p_gemm_ex", f.ptr(X), f.ptr(W), f.ptr(b), None, f.ptr(q), M, C_, C_, 0, None, None, None, 1, None)
+            att(f.ptr(q), two)
+            run(L, "ia2p_qproj_attention", f.ptr(X), f.ptr(W), f.ptr(b), None, f.ptr(one), C_, B, heads, Nq, C_, *segs)
+            qref = X.float() @ W.float().t() + b.float()
+    finally:
+        L.ia2p_debug_set_gemm_tile(-1)
+    assert torch.equal(one, two), float((one.float() - two.float()).abs().max())
+    sp = lambda x: x.reshape(B, -1, heads, 64).transpose(1, 2)
+    ref = _sdpa(sp(qref), sp(kv[..., :C_]), sp(kv[..., C_:]))
+    if Li:
+        ref = ref + scale * _sdpa(sp(qref), sp(kvi[..., :C_]), sp(kvi[..., C_:]))
+    ref = ref.transpose(1, 2).reshape(B, Nq, C_)
+    assert rel_l2(one, ref) < 3e-3, rel_l2(one, ref)     # Q is rounded to fp16 between the projection and the scores, as in the reference
+
+
+def test_qproj_attention_rejects_bad_shapes(L):
+    f = _ffi()
+    x, w, kv = rnd(200, 128, seed=1), rnd(128, 128, seed=2), rnd(77, 256, seed=3)
+    o = torch.empty(200, 128, dtype=torch.half, device="cuda")
+    rc = L.ia2p_qproj_attention(f.current_stream(), f.ptr(x), f.ptr(w), None, None, f.ptr(o), 128, 1, 2, 200, 128, 1,
+                                f.ptr(kv), C.c_void_p(kv.data_ptr() + 256), 256, 77, 1.0, None, None, 0, 0, 0.0)
+    assert rc != 0                                       # Nq = 200 is not a multiple of 128
+    kl = rnd(300, 256, seed=4)
+    rc = L.ia2p_qproj_attention(f.current_stream(), f.ptr(x), f.ptr(w), None, None, f.ptr(o), 128, 1, 2, 128, 128, 1,
+                                f.ptr(kl), C.c_void_p(kl.data_ptr() + 256), 256, 300, 1.0, None, None, 0, 0, 0.0)
+    assert rc != 0                                       # 300 keys = 5 tiles: only contexts of <= 3 key tiles are fused (callers use the two launches)
+    rc = L.ia2p_qproj_attention(f.current_stream(), None, f.ptr(w), None, None, f.ptr(o), 128, 1, 2, 128, 128, 1,
+                                f.ptr(kv), C.c_void_p(kv.data_ptr() + 256), 256, 77, 1.0, None, None, 0, 0, 0.0)
+    assert rc != 0
+
+
 @pytest.mark.parametrize("B,HW,C_,silu,eps", [(8, 4096, 320, 1, 1e-5), (2, 256, 1280, 0, 1e-6), (1, 1024, 1920, 1, 1e-5),
                                              (2, 256, 2560, 1, 1e-5), (2, 64, 64, 1, 1e-5), (1, 576, 960, 1, 1e-5)])
 def test_groupnorm_silu(L, B, HW, C_, silu, eps):

@@ -323,6 +323,36 @@ def test_layernorm_fold_switch_agrees(tiny_models, monkeypatch):
     assert rel_l2(a, b) <= 3e-3 and not torch.equal(a, b)
 
 
+def test_fused_qproj_cross_attention_switch_agrees(tiny_models, monkeypatch):
+    """Where a level has a multiple of 128 queries per image the executor runs to_q + cross-attention as ONE launch (qproj_xattn_kernel);
+    IA2P_XATTN_FUSE=0 (read when a context is created) keeps the two launches. Same arithmetic: the outputs agree to fp16 accuracy (bit for
+    bit unless the stand-alone to_q GEMM was planned with a K split), with and without the IP-Adapter's second softmax."""
+    from instructany2pix_amd.attention_processor import AttnProcessor2_0
+    from instructany2pix_amd.unet import HipUNet2DConditionModel
+    cfg, sd, ipsd, _, oracle = tiny_models
+    monkeypatch.setenv("IA2P_XATTN_FUSE", "0")
+    plain = HipUNet2DConditionModel(cfg, DEV)
+    monkeypatch.delenv("IA2P_XATTN_FUSE")
+    monkeypatch.setenv("IA2P_XATTN_MIN_TILES", "1")      # (by default only launches of >= 256 tiles are fused: the tiny model has fewer)
+    hip = HipUNet2DConditionModel(cfg, DEV)
+    monkeypatch.delenv("IA2P_XATTN_MIN_TILES")
+    plain.load_state_dict(sd); hip.load_state_dict(sd)
+    for L_, ip in ((81, True), (77, False)):
+        for m in (hip, plain):
+            if ip:
+                _install_ip(m, cfg, ipsd, 0.8)
+            else:
+                m.set_attn_processor(AttnProcessor2_0())
+        x, ctx, te, tid = (t.to(DEV) for t in _inputs(cfg, 2, 32, 32, L_, seed=43))
+        kw = dict(encoder_hidden_states=ctx, added_cond_kwargs=dict(text_embeds=te, time_ids=tid))
+        hip.profile(True); plain.profile(True)
+        a, b = hip(x, 301, **kw)[0].clone(), plain(x, 301, **kw)[0].clone()
+        ka, kb = hip.profile_read(), plain.profile_read()
+        hip.profile(False); plain.profile(False)
+        assert ka.get("qproj_xattn_kernel", {}).get("launches", 0) > 0 and "qproj_xattn_kernel" not in kb
+        assert rel_l2(a, b) <= 1e-3, rel_l2(a, b)
+
+
 def test_context_kv_hoisting_is_bit_identical_and_invalidates(tiny_models):
     """`ia2p_project_context` + `ia2p_unet_forward_kv` == `ia2p_unet_forward`, bit for bit; the Python cache re-projects when the
     context tensor is another object, was modified in place, or the weights / IP-Adapter topology changed."""
