@@ -356,10 +356,16 @@ def test_qproj_attention_rejects_bad_shapes(L):
 
 
 @pytest.mark.parametrize("B,HW,C_,silu,eps", [(8, 4096, 320, 1, 1e-5), (2, 256, 1280, 0, 1e-6), (1, 1024, 1920, 1, 1e-5),
-                                             (2, 256, 2560, 1, 1e-5), (2, 64, 64, 1, 1e-5), (1, 576, 960, 1, 1e-5)])
+                                             (2, 256, 2560, 1, 1e-5), (2, 64, 64, 1, 1e-5), (1, 576, 960, 1, 1e-5),
+                                             # the UNet's (channels, pixels) shapes at 512^2 / 768^2 / 1024^2 and the refiner's widths
+                                             (2, 4096, 640, 1, 1e-5), (2, 4096, 960, 1, 1e-5), (3, 1024, 640, 1, 1e-5), (2, 1024, 1280, 0, 1e-6),
+                                             (1, 9216, 320, 1, 1e-5), (1, 9216, 640, 1, 1e-5), (1, 2304, 1280, 1, 1e-5), (1, 16384, 320, 1, 1e-5),
+                                             (2, 256, 1920, 1, 1e-5), (1, 1000, 384, 1, 1e-5), (2, 1024, 768, 0, 1e-6), (1, 4096, 1152, 1, 1e-5),
+                                             (1, 1024, 1536, 1, 1e-5), (2, 256, 2304, 1, 1e-5), (1, 256, 3072, 1, 1e-5), (1, 70, 320, 1, 1e-5)])
 def test_groupnorm_silu(L, B, HW, C_, silu, eps):
     f = _ffi()
     x = (rnd(B, HW, C_, seed=21) * 2 + 0.7).half()
+    x[:, :, : C_ // 32] += 40.0                # one group far from zero: E[x^2] - mean^2 would lose the variance there
     ga, be = (1 + 0.1 * rnd(C_, seed=22)).half(), (0.05 * rnd(C_, seed=23)).half()
     y = torch.empty_like(x)
     part = torch.empty(B * 64 * 32 * 2, dtype=torch.float32, device="cuda")
