@@ -169,9 +169,12 @@ __device__ __forceinline__ void attn_core(const AttnArgs& p, int b, int hd, cons
       // Two named score sets (A / B), swapped by a two-step body: a runtime-indexed set would live in scratch.
       auto qk = [&](int tl, f16v (&st)[2]) {       // S^T[key][q] for the two 32-key halves of tile tl; K fragments read ahead of the MFMAs
         const char* sKt = sK + (tbase + tl) * 8192;
+        // short contexts end in short tiles (77 text keys = 64 + 13, 4 image-token keys): a tile with <= 32 live keys is ONE half
+        const int nkh = ((MODE != 0 || PRE) && seg.nkeys - (s0 + tl * 64) <= 32) ? 1 : 2;       // wave-uniform
         h8 kf[2][4];
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
+          if (kh >= nkh) break;
           const int row = kh * 32 + r31;
           const char* kp = sKt + row * 128;
           const int sw = (row >> 1) & 7;
@@ -181,6 +184,7 @@ __device__ __forceinline__ void attn_core(const AttnArgs& p, int b, int hd, cons
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
+          if (kh >= nkh) break;
 #pragma unroll
           for (int r = 0; r < 16; ++r) st[kh][r] = 0.f;
 #pragma unroll
@@ -190,12 +194,14 @@ __device__ __forceinline__ void attn_core(const AttnArgs& p, int b, int hd, cons
       };
       auto soft_pv = [&](int tl, f16v (&st)[2]) {
         const int k0 = s0 + tl * 64;
+        const int nkh = ((MODE != 0 || PRE) && seg.nkeys - k0 <= 32) ? 1 : 2;                   // as in qk
         const char* sVt = sV + (tbase + tl) * 8192;
         // V^T fragments of the whole tile: issued now, their latency hides under the softmax arithmetic below
         const int gi = (lane >> 4) & 1, li = lane & 15;
         h8 vf[2][2][2];
 #pragma unroll
-        for (int kh = 0; kh < 2; ++kh)
+        for (int kh = 0; kh < 2; ++kh) {
+          if (kh >= nkh) break;
 #pragma unroll
           for (int s2 = 0; s2 < 2; ++s2) {
             const int kb0 = kh * 32 + s2 * 16 + 4 * hh + (li >> 2);   // row this lane addresses for j<4
@@ -210,23 +216,28 @@ __device__ __forceinline__ void attn_core(const AttnArgs& p, int b, int hd, cons
               vf[kh][s2][d][4] = hi[0]; vf[kh][s2][d][5] = hi[1]; vf[kh][s2][d][6] = hi[2]; vf[kh][s2][d][7] = hi[3];
             }
           }
+        }
         __builtin_amdgcn_sched_barrier(0);
         // st[kh][r] <-> key = k0 + 32kh + (r&3) + 8(r>>2) + 4*hh, query = q0 + lane%32
         // softmax on RAW scores: max commutes with the positive scale, and exp2(c*s - c*m) is one FMA + one v_exp_f32
         if (k0 + 64 > seg.nkeys) {        // only the last, partial tile of a segment needs masking (wave-uniform)
 #pragma unroll
-          for (int kh = 0; kh < 2; ++kh)
+          for (int kh = 0; kh < 2; ++kh) {
+            if (kh >= nkh) break;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int key = k0 + kh * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
               if (key >= seg.nkeys) st[kh][r] = MASKED;
             }
+          }
         }
         float mx = st[0][0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st[0][r]);
+        if (nkh == 2) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[1][r]);
+          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[1][r]);
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float mnew = fmaxf(mrun, mx);
         const float mc = mnew * p.scale_log2e;
@@ -235,7 +246,8 @@ __device__ __forceinline__ void attn_core(const AttnArgs& p, int b, int hd, cons
         typedef float f2v __attribute__((ext_vector_type(2)));
         if (!ip_tile) {
 #pragma unroll
-          for (int kh = 0; kh < 2; ++kh)
+          for (int kh = 0; kh < 2; ++kh) {
+            if (kh >= nkh) break;
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
               const float e0 = __builtin_amdgcn_exp2f(fmaf(st[kh][r], p.scale_log2e, -mc));
@@ -245,6 +257,7 @@ __device__ __forceinline__ void attn_core(const AttnArgs& p, int b, int hd, cons
               const h2 pr = __builtin_convertvector((f2v){e0, e1}, h2);      // ONE v_cvt_pk_f16_f32 per pair
               pf[kh][r >> 3][r & 7] = pr[0]; pf[kh][r >> 3][(r & 7) + 1] = pr[1];
             }
+          }
           if (__any(mnew != mrun)) {        // running max moved for some query of this wave: rescale (rare after the first tiles)
             const float alpha = __builtin_amdgcn_exp2f((mrun - mnew) * p.scale_log2e);
             lrun *= alpha;
@@ -260,29 +273,35 @@ __device__ __forceinline__ void attn_core(const AttnArgs& p, int b, int hd, cons
           // of the text keys, to be divided by l_t at the end: scale these probabilities by (w_ip / w_text) * l_t / l_ip so that the common
           // division leaves  w_text * text / l_t + w_ip * ip / l_ip  (reference attention_processor.py:371,387,397: two softmaxes, text + scale * ip)
 #pragma unroll
-          for (int kh = 0; kh < 2; ++kh)
+          for (int kh = 0; kh < 2; ++kh) {
+            if (kh >= nkh) break;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { st[kh][r] = __builtin_amdgcn_exp2f(fmaf(st[kh][r], p.scale_log2e, -mc)); psum += st[kh][r]; }
+          }
           const float li = psum + __shfl_xor(psum, 32, 64);
           const float c = seg.weight / p.seg[0].weight * lt / li;
 #pragma unroll
-          for (int kh = 0; kh < 2; ++kh)
+          for (int kh = 0; kh < 2; ++kh) {
+            if (kh >= nkh) break;
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
               const h2 pr = __builtin_convertvector((f2v){st[kh][r] * c, st[kh][r + 1] * c}, h2);
               pf[kh][r >> 3][r & 7] = pr[0]; pf[kh][r >> 3][(r & 7) + 1] = pr[1];
             }
+          }
         }
 
         // ---- O^T[d][q] += V^T[d][key] . P^T[key][q]; k-step (kh,s2): slot (hh, j) <-> key 32kh + 16s2 + 8(j>>2) + 4hh + (j&3)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int kh = 0; kh < 2; ++kh)
+        for (int kh = 0; kh < 2; ++kh) {
+          if (kh >= nkh) break;
 #pragma unroll
           for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
             for (int d = 0; d < 2; ++d)
               o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[kh][s2][d], pf[kh][s2], o[d], 0, 0, 0);
+        }
       };
       f16v sA[2];
       if constexpr (MODE != 0) {           // two-segment launches (short contexts, both segments staged at once): no room for a second score set
