@@ -9,7 +9,7 @@
  *   operator plugin attn.processor(attn, hidden_states, encoder_hidden_states)
  *                   instructany2pix/diffusion/ip_adapter/attention_processor.py:205-279 (AttnProcessor2_0),
  *                   :310-412 (IPAttnProcessor2_0); installed by ip_adapter.py:120-142, scale set by :211-214
- *                   -> ia2p_set_ip_adapter, ia2p_attention (+ ia2p_gemm for the projections)
+ *                   -> ia2p_set_ip_adapter, ia2p_attention / ia2p_qproj_attention (+ ia2p_gemm for the projections)
  *   sampler update  _backward_ddim pnp_pipeline.py:73-85; CFG combine sdxl_pipeline.py:842-844;
  *                   DDIMScheduler.step (diffusers 0.26.3) called at sdxl_pipeline.py:851
  *                   -> ia2p_ddim_step

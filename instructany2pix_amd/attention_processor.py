@@ -167,6 +167,7 @@ class IPAttnProcessor2_0(_HipAttnBase):
         self.to_v_ip = nn.Linear(cross_attention_dim or hidden_size, hidden_size, bias=False)
         self.store_attn_map = False
         self.attn_map = None
+        self.fuse_to_q = True
 
     @torch.no_grad()
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None, *args, **kwargs):
@@ -185,14 +186,20 @@ class IPAttnProcessor2_0(_HipAttnBase):
         wq, bq = self._stack("q", [attn.to_q], dev)
         wkv, bkv = self._stack("kv", [attn.to_k, attn.to_v], dev)            # :358-359
         wip, _ = self._stack("kvip", [self.to_k_ip, self.to_v_ip], dev)      # :379-380
-        q = self._gemm(self._rows(hidden_states.reshape(B * Nq, -1), wq.shape[1]), wq, bq)
+        x = self._rows(hidden_states.reshape(B * Nq, -1), wq.shape[1])
         kv = self._gemm(self._rows(text.reshape(B * end, -1), wkv.shape[1]), wkv, bkv)
         kvip = self._gemm(self._rows(ip.reshape(B * self.num_tokens, -1), wip.shape[1]), wip, None)
         o = torch.empty(B * Nq, inner, dtype=torch.float16, device=dev)
-        # :371 SDPA(q, k, v) + scale * :387 SDPA(q, ip_k, ip_v) -- two softmaxes, one launch (:397)
-        _ffi.check(L.ia2p_attention(_ffi.current_stream(), _p(q), inner, _p(o), inner, B, heads, Nq, 2,
-                                    _p(kv), _p(kv, inner), 2 * inner, end, 1.0,
-                                    _p(kvip), _p(kvip, inner), 2 * inner, self.num_tokens, float(self.scale)))
+        segs = (2, _p(kv), _p(kv, inner), 2 * inner, end, 1.0, _p(kvip), _p(kvip, inner), 2 * inner, self.num_tokens, float(self.scale))
+        # to_q (:344) and the two SDPA calls in ONE launch when a 128 x 64 tile of to_q is 128 queries of one head and the context is short
+        # (what the executor does, DESIGN.md §4 qproj_xattn_kernel); attn_map needs Q in memory, so it keeps the two launches
+        fused = self.fuse_to_q and not self.store_attn_map and Nq % 128 == 0 and (end + 63) // 64 + (self.num_tokens + 63) // 64 <= 3
+        if fused:
+            _ffi.check(L.ia2p_qproj_attention(_ffi.current_stream(), _p(x), _p(wq), _ffi.ptr(bq), None, _p(o), inner, B, heads, Nq, wq.shape[1], *segs))
+        else:
+            q = self._gemm(x, wq, bq)
+            # :371 SDPA(q, k, v) + scale * :387 SDPA(q, ip_k, ip_v) -- two softmaxes, one launch (:397)
+            _ffi.check(L.ia2p_attention(_ffi.current_stream(), _p(q), inner, _p(o), inner, B, heads, Nq, *segs))
         if self.store_attn_map:
             amap = torch.empty(B, heads, Nq, self.num_tokens, dtype=torch.float16, device=dev)
             _ffi.check(L.ia2p_ip_attn_map(_ffi.current_stream(), _p(q), inner, _p(kvip), 2 * inner, _p(amap), B, heads, Nq, self.num_tokens))
