@@ -106,12 +106,10 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const half_t* x, const hal
   half_t* ol = wl + (size_t)Co * 64;                    // [4 waves][16 pixels][Co] output staging
   const int KT = Cin * 9;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < Co * 8; i += 256) *(h8*)(wl + (size_t)i * 8) = *(const h8*)(w + (size_t)i * 8);
-  __syncthreads();
   const int npix = B * H * W;
   const int p0 = (blockIdx.x * 4 + wave) * 16;
   const int pl = lane & 15, kq = lane >> 4;
-  // im2col fragment: lane holds X[k = 32*s + 8*kq + j][pixel pl]
+  // im2col fragment: lane holds X[k = 32*s + 8*kq + j][pixel pl]; gathered FIRST so that its loads fly while the weights are staged
   h8 xf[2];
   {
     const int pp = min(p0 + pl, npix - 1);
@@ -128,6 +126,17 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const half_t* x, const hal
         xf[s2][j] = ok ? v : (half_t)0.f;
       }
   }
+  {
+    h8 wreg[8];                                 // weight image: loads of up to 8 pieces per thread in flight, then the LDS writes
+    for (int i0 = tid; i0 < Co * 8; i0 += 256 * 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) wreg[u] = *(const h8*)(w + (size_t)min(i0 + u * 256, Co * 8 - 1) * 8);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + u * 256 < Co * 8) *(h8*)(wl + (size_t)(i0 + u * 256) * 8) = wreg[u];
+    }
+  }
+  __syncthreads();
   half_t* ow = ol + (size_t)wave * 16 * Co;
   for (int n0 = 0; n0 < Co; n0 += 16) {
     f4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -166,11 +175,8 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const half_t* x, int ldx,
   extern __shared__ __attribute__((aligned(16))) char cout_smem[];
   half_t* wl = (half_t*)cout_smem;                      // [Co][9][C]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < (Co * 9 * C) >> 3; i += 256) *(h8*)(wl + (size_t)i * 8) = *(const h8*)(w + (size_t)i * 8);
-  __syncthreads();
   const int npix = B * H * W;
   const int p0 = (blockIdx.x * 4 + wave) * 16;
-  if (p0 >= npix) return;
   const int pl = lane & 15, kq = lane >> 4;
   const int pp = min(p0 + pl, npix - 1);
   const int b = pp / (H * W), rem = pp - b * H * W, oy = rem / W, ox = rem - oy * W;
@@ -178,24 +184,66 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const half_t* x, int ldx,
   const bool wreal = pl < Co;
   f4 acc = {0.f, 0.f, 0.f, 0.f};
   const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 1
-  for (int tap = 0; tap < 9; ++tap) {
+  auto tap_ptr = [&](int tap, bool& ok) -> const half_t* {
     const int ky = tap / 3, kx = tap - ky * 3;
     const int iy = oy + ky - 1, ix = ox + kx - 1;
-    const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-    const half_t* xp = x + ((size_t)(b * H + min(max(iy, 0), H - 1)) * W + min(max(ix, 0), W - 1)) * ldx + kq * 8;
-    const half_t* wp = wl + ((size_t)ncol * 9 + tap) * C + kq * 8;
-    if constexpr (NC > 0) {
-      h8 a[NC], wv[NC];
+    ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+    return x + ((size_t)(b * H + min(max(iy, 0), H - 1)) * W + min(max(ix, 0), W - 1)) * ldx + kq * 8;
+  };
+  auto stage_weights = [&]() {
+    constexpr int U = 4;                                // pieces per thread in flight
+    const int n = (Co * 9 * C) >> 3;
+    for (int i0 = tid; i0 < n; i0 += 256 * U) {
+      h8 r[U];
 #pragma unroll
-      for (int u = 0; u < NC; ++u) { a[u] = *(const h8*)(xp + u * 32); wv[u] = *(const h8*)(wp + u * 32); }
+      for (int u = 0; u < U; ++u) r[u] = *(const h8*)(w + (size_t)min(i0 + u * 256, n - 1) * 8);
 #pragma unroll
-      for (int u = 0; u < NC; ++u) {
-        if (!ok) a[u] = zero8;
-        if (!wreal) wv[u] = zero8;
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u], wv[u], acc, 0, 0, 0);      // D[row = pixel 4*kq + i][col = output channel pl]
+      for (int u = 0; u < U; ++u)
+        if (i0 + u * 256 < n) *(h8*)(wl + (size_t)(i0 + u * 256) * 8) = r[u];
+    }
+    __syncthreads();
+  };
+  if constexpr (NC > 0) {
+    // A kernel ROW of taps (3 x NC 16-byte loads per lane) is in flight at once, the first row already while the weights are staged: a wave's
+    // chain is 3 load round trips instead of 9 (the kernel is latency-bound: 2 workgroups per CU, every wave waiting on its own loads).
+    constexpr int TB = NC <= 10 ? 3 : 1;               // taps per batch (registers: TB * NC * 4)
+    h8 a[TB][NC];
+    bool ok[TB];
+    auto load_batch = [&](int t0) {
+#pragma unroll
+      for (int tt = 0; tt < TB; ++tt) {
+        const half_t* xp = tap_ptr(t0 + tt, ok[tt]);
+#pragma unroll
+        for (int u = 0; u < NC; ++u) a[tt][u] = *(const h8*)(xp + u * 32);
       }
-    } else {
+    };
+    load_batch(0);
+    stage_weights();
+#pragma unroll 1
+    for (int t0 = 0; t0 < 9; t0 += TB) {
+#pragma unroll
+      for (int tt = 0; tt < TB; ++tt) {
+        const half_t* wp = wl + ((size_t)ncol * 9 + t0 + tt) * C + kq * 8;
+        h8 wv[NC];
+#pragma unroll
+        for (int u = 0; u < NC; ++u) wv[u] = *(const h8*)(wp + u * 32);
+#pragma unroll
+        for (int u = 0; u < NC; ++u) {
+          h8 av = a[tt][u];
+          if (!ok[tt]) av = zero8;
+          if (!wreal) wv[u] = zero8;
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, wv[u], acc, 0, 0, 0);      // D[row = pixel 4*kq + i][col = output channel pl]
+        }
+      }
+      if (t0 + TB < 9) load_batch(t0 + TB);
+    }
+  } else {
+    stage_weights();
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+      bool ok;
+      const half_t* xp = tap_ptr(tap, ok);
+      const half_t* wp = wl + ((size_t)ncol * 9 + tap) * C + kq * 8;
 #pragma unroll 4
       for (int c0 = 0; c0 < C; c0 += 32) {
         h8 a = *(const h8*)(xp + c0);
@@ -206,6 +254,7 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const half_t* x, int ldx,
       }
     }
   }
+  if (p0 >= npix) return;
   if (wreal) {
     const float bs = (float)bias[pl];
 #pragma unroll

@@ -20,7 +20,8 @@ def time_it(fn, reps=50):
 
 s = _ffi.current_stream()
 tot = 0.0
-for (B, h, N, cnt, label) in [(8, 20, 256, 60, "self L2"), (8, 10, 1024, 10, "self L1"), (16, 20, 256, 0, "self L2 B16"), (8, 20, 576, 0, "self L2 768px")]:
+for (B, h, N, cnt, label) in [(8, 20, 256, 60, "self L2"), (8, 10, 1024, 10, "self L1"), (16, 20, 256, 0, "self L2 B16"), (8, 20, 576, 0, "self L2 768px"),
+                             (2, 10, 4096, 0, "self L1 1024px"), (2, 20, 1024, 0, "self L2 1024px"), (1, 10, 4096, 0, "self L1 1024px B1")]:
     Cc = h * 64
     qkv = torch.randn(B, N, 3 * Cc, device="cuda").half()
     out = torch.empty(B, N, Cc, device="cuda", dtype=torch.half)
