@@ -3,7 +3,7 @@
 CPU (torch fp32) restatement of the reference's denoise hot path: conditional UNet forward with the
 IP-Adapter attention plugins + DDIM inversion/sampling loop. It is the CHECKER for the HIP path:
 only `tests/`, `__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` may import it, and the
-product package `instructany2pix_amd` never does (tests/test_layout.py enforces that).
+product package `instructany2pix_amd` never does (tests/test_abi_cpu.py::test_product_never_imports_oracle enforces that).
 
 Parity pin: golden vectors in tests/golden/ generated from the reference's own importable files
 (generator script tests/golden/gen_goldens.py). diffusers==0.26.3 itself is absent: wiring that only
