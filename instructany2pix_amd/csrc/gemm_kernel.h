@@ -252,6 +252,9 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   else asm volatile("" : "+v"(ln_s1), "+v"(ln_s2));
   // fused cross-attention: the context K / V of this tile's (batch element, head) travel to registers while the projection runs
   AttnKvRegs kvr;       // loaded inside the k-loop, behind the first tile     // folds now; the counted wait leaves the prologue DMA in flight
+#ifdef IA2P_CLOCK_STAMP     // diagnostic build only (tools/micro/gemm_clock.hip): in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz around the k-loop
+  const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   if constexpr (PP) {
     // Barrier sequence b0, b1, ...; interval I_n lies between b_n and b_n+1. Group 0 reads tile t in I_2t and multiplies it in I_2t+1; group 1
     // reads it in I_2t+1 and multiplies it in I_2t+2. Every wave waits for its DMA pieces of tile t before b_2t; the slot of tile t-1 is free
@@ -370,6 +373,12 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   }
 
   }
+#ifdef IA2P_CLOCK_STAMP
+  if (tid == 0 && p.partial && nsplit == 1) {      // (the stamps go to a buffer nothing else reads)
+    unsigned long long* o = (unsigned long long*)p.partial + 2 * blockIdx.x;
+    o[0] = __builtin_amdgcn_s_memtime() - stamp_c0; o[1] = __builtin_amdgcn_s_memrealtime() - stamp_r0;
+  }
+#endif
   // Ping-pong tile: no separate prefetch workgroups (a workgroup holds a whole CU's LDS, so they would queue up behind the tiles): every
   // tile workgroup touches its slice of the next contraction's weights here; the loads fly during the epilogue.
   unsigned pfacc = 0;

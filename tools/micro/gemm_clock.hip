@@ -1,0 +1,65 @@
+// In-kernel clock of the GEMM tiles under load (MI355X_MICROARCH.md "DVFS give-back" item 6): a DIAGNOSTIC build of the product's kernel template
+// (gemm_kernel.h compiled with -DIA2P_CLOCK_STAMP: s_memtime / s_memrealtime stamped around the k-loop, written to a buffer of their own) is
+// launched back to back on random fp16 data for >= 2 s; clock = median over workgroups of d(s_memtime) / d(s_memrealtime) x 100 MHz.
+// The product library is built WITHOUT the stamps. Build (from the repo root):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DIA2P_CLOCK_STAMP -mllvm -amdgpu-kernarg-preload-count=16 tools/micro/gemm_clock.hip -o tools/micro/gemm_clock
+#include "../../instructany2pix_amd/csrc/gemm_kernel.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <vector>
+
+bool ia2p_splitk_inkernel(int, int, int) { return false; }
+
+template <int BM, int BN, int ST, int WGM, int PP>
+static void run(const char* name, int M, int N, int K, const half_t* A, const half_t* W, half_t* C, const half_t* zero, unsigned long long* stamps) {
+  GemmArgs a;
+  memset(&a, 0, sizeof a);
+  a.pad = 1; a.A = A; a.W = W; a.C = C; a.zero = zero; a.M = M; a.N = N; a.K = K; a.lda = K; a.ldw = K; a.ldc = N; a.rows_per_batch = 1;
+  a.partial = (float*)stamps; a.acc_scale = a.bias_scale = 1.f;
+  const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  const auto t0 = std::chrono::steady_clock::now();
+  long launches = 0;
+  float ms = 0;
+  while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 2.5) {
+    hipEventRecord(e0);
+    for (int i = 0; i < 200; ++i) launch_cfg<BM, BN, ST, false, WGM, 64, PP>(a, 0);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms, e0, e1);
+    launches += 200;
+  }
+  std::vector<unsigned long long> h(2 * tiles);
+  hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost);
+  std::vector<double> ghz, cyc;
+  for (int i = 0; i < tiles; ++i) if (h[2 * i + 1]) { ghz.push_back((double)h[2 * i] / (double)h[2 * i + 1] * 0.1); cyc.push_back((double)h[2 * i]); }
+  std::sort(ghz.begin(), ghz.end()); std::sort(cyc.begin(), cyc.end());
+  const double us = ms * 1e3 / 200, tf = 2.0 * M * N * K / us / 1e6, g = ghz[ghz.size() / 2], c = cyc[cyc.size() / 2];
+  const double loop_us = c / (g * 1e3);
+  printf("%-22s %5d x %5d x %5d: %7.2f us/launch = %6.0f TFLOP/s; in-kernel clock %.2f GHz (min %.2f max %.2f over %zu workgroups); k-loop %6.0f cycles = %5.2f us"
+         " = %5.1f cycles per k-step; MFMA peak AT THAT CLOCK %.0f TFLOP/s\n", name, M, N, K, us, tf, g, ghz.front(), ghz.back(), ghz.size(), c, loop_us,
+         c / (K / 64), 256 * 4 * 1024.0 * g / 1e3);
+}
+
+int main() {
+  const int M = 2048, Nmax = 10240, Kmax = 5120;
+  std::mt19937 rng(1);
+  std::normal_distribution<float> nd(0.f, 1.f);
+  std::vector<half_t> hA((size_t)M * Kmax), hW((size_t)Nmax * Kmax);
+  for (auto& v : hA) v = (half_t)nd(rng);
+  for (auto& v : hW) v = (half_t)(nd(rng) * 0.02f);
+  half_t *A, *W, *C, *zero; unsigned long long* stamps;
+  hipMalloc(&A, hA.size() * 2); hipMalloc(&W, hW.size() * 2); hipMalloc(&C, (size_t)M * Nmax * 2); hipMalloc(&zero, 4096); hipMalloc(&stamps, 1 << 20);
+  hipMemcpy(A, hA.data(), hA.size() * 2, hipMemcpyHostToDevice); hipMemcpy(W, hW.data(), hW.size() * 2, hipMemcpyHostToDevice);
+  hipMemset(zero, 0, 4096); hipMemset(stamps, 0, 1 << 20);
+  run<128, 128, 2, 2, 0>("128x128x2 (QKV)", M, 3840, 1280, A, W, C, zero, stamps);
+  run<256, 128, 3, 4, 1>("256x128x3 pp (QKV)", M, 3840, 1280, A, W, C, zero, stamps);
+  run<128, 160, 2, 2, 0>("128x160x2 (FF-in*)", M, 10240, 1280, A, W, C, zero, stamps);
+  run<256, 128, 3, 4, 1>("256x128x3 pp K=5120", M, 3840, 5120, A, W, C, zero, stamps);
+  run<128, 128, 2, 2, 0>("128x128x2 K=5120", M, 3840, 5120, A, W, C, zero, stamps);
+  run<64, 64, 2, 2, 0>("64x64x2 (out-proj)", M, 1280, 1280, A, W, C, zero, stamps);
+  return 0;
+}
