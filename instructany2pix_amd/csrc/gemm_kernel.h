@@ -86,6 +86,9 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef IA2P_CLOCK_STAMP
+  const unsigned long long stamp_entry = __builtin_amdgcn_s_memrealtime();
+#endif
 
   // ---- tile of this workgroup; blocks b, b+8, ... share an XCD (its L2): give each XCD a contiguous tile range
   const int tiles_m = (hM + BM - 1) / BM, tiles_n = (hN + BN - 1) / BN;
@@ -375,8 +378,9 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   }
 #ifdef IA2P_CLOCK_STAMP
   if (tid == 0 && p.partial && nsplit == 1) {      // (the stamps go to a buffer nothing else reads)
-    unsigned long long* o = (unsigned long long*)p.partial + 2 * blockIdx.x;
-    o[0] = __builtin_amdgcn_s_memtime() - stamp_c0; o[1] = __builtin_amdgcn_s_memrealtime() - stamp_r0;
+    unsigned long long* o = (unsigned long long*)p.partial + 8 * blockIdx.x;
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    o[0] = __builtin_amdgcn_s_memtime() - stamp_c0; o[1] = r1 - stamp_r0; o[2] = stamp_entry; o[3] = stamp_r0; o[4] = r1;
   }
 #endif
   // Ping-pong tile: no separate prefetch workgroups (a workgroup holds a whole CU's LDS, so they would queue up behind the tiles): every
@@ -720,6 +724,11 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
     }
   }
   if (PP) asm volatile("" ::"v"(pfacc));
+#ifdef IA2P_CLOCK_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the C stores of this wave have left
+  __syncthreads();
+  if (tid == 0 && p.partial && nsplit == 1) ((unsigned long long*)p.partial)[8 * blockIdx.x + 5] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int BK = 64, int PP = 0, int WGN = 2>

@@ -32,16 +32,24 @@ static void run(const char* name, int M, int N, int K, const half_t* A, const ha
     hipEventElapsedTime(&ms, e0, e1);
     launches += 200;
   }
-  std::vector<unsigned long long> h(2 * tiles);
+  std::vector<unsigned long long> h(8 * tiles);
   hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost);
-  std::vector<double> ghz, cyc;
-  for (int i = 0; i < tiles; ++i) if (h[2 * i + 1]) { ghz.push_back((double)h[2 * i] / (double)h[2 * i + 1] * 0.1); cyc.push_back((double)h[2 * i]); }
-  std::sort(ghz.begin(), ghz.end()); std::sort(cyc.begin(), cyc.end());
+  std::vector<double> ghz, cyc, pro, epi;
+  unsigned long long first_entry = ~0ull, last_exit = 0;
+  for (int i = 0; i < tiles; ++i) if (h[8 * i + 1]) {
+    ghz.push_back((double)h[8 * i] / (double)h[8 * i + 1] * 0.1); cyc.push_back((double)h[8 * i]);
+    pro.push_back((double)(h[8 * i + 3] - h[8 * i + 2]) * 0.01); epi.push_back((double)(h[8 * i + 5] - h[8 * i + 4]) * 0.01);     // us (100 MHz counter)
+    first_entry = std::min(first_entry, h[8 * i + 2]); last_exit = std::max(last_exit, h[8 * i + 5]);
+  }
+  std::sort(ghz.begin(), ghz.end()); std::sort(cyc.begin(), cyc.end()); std::sort(pro.begin(), pro.end()); std::sort(epi.begin(), epi.end());
   const double us = ms * 1e3 / 200, tf = 2.0 * M * N * K / us / 1e6, g = ghz[ghz.size() / 2], c = cyc[cyc.size() / 2];
   const double loop_us = c / (g * 1e3);
   printf("%-22s %5d x %5d x %5d: %7.2f us/launch = %6.0f TFLOP/s; in-kernel clock %.2f GHz (min %.2f max %.2f over %zu workgroups); k-loop %6.0f cycles = %5.2f us"
          " = %5.1f cycles per k-step; MFMA peak AT THAT CLOCK %.0f TFLOP/s\n", name, M, N, K, us, tf, g, ghz.front(), ghz.back(), ghz.size(), c, loop_us,
          c / (K / 64), 256 * 4 * 1024.0 * g / 1e3);
+  printf("%-22s   entry -> k-loop %.2f us (median; max %.2f), k-loop end -> stores left %.2f us (median; max %.2f), first entry -> last exit %.2f us, so %.2f us of the"
+         " launch interval lie between kernels\n", "", pro[pro.size() / 2], pro.back(), epi[epi.size() / 2], epi.back(), (double)(last_exit - first_entry) * 0.01,
+         us - (double)(last_exit - first_entry) * 0.01);
 }
 
 int main() {
