@@ -14,6 +14,8 @@
 // Algorithmic traffic: read x twice (second read normally served by L2 / Infinity Cache), write y once.
 #include "common.h"
 
+#include <cstdlib>
+
 struct GNArgs {
   const half_t* x; half_t* y;
   const half_t* gamma; const half_t* beta;
@@ -169,8 +171,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* ax, half_t*
 
 // partial must hold B*chunks*G*2 floats. Returns the chunk count it used via *chunks_out when partial == null.
 int ia2p_gn_chunks(int B, int HW) {
+  static const int cap = getenv("IA2P_GN_STATS_WGS") ? atoi(getenv("IA2P_GN_STATS_WGS")) : 512;      // tuning hook (tools/gn_bench.py)
   int chunks = 1;
-  while (chunks < 64 && B * chunks < 512 && (HW / (chunks * 2)) >= 8) chunks *= 2;
+  while (chunks < 64 && B * chunks < cap && (HW / (chunks * 2)) >= 8) chunks *= 2;
   return chunks;
 }
 
@@ -188,8 +191,9 @@ hipError_t ia2p_launch_groupnorm(const half_t* x, int ldx, half_t* y, int ldy, c
   if (V > 2 || C % 8 || C % G) return hipErrorInvalidValue;
   const int TX = nvec / V, TY = 256 / TX;
   // apply pass: ~2k workgroups, each thread streaming >= 4 rows
+  static const int acap = getenv("IA2P_GN_APPLY_WGS") ? atoi(getenv("IA2P_GN_APPLY_WGS")) : 2048;    // tuning hook
   int ablocks = 1;
-  while (B * ablocks < 2048 && HW / (ablocks * 2) >= 4 * TY) ablocks *= 2;
+  while (B * ablocks < acap && HW / (ablocks * 2) >= 4 * TY) ablocks *= 2;
   a.arows = (HW + ablocks - 1) / ablocks;
   ablocks = (HW + a.arows - 1) / a.arows;
   dim3 grid(a.chunks, B), agrid(ablocks, B), block(256);
