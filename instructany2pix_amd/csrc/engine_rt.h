@@ -136,7 +136,7 @@ struct RunCtx {
   bool prefetch = true;
   const half_t* tail_pf = nullptr;   // what the LAST contraction of a pass prefetches: the first weights of the next pass (embedding MLPs)
   size_t tail_pf_bytes = 0;
-  int xattn_min_tiles = 256; // ... and only when the fused launch has at least this many 128-query x head tiles (IA2P_XATTN_MIN_TILES)
+  int xattn_min_tiles = 128; // ... and only when the fused launch has at least this many 128-query x head tiles (IA2P_XATTN_MIN_TILES; 40-tile launches lose 4 us each, 160-tile ones gain 1)
   bool xattn_fuse = true;    // to_q + cross-attention as one launch where the shape allows (IA2P_XATTN_FUSE=0: two launches, for A/B runs)
   bool ln_fold = true;       // LayerNorms folded into their consumer GEMMs (IA2P_LN_FOLD=0: separate layernorm_kernel launches, for A/B runs)
   bool prof = false;

@@ -333,7 +333,7 @@ def test_fused_qproj_cross_attention_switch_agrees(tiny_models, monkeypatch):
     monkeypatch.setenv("IA2P_XATTN_FUSE", "0")
     plain = HipUNet2DConditionModel(cfg, DEV)
     monkeypatch.delenv("IA2P_XATTN_FUSE")
-    monkeypatch.setenv("IA2P_XATTN_MIN_TILES", "1")      # (by default only launches of >= 256 tiles are fused: the tiny model has fewer)
+    monkeypatch.setenv("IA2P_XATTN_MIN_TILES", "1")      # (by default only launches of >= 128 tiles are fused: the tiny model has fewer)
     hip = HipUNet2DConditionModel(cfg, DEV)
     monkeypatch.delenv("IA2P_XATTN_MIN_TILES")
     plain.load_state_dict(sd); hip.load_state_dict(sd)
