@@ -168,6 +168,13 @@ ia2p_status ia2p_conv3x3(void* stream, const void* x, const void* Wp, const void
                          void* y, int B, int Hs, int Ws, int Cin, int Co, int stride, int up);
 ia2p_status ia2p_pack_conv3x3(void* stream, const void* w_oihw, void* w_packed, int Co, int Cin);
 ia2p_status ia2p_pack_geglu(void* stream, const void* src, void* dst, int rows, int rowlen);
+/* The UNet's latent-boundary 3x3 convolutions (diffusers UNet2DConditionModel.conv_in / .conv_out behind pnp_pipeline.py:253-260; the VAE's too), pad 1:
+ *   ia2p_conv_in : x NCHW [B,Cin,H,W] (Cin*9 <= 64), w OIHW [Co,Cin,3,3] (Co % 8 == 0), bias [Co] -> y channels-last [B*H*W, Co];
+ *                  w_scratch: Co*64 fp16 elements for the zero-padded [Co][64] weight image the kernel reads (the executors keep it in their arena)
+ *   ia2p_conv_out: x channels-last [B*H*W, C] (C % 32 == 0), w packed [Co][3][3][C] (ia2p_pack_conv3x3), Co <= 8, bias [Co] -> y NCHW [B,Co,H,W] */
+ia2p_status ia2p_conv_in(void* stream, const void* x_nchw, const void* w_oihw, const void* bias, void* y_nhwc, void* w_scratch,
+                         int B, int Cin, int H, int W, int Co);
+ia2p_status ia2p_conv_out(void* stream, const void* x_nhwc, const void* w_packed, const void* bias, void* y_nchw, int B, int C, int H, int W, int Co);
 /* O[b,q,h*64:] = sum_s weight_s * softmax(Q K_s^T / 8) V_s over nseg <= 2 key segments (head_dim 64).
  * Q rows have stride ldq, K_s/V_s rows stride ld_s; segment s has nkeys_s keys per batch. */
 ia2p_status ia2p_attention(void* stream, const void* Q, int ldq, void* O, int ldo, int B, int heads, int Nq, int nseg,

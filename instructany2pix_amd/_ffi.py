@@ -78,6 +78,8 @@ SIGNATURES = {
     "ia2p_conv3x3": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I]),
     "ia2p_pack_conv3x3": (_I, [_P, _P, _P, _I, _I]),
     "ia2p_pack_geglu": (_I, [_P, _P, _P, _I, _I]),
+    "ia2p_conv_in": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I]),
+    "ia2p_conv_out": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I]),
     "ia2p_attention": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _F, _P, _P, _I, _I, _F]),
     "ia2p_qproj_attention": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _F, _P, _P, _I, _I, _F]),
     "ia2p_linear_small": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I]),

@@ -1091,6 +1091,21 @@ ia2p_status ia2p_pack_conv3x3(void* stream, const void* src, void* dst, int Co, 
   hipError_t e = ia2p_launch_pack_conv((const half_t*)src, (half_t*)dst, Co, Cin, (hipStream_t)stream);
   RET_HIP(e, "pack_conv3x3");
 }
+// latent-boundary convolutions as operators (the executors call the launchers directly): conv_in reads NCHW and writes channels-last,
+// conv_out reads channels-last and writes NCHW; reference call sites: the diffusers UNet's conv_in / conv_out behind pnp_pipeline.py:253-260
+ia2p_status ia2p_conv_in(void* stream, const void* x_nchw, const void* w_oihw, const void* bias, void* y_nhwc, void* w_scratch, int B, int Cin, int H, int W, int Co) {
+  if (!x_nchw || !w_oihw || !bias || !y_nhwc || !w_scratch) return fail(nullptr, IA2P_ERR_INVALID, "conv_in: null argument");
+  if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cin * 9 > 64 || Co < 8 || Co % 8) return fail(nullptr, IA2P_ERR_SHAPE, "conv_in: Cin*9=%d must be <= 64, Co=%d a multiple of 8", Cin * 9, Co);
+  hipError_t e = ia2p_launch_pack_conv_in((const half_t*)w_oihw, (half_t*)w_scratch, Co, Cin * 9, (hipStream_t)stream);
+  if (e == hipSuccess) e = ia2p_launch_conv_in((const half_t*)x_nchw, (const half_t*)w_scratch, (const half_t*)bias, (half_t*)y_nhwc, B, Cin, H, W, Co, (hipStream_t)stream);
+  RET_HIP(e, "conv_in");
+}
+ia2p_status ia2p_conv_out(void* stream, const void* x_nhwc, const void* w_packed, const void* bias, void* y_nchw, int B, int C, int H, int W, int Co) {
+  if (!x_nhwc || !w_packed || !bias || !y_nchw) return fail(nullptr, IA2P_ERR_INVALID, "conv_out: null argument");
+  if (B < 1 || H < 1 || W < 1 || C < 32 || C % 32 || Co < 1 || Co > 8) return fail(nullptr, IA2P_ERR_SHAPE, "conv_out: C=%d must be a multiple of 32, Co=%d <= 8", C, Co);
+  hipError_t e = ia2p_launch_conv_out((const half_t*)x_nhwc, C, (const half_t*)w_packed, (const half_t*)bias, (half_t*)y_nchw, B, C, H, W, Co, (hipStream_t)stream);
+  RET_HIP(e, "conv_out");
+}
 ia2p_status ia2p_pack_geglu(void* stream, const void* src, void* dst, int rows, int rowlen) {
   if (!src || !dst || rows % 32) return fail(nullptr, IA2P_ERR_SHAPE, "pack_geglu: rows must be a multiple of 32");
   hipError_t e = ia2p_launch_pack_geglu((const half_t*)src, (half_t*)dst, rows, rowlen, (hipStream_t)stream);

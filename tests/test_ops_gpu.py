@@ -236,6 +236,39 @@ def test_conv3x3_every_tile(L, tile, B, H, W, Cin, Co, stride, up):
         L.ia2p_debug_set_gemm_tile(-1)
 
 
+@pytest.mark.parametrize("B,Cin,H,W,Co", [(8, 4, 64, 64, 320), (1, 4, 128, 128, 320), (2, 4, 13, 9, 64), (1, 3, 40, 24, 128), (1, 7, 5, 5, 8), (3, 4, 16, 16, 384)])
+def test_conv_in_boundary(L, B, Cin, H, W, Co):
+    """latent-boundary conv (NCHW in, channels-last out): every pixel count incl. ones that do not fill a 16-pixel wave tile"""
+    f = _ffi()
+    x, w, b = rnd(B, Cin, H, W, seed=41), rnd(Co, Cin, 3, 3, seed=42, scale=(Cin * 9) ** -0.5), rnd(Co, seed=43, scale=0.2)
+    y = torch.full((B * H * W, Co), float("nan"), dtype=torch.half, device="cuda")
+    ws = torch.empty(Co * 64, dtype=torch.half, device="cuda")
+    run(L, "ia2p_conv_in", f.ptr(x), f.ptr(w), f.ptr(b), f.ptr(y), f.ptr(ws), B, Cin, H, W, Co)
+    ref = F.conv2d(x.float(), w.float(), b.float(), padding=1).permute(0, 2, 3, 1).reshape(B * H * W, Co)
+    assert rel_l2(y, ref) < 1e-3, rel_l2(y, ref)
+
+
+@pytest.mark.parametrize("B,C_,H,W,Co", [(8, 320, 64, 64, 4), (1, 320, 128, 128, 4), (2, 128, 13, 9, 3), (1, 384, 24, 40, 4), (1, 512, 8, 8, 8), (2, 64, 5, 7, 1), (1, 96, 16, 16, 4)])
+def test_conv_out_boundary(L, B, C_, H, W, Co):
+    """latent-boundary conv (channels-last in, NCHW out): the unrolled channel counts (128 / 320 / 384 / 512) and the generic loop"""
+    f = _ffi()
+    x, w, b = rnd(B * H * W, C_, seed=44), rnd(Co, C_, 3, 3, seed=45, scale=(C_ * 9) ** -0.5), rnd(Co, seed=46, scale=0.2)
+    wp = torch.empty(Co * 9 * C_, dtype=torch.half, device="cuda")
+    run(L, "ia2p_pack_conv3x3", f.ptr(w), f.ptr(wp), Co, C_)
+    y = torch.full((B, Co, H, W), float("nan"), dtype=torch.half, device="cuda")
+    run(L, "ia2p_conv_out", f.ptr(x), f.ptr(wp), f.ptr(b), f.ptr(y), B, C_, H, W, Co)
+    ref = F.conv2d(x.float().reshape(B, H, W, C_).permute(0, 3, 1, 2), w.float(), b.float(), padding=1)
+    assert rel_l2(y, ref) < 1e-3, rel_l2(y, ref)
+
+
+def test_boundary_convs_reject_bad_shapes(L):
+    f = _ffi()
+    x = rnd(1, 8, 4, 4, seed=1)
+    assert L.ia2p_conv_in(f.current_stream(), f.ptr(x), f.ptr(x), f.ptr(x), f.ptr(x), f.ptr(x), 1, 8, 4, 4, 64) != 0      # Cin * 9 > 64
+    assert L.ia2p_conv_out(f.current_stream(), f.ptr(x), f.ptr(x), f.ptr(x), f.ptr(x), 1, 48, 4, 4, 4) != 0              # C % 32
+    assert L.ia2p_conv_out(f.current_stream(), f.ptr(x), f.ptr(x), f.ptr(x), f.ptr(x), 1, 64, 4, 4, 9) != 0              # Co > 8
+
+
 def _sdpa(q, k, v):
     s = (q.float() @ k.float().transpose(-1, -2)) / 8.0
     return s.softmax(-1) @ v.float()
