@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256, 2) void attention_f16_kernel(const half_t* aQ,
     const int nq = (p.Nq + 127) >> 7, nwg = nq * p.heads * p.B;
     int bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, x = bid & 7, i = bid >> 3;
-    if (p.xcd_map) bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    if (p.xcd_map & 1) bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
     qb = bid % nq;
     const int bh = bid / nq;
     hd = bh % p.heads; b = bh / p.heads;
@@ -63,6 +63,9 @@ __global__ __launch_bounds__(256, 2) void attention_f16_kernel(const half_t* aQ,
   const int q = q0 + r31;
   if (q < p.Nq) {
     half_t* op = p.O + ((size_t)b * p.Nq + q) * p.ldo + hd * 64 + 4 * hh;
+    const bool wt = (p.xcd_map & 2) != 0;                 // write-through O (set by the launcher)
+    const __amdgpu_buffer_rsrc_t o_rsrc = wt_rsrc((void*)p.O, (size_t)p.B * p.Nq * p.ldo * 2);
+    const size_t ob = (((size_t)b * p.Nq + q) * p.ldo + hd * 64 + 4 * hh) * 2;
 #pragma unroll
     for (int d = 0; d < 2; ++d)
 #pragma unroll
@@ -70,7 +73,8 @@ __global__ __launch_bounds__(256, 2) void attention_f16_kernel(const half_t* aQ,
         h4 v;
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = (half_t)otot[d][g * 4 + r];
-        *(h4*)(op + d * 32 + g * 8) = v;
+        if (wt) store8_wt(o_rsrc, ob + (d * 32 + g * 8) * 2, v);
+        else *(h4*)(op + d * 32 + g * 8) = v;
       }
   }
 }
@@ -89,7 +93,7 @@ hipError_t ia2p_launch_attention(const AttnArgs& a, hipStream_t s) {
   }
   static const int xcd_map = getenv("IA2P_ATTN_XCD") ? atoi(getenv("IA2P_ATTN_XCD")) : 1;     // A/B switch
   AttnArgs b = a;
-  b.xcd_map = xcd_map;
+  b.xcd_map = (xcd_map ? 1 : 0) | (((ia2p_wt_mask() & 8) && (size_t)a.B * a.Nq * a.ldo * 2 < (size_t)0x7ffffff0) ? 2 : 0);
   // mode: 0 = one key segment; 1 = two segments with a second one of <= 64 keys and a non-zero first weight (the IP-Adapter call: merged
   // accumulator); 2 = any other two-segment call
   const int mode = b.nseg == 1 ? 0 : (b.seg[1].nkeys <= 64 && b.seg[0].weight != 0.f) ? 1 : 2;

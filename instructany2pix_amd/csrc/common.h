@@ -4,6 +4,7 @@
 // convolution is an implicit GEMM whose K axis (tap, channel) is contiguous in channels.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 
 typedef _Float16 half_t;
@@ -40,6 +41,28 @@ __device__ __forceinline__ float erf_as_f(float x) {
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erf_as_f(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float quick_gelu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x)); }
 __device__ __forceinline__ float gelu_tanh_f(float x) { return 0.5f * x * (1.0f + tanhf(0.79788456080286535588f * (x + 0.044715f * x * x * x))); }   // "gelu_new" (GPT-2)
+// Write-through (`sc1`) stores for tensors the NEXT kernel reads: the bytes leave the L2 while the kernel still runs, so the end-of-kernel
+// write-back (which sits on the critical path between two dependent launches) has nothing left to flush. Offsets are 32-bit: callers use
+// them only for tensors under 2 GiB.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wt_rsrc(void* base, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(bytes < (size_t)0x7ffffff0 ? bytes : (size_t)0x7ffffff0), 0x00020000);
+}
+__device__ __forceinline__ void store16_wt(__amdgpu_buffer_rsrc_t r, size_t byte_off, h8 v) {
+  typedef unsigned u4v __attribute__((__vector_size__(4 * sizeof(unsigned))));
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), r, (int)byte_off, 0, 16);
+}
+__device__ __forceinline__ void store8_wt(__amdgpu_buffer_rsrc_t r, size_t byte_off, h4 v) {
+  typedef unsigned u2v __attribute__((__vector_size__(2 * sizeof(unsigned))));
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, v), r, (int)byte_off, 0, 16);
+}
+// IA2P_WT: bit mask of the kernels that store write-through (1 GEMM C, 2 K-split reduce, 4 GroupNorm, 8 attention, 16 concat); A/B switch.
+// Same-box A/B at batch 8 (tools/ab_vals.sh): GEMM C -0.14 ms per step, GroupNorm -0.06, reduce / concat -0.02 each; attention +0.33 (its 8-byte
+// per-query pieces are partial lines: write-through pays for every one of them), so it stays write-back.
+static inline int ia2p_wt_mask() {
+  static const int m = getenv("IA2P_WT") ? atoi(getenv("IA2P_WT")) : 23;
+  return m;
+}
+
 __device__ __forceinline__ float act_f(float x, int act) { return act == 1 ? gelu_erf_f(x) : act == 2 ? quick_gelu_f(x) : act == 3 ? gelu_tanh_f(x) : x; }
 
 // ---- launch descriptors shared by kernels and the host executor --------------------------------------
@@ -68,6 +91,7 @@ struct GemmArgs {
   int geglu;             // 1: W/bias rows interleaved in 16-row (a,g) pairs; out[m, n/2] = a * gelu(g)
   int m_fastest;         // tile order: 1 = consecutive blocks walk M (weights panel shared), 0 = walk N
   int vec8;              // set by the launcher: strides / bases allow 16-byte epilogue accesses
+  int c_wt;              // set by the launcher: C leaves through write-through (sc1) stores, so the end-of-kernel write-back has nothing left to do
   int group_w;           // > 0: grouped tile order in column panels of this many tiles (set by the launcher; overrides m_fastest)
   // weight prefetch: extra workgroups (launched after the tiles) stream the NEXT contraction's weights once,
   // sequentially, so they are in the Infinity Cache / L2 instead of HBM-cold when that kernel starts

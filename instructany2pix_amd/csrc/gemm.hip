@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* hpartia
   // one WAVE per output row (4 rows per workgroup): every load of a row is independent, the row statistics need no workgroup barrier
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nq = hN >> 2;
+  const __amdgpu_buffer_rsrc_t c_rsrc = wt_rsrc((void*)hC, (size_t)hM * hldc * 2);
   for (int m = blockIdx.x * 4 + wave; m < hM; m += gridDim.x * 4) {
     float mu = 0.f, rs = 1.f;
     if (p.ln_stats) {
@@ -96,7 +97,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* hpartia
       if (p.rowvec) { const float e_bs = p.bias_scale == 0.f ? 1.f : p.bias_scale; const h4 b = *(const h4*)(p.rowvec + (size_t)(m / p.rows_per_batch) * p.rowvec_ld + n); v[0] = fmaf((float)b[0], e_bs, v[0]); v[1] = fmaf((float)b[1], e_bs, v[1]); v[2] = fmaf((float)b[2], e_bs, v[2]); v[3] = fmaf((float)b[3], e_bs, v[3]); }
       if (hresidual) { const h4 b = *(const h4*)(hresidual + (size_t)m * hldr + n); v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3]; }
       h4 o; o[0] = (half_t)v[0]; o[1] = (half_t)v[1]; o[2] = (half_t)v[2]; o[3] = (half_t)v[3];
-      *(h4*)(hC + (size_t)m * hldc + n) = o;
+      if (p.c_wt) store8_wt(c_rsrc, ((size_t)m * hldc + n) * 2, o);
+      else *(h4*)(hC + (size_t)m * hldc + n) = o;
       if (hstats_out) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { const float f = (float)o[r]; st1 += f; st2 += f * f; }
@@ -270,7 +272,9 @@ extern "C" void ia2p_debug_gemm_plan(int M, int N, int K, int conv, int geglu, i
   if (splitk) *splitk = pl.splitk;
 }
 
-hipError_t ia2p_launch_splitk_reduce(const GemmArgs& a, hipStream_t s) {
+hipError_t ia2p_launch_splitk_reduce(const GemmArgs& a0, hipStream_t s) {
+  GemmArgs a = a0;
+  a.c_wt = ((ia2p_wt_mask() & 2) && (size_t)a.M * a.ldc * 2 < (size_t)0x7ffffff0) ? 1 : 0;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(std::min(16384, (a.M + 3) / 4)), dim3(256), 0, s, (const float*)a.partial, a.C, a.residual, a.stats_out, a.M, a.N, a.splitk,
                      a.ldc, a.ldr, a);
   return hipGetLastError();

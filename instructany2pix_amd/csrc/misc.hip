@@ -269,14 +269,16 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const half_t* x, int ldx,
 }
 
 // ---- channel concat of two channels-last tensors (torch.cat([h, skip], dim=1) of the up path) --------------------------
-__global__ void concat_kernel(const half_t* a, int lda, int Ca, const half_t* b, int ldb, int Cb, half_t* y, long M) {
+__global__ void concat_kernel(const half_t* a, int lda, int Ca, const half_t* b, int ldb, int Cb, half_t* y, long M, int wt) {
   const int va = Ca >> 3, vb = Cb >> 3, vt = va + vb;
   const long total = M * vt;
+  const __amdgpu_buffer_rsrc_t y_rsrc = wt_rsrc((void*)y, (size_t)M * (Ca + Cb) * 2);
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long m = i / vt;
     const int v = (int)(i - m * vt);
     const uint4 d = v < va ? *(const uint4*)(a + m * lda + v * 8) : *(const uint4*)(b + m * ldb + (v - va) * 8);
-    *(uint4*)(y + m * (long)(Ca + Cb) + v * 8) = d;
+    if (wt) store16_wt(y_rsrc, (size_t)(m * (long)(Ca + Cb) + v * 8) * 2, __builtin_bit_cast(h8, d));
+    else *(uint4*)(y + m * (long)(Ca + Cb) + v * 8) = d;
   }
 }
 
@@ -651,7 +653,8 @@ hipError_t ia2p_launch_conv_out(const half_t* x, int ldx, const half_t* w, const
 }
 hipError_t ia2p_launch_concat(const half_t* a, int lda, int Ca, const half_t* b, int ldb, int Cb, half_t* y, long M, hipStream_t s) {
   if (Ca % 8 || Cb % 8) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(concat_kernel, dim3(grid_for(M * ((Ca + Cb) / 8), 256)), dim3(256), 0, s, a, lda, Ca, b, ldb, Cb, y, M);
+  hipLaunchKernelGGL(concat_kernel, dim3(grid_for(M * ((Ca + Cb) / 8), 256)), dim3(256), 0, s, a, lda, Ca, b, ldb, Cb, y, M,
+                     ((ia2p_wt_mask() & 16) && (size_t)M * (Ca + Cb) * 2 < (size_t)0x7ffffff0) ? 1 : 0);
   return hipGetLastError();
 }
 hipError_t ia2p_launch_ddim_step(const half_t* x, const half_t* eps_u, const half_t* eps_c, float g, float c_x, float c_e,

@@ -96,7 +96,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* ax, half_t*
   // scalar arguments (the first 16 dwords are preloaded into SGPRs: build.py PRELOAD), re-assembled into the descriptor the body uses
   GNArgs p;
   p.x = ax; p.y = ay; p.gamma = agamma; p.beta = abeta; p.partial = apartial; p.B = aB; p.HW = aHW; p.C = aC; p.G = aG; p.chunks = achunks;
-  p.rows = arows_; p.arows = aarows; p.ldx = aldx; p.ldy = aldy; p.eps = aeps; p.silu = asilu;
+  p.rows = arows_; p.arows = aarows; p.ldx = aldx; p.ldy = aldy; p.eps = aeps; p.silu = asilu & 1;
+  const bool wt = (asilu & 2) != 0;          // write-through output (bit 1 of the flag word)
   extern __shared__ float stat[];   // [G][2] mean, rstd
   const int nvec = p.C >> 3, TX = nvec / V, TY = blockDim.x / TX;
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
@@ -142,6 +143,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* ax, half_t*
   }
   const half_t* base = p.x + (size_t)b * p.HW * p.ldx;
   half_t* obase = p.y + (size_t)b * p.HW * p.ldy;
+  const __amdgpu_buffer_rsrc_t y_rsrc = wt_rsrc((void*)obase, (size_t)p.HW * p.ldy * 2);
   for (int r = r0 + ty; r < r1; r += 4 * TY) {         // 4 rows in flight per thread
     h8 d[4][V];
 #pragma unroll
@@ -163,7 +165,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* ax, half_t*
             if (p.silu) f = silu_f(f);
             o[e] = (half_t)f;
           }
-          *(h8*)(obase + (size_t)(r + u * TY) * p.ldy + (tx + v * TX) * 8) = o;
+          if (wt) store16_wt(y_rsrc, ((size_t)(r + u * TY) * p.ldy + (tx + v * TX) * 8) * 2, o);
+          else *(h8*)(obase + (size_t)(r + u * TY) * p.ldy + (tx + v * TX) * 8) = o;
         }
       }
   }
@@ -199,12 +202,13 @@ hipError_t ia2p_launch_groupnorm(const half_t* x, int ldx, half_t* y, int ldy, c
   dim3 grid(a.chunks, B), agrid(ablocks, B), block(256);
   const size_t sm1 = (size_t)2 * TY * C * sizeof(float), sm2 = (size_t)G * 2 * sizeof(float) + (size_t)(256 / G) * G * 2 * sizeof(double);
   if (sm1 > 65536) return hipErrorInvalidValue;
+  const int wtf = ((ia2p_wt_mask() & 4) && (size_t)HW * ldy * 2 < (size_t)0x7ffffff0) ? 2 : 0;      // write-through y (per batch element: 32-bit offsets)
   if (V == 1) {
     hipLaunchKernelGGL(gn_stats_kernel<1>, grid, block, sm1, s, a.x, a.y, a.gamma, a.beta, a.partial, a.B, a.HW, a.C, a.G, a.chunks, a.rows, a.arows, a.ldx, a.ldy, a.eps, a.silu);
-    hipLaunchKernelGGL(gn_apply_kernel<1>, agrid, block, sm2, s, a.x, a.y, a.gamma, a.beta, a.partial, a.B, a.HW, a.C, a.G, a.chunks, a.rows, a.arows, a.ldx, a.ldy, a.eps, a.silu);
+    hipLaunchKernelGGL(gn_apply_kernel<1>, agrid, block, sm2, s, a.x, a.y, a.gamma, a.beta, a.partial, a.B, a.HW, a.C, a.G, a.chunks, a.rows, a.arows, a.ldx, a.ldy, a.eps, a.silu | wtf);
   } else {
     hipLaunchKernelGGL(gn_stats_kernel<2>, grid, block, sm1, s, a.x, a.y, a.gamma, a.beta, a.partial, a.B, a.HW, a.C, a.G, a.chunks, a.rows, a.arows, a.ldx, a.ldy, a.eps, a.silu);
-    hipLaunchKernelGGL(gn_apply_kernel<2>, agrid, block, sm2, s, a.x, a.y, a.gamma, a.beta, a.partial, a.B, a.HW, a.C, a.G, a.chunks, a.rows, a.arows, a.ldx, a.ldy, a.eps, a.silu);
+    hipLaunchKernelGGL(gn_apply_kernel<2>, agrid, block, sm2, s, a.x, a.y, a.gamma, a.beta, a.partial, a.B, a.HW, a.C, a.G, a.chunks, a.rows, a.arows, a.ldx, a.ldy, a.eps, a.silu | wtf);
   }
   return hipGetLastError();
 }
