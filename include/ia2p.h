@@ -176,7 +176,8 @@ ia2p_status ia2p_conv_in(void* stream, const void* x_nchw, const void* w_oihw, c
                          int B, int Cin, int H, int W, int Co);
 ia2p_status ia2p_conv_out(void* stream, const void* x_nhwc, const void* w_packed, const void* bias, void* y_nchw, int B, int C, int H, int W, int Co);
 /* O[b,q,h*64:] = sum_s weight_s * softmax(Q K_s^T / 8) V_s over nseg <= 2 key segments (head_dim 64).
- * Q rows have stride ldq, K_s/V_s rows stride ld_s; segment s has nkeys_s keys per batch. */
+ * Q rows have stride ldq, K_s/V_s rows stride ld_s; segment s has nkeys_s keys per batch. Strides are multiples of 8 elements, O is 16-byte aligned
+ * (a query's 64 channels of one head leave as one 128-byte line). */
 ia2p_status ia2p_attention(void* stream, const void* Q, int ldq, void* O, int ldo, int B, int heads, int Nq, int nseg,
                            const void* K0, const void* V0, int ld0, int nkeys0, float w0,
                            const void* K1, const void* V1, int ld1, int nkeys1, float w1);

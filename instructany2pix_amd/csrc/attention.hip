@@ -59,24 +59,9 @@ __global__ __launch_bounds__(256, 2) void attention_f16_kernel(const half_t* aQ,
   f16v otot[2];
   attn_core<MODE>(p, b, hd, qf, sK, sV, tid, otot);
 
-  // ---- store: otot[d][r] <-> channel 32d + (r&3) + 8(r>>2) + 4hh of query q0 + lane%32
-  const int q = q0 + r31;
-  if (q < p.Nq) {
-    half_t* op = p.O + ((size_t)b * p.Nq + q) * p.ldo + hd * 64 + 4 * hh;
-    const bool wt = (p.xcd_map & 2) != 0;                 // write-through O (set by the launcher)
-    const __amdgpu_buffer_rsrc_t o_rsrc = wt_rsrc((void*)p.O, (size_t)p.B * p.Nq * p.ldo * 2);
-    const size_t ob = (((size_t)b * p.Nq + q) * p.ldo + hd * 64 + 4 * hh) * 2;
-#pragma unroll
-    for (int d = 0; d < 2; ++d)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        h4 v;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = (half_t)otot[d][g * 4 + r];
-        if (wt) store8_wt(o_rsrc, ob + (d * 32 + g * 8) * 2, v);
-        else *(h4*)(op + d * 32 + g * 8) = v;
-      }
-  }
+  // ---- store through LDS: whole 128-byte lines per query and head (attention_core.h attn_store_o)
+  __syncthreads();                                  // every wave is through with the K / V images
+  attn_store_o(otot, p.O, (size_t)p.B * p.Nq * p.ldo, b, q0, hd, p.Nq, p.ldo, smem + wave * 4096, lane, (p.xcd_map & 2) != 0);
 }
 
 hipError_t ia2p_launch_attention(const AttnArgs& a, hipStream_t s) {

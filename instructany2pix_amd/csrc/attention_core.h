@@ -336,3 +336,34 @@ __device__ __forceinline__ void attn_core(const AttnArgs& p, int b, int hd, cons
       for (int r = 0; r < 16; ++r) otot[d][r] = o[d][r] * w;
   }
 }
+
+// O of one wave's 32 queries (otot[d][r] <-> channel 32d + (r&3) + 8(r>>2) + 4*(lane/32) of query q0 + lane%32) through a 4 KiB LDS tile of the
+// wave's own -- a query's 64 channels of one head are ONE 128-byte line: written from the accumulator layout they leave as sixteen 8-byte pieces
+// per line, read back row-major they leave as whole lines (16 bytes per lane), optionally write-through (wt). The caller has made sure that no
+// wave still reads the K / V images under `tile` (a workgroup barrier after the core).
+__device__ __forceinline__ void attn_store_o(const f16v (&otot)[2], half_t* O, size_t o_elems, int b, int q0, int hd, int Nq, int ldo, char* tile, int lane, bool wt) {
+  const int r31 = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      h4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = (half_t)otot[d][g * 4 + r];
+      *(h4*)(tile + r31 * 128 + (((d * 4 + g) ^ (r31 & 7)) << 4) + hh * 8) = v;       // 16-byte chunk d*4+g, XOR-swizzled by the row
+    }
+  __builtin_amdgcn_s_waitcnt(0xc07f);         // lgkmcnt(0): the wave's own writes are visible to itself
+  __builtin_amdgcn_wave_barrier();
+  const __amdgpu_buffer_rsrc_t o_rsrc = wt_rsrc((void*)O, o_elems * 2);
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+    const int row = ps * 8 + (lane >> 3), ch = lane & 7;
+    const h8 v = *(const h8*)(tile + row * 128 + ((ch ^ (row & 7)) << 4));
+    const int q = q0 + row;
+    if (q < Nq) {
+      const size_t e = ((size_t)b * Nq + q) * ldo + hd * 64 + ch * 8;
+      if (wt) store16_wt(o_rsrc, e * 2, v);
+      else *(h8*)(O + e) = v;
+    }
+  }
+}

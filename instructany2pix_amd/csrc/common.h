@@ -56,10 +56,10 @@ __device__ __forceinline__ void store8_wt(__amdgpu_buffer_rsrc_t r, size_t byte_
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, v), r, (int)byte_off, 0, 16);
 }
 // IA2P_WT: bit mask of the kernels that store write-through (1 GEMM C, 2 K-split reduce, 4 GroupNorm, 8 attention, 16 concat); A/B switch.
-// Same-box A/B at batch 8 (tools/ab_vals.sh): GEMM C -0.14 ms per step, GroupNorm -0.06, reduce / concat -0.02 each; attention +0.33 (its 8-byte
-// per-query pieces are partial lines: write-through pays for every one of them), so it stays write-back.
+// Same-box A/B at batch 8 (tools/ab_vals.sh): GEMM C -0.14 ms per step, GroupNorm -0.06, reduce / concat -0.02 each; attention +0.33 while O left
+// as 8-byte per-query pieces (partial lines: write-through pays for every one of them), -0.06 once O goes through LDS and leaves as whole lines.
 static inline int ia2p_wt_mask() {
-  static const int m = getenv("IA2P_WT") ? atoi(getenv("IA2P_WT")) : 23;
+  static const int m = getenv("IA2P_WT") ? atoi(getenv("IA2P_WT")) : 31;
   return m;
 }
 

@@ -1114,7 +1114,7 @@ ia2p_status ia2p_pack_geglu(void* stream, const void* src, void* dst, int rows, 
 ia2p_status ia2p_attention(void* stream, const void* Q, int ldq, void* O, int ldo, int B, int heads, int Nq, int nseg,
                            const void* K0, const void* V0, int ld0, int nkeys0, float w0, const void* K1, const void* V1, int ld1, int nkeys1, float w1) {
   if (!Q || !O || !K0 || !V0 || nseg < 1 || nseg > 2 || (nseg == 2 && (!K1 || !V1))) return fail(nullptr, IA2P_ERR_INVALID, "attention: bad argument");
-  if (nkeys0 < 1 || (nseg == 2 && nkeys1 < 1) || ldq % 8 || ldo % 4 || ld0 % 8 || (nseg == 2 && ld1 % 8)) return fail(nullptr, IA2P_ERR_SHAPE, "attention: key counts must be >= 1 and strides multiples of 8");
+  if (nkeys0 < 1 || (nseg == 2 && nkeys1 < 1) || ldq % 8 || ldo % 8 || (((uintptr_t)O) & 15) || ld0 % 8 || (nseg == 2 && ld1 % 8)) return fail(nullptr, IA2P_ERR_SHAPE, "attention: key counts must be >= 1, strides multiples of 8, O 16-byte aligned");
   AttnArgs a;
   memset(&a, 0, sizeof a);
   a.Q = (const half_t*)Q; a.ldq = ldq; a.O = (half_t*)O; a.ldo = ldo; a.B = B; a.heads = heads; a.Nq = Nq; a.nseg = nseg;
@@ -1129,8 +1129,8 @@ ia2p_status ia2p_qproj_attention(void* stream, const void* X, const void* Wq, co
                                  const void* K1, const void* V1, int ld1, int nkeys1, float w1) {
   if (!X || !Wq || !O || !K0 || !V0 || nseg < 1 || nseg > 2 || (nseg == 2 && (!K1 || !V1))) return fail(nullptr, IA2P_ERR_INVALID, "qproj_attention: bad argument");
   if (ln && (!ln->stats || !ln->colsum || !ln->fbias || ln->slots < 1)) return fail(nullptr, IA2P_ERR_INVALID, "qproj_attention: incomplete ia2p_ln_fold");
-  if (B < 1 || heads < 1 || Nq < 128 || Nq % 128 || K < 64 || K % 64 || nkeys0 < 1 || (nseg == 2 && nkeys1 < 1) || ldo % 4 || ld0 % 8 || (nseg == 2 && ld1 % 8))
-    return fail(nullptr, IA2P_ERR_SHAPE, "qproj_attention: Nq=%d must be a multiple of 128, K=%d of 64, key counts >= 1, key strides multiples of 8, ldo of 4", Nq, K);
+  if (B < 1 || heads < 1 || Nq < 128 || Nq % 128 || K < 64 || K % 64 || nkeys0 < 1 || (nseg == 2 && nkeys1 < 1) || ldo % 8 || (((uintptr_t)O) & 15) || ld0 % 8 || (nseg == 2 && ld1 % 8))
+    return fail(nullptr, IA2P_ERR_SHAPE, "qproj_attention: Nq=%d must be a multiple of 128, K=%d of 64, key counts >= 1, strides multiples of 8, O 16-byte aligned", Nq, K);
   GemmArgs a;
   memset(&a, 0, sizeof a);
   a.pad = 1;

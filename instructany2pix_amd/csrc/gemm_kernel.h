@@ -492,21 +492,8 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
     attn_kv_store(ap, tid, kvr, smem, smem + 32768);     // only short contexts are fused (the launcher checks): their K / V are in registers by now
     __syncthreads();
     attn_core<XA - 1, true>(ap, b, hd, qf, smem, smem + 32768, tid, otot);
-    // otot[d][r] <-> channel 32d + (r&3) + 8(r>>2) + 4hh of query q0 + lane%32
-    half_t* op = ap.O + ((size_t)b * ap.Nq + q0 + r31) * ap.ldo + hd * 64 + 4 * hh;
-    const bool owt = (ap.xcd_map & 2) != 0;
-    const __amdgpu_buffer_rsrc_t o_rsrc = wt_rsrc((void*)ap.O, (size_t)ap.B * ap.Nq * ap.ldo * 2);
-    const size_t ob = (((size_t)b * ap.Nq + q0 + r31) * ap.ldo + hd * 64 + 4 * hh) * 2;
-#pragma unroll
-    for (int d = 0; d < 2; ++d)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        h4 v;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = (half_t)otot[d][g * 4 + r];
-        if (owt) store8_wt(o_rsrc, ob + (d * 32 + g * 8) * 2, v);
-        else *(h4*)(op + d * 32 + g * 8) = v;
-      }
+    __syncthreads();                  // every wave is through with the K / V images
+    attn_store_o(otot, ap.O, (size_t)ap.B * ap.Nq * ap.ldo, b, q0, hd, ap.Nq, ap.ldo, smem + wave * 4096, lane, (ap.xcd_map & 2) != 0);
     return;
   }
   bool from_slabs = false;

@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256, 2) void qproj_xattn_kernel(const half_t* hA, c
 bool ia2p_qproj_xattn_ok(const GemmArgs& a, const AttnArgs& x) {
   return x.Nq > 0 && x.Nq % 128 == 0 && a.M == x.B * x.Nq && a.N == x.heads * 64 && a.K >= 64 && a.K % 64 == 0 && a.splitk <= 1 && !a.geglu && !a.residual && !a.rowvec &&
          !a.stats_out && !a.act && x.nseg >= 1 && x.nseg <= 2 && x.seg[0].nkeys > 0 && (x.nseg == 1 || x.seg[1].nkeys > 0) &&
-         (!a.bias || ((((uintptr_t)a.bias) & 15) == 0 && a.N % 8 == 0)) && x.ldo % 4 == 0 &&
+         (!a.bias || ((((uintptr_t)a.bias) & 15) == 0 && a.N % 8 == 0)) && x.ldo % 8 == 0 && ((((uintptr_t)x.O) & 15) == 0) &&
          attn_kv_resident(x);      // short contexts only: their K / V ride in registers through the projection loop
 }
 
