@@ -44,16 +44,19 @@ __device__ __forceinline__ float gelu_tanh_f(float x) { return 0.5f * x * (1.0f 
 // Write-through (`sc1`) stores for tensors the NEXT kernel reads: the bytes leave the L2 while the kernel still runs, so the end-of-kernel
 // write-back (which sits on the critical path between two dependent launches) has nothing left to flush. Offsets are 32-bit: callers use
 // them only for tensors under 2 GiB.
+#ifndef IA2P_WT_AUX
+#define IA2P_WT_AUX 16      // cache-policy bits of the write-through stores: 16 = sc1 (build-time knob for A/B builds: IA2P_EXTRA_FLAGS=-DIA2P_WT_AUX=18 adds nt)
+#endif
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t wt_rsrc(void* base, size_t bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(bytes < (size_t)0x7ffffff0 ? bytes : (size_t)0x7ffffff0), 0x00020000);
 }
 __device__ __forceinline__ void store16_wt(__amdgpu_buffer_rsrc_t r, size_t byte_off, h8 v) {
   typedef unsigned u4v __attribute__((__vector_size__(4 * sizeof(unsigned))));
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), r, (int)byte_off, 0, 16);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, v), r, (int)byte_off, 0, IA2P_WT_AUX);
 }
 __device__ __forceinline__ void store8_wt(__amdgpu_buffer_rsrc_t r, size_t byte_off, h4 v) {
   typedef unsigned u2v __attribute__((__vector_size__(2 * sizeof(unsigned))));
-  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, v), r, (int)byte_off, 0, 16);
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, v), r, (int)byte_off, 0, IA2P_WT_AUX);
 }
 // IA2P_WT: bit mask of the kernels that store write-through (1 GEMM C, 2 K-split reduce, 4 GroupNorm, 8 attention, 16 concat); A/B switch.
 // Same-box A/B at batch 8 (tools/ab_vals.sh): GEMM C -0.14 ms per step, GroupNorm -0.06, reduce / concat -0.02 each; attention +0.33 while O left
