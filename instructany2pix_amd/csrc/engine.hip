@@ -319,7 +319,9 @@ static void set_prefetch(RunCtx* c, GemmArgs& a, const half_t* W, size_t bytes) 
   ++c->widx;
   if (nx.second > ((size_t)96 << 20)) return;           // larger than the Infinity Cache can usefully hold
   a.pf = nx.first; a.pf_bytes = (long)nx.second;
-  a.pf_blocks = (int)std::min<size_t>(128, (nx.second + 131071) / 131072);
+  static const size_t pf_cap = getenv("IA2P_PF_BLOCKS") ? (size_t)atoi(getenv("IA2P_PF_BLOCKS")) : 128;            // tuning hooks: most prefetch workgroups per launch,
+  static const size_t pf_per = getenv("IA2P_PF_BLOCK_BYTES") ? (size_t)atol(getenv("IA2P_PF_BLOCK_BYTES")) : 131072;   // bytes per workgroup below that
+  a.pf_blocks = (int)std::max<size_t>(1, std::min<size_t>(pf_cap, (nx.second + pf_per - 1) / pf_per));
 }
 
 // In-place measurement of the candidate plans of one GEMM / conv site (autotune pass). Every candidate runs once untimed and

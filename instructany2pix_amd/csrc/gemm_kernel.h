@@ -103,12 +103,16 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
     const char* src = (const char*)p.pf;
     unsigned acc = 0;
     constexpr long SW = NWAVE * 64 * 16;   // bytes swept by the workgroup per pass
-    for (long o = lo + tid * 16; o < hi; o += 4 * SW) {
-      unsigned v[4];
+#ifndef IA2P_PF_UNROLL
+#define IA2P_PF_UNROLL 4      // loads in flight per thread (build-time knob for A/B builds)
+#endif
+    constexpr int PU = IA2P_PF_UNROLL;
+    for (long o = lo + tid * 16; o < hi; o += PU * SW) {
+      unsigned v[PU];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = *(const unsigned*)(src + min(o + u * SW, hi - 16));   // one dword per 16-B slot pulls the whole line
+      for (int u = 0; u < PU; ++u) v[u] = *(const unsigned*)(src + min(o + u * SW, hi - 16));   // one dword per 16-B slot pulls the whole line
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc ^= v[u];
+      for (int u = 0; u < PU; ++u) acc ^= v[u];
     }
     asm volatile("" ::"v"(acc));    // keep the loads alive
     return;
