@@ -5,6 +5,9 @@
 #include "common.h"
 
 #define MASKED (-1.0e30f)
+#ifndef IA2P_ATTN_PK
+#define IA2P_ATTN_PK 1      // packed fp32 softmax arithmetic (build-time knob for A/B builds)
+#endif
 
 __device__ __forceinline__ fp16x4 lds_tr16(const char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4f16((fp16x4 __attribute__((address_space(3)))*)p);
@@ -245,19 +248,28 @@ __device__ __forceinline__ void attn_core(const AttnArgs& p, int b, int hd, cons
         h8 pf[2][2];
         typedef float f2v __attribute__((ext_vector_type(2)));
         if (!ip_tile) {
+          const f2v sc2 = {p.scale_log2e, p.scale_log2e}, mc2 = {mc, mc};
+          f2v psum2 = {0.f, 0.f};
 #pragma unroll
           for (int kh = 0; kh < 2; ++kh) {
             if (kh >= nkh) break;
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-              const float e0 = __builtin_amdgcn_exp2f(fmaf(st[kh][r], p.scale_log2e, -mc));
-              const float e1 = __builtin_amdgcn_exp2f(fmaf(st[kh][r + 1], p.scale_log2e, -mc));
-              psum += e0;
-              psum += e1;
-              const h2 pr = __builtin_convertvector((f2v){e0, e1}, h2);      // ONE v_cvt_pk_f16_f32 per pair
+              // pairs: ONE v_pk_fma_f32 for the two scaled differences, one v_pk_add_f32 into a two-lane running sum (half the fma / add
+              // issue slots of the scalar form, and no serial chain through the sum), one v_cvt_pk_f16_f32
+#if IA2P_ATTN_PK
+              const f2v t = (f2v){st[kh][r], st[kh][r + 1]} * sc2 - mc2;
+              const f2v e = {__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+              psum2 += e;
+#else
+              const f2v e = {__builtin_amdgcn_exp2f(fmaf(st[kh][r], p.scale_log2e, -mc)), __builtin_amdgcn_exp2f(fmaf(st[kh][r + 1], p.scale_log2e, -mc))};
+              psum2[0] += e[0]; psum2[0] += e[1];
+#endif
+              const h2 pr = __builtin_convertvector(e, h2);
               pf[kh][r >> 3][r & 7] = pr[0]; pf[kh][r >> 3][(r & 7) + 1] = pr[1];
             }
           }
+          psum = psum2[0] + psum2[1];
           if (__any(mnew != mrun)) {        // running max moved for some query of this wave: rescale (rare after the first tiles)
             const float alpha = __builtin_amdgcn_exp2f((mrun - mnew) * p.scale_log2e);
             lrun *= alpha;
