@@ -5,6 +5,9 @@
 #include "common.h"
 
 #define MASKED (-1.0e30f)
+#ifndef IA2P_ATTN_DMA
+#define IA2P_ATTN_DMA 1     // long single-segment contexts: K / V staged by double-buffered LDS-DMA (build-time knob for A/B builds)
+#endif
 #ifndef IA2P_ATTN_PK
 #define IA2P_ATTN_PK 1      // packed fp32 softmax arithmetic (build-time knob for A/B builds)
 #endif
@@ -152,10 +155,36 @@ __device__ __forceinline__ void attn_core(const AttnArgs& p, int b, int hd, cons
         for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
     }
 
-    for (int s0 = 0; s0 < seg.nkeys; s0 += 256) {
-      const int nsk = min(256, seg.nkeys - s0);          // keys in this super-tile
+    // Self-attention (one long segment): stages of 128 keys, double buffered, filled by LDS-DMA (16 bytes per lane, the swizzles of the two
+    // images applied through the SOURCE address) -- the stage after this one flies while this one is consumed, no staging registers, one
+    // barrier per stage. Rows past the end re-read the last key (finite data; their scores are masked, so their probabilities are 0).
+    constexpr bool DMA = IA2P_ATTN_DMA && MODE == 0 && !PRE;
+    constexpr int SSZ = DMA ? 128 : 256;
+    auto stage_dma = [&](int s0n, int buf) {
+      const int wv = tid >> 6, ln = tid & 63;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int pi = wv * 8 + u;                        // 32 pieces of 1 KiB: 0-15 K rows, 16-31 V rows (waves 0-1 / 2-3)
+        const bool isV = pi >= 16;
+        const int row = (pi & 15) * 8 + (ln >> 3), cp = ln & 7;
+        const int g = cp ^ (isV ? (((row >> 1) & 1) << 2) : ((row >> 1) & 7));
+        const half_t* src = (isV ? Vb : Kb) + (size_t)min(s0n + row, seg.nkeys - 1) * seg.ld + g * 8;
+        char* dst = (isV ? sV : sK) + buf * 16384 + (pi & 15) * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      }
+    };
+    if (DMA) stage_dma(0, 0);
+    char* sKs = sK;
+    char* sVs = sV;
+    for (int s0 = 0; s0 < seg.nkeys; s0 += SSZ) {
+      const int nsk = min(SSZ, seg.nkeys - s0);          // keys in this super-tile
       const int ntile = (nsk + 63) >> 6;
-      if (!resident) {
+      if (DMA) {
+        const int stg = s0 / SSZ;
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // this stage has landed for every wave; the other buffer is free
+        if (s0 + SSZ < seg.nkeys) stage_dma(s0 + SSZ, (stg + 1) & 1);
+        sKs = sK + (stg & 1) * 16384; sVs = sV + (stg & 1) * 16384;
+      } else if (!resident) {
         __syncthreads();  // previous super-tile fully consumed
         switch (ntile) {   // wave-uniform; each arm is fully unrolled so the staging registers never go to scratch
           case 1: stage_kv<1>(Kb, Vb, seg.ld, s0, nsk, tid, sK, sV); break;
@@ -171,7 +200,7 @@ __device__ __forceinline__ void attn_core(const AttnArgs& p, int b, int hd, cons
       // exponentials -- a wave's in-order stream otherwise leaves the MFMA pipe idle for the whole softmax (PMC r01i: 13.5 VALU per MFMA).
       // Two named score sets (A / B), swapped by a two-step body: a runtime-indexed set would live in scratch.
       auto qk = [&](int tl, f16v (&st)[2]) {       // S^T[key][q] for the two 32-key halves of tile tl; K fragments read ahead of the MFMAs
-        const char* sKt = sK + (tbase + tl) * 8192;
+        const char* sKt = sKs + (tbase + tl) * 8192;
         // short contexts end in short tiles (77 text keys = 64 + 13, 4 image-token keys): a tile with <= 32 live keys is ONE half
         const int nkh = ((MODE != 0 || PRE) && seg.nkeys - (s0 + tl * 64) <= 32) ? 1 : 2;       // wave-uniform
         h8 kf[2][4];
@@ -198,7 +227,7 @@ __device__ __forceinline__ void attn_core(const AttnArgs& p, int b, int hd, cons
       auto soft_pv = [&](int tl, f16v (&st)[2]) {
         const int k0 = s0 + tl * 64;
         const int nkh = ((MODE != 0 || PRE) && seg.nkeys - k0 <= 32) ? 1 : 2;                   // as in qk
-        const char* sVt = sV + (tbase + tl) * 8192;
+        const char* sVt = sVs + (tbase + tl) * 8192;
         // V^T fragments of the whole tile: issued now, their latency hides under the softmax arithmetic below
         const int gi = (lane >> 4) & 1, li = lane & 15;
         h8 vf[2][2][2];
