@@ -166,6 +166,11 @@ ia2p_status ia2p_gemm_splitk(void* stream, const void* A, const void* W, const v
  * stride 1|2; up=1 convolves the nearest-x2 upsampled x; rowvec [B,Co] (time embedding) and residual optional. */
 ia2p_status ia2p_conv3x3(void* stream, const void* x, const void* Wp, const void* bias, const void* rowvec, const void* residual,
                          void* y, int B, int Hs, int Ws, int Cin, int Co, int stride, int up);
+/* The tail of a ResnetBlock2D with a channel change as ONE implicit GEMM (what the executor does; diffusers ResnetBlock2D `conv2(h) + conv_shortcut(x)`
+ * behind pnp_pipeline.py:253-260):  y = conv3x3(x, W2) + conv1x1(x2, Wsc) + bias, K = 9 Cin + Cin2, stride 1. Wcat [Co][9 Cin + Cin2] holds, per output
+ * channel, the ia2p_pack_conv3x3 row of W2 followed by the row of Wsc; bias = b2 + bsc; x [B,Hs,Ws,Cin], x2 [B,Hs,Ws,Cin2] channels-last. */
+ia2p_status ia2p_conv3x3_cat(void* stream, const void* x, const void* x2, const void* Wcat, const void* bias, void* y,
+                             int B, int Hs, int Ws, int Cin, int Cin2, int Co);
 ia2p_status ia2p_pack_conv3x3(void* stream, const void* w_oihw, void* w_packed, int Co, int Cin);
 ia2p_status ia2p_pack_geglu(void* stream, const void* src, void* dst, int rows, int rowlen);
 /* The UNet's latent-boundary 3x3 convolutions (diffusers UNet2DConditionModel.conv_in / .conv_out behind pnp_pipeline.py:253-260; the VAE's too), pad 1:

@@ -85,6 +85,9 @@ struct GemmArgs {
   int stride, up;        // conv stride (1|2); up=1 reads a nearest-x2 upsampled view of the source
   int pad;               // zero rows/cols before the image (1; the VAE's stride-2 downsample pads only after: 0)
   int Cin;               // channels per tap (Cin % 64 == 0)
+  // CONV3x3 with an appended 1x1 block (K = 9 Cin + Cin2): the last Cin2 columns of the contraction read the pixel itself from a SECOND
+  // tensor -- a ResnetBlock2D's conv2(h) + conv_shortcut(x) as ONE implicit GEMM (stride 1, no upsampling); A2 == nullptr: plain 3x3
+  const half_t* A2; int lda2, Cin2;
   // epilogue
   const half_t* bias;    // [N] (GEGLU: packed order) or null
   const half_t* rowvec;  // per-batch vector added to every row of that batch (time embedding) or null

@@ -27,6 +27,7 @@ struct Resnet {
   int cin, cout, temb_off;
   bool shortcut;
   size_t n1g, n1b, w1, b1, n2g, n2b, w2, b2, wsc, bsc;
+  size_t wcat, bcat;      // derived at finalize when the block has a shortcut: [cout][9 cout + cin] = conv2 rows with the shortcut rows appended; b2 + bsc
 };
 struct TBlock {
   size_t ln1g, ln1b, wqkv, wo1, bo1, ln2g, ln2b, wq2, wkv2, wkvip, wo2, bo2, ln3g, ln3b, wff1, bff1, wff2, bff2;
@@ -121,7 +122,11 @@ struct Planner {
     r.n2g = vec(p + ".norm2.weight", cout); r.n2b = vec(p + ".norm2.bias", cout);
     r.w2 = conv3(p + ".conv2.weight", cout, cout); r.b2 = vec(p + ".conv2.bias", cout);
     r.wsc = r.bsc = 0;
-    if (r.shortcut) { r.wsc = mat(p + ".conv_shortcut.weight", cout, cin); r.bsc = vec(p + ".conv_shortcut.bias", cout); }
+    r.wcat = r.bcat = 0;
+    if (r.shortcut) {
+      r.wsc = mat(p + ".conv_shortcut.weight", cout, cin); r.bsc = vec(p + ".conv_shortcut.bias", cout);
+      r.wcat = take_fold((size_t)cout * (9 * cout + cin)); r.bcat = take_fold(cout);
+    }
     return r;
   }
   Transformer transformer(const std::string& p, int ch, int heads, int depth, int ctx, std::vector<std::pair<std::string, size_t>>& ipslots) {
@@ -421,19 +426,21 @@ void op_gemm(RunCtx* c, const half_t* A, int lda, const half_t* W, const half_t*
   run_gemm(c, a, false, "gemm", 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * (geglu ? N / 2 : N) + (residual ? (double)M * N : 0)), stat_slots);
 }
 void op_conv3(RunCtx* c, const half_t* X, int B, int Hs, int Ws, int Cin, const half_t* W, const half_t* bias, int Co,
-              int stride, int up, const half_t* rowvec, int rowvec_ld, const half_t* residual, half_t* Y, int pad_lo) {
+              int stride, int up, const half_t* rowvec, int rowvec_ld, const half_t* residual, half_t* Y, int pad_lo, const half_t* X2, int Cin2) {
   GemmArgs a;
   memset(&a, 0, sizeof a);
+  if (X2 && (stride != 1 || up || pad_lo != 1 || Cin2 % 64)) { fail(c, IA2P_ERR_SHAPE, "conv3x3 with an appended 1x1 block: stride 1, no upsampling, Cin2 % 64 == 0"); return; }
   a.pad = pad_lo;           // zero rows/cols before the image; one row/col of zeros after it in every mode
   const int Hv = Hs << up, Wv = Ws << up;
   a.Ho = (Hv + pad_lo + 1 - 3) / stride + 1; a.Wo = (Wv + pad_lo + 1 - 3) / stride + 1;
-  a.A = X; a.W = W; a.C = Y; a.zero = zero_page(); a.M = B * a.Ho * a.Wo; a.N = Co; a.K = 9 * Cin; a.ldw = a.K; a.lda = Cin; a.ldc = Co;
+  a.A = X; a.W = W; a.C = Y; a.zero = zero_page(); a.M = B * a.Ho * a.Wo; a.N = Co; a.K = 9 * Cin + (X2 ? Cin2 : 0); a.ldw = a.K; a.lda = Cin; a.ldc = Co;
+  a.A2 = X2; a.lda2 = Cin2; a.Cin2 = X2 ? Cin2 : 0;
   a.Hs = Hs; a.Ws = Ws; a.stride = stride; a.up = up; a.Cin = Cin;
   a.bias = bias; a.rowvec = rowvec; a.rowvec_ld = rowvec_ld; a.rows_per_batch = a.Ho * a.Wo; a.residual = residual; a.ldr = Co;
   a.m_fastest = 0;
   a.acc_scale = c->ep_acc_scale; a.bias_scale = c->ep_bias_scale; c->ep_acc_scale = c->ep_bias_scale = 1.f;
   set_prefetch(c, a, W, (size_t)Co * a.K * sizeof(half_t));
-  run_gemm(c, a, true, "conv3x3", 2.0 * a.M * (double)Co * a.K, 2.0 * ((double)B * Hs * Ws * Cin + (double)Co * a.K + (double)a.M * Co + (residual ? (double)a.M * Co : 0)));
+  run_gemm(c, a, true, "conv3x3", 2.0 * a.M * (double)Co * a.K, 2.0 * ((double)B * Hs * Ws * Cin + (double)Co * a.K + (double)a.M * Co + (residual ? (double)a.M * Co : 0) + (X2 ? (double)a.M * Cin2 : 0)));
 }
 void op_gn(RunCtx* c, const half_t* x, half_t* y, size_t g, size_t b, int B, int HW, int C, float eps, int silu, float* partial) {
   ProfScope ps(c, PK_GN, 8.0 * B * HW * C, 4.0 * B * HW * C);
@@ -469,15 +476,17 @@ static T2 run_resnet(Fwd& f, const Resnet& r, T2 x, int H, int Wd) {
   wsfree(c, hh);
   T2 xs{(size_t)-1, nullptr};
   const half_t* resid = x.p;
-  if (r.shortcut) {
+  const bool cat = r.shortcut && c->sc_fuse;      // conv2(h) + conv_shortcut(x) as ONE implicit GEMM (K = 9 cout + cin): no shortcut launch, no xs round trip
+  if (r.shortcut && !cat) {
     xs = wsalloc(c, (size_t)M * r.cout);
     op_gemm(c, x.p, r.cin, W_(c, r.wsc), W_(c, r.bsc), nullptr, 0, xs.p, r.cout, M, r.cout, r.cin);
     resid = xs.p;
   }
   T2 out = wsalloc(c, (size_t)M * r.cout);
-  op_conv3(c, n2.p, f.B, H, Wd, r.cout, W_(c, r.w2), W_(c, r.b2), r.cout, 1, 0, nullptr, 0, c->dry ? nullptr : resid, out.p);
+  if (cat) op_conv3(c, n2.p, f.B, H, Wd, r.cout, W_(c, r.wcat), W_(c, r.bcat), r.cout, 1, 0, nullptr, 0, nullptr, out.p, 1, c->dry ? nullptr : x.p, r.cin);
+  else op_conv3(c, n2.p, f.B, H, Wd, r.cout, W_(c, r.w2), W_(c, r.b2), r.cout, 1, 0, nullptr, 0, c->dry ? nullptr : resid, out.p);
   wsfree(c, n2);
-  if (r.shortcut) wsfree(c, xs);
+  if (r.shortcut && !cat) wsfree(c, xs);
   return out;
 }
 
@@ -830,8 +839,16 @@ static ia2p_status fold_all(ia2p_ctx* c, hipStream_t stream, bool sync) {
       if (e == hipSuccess) e = ia2p_launch_fold_ln(H(b.wq2), H(b.ln2g), H(b.ln2b), nullptr, H(b.fq2), F(b.cs2), F(b.lb2), C, C, stream);
       if (e == hipSuccess) e = ia2p_launch_fold_ln(H(b.wff1), H(b.ln3g), H(b.ln3b), H(b.bff1), H(b.fff1), F(b.cs3), F(b.lb3), 8 * C, C, stream);
     }
+  // conv2 + conv_shortcut of a ResnetBlock2D as ONE implicit GEMM: weight rows concatenated along K, biases added
+  std::vector<const Resnet*> rs;
+  for (const Stage& s : c->down) for (const Resnet& r : s.res) rs.push_back(&r);
+  rs.push_back(&c->mid_r0); rs.push_back(&c->mid_r1);
+  for (const Stage& s : c->up) for (const Resnet& r : s.res) rs.push_back(&r);
+  for (const Resnet* r : rs)
+    if (r->shortcut && e == hipSuccess)
+      e = ia2p_launch_cat_rows(H(r->w2), 9 * r->cout, H(r->wsc), r->cin, H(r->b2), H(r->bsc), H(r->wcat), H(r->bcat), r->cout, stream);
   if (e == hipSuccess && sync) e = hipStreamSynchronize(stream);
-  if (e != hipSuccess) return fail(c, IA2P_ERR_HIP, "LayerNorm folding: %s", hipGetErrorString(e));
+  if (e != hipSuccess) return fail(c, IA2P_ERR_HIP, "weight folding: %s", hipGetErrorString(e));
   c->fold_dirty = false;
   return IA2P_OK;
 }
@@ -1087,6 +1104,20 @@ ia2p_status ia2p_conv3x3(void* stream, const void* x, const void* Wp, const void
   a.rowvec = (const half_t*)rowvec; a.rowvec_ld = Co; a.rows_per_batch = a.Ho * a.Wo; a.residual = (const half_t*)residual; a.ldr = Co;
   hipError_t e = ia2p_launch_gemm(a, true, (hipStream_t)stream, nullptr);
   RET_HIP(e, "conv3x3");
+}
+// ResnetBlock2D tail as one implicit GEMM: y = conv3x3(x, W2) + conv1x1(x2, Wsc) + bias (+ rowvec), K = 9 Cin + Cin2; Wcat rows = [packed W2 row | Wsc row]
+ia2p_status ia2p_conv3x3_cat(void* stream, const void* x, const void* x2, const void* Wcat, const void* bias, void* y, int B, int Hs, int Ws, int Cin, int Cin2, int Co) {
+  if (!x || !x2 || !Wcat || !y) return fail(nullptr, IA2P_ERR_INVALID, "conv3x3_cat: null argument");
+  if (Cin % 64 || Cin2 % 64 || Cin2 < 64 || Co % 4) return fail(nullptr, IA2P_ERR_SHAPE, "conv3x3_cat: Cin=%d, Cin2=%d (multiples of 64) Co=%d (mult of 4)", Cin, Cin2, Co);
+  GemmArgs a;
+  memset(&a, 0, sizeof a);
+  a.pad = 1;
+  a.Ho = Hs; a.Wo = Ws;
+  a.A = (const half_t*)x; a.W = (const half_t*)Wcat; a.C = (half_t*)y; a.zero = zero_page(); a.M = B * Hs * Ws; a.N = Co; a.K = 9 * Cin + Cin2; a.ldw = a.K; a.lda = Cin; a.ldc = Co;
+  a.Hs = Hs; a.Ws = Ws; a.stride = 1; a.up = 0; a.Cin = Cin; a.bias = (const half_t*)bias; a.rows_per_batch = Hs * Ws;
+  a.A2 = (const half_t*)x2; a.lda2 = Cin2; a.Cin2 = Cin2;
+  hipError_t e = ia2p_launch_gemm(a, true, (hipStream_t)stream, nullptr);
+  RET_HIP(e, "conv3x3_cat");
 }
 ia2p_status ia2p_pack_conv3x3(void* stream, const void* src, void* dst, int Co, int Cin) {
   if (!src || !dst) return fail(nullptr, IA2P_ERR_INVALID, "pack_conv3x3: null argument");

@@ -43,6 +43,7 @@ hipError_t ia2p_launch_ddim_step(const half_t* x, const half_t* eps_u, const hal
                                  half_t* out, half_t* out2, long n, hipStream_t s);
 hipError_t ia2p_launch_mask_blend(const half_t* x, const half_t* init, const half_t* noise, const half_t* mask, float c0, float c1,
                                   half_t* out, half_t* out2, int B, int C, long HW, hipStream_t s);
+hipError_t ia2p_launch_cat_rows(const half_t* a, int Ka, const half_t* b, int Kb, const half_t* bias_a, const half_t* bias_b, half_t* dst, half_t* bias_dst, int rows, hipStream_t s);
 hipError_t ia2p_launch_fold_ln(const half_t* W, const half_t* gamma, const half_t* beta, const half_t* bias, half_t* Wf, float* cs, float* lb,
                                int N, int K, hipStream_t s);
 hipError_t ia2p_launch_clip_embed(const int* ids, const half_t* tok, const half_t* embeds, const half_t* pos, half_t* x, float* stats, int rows, int T, int H,
@@ -137,6 +138,7 @@ struct RunCtx {
   const half_t* tail_pf = nullptr;   // what the LAST contraction of a pass prefetches: the first weights of the next pass (embedding MLPs)
   size_t tail_pf_bytes = 0;
   int xattn_min_tiles = 128; // ... and only when the fused launch has at least this many 128-query x head tiles (IA2P_XATTN_MIN_TILES; 40-tile launches lose 4 us each, 160-tile ones gain 1)
+  bool sc_fuse = true;       // ResnetBlock2D: conv2 + conv_shortcut as one implicit GEMM (IA2P_SC_FUSE=0: separate 1x1 launch + residual, for A/B runs)
   bool xattn_fuse = true;    // to_q + cross-attention as one launch where the shape allows (IA2P_XATTN_FUSE=0: two launches, for A/B runs)
   bool ln_fold = true;       // LayerNorms folded into their consumer GEMMs (IA2P_LN_FOLD=0: separate layernorm_kernel launches, for A/B runs)
   bool prof = false;
@@ -158,6 +160,7 @@ struct RunCtx {
     if (const char* e = getenv("IA2P_PREFETCH")) prefetch = atoi(e) != 0;
     if (const char* e = getenv("IA2P_LN_FOLD")) ln_fold = atoi(e) != 0;
     if (const char* e = getenv("IA2P_XATTN_FUSE")) xattn_fuse = atoi(e) != 0;
+    if (const char* e = getenv("IA2P_SC_FUSE")) sc_fuse = atoi(e) != 0;
     if (const char* e = getenv("IA2P_XATTN_MIN_TILES")) xattn_min_tiles = atoi(e);
     for (int k = 0; k < PK_NCLASS; ++k) { p_ms[k] = p_fl[k] = p_by[k] = 0; p_n[k] = 0; }
     for (int k = 0; k < PR_NREGION; ++k) { r_ms[k] = r_fl[k] = r_by[k] = 0; r_n[k] = 0; }
@@ -198,7 +201,7 @@ void op_gemm(RunCtx* c, const half_t* A, int lda, const half_t* W, const half_t*
              half_t* C, int ldc, int M, int N, int K, int geglu = 0, int rpb = 0, int bstride = 0, int roff = 0, int ldw = 0,
              const LnIn* ln = nullptr, float* stats_out = nullptr, int* stat_slots = nullptr, int act = 0);
 void op_conv3(RunCtx* c, const half_t* X, int B, int Hs, int Ws, int Cin, const half_t* W, const half_t* bias, int Co,
-              int stride, int up, const half_t* rowvec, int rowvec_ld, const half_t* residual, half_t* Y, int pad_lo = 1);
+              int stride, int up, const half_t* rowvec, int rowvec_ld, const half_t* residual, half_t* Y, int pad_lo = 1, const half_t* X2 = nullptr, int Cin2 = 0);
 void op_gn(RunCtx* c, const half_t* x, half_t* y, size_t g, size_t b, int B, int HW, int C, float eps, int silu, float* partial);
 void op_ln(RunCtx* c, const half_t* x, half_t* y, size_t g, size_t b, int M, int C);
 

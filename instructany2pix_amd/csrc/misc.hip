@@ -673,6 +673,22 @@ hipError_t ia2p_launch_prior_step(const float* smp, const half_t* o_c, const hal
   hipLaunchKernelGGL(prior_step_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, smp, o_c, o_u, noise, g, sqrt_a, sqrt_b, k0, k1, sigma, out, n);
   return hipGetLastError();
 }
+// dst[r] = [a[r] | b[r]] (rows of Ka and Kb elements, both multiples of 8), bias_dst = bias_a + bias_b (fp32 add, one rounding)
+__global__ void cat_rows_kernel(const half_t* a, int Ka, const half_t* b, int Kb, const half_t* bias_a, const half_t* bias_b, half_t* dst, half_t* bias_dst, int rows) {
+  const int va = Ka >> 3, vt = (Ka + Kb) >> 3;
+  const long total = (long)rows * vt;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / vt;
+    const int v = (int)(i - r * vt);
+    *(uint4*)(dst + r * (long)(Ka + Kb) + v * 8) = v < va ? *(const uint4*)(a + r * (long)Ka + v * 8) : *(const uint4*)(b + r * (long)Kb + (v - va) * 8);
+  }
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += gridDim.x * blockDim.x) bias_dst[r] = (half_t)((float)bias_a[r] + (float)bias_b[r]);
+}
+hipError_t ia2p_launch_cat_rows(const half_t* a, int Ka, const half_t* b, int Kb, const half_t* bias_a, const half_t* bias_b, half_t* dst, half_t* bias_dst, int rows, hipStream_t s) {
+  if (Ka % 8 || Kb % 8) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(cat_rows_kernel, dim3(grid_for((long)rows * ((Ka + Kb) / 8), 256)), dim3(256), 0, s, a, Ka, b, Kb, bias_a, bias_b, dst, bias_dst, rows);
+  return hipGetLastError();
+}
 hipError_t ia2p_launch_fold_ln(const half_t* W, const half_t* gamma, const half_t* beta, const half_t* bias, half_t* Wf, float* cs, float* lb,
                                int N, int K, hipStream_t s) {
   hipLaunchKernelGGL(fold_ln_kernel, dim3(N), dim3(256), 0, s, W, gamma, beta, bias, Wf, cs, lb, K);

@@ -269,6 +269,28 @@ def test_boundary_convs_reject_bad_shapes(L):
     assert L.ia2p_conv_out(f.current_stream(), f.ptr(x), f.ptr(x), f.ptr(x), f.ptr(x), 1, 64, 4, 4, 9) != 0              # Co > 8
 
 
+@pytest.mark.parametrize("tile", [-1, 0, 4, 6, 8, 12, 16])
+@pytest.mark.parametrize("B,H,W,Cin,Cin2,Co", [(2, 16, 16, 1280, 640, 1280), (1, 32, 32, 320, 960, 320), (2, 9, 7, 128, 64, 192)])
+def test_conv3x3_with_appended_shortcut(L, B, H, W, Cin, Cin2, Co, tile):
+    """conv2(h) + conv_shortcut(x) of a ResnetBlock2D as ONE implicit GEMM (K = 9 Cin + Cin2), every tile family incl. K-split plans"""
+    f = _ffi()
+    h, x = rnd(B, H, W, Cin, seed=51), rnd(B, H, W, Cin2, seed=52)
+    w2, wsc = rnd(Co, Cin, 3, 3, seed=53, scale=(9 * Cin) ** -0.5), rnd(Co, Cin2, seed=54, scale=Cin2 ** -0.5)
+    b = rnd(Co, seed=55, scale=0.2)
+    wp = torch.empty(Co, 9 * Cin, dtype=torch.half, device="cuda")
+    run(L, "ia2p_pack_conv3x3", f.ptr(w2), f.ptr(wp), Co, Cin)
+    wcat = torch.cat([wp, wsc], dim=1).contiguous()
+    y = torch.full((B * H * W, Co), float("nan"), dtype=torch.half, device="cuda")
+    L.ia2p_debug_set_gemm_tile(tile)
+    try:
+        run(L, "ia2p_conv3x3_cat", f.ptr(h), f.ptr(x), f.ptr(wcat), f.ptr(b), f.ptr(y), B, H, W, Cin, Cin2, Co)
+    finally:
+        L.ia2p_debug_set_gemm_tile(-1)
+    ref = F.conv2d(h.float().permute(0, 3, 1, 2), w2.float(), None, padding=1) + F.conv2d(x.float().permute(0, 3, 1, 2), wsc.float()[:, :, None, None]) + b.float()[None, :, None, None]
+    ref = ref.permute(0, 2, 3, 1).reshape(B * H * W, Co)
+    assert rel_l2(y, ref) < 1.5e-3, rel_l2(y, ref)
+
+
 def _sdpa(q, k, v):
     s = (q.float() @ k.float().transpose(-1, -2)) / 8.0
     return s.softmax(-1) @ v.float()
