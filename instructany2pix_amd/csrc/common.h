@@ -88,6 +88,7 @@ struct GemmArgs {
   // CONV3x3 with an appended 1x1 block (K = 9 Cin + Cin2): the last Cin2 columns of the contraction read the pixel itself from a SECOND
   // tensor -- a ResnetBlock2D's conv2(h) + conv_shortcut(x) as ONE implicit GEMM (stride 1, no upsampling); A2 == nullptr: plain 3x3
   const half_t* A2; int lda2, Cin2;
+  const half_t* A3; int lda3, Cin3;   // a second appended block (K = 9 Cin + Cin2 + Cin3): the skip half of an up-block input that is never concatenated
   // epilogue
   const half_t* bias;    // [N] (GEGLU: packed order) or null
   const half_t* rowvec;  // per-batch vector added to every row of that batch (time embedding) or null

@@ -426,25 +426,28 @@ void op_gemm(RunCtx* c, const half_t* A, int lda, const half_t* W, const half_t*
   run_gemm(c, a, false, "gemm", 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * (geglu ? N / 2 : N) + (residual ? (double)M * N : 0)), stat_slots);
 }
 void op_conv3(RunCtx* c, const half_t* X, int B, int Hs, int Ws, int Cin, const half_t* W, const half_t* bias, int Co,
-              int stride, int up, const half_t* rowvec, int rowvec_ld, const half_t* residual, half_t* Y, int pad_lo, const half_t* X2, int Cin2) {
+              int stride, int up, const half_t* rowvec, int rowvec_ld, const half_t* residual, half_t* Y, int pad_lo, const half_t* X2, int Cin2,
+              const half_t* X3, int Cin3) {
   GemmArgs a;
   memset(&a, 0, sizeof a);
-  if (X2 && (stride != 1 || up || pad_lo != 1 || Cin2 % 64)) { fail(c, IA2P_ERR_SHAPE, "conv3x3 with an appended 1x1 block: stride 1, no upsampling, Cin2 % 64 == 0"); return; }
+  if ((X2 && (stride != 1 || up || pad_lo != 1 || Cin2 % 64)) || (X3 && (!X2 || Cin3 % 64))) { fail(c, IA2P_ERR_SHAPE, "conv3x3 with appended 1x1 blocks: stride 1, no upsampling, Cin2 / Cin3 % 64 == 0"); return; }
   a.pad = pad_lo;           // zero rows/cols before the image; one row/col of zeros after it in every mode
   const int Hv = Hs << up, Wv = Ws << up;
   a.Ho = (Hv + pad_lo + 1 - 3) / stride + 1; a.Wo = (Wv + pad_lo + 1 - 3) / stride + 1;
-  a.A = X; a.W = W; a.C = Y; a.zero = zero_page(); a.M = B * a.Ho * a.Wo; a.N = Co; a.K = 9 * Cin + (X2 ? Cin2 : 0); a.ldw = a.K; a.lda = Cin; a.ldc = Co;
+  a.A = X; a.W = W; a.C = Y; a.zero = zero_page(); a.M = B * a.Ho * a.Wo; a.N = Co; a.K = 9 * Cin + (X2 ? Cin2 : 0) + (X3 ? Cin3 : 0); a.ldw = a.K; a.lda = Cin; a.ldc = Co;
   a.A2 = X2; a.lda2 = Cin2; a.Cin2 = X2 ? Cin2 : 0;
+  a.A3 = X3; a.lda3 = Cin3; a.Cin3 = X3 ? Cin3 : 0;
   a.Hs = Hs; a.Ws = Ws; a.stride = stride; a.up = up; a.Cin = Cin;
   a.bias = bias; a.rowvec = rowvec; a.rowvec_ld = rowvec_ld; a.rows_per_batch = a.Ho * a.Wo; a.residual = residual; a.ldr = Co;
   a.m_fastest = 0;
   a.acc_scale = c->ep_acc_scale; a.bias_scale = c->ep_bias_scale; c->ep_acc_scale = c->ep_bias_scale = 1.f;
   set_prefetch(c, a, W, (size_t)Co * a.K * sizeof(half_t));
-  run_gemm(c, a, true, "conv3x3", 2.0 * a.M * (double)Co * a.K, 2.0 * ((double)B * Hs * Ws * Cin + (double)Co * a.K + (double)a.M * Co + (residual ? (double)a.M * Co : 0) + (X2 ? (double)a.M * Cin2 : 0)));
+  run_gemm(c, a, true, "conv3x3", 2.0 * a.M * (double)Co * a.K, 2.0 * ((double)B * Hs * Ws * Cin + (double)Co * a.K + (double)a.M * Co + (residual ? (double)a.M * Co : 0) + (X2 ? (double)a.M * (Cin2 + (X3 ? Cin3 : 0)) : 0)));
 }
-void op_gn(RunCtx* c, const half_t* x, half_t* y, size_t g, size_t b, int B, int HW, int C, float eps, int silu, float* partial) {
+void op_gn(RunCtx* c, const half_t* x, half_t* y, size_t g, size_t b, int B, int HW, int C, float eps, int silu, float* partial, const half_t* x2, int Ca) {
   ProfScope ps(c, PK_GN, 8.0 * B * HW * C, 4.0 * B * HW * C);
-  CHECK_LAUNCH(c, ia2p_launch_groupnorm(x, C, y, C, W_(c, g), W_(c, b), partial, B, HW, C, c->groups, eps, silu, c->stream), "groupnorm");
+  if (x2) CHECK_LAUNCH(c, ia2p_launch_groupnorm(x, Ca, y, C, W_(c, g), W_(c, b), partial, B, HW, C, c->groups, eps, silu, c->stream, x2, C - Ca, Ca), "groupnorm");
+  else CHECK_LAUNCH(c, ia2p_launch_groupnorm(x, C, y, C, W_(c, g), W_(c, b), partial, B, HW, C, c->groups, eps, silu, c->stream), "groupnorm");
 }
 void op_ln(RunCtx* c, const half_t* x, half_t* y, size_t g, size_t b, int M, int C) {
   ProfScope ps(c, PK_LN, 8.0 * M * C, 4.0 * M * C);
@@ -462,12 +465,14 @@ struct Fwd {
 
 struct RegionScope { RunCtx* c; int prev; RegionScope(RunCtx* c_, int r) : c(c_), prev(c_->region) { c->region = r; } ~RegionScope() { c->region = prev; } };
 
-static T2 run_resnet(Fwd& f, const Resnet& r, T2 x, int H, int Wd) {
+// x2 != null: the block input is [x (cx channels) | x2 (cin - cx channels)], never concatenated (up path: hidden state | skip) -- GroupNorm reads the two
+// tensors, and the shortcut rides in conv2 as two appended K-blocks. Only with the fused shortcut (c->sc_fuse); the caller concatenates otherwise.
+static T2 run_resnet(Fwd& f, const Resnet& r, T2 x, int H, int Wd, const half_t* x2 = nullptr, int cx = 0) {
   ia2p_ctx* c = f.c;
   RegionScope rs(c, PR_CONV_BLOCK);
   const int HW = H * Wd, M = f.B * HW;
   T2 n1 = wsalloc(c, (size_t)M * r.cin);
-  op_gn(c, x.p, n1.p, r.n1g, r.n1b, f.B, HW, r.cin, c->cfg.norm_eps, 1, f.gn_partial);
+  op_gn(c, x.p, n1.p, r.n1g, r.n1b, f.B, HW, r.cin, c->cfg.norm_eps, 1, f.gn_partial, x2, cx);
   T2 hh = wsalloc(c, (size_t)M * r.cout);
   op_conv3(c, n1.p, f.B, H, Wd, r.cin, W_(c, r.w1), W_(c, r.b1), r.cout, 1, 0, c->dry ? nullptr : f.temb_all.p + r.temb_off, c->temb_total, nullptr, hh.p);
   wsfree(c, n1);
@@ -483,7 +488,8 @@ static T2 run_resnet(Fwd& f, const Resnet& r, T2 x, int H, int Wd) {
     resid = xs.p;
   }
   T2 out = wsalloc(c, (size_t)M * r.cout);
-  if (cat) op_conv3(c, n2.p, f.B, H, Wd, r.cout, W_(c, r.wcat), W_(c, r.bcat), r.cout, 1, 0, nullptr, 0, nullptr, out.p, 1, c->dry ? nullptr : x.p, r.cin);
+  if (cat && x2) op_conv3(c, n2.p, f.B, H, Wd, r.cout, W_(c, r.wcat), W_(c, r.bcat), r.cout, 1, 0, nullptr, 0, nullptr, out.p, 1, x.p, cx, x2, r.cin - cx);
+  else if (cat) op_conv3(c, n2.p, f.B, H, Wd, r.cout, W_(c, r.wcat), W_(c, r.bcat), r.cout, 1, 0, nullptr, 0, nullptr, out.p, 1, x.p, r.cin);
   else op_conv3(c, n2.p, f.B, H, Wd, r.cout, W_(c, r.w2), W_(c, r.b2), r.cout, 1, 0, nullptr, 0, c->dry ? nullptr : resid, out.p);
   wsfree(c, n2);
   if (r.shortcut && !cat) wsfree(c, xs);
@@ -705,14 +711,21 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
       const int cs = skip_c.back(); skip_c.pop_back();
       const int cx = st.res[j].cin - cs;
       const long M = (long)B * H * Wd;
-      T2 cat = wsalloc(c, (size_t)M * st.res[j].cin);
-      {
-        ProfScope ps(c, PK_CONCAT, 0, 4.0 * M * st.res[j].cin);
-        CHECK_LAUNCH(c, ia2p_launch_concat(x.p, cx, cx, sk.p, cs, cs, cat.p, M, c->stream), "concat");
+      T2 r;
+      if (c->sc_fuse && c->cat_free && st.res[j].shortcut && cx % 64 == 0 && cs % 64 == 0) {
+        // torch.cat([hidden, skip]) never materialised: GroupNorm and the appended shortcut blocks of conv2 read the two tensors
+        r = run_resnet(f, st.res[j], x, H, Wd, sk.p, cx);
+        wsfree(c, x); wsfree(c, sk);
+      } else {
+        T2 cat = wsalloc(c, (size_t)M * st.res[j].cin);
+        {
+          ProfScope ps(c, PK_CONCAT, 0, 4.0 * M * st.res[j].cin);
+          CHECK_LAUNCH(c, ia2p_launch_concat(x.p, cx, cx, sk.p, cs, cs, cat.p, M, c->stream), "concat");
+        }
+        wsfree(c, x); wsfree(c, sk);
+        r = run_resnet(f, st.res[j], cat, H, Wd);
+        wsfree(c, cat);
       }
-      wsfree(c, x); wsfree(c, sk);
-      T2 r = run_resnet(f, st.res[j], cat, H, Wd);
-      wsfree(c, cat);
       if (!st.att.empty()) { T2 t = run_transformer(f, st.att[j], r, H, Wd); wsfree(c, r); r = t; }
       x = r;
     }

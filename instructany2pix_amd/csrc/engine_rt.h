@@ -29,7 +29,7 @@ bool ia2p_qproj_xattn_ok(const GemmArgs& a, const AttnArgs& x);
 hipError_t ia2p_launch_qproj_xattn(const GemmArgs& a, const AttnArgs& x, hipStream_t s);   // qxattn.hip: to_q tile -> attention core, one launch
 int ia2p_gn_chunks(int B, int HW);
 hipError_t ia2p_launch_groupnorm(const half_t* x, int ldx, half_t* y, int ldy, const half_t* gamma, const half_t* beta,
-                                 float* partial, int B, int HW, int C, int G, float eps, int silu, hipStream_t s);
+                                 float* partial, int B, int HW, int C, int G, float eps, int silu, hipStream_t s, const half_t* x2 = nullptr, int ldx2 = 0, int Ca = 0);
 hipError_t ia2p_launch_layernorm(const half_t* x, int ldx, half_t* y, int ldy, const half_t* gamma, const half_t* beta,
                                  int M, int C, float eps, hipStream_t s);
 hipError_t ia2p_launch_embed(float t, const half_t* text_embeds, const half_t* time_ids, half_t* tsin, half_t* addin,
@@ -138,6 +138,7 @@ struct RunCtx {
   const half_t* tail_pf = nullptr;   // what the LAST contraction of a pass prefetches: the first weights of the next pass (embedding MLPs)
   size_t tail_pf_bytes = 0;
   int xattn_min_tiles = 128; // ... and only when the fused launch has at least this many 128-query x head tiles (IA2P_XATTN_MIN_TILES; 40-tile launches lose 4 us each, 160-tile ones gain 1)
+  bool cat_free = true;      // up path: torch.cat([hidden, skip]) never materialised (needs sc_fuse; IA2P_CAT_FREE=0: concat_kernel, for A/B runs)
   bool sc_fuse = true;       // ResnetBlock2D: conv2 + conv_shortcut as one implicit GEMM (IA2P_SC_FUSE=0: separate 1x1 launch + residual, for A/B runs)
   bool xattn_fuse = true;    // to_q + cross-attention as one launch where the shape allows (IA2P_XATTN_FUSE=0: two launches, for A/B runs)
   bool ln_fold = true;       // LayerNorms folded into their consumer GEMMs (IA2P_LN_FOLD=0: separate layernorm_kernel launches, for A/B runs)
@@ -161,6 +162,7 @@ struct RunCtx {
     if (const char* e = getenv("IA2P_LN_FOLD")) ln_fold = atoi(e) != 0;
     if (const char* e = getenv("IA2P_XATTN_FUSE")) xattn_fuse = atoi(e) != 0;
     if (const char* e = getenv("IA2P_SC_FUSE")) sc_fuse = atoi(e) != 0;
+    if (const char* e = getenv("IA2P_CAT_FREE")) cat_free = atoi(e) != 0;
     if (const char* e = getenv("IA2P_XATTN_MIN_TILES")) xattn_min_tiles = atoi(e);
     for (int k = 0; k < PK_NCLASS; ++k) { p_ms[k] = p_fl[k] = p_by[k] = 0; p_n[k] = 0; }
     for (int k = 0; k < PR_NREGION; ++k) { r_ms[k] = r_fl[k] = r_by[k] = 0; r_n[k] = 0; }
@@ -201,8 +203,8 @@ void op_gemm(RunCtx* c, const half_t* A, int lda, const half_t* W, const half_t*
              half_t* C, int ldc, int M, int N, int K, int geglu = 0, int rpb = 0, int bstride = 0, int roff = 0, int ldw = 0,
              const LnIn* ln = nullptr, float* stats_out = nullptr, int* stat_slots = nullptr, int act = 0);
 void op_conv3(RunCtx* c, const half_t* X, int B, int Hs, int Ws, int Cin, const half_t* W, const half_t* bias, int Co,
-              int stride, int up, const half_t* rowvec, int rowvec_ld, const half_t* residual, half_t* Y, int pad_lo = 1, const half_t* X2 = nullptr, int Cin2 = 0);
-void op_gn(RunCtx* c, const half_t* x, half_t* y, size_t g, size_t b, int B, int HW, int C, float eps, int silu, float* partial);
+              int stride, int up, const half_t* rowvec, int rowvec_ld, const half_t* residual, half_t* Y, int pad_lo = 1, const half_t* X2 = nullptr, int Cin2 = 0, const half_t* X3 = nullptr, int Cin3 = 0);
+void op_gn(RunCtx* c, const half_t* x, half_t* y, size_t g, size_t b, int B, int HW, int C, float eps, int silu, float* partial, const half_t* x2 = nullptr, int Ca = 0);
 void op_ln(RunCtx* c, const half_t* x, half_t* y, size_t g, size_t b, int M, int C);
 
 // ---- weight arena plumbing shared by the three contexts

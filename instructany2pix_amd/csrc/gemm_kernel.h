@@ -177,7 +177,10 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   const int nk_all = hK / BK;
   const int kt0 = (int)((long)split * nk_all / nsplit), kt1 = (int)((long)(split + 1) * nk_all / nsplit);   // this workgroup's k-tiles
   int tap = (kt0 * BK) / (CONV ? p.Cin : BK), ci0 = CONV ? (kt0 * BK) % p.Cin : 0;  // conv: position of the k-tile being staged
-  if (CONV && tap >= 9) { ci0 = kt0 * BK - 9 * p.Cin; tap = 9; }                      // (inside the appended 1x1 block)
+  if (CONV && tap >= 9) {                                                             // (inside the appended 1x1 blocks)
+    ci0 = kt0 * BK - 9 * p.Cin; tap = 9;
+    if (ci0 >= p.Cin2) { ci0 -= p.Cin2; tap = 10; }
+  }
   bool tap_fresh = true;
   int cin_main = 0, cin_extra = 0;                         // (two named scalars: a select between two argument FIELDS became a 2-entry table in scratch)
   if (CONV) { cin_main = p.Cin; cin_extra = p.Cin2; asm volatile("" : "+s"(cin_main), "+s"(cin_extra)); }
@@ -205,12 +208,24 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
             a_inc[i] = ok ? BK : 0;
           }
         } else {              // appended 1x1 block: the output pixel itself, from the second tensor (stride 1: pixel index = output row)
+          // (two copies of the loop, not a select between p.A2 and p.A3: a select between FIELDS of the by-value argument struct is compiled
+          //  as an indexed access and pushes the whole struct to scratch)
+          if (tap == 9) {
 #pragma unroll
-          for (int i = 0; i < A_PW; ++i) {
-            const int m = bm0 + (wave * A_PW + i) * RPP + srow;      // (re-derived: happens once per launch)
-            const bool ok = m < hM;
-            a_ptr[i] = ok ? p.A2 + (size_t)m * p.lda2 + ci0 + a_ch[i] : hzero;
-            a_inc[i] = ok ? BK : 0;
+            for (int i = 0; i < A_PW; ++i) {
+              const int m = bm0 + (wave * A_PW + i) * RPP + srow;      // (re-derived: happens once or twice per launch)
+              const bool ok = m < hM;
+              a_ptr[i] = ok ? p.A2 + (size_t)m * p.lda2 + ci0 + a_ch[i] : hzero;
+              a_inc[i] = ok ? BK : 0;
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < A_PW; ++i) {
+              const int m = bm0 + (wave * A_PW + i) * RPP + srow;
+              const bool ok = m < hM;
+              a_ptr[i] = ok ? p.A3 + (size_t)m * p.lda3 + ci0 + a_ch[i] : hzero;
+              a_inc[i] = ok ? BK : 0;
+            }
           }
         }
         tap_fresh = false;
@@ -218,7 +233,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
 #pragma unroll
       for (int i = 0; i < A_PW; ++i) { GLDS16(a_ptr[i], sA + i * 1024); a_ptr[i] += a_inc[i]; }
       ci0 += BK;
-      if (ci0 >= (tap < 9 ? cin_main : cin_extra)) { ci0 = 0; ++tap; tap_fresh = true; }
+      if (tap < 10 && ci0 >= (tap < 9 ? cin_main : cin_extra)) { ci0 = 0; ++tap; tap_fresh = true; }      // (the last block runs to the end of K)
     } else {
 #pragma unroll
       for (int i = 0; i < A_PW; ++i) { GLDS16(a_ptr[i], sA + i * 1024); a_ptr[i] += a_inc[i]; }   // running pointers: no per-step multiply

@@ -24,16 +24,17 @@ struct GNArgs {
   int arows;                       // pixels per apply block (finer than the stats chunking)
   int ldx, ldy;
   float eps; int silu;
+  const half_t* x2; int ldx2, Ca;   // optional second source: channels [Ca, C) come from x2 (the skip half of an up-block input that is never concatenated)
 };
 
 // thread map: TX = (C/8)/V threads across channels (V vectors of 8 channels each), TY = blockDim/TX rows in flight
 template <int V>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* ax, half_t* ay, const half_t* agamma, const half_t* abeta, float* apartial, int aB, int aHW, int aC, int aG,
-                                                           int achunks, int arows_, int aarows, int aldx, int aldy, float aeps, int asilu) {
+                                                           int achunks, int arows_, int aarows, int aldx, int aldy, float aeps, int asilu, const half_t* ax2, int aldx2, int aCa) {
   // scalar arguments (the first 16 dwords are preloaded into SGPRs: build.py PRELOAD), re-assembled into the descriptor the body uses
   GNArgs p;
   p.x = ax; p.y = ay; p.gamma = agamma; p.beta = abeta; p.partial = apartial; p.B = aB; p.HW = aHW; p.C = aC; p.G = aG; p.chunks = achunks;
-  p.rows = arows_; p.arows = aarows; p.ldx = aldx; p.ldy = aldy; p.eps = aeps; p.silu = asilu;
+  p.rows = arows_; p.arows = aarows; p.ldx = aldx; p.ldy = aldy; p.eps = aeps; p.silu = asilu; p.x2 = ax2; p.ldx2 = aldx2; p.Ca = aCa;
   extern __shared__ float red[];   // [2][TY][C]
   const int nvec = p.C >> 3, TX = nvec / V, TY = blockDim.x / TX;
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
@@ -44,7 +45,14 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* ax, half_t*
 #pragma unroll
     for (int e = 0; e < 8; ++e) { s[v][e] = 0.f; ss[v][e] = 0.f; }
   if (ty < TY) {
-    const half_t* base = p.x + (size_t)b * p.HW * p.ldx;
+    const half_t* src[V]; int sld[V];                 // a thread's channels are fixed: so is the tensor they come from
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const int c0 = (tx + v * TX) * 8;
+      const bool second = p.x2 && c0 >= p.Ca;
+      src[v] = second ? p.x2 + (size_t)b * p.HW * p.ldx2 + (c0 - p.Ca) : p.x + (size_t)b * p.HW * p.ldx + c0;
+      sld[v] = second ? p.ldx2 : p.ldx;
+    }
     for (int r = r0 + ty; r < r1; r += 4 * TY) {       // 4 rows (4*V 16-byte loads) in flight per thread
       h8 d[4][V];
 #pragma unroll
@@ -52,7 +60,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* ax, half_t*
 #pragma unroll
         for (int v = 0; v < V; ++v) {
           const int rr = min(r + u * TY, r1 - 1);
-          d[u][v] = *(const h8*)(base + (size_t)rr * p.ldx + (tx + v * TX) * 8);
+          d[u][v] = *(const h8*)(src[v] + (size_t)rr * sld[v]);
         }
 #pragma unroll
       for (int u = 0; u < 4; ++u)
@@ -92,11 +100,11 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* ax, half_t*
 
 template <int V>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* ax, half_t* ay, const half_t* agamma, const half_t* abeta, float* apartial, int aB, int aHW, int aC, int aG,
-                                                           int achunks, int arows_, int aarows, int aldx, int aldy, float aeps, int asilu) {
+                                                           int achunks, int arows_, int aarows, int aldx, int aldy, float aeps, int asilu, const half_t* ax2, int aldx2, int aCa) {
   // scalar arguments (the first 16 dwords are preloaded into SGPRs: build.py PRELOAD), re-assembled into the descriptor the body uses
   GNArgs p;
   p.x = ax; p.y = ay; p.gamma = agamma; p.beta = abeta; p.partial = apartial; p.B = aB; p.HW = aHW; p.C = aC; p.G = aG; p.chunks = achunks;
-  p.rows = arows_; p.arows = aarows; p.ldx = aldx; p.ldy = aldy; p.eps = aeps; p.silu = asilu & 1;
+  p.rows = arows_; p.arows = aarows; p.ldx = aldx; p.ldy = aldy; p.eps = aeps; p.silu = asilu & 1; p.x2 = ax2; p.ldx2 = aldx2; p.Ca = aCa;
   const bool wt = (asilu & 2) != 0;          // write-through output (bit 1 of the flag word)
   extern __shared__ float stat[];   // [G][2] mean, rstd
   const int nvec = p.C >> 3, TX = nvec / V, TY = blockDim.x / TX;
@@ -141,7 +149,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* ax, half_t*
       sh[v][e] = (float)be[e] - mean * sc[v][e];
     }
   }
-  const half_t* base = p.x + (size_t)b * p.HW * p.ldx;
+  const half_t* src[V]; int sld[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    const int c0 = (tx + v * TX) * 8;
+    const bool second = p.x2 && c0 >= p.Ca;
+    src[v] = second ? p.x2 + (size_t)b * p.HW * p.ldx2 + (c0 - p.Ca) : p.x + (size_t)b * p.HW * p.ldx + c0;
+    sld[v] = second ? p.ldx2 : p.ldx;
+  }
   half_t* obase = p.y + (size_t)b * p.HW * p.ldy;
   const __amdgpu_buffer_rsrc_t y_rsrc = wt_rsrc((void*)obase, (size_t)p.HW * p.ldy * 2);
   for (int r = r0 + ty; r < r1; r += 4 * TY) {         // 4 rows in flight per thread
@@ -151,7 +166,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* ax, half_t*
 #pragma unroll
       for (int v = 0; v < V; ++v) {
         const int rr = min(r + u * TY, r1 - 1);
-        d[u][v] = *(const h8*)(base + (size_t)rr * p.ldx + (tx + v * TX) * 8);
+        d[u][v] = *(const h8*)(src[v] + (size_t)rr * sld[v]);
       }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
@@ -181,8 +196,10 @@ int ia2p_gn_chunks(int B, int HW) {
 }
 
 hipError_t ia2p_launch_groupnorm(const half_t* x, int ldx, half_t* y, int ldy, const half_t* gamma, const half_t* beta,
-                                 float* partial, int B, int HW, int C, int G, float eps, int silu, hipStream_t s) {
+                                 float* partial, int B, int HW, int C, int G, float eps, int silu, hipStream_t s, const half_t* x2, int ldx2, int Ca) {
+  if (x2 && (Ca % 8 || Ca <= 0 || Ca >= C)) return hipErrorInvalidValue;
   GNArgs a;
+  a.x2 = x2; a.ldx2 = ldx2; a.Ca = Ca;
   a.x = x; a.y = y; a.gamma = gamma; a.beta = beta; a.partial = partial;
   a.B = B; a.HW = HW; a.C = C; a.G = G; a.ldx = ldx; a.ldy = ldy; a.eps = eps; a.silu = silu;
   a.chunks = ia2p_gn_chunks(B, HW);
@@ -204,11 +221,11 @@ hipError_t ia2p_launch_groupnorm(const half_t* x, int ldx, half_t* y, int ldy, c
   if (sm1 > 65536) return hipErrorInvalidValue;
   const int wtf = ((ia2p_wt_mask() & 4) && (size_t)HW * ldy * 2 < (size_t)0x7ffffff0) ? 2 : 0;      // write-through y (per batch element: 32-bit offsets)
   if (V == 1) {
-    hipLaunchKernelGGL(gn_stats_kernel<1>, grid, block, sm1, s, a.x, a.y, a.gamma, a.beta, a.partial, a.B, a.HW, a.C, a.G, a.chunks, a.rows, a.arows, a.ldx, a.ldy, a.eps, a.silu);
-    hipLaunchKernelGGL(gn_apply_kernel<1>, agrid, block, sm2, s, a.x, a.y, a.gamma, a.beta, a.partial, a.B, a.HW, a.C, a.G, a.chunks, a.rows, a.arows, a.ldx, a.ldy, a.eps, a.silu | wtf);
+    hipLaunchKernelGGL(gn_stats_kernel<1>, grid, block, sm1, s, a.x, a.y, a.gamma, a.beta, a.partial, a.B, a.HW, a.C, a.G, a.chunks, a.rows, a.arows, a.ldx, a.ldy, a.eps, a.silu, a.x2, a.ldx2, a.Ca);
+    hipLaunchKernelGGL(gn_apply_kernel<1>, agrid, block, sm2, s, a.x, a.y, a.gamma, a.beta, a.partial, a.B, a.HW, a.C, a.G, a.chunks, a.rows, a.arows, a.ldx, a.ldy, a.eps, a.silu | wtf, a.x2, a.ldx2, a.Ca);
   } else {
-    hipLaunchKernelGGL(gn_stats_kernel<2>, grid, block, sm1, s, a.x, a.y, a.gamma, a.beta, a.partial, a.B, a.HW, a.C, a.G, a.chunks, a.rows, a.arows, a.ldx, a.ldy, a.eps, a.silu);
-    hipLaunchKernelGGL(gn_apply_kernel<2>, agrid, block, sm2, s, a.x, a.y, a.gamma, a.beta, a.partial, a.B, a.HW, a.C, a.G, a.chunks, a.rows, a.arows, a.ldx, a.ldy, a.eps, a.silu | wtf);
+    hipLaunchKernelGGL(gn_stats_kernel<2>, grid, block, sm1, s, a.x, a.y, a.gamma, a.beta, a.partial, a.B, a.HW, a.C, a.G, a.chunks, a.rows, a.arows, a.ldx, a.ldy, a.eps, a.silu, a.x2, a.ldx2, a.Ca);
+    hipLaunchKernelGGL(gn_apply_kernel<2>, agrid, block, sm2, s, a.x, a.y, a.gamma, a.beta, a.partial, a.B, a.HW, a.C, a.G, a.chunks, a.rows, a.arows, a.ldx, a.ldy, a.eps, a.silu | wtf, a.x2, a.ldx2, a.Ca);
   }
   return hipGetLastError();
 }
