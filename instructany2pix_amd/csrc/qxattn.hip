@@ -11,10 +11,13 @@
 // to running `gemm_f16_kernel<128, 64, ...>` + `attention_f16_kernel` (tests/test_ops_gpu.py).
 #include "gemm_kernel.h"
 
+#ifndef IA2P_QX_STAGES
+#define IA2P_QX_STAGES 2      // LDS ring depth of the projection loop (build-time knob for A/B builds)
+#endif
 template <int MODE>      // attention core mode: 0 one key segment; 1 text + <= 64 image-token keys; 2 generic two segments
 __global__ __launch_bounds__(256, 2) void qproj_xattn_kernel(const half_t* hA, const half_t* hW, const half_t* hzero, int hM, int hN, int hK, int hlda, int hldw, int hrpb,
                                                              int hbstride, int hroff, int hsplitk, int hgroup_w, const GemmArgs p, const AttnArgs xa) {
-  gemm_tile_body<128, 64, 2, false, 2, 64, 0, 2, MODE + 1>(hA, hW, hzero, hM, hN, hK, hlda, hldw, hrpb, hbstride, hroff, hsplitk, hgroup_w, p, &xa);
+  gemm_tile_body<128, 64, IA2P_QX_STAGES, false, 2, 64, 0, 2, MODE + 1>(hA, hW, hzero, hM, hN, hK, hlda, hldw, hrpb, hbstride, hroff, hsplitk, hgroup_w, p, &xa);
 }
 
 // Q = epilogue(A . W^T) is [B * Nq, heads * 64]; x.Q / x.ldq are ignored (Q stays on chip). Requires Nq % 128 == 0 (a tile must not straddle
@@ -29,8 +32,8 @@ bool ia2p_qproj_xattn_ok(const GemmArgs& a, const AttnArgs& x) {
 
 hipError_t ia2p_launch_qproj_xattn(const GemmArgs& a, const AttnArgs& x, hipStream_t s) {
   if (!ia2p_qproj_xattn_ok(a, x)) return hipErrorInvalidValue;
-  constexpr int BM = 128, BN = 64, SMEM = 65536;       // K / V images of the attention core: 2 x 32 KiB (the GEMM ring needs 48 KiB)
-  static_assert(EpiCfg<BM, BN, 2, 2, 64, 2>::SMEM <= SMEM, "LDS budget");
+  constexpr int BM = 128, BN = 64, SMEM = EpiCfg<128, 64, IA2P_QX_STAGES, 2, 64, 2>::SMEM > 65536 ? EpiCfg<128, 64, IA2P_QX_STAGES, 2, 64, 2>::SMEM : 65536;       // K / V images of the attention core: 2 x 32 KiB (the GEMM ring needs 48 KiB)
+  static_assert(EpiCfg<BM, BN, IA2P_QX_STAGES, 2, 64, 2>::SMEM <= SMEM, "LDS budget");
   static bool attr_set[64] = {false};                  // per device (the attribute is)
   int dev = 0;
   (void)hipGetDevice(&dev);
