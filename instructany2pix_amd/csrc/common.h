@@ -66,6 +66,9 @@ static inline int ia2p_wt_mask() {
   return m;
 }
 
+// the folded-LayerNorm epilogue of one element, rstd * (acc - mean * colsum) + fbias, as TWO explicit FMAs: every site (GEMM epilogues, the K-split
+// reduce, the fused to_q tile) must round identically -- left to the compiler, the contraction of the plain expression differed between two instantiations
+__device__ __forceinline__ float ln_fold_f(float acc, float mean, float rstd, float colsum, float fbias) { return fmaf(rstd, fmaf(-mean, colsum, acc), fbias); }
 __device__ __forceinline__ float act_f(float x, int act) { return act == 1 ? gelu_erf_f(x) : act == 2 ? quick_gelu_f(x) : act == 3 ? gelu_tanh_f(x) : x; }
 
 // ---- launch descriptors shared by kernels and the host executor --------------------------------------

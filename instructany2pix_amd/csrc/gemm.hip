@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* hpartia
       if (p.ln_stats) {
         const f4 cs = *(const f4*)(p.ln_cs + n), lb = *(const f4*)(p.ln_bias + n);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = rs * (v[r] - mu * cs[r]) + lb[r];
+        for (int r = 0; r < 4; ++r) v[r] = ln_fold_f(v[r], mu, rs, cs[r], lb[r]);
       } else {
         const float e_as = p.acc_scale == 0.f ? 1.f : p.acc_scale, e_bs = p.bias_scale == 0.f ? 1.f : p.bias_scale;
         v[0] *= e_as; v[1] *= e_as; v[2] *= e_as; v[3] *= e_as;

@@ -503,7 +503,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
         float v[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
         if (p.ln_stats) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = rs * (v[e] - mu * ln_cs[cl + e]) + ln_lb[cl + e];
+          for (int e = 0; e < 8; ++e) v[e] = ln_fold_f(v[e], mu, rs, ln_cs[cl + e], ln_lb[cl + e]);
         } else {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] *= e_as;
@@ -615,8 +615,8 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
             const float mu = ln_rows[ch * CR + r], rs = ln_rows[BM + ch * CR + r];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-              va[e] = rs * (va[e] - mu * ln_cs[cl + e]) + ln_lb[cl + e];
-              vg[e] = rs * (vg[e] - mu * ln_cs[cl + 16 + e]) + ln_lb[cl + 16 + e];
+              va[e] = ln_fold_f(va[e], mu, rs, ln_cs[cl + e], ln_lb[cl + e]);
+              vg[e] = ln_fold_f(vg[e], mu, rs, ln_cs[cl + 16 + e], ln_lb[cl + 16 + e]);
             }
           } else {
 #pragma unroll
@@ -661,7 +661,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
             if (p.ln_stats) {
               const float mu = ln_rows[ch * CR + r], rs = ln_rows[BM + ch * CR + r];
 #pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] = rs * (v[e] - mu * ln_cs[cl + e]) + ln_lb[cl + e];
+              for (int e = 0; e < 8; ++e) v[e] = ln_fold_f(v[e], mu, rs, ln_cs[cl + e], ln_lb[cl + e]);
             } else {
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] *= e_as;
@@ -710,7 +710,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
               if (p.ln_stats) {
                 const float mu = ln_rows[ch * CR + r], rs = ln_rows[BM + ch * CR + r];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = rs * (v[e] - mu * ln_cs[cl + e]) + ln_lb[cl + e];
+                for (int e = 0; e < 4; ++e) v[e] = ln_fold_f(v[e], mu, rs, ln_cs[cl + e], ln_lb[cl + e]);
               } else {
                 v[0] *= e_as; v[1] *= e_as; v[2] *= e_as; v[3] *= e_as;
                 if (p.bias) { const h4 b = *(const h4*)(p.bias + n); v[0] = fmaf((float)b[0], e_bs, v[0]); v[1] = fmaf((float)b[1], e_bs, v[1]); v[2] = fmaf((float)b[2], e_bs, v[2]); v[3] = fmaf((float)b[3], e_bs, v[3]); }
