@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-python3 bench.py --batch 2 --latent 128 --ctx 81 --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-secondary --kernel-table gpurun_out/kt_1024b2.json > gpurun_out/kt_1024b2.out 2> gpurun_out/kt_1024b2.err
+python3 bench.py --batch ${KB:-2} --latent 128 --ctx ${KC:-81} --steps 10 --warmup 3 --repeats 1 --no-cpu-baseline --no-secondary --kernel-table gpurun_out/kt_1024b2.json > gpurun_out/kt_1024b2.out 2> gpurun_out/kt_1024b2.err
 python3 - <<PY
 import json
 d = json.load(open("gpurun_out/kt_1024b2.json"))
