@@ -2,6 +2,7 @@
 """Headline benchmark of the denoise hot path: denoise-steps/sec (512x512, 50-step DDIM, batch 8).
 
   python bench.py --gpus 1 --steps 50 --warmup 3
+  python bench.py --gpus N ...            (no launcher in the environment: starts its own N ranks, one per GPU, and relays rank 0's line)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One "step" = one pass of the hot path over one batch: conditional-UNet evaluation (SDXL-base architecture,
@@ -123,6 +124,91 @@ def cpu_baseline(cfg, unet_specs, ip_specs, seed, dev, inputs_cpu, L, sample_bat
             times.append(time.time() - t0)
     log(f"[cpu_baseline] step times {times} (first = warm-up)")
     return times[1:], cores
+
+
+
+def self_launch(n, argv):
+    """`--gpus N` without a launcher in the environment (no WORLD_SIZE): start N fresh rank processes -- one per GPU, RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set, a free rendezvous port -- relay rank 0's JSON line, and fail if any rank fails. This parent never touches a GPU (no torch import,
+    no HIP call): the ranks are ordinary children, not exec'ed replacements of a process that initialised the device."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), IA2P_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out = procs[0].stdout.read().decode()
+    rcs = []
+    deadline = time.time() + 3600
+    for p in procs:
+        try:
+            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rcs.append(-9)
+    if any(rcs):
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        log(f"[bench] rank exit codes {rcs}: a rank failed, no result line")
+        return 1
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    if not lines:
+        log("[bench] rank 0 printed no result line")
+        return 1
+    print(lines[-1], flush=True)
+    return 0
+
+
+class StubWorkload:
+    """IA2P_BENCH_STUB=<ms>: a step that only sleeps. Exercises the launcher, the rendezvous, the barrier / max-over-ranks timing and the result line
+    on a box without a GPU (tests/test_dist_cpu.py); its line says "stub" in `metric` and `data` and is never a measurement."""
+
+    def __init__(self, ms, rank):
+        self.ms, self.rank = ms, rank
+
+    def run(self, n):
+        time.sleep(1e-3 * self.ms * n * (1.0 + 0.25 * self.rank))       # rank r is 25 % slower than rank r-1: max-over-ranks must pick the last one
+
+    def timed(self, n):
+        t0 = time.perf_counter()
+        self.run(n)
+        dt = time.perf_counter() - t0
+        return dt, 1e3 * dt
+
+
+def stub_main(args):
+    import torch
+    from instructany2pix_amd import dist as D
+    rank, world, _ = D.init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    wl = StubWorkload(float(os.environ["IA2P_BENCH_STUB"]), rank)
+    buf = torch.arange(1 << 16, dtype=torch.float32) if rank == 0 else torch.zeros(1 << 16)
+    t_b = time.time()
+    D.broadcast_flat(buf, src=0, chunk_bytes=1 << 16)
+    bcast_s = time.time() - t_b
+    assert float(buf[-1]) == float((1 << 16) - 1), "weight broadcast did not arrive"
+    wl.run(args.warmup)
+    D.barrier()
+    wall, _ = wl.timed(args.steps)
+    D.barrier()
+    elapsed = D.max_over_ranks(wall)
+    per_rank = D.gather_floats(1e3 * wall / args.steps)
+    if rank == 0:
+        print(json.dumps({"metric": "STUB (sleeping step, no GPU work): launcher / rendezvous / timing plumbing only", "value": world * args.steps / elapsed, "unit": "steps/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "stub",
+                          "config": {"workload": "stub", "ranks": world, "dist_backend": torch.distributed.get_backend() if world > 1 else "none (single process)",
+                                     "weight_broadcast": {"bytes": int(buf.numel() * 4), "seconds": bcast_s}, "per_rank_ms_per_step": per_rank,
+                                     "self_launched": bool(os.environ.get("IA2P_BENCH_SELF_LAUNCHED"))}}), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 class Workload:
@@ -264,6 +350,11 @@ def main():
     ap.add_argument("--kernel-table", default=None, help="write the per-kernel timing table (JSON) to this file")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:      # no launcher around us: be the launcher (before anything touches a GPU)
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+    if os.environ.get("IA2P_BENCH_STUB"):
+        return stub_main(args)
+
     import torch
     from instructany2pix_amd import dist as D
     from instructany2pix_amd.attention_processor import AttnProcessor2_0
@@ -273,7 +364,7 @@ def main():
 
     rank, world, local = D.init_distributed()
     if world != args.gpus:
-        log(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: refusing to print a line whose n_gpus would not be what was asked for")
     dev = torch.device(f"cuda:{os.environ.get('IA2P_FORCE_DEVICE', local)}")     # (override: tests with several ranks on one GPU)
     torch.cuda.set_device(dev)
     cfg = sdxl_base() if args.unet == "base" else sdxl_refiner()
@@ -344,6 +435,7 @@ def main():
     wall, ev_ms = wl.timed(args.steps)
     D.barrier()
     elapsed = D.max_over_ranks(wall, device=dev if world > 1 else "cpu")
+    per_rank_ms = D.gather_floats(1e3 * wall / args.steps, device=dev if world > 1 else "cpu")      # a straggler shows here
     assert torch.isfinite(wl.x).all(), "non-finite latents after the timed run"
     runs = [ev_ms / args.steps]
     for _ in range(max(0, args.repeats - 1)):
@@ -363,7 +455,8 @@ def main():
                                f"context {L} tokens ({'77 text + %d IP-Adapter image tokens' % (L - 77) if use_ip else 'text only'}), {'SDXL-base UNet (2.567 G params) + IP-Adapter' if args.unet == 'base' else 'SDXL-refiner UNet (2.260 G params)'}, "
                                f"synthetic seeded weights", "global_batch": B * world, "parallelism": f"dp{world}", "kernel_plans": plans,
                    "image_steps_per_s": world * (B // 2 if args.guidance else B) * args.steps / elapsed,
-                   "ranks": world, "dist_backend": backend or "none (single process)",
+                   "ranks": world, "dist_backend": backend or "none (single process)", "per_rank_ms_per_step": per_rank_ms,
+                   "self_launched": bool(os.environ.get("IA2P_BENCH_SELF_LAUNCHED")),
                    "weight_broadcast": {"bytes": int(unet.arena_raw.numel()), "seconds": bcast_s, "note": "head of the arena only; LayerNorm-folded tail derived per rank"} if world > 1 else None},
         "timing": {"method": "rank 0: HIP events on the launch stream around each K-step run; run 0 is the region `value` is quoted on (wall clock, max over ranks)",
                    "runs_ms_per_step": runs, "median_ms_per_step": statistics.median(runs), "steps_per_s_median": 1e3 / statistics.median(runs)},

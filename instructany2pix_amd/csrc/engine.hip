@@ -390,7 +390,6 @@ static void run_gemm(RunCtx* c, GemmArgs& a, bool conv, const char* what, double
          (size_t)pl.splitk * a.M * a.N * sizeof(float), c->tune_slab_bytes);
     return;
   }
-  if (stat_slots) *stat_slots = (pl.splitk > 1 && !ia2p_splitk_inkernel(a.M, a.N, pl.splitk)) ? 1 : (a.N + IA2P_GEMM_TILES[pl.variant].bn - 1) / IA2P_GEMM_TILES[pl.variant].bn;
   T2 slab{(size_t)-1, nullptr};
   if (pl.splitk > 1) {
     a.splitk = pl.splitk;
@@ -398,14 +397,17 @@ static void run_gemm(RunCtx* c, GemmArgs& a, bool conv, const char* what, double
     else { slab = wsalloc(c, (size_t)pl.splitk * a.M * a.N * 2); a.partial = (float*)slab.p; }
   }
   struct Rel { RunCtx* c; T2 t; ~Rel() { wsfree(c, t); } } rel{c, slab};
+  int combined = pl.splitk > 1 && ia2p_splitk_inkernel(a.M, a.N, pl.splitk);     // (dry pass: the policy's answer; the launcher reports what it really did)
   {
     ProfScope ps(c, (conv ? PK_CONV0 : PK_GEMM0) + pl.variant, flops, bytes);
-    CHECK_LAUNCH(c, ia2p_launch_gemm_variant(a, conv, pl.variant, c->stream, false), what);
+    CHECK_LAUNCH(c, ia2p_launch_gemm_variant(a, conv, pl.variant, c->stream, false, &combined), what);
   }
-  if (pl.splitk > 1 && !ia2p_splitk_inkernel(a.M, a.N, pl.splitk)) {
+  if (pl.splitk > 1 && !combined) {
     ProfScope ps(c, PK_REDUCE, 0, (double)pl.splitk * a.M * a.N * 4 + 2.0 * a.M * a.N);
     CHECK_LAUNCH(c, ia2p_launch_splitk_reduce(a, c->stream), what);
   }
+  // row-statistics slots of this launch's output: one per tile column, or ONE when a reduce launch wrote it
+  if (stat_slots) *stat_slots = (pl.splitk > 1 && !combined) ? 1 : (a.N + IA2P_GEMM_TILES[pl.variant].bn - 1) / IA2P_GEMM_TILES[pl.variant].bn;
 }
 
 void op_gemm(RunCtx* c, const half_t* A, int lda, const half_t* W, const half_t* bias, const half_t* residual, int ldr,
@@ -1085,9 +1087,9 @@ ia2p_status ia2p_gemm_ex(void* stream, const void* A, const void* W, const void*
   if (ln) { a.ln_stats = ln->stats; a.ln_slots = ln->slots; a.ln_cs = ln->colsum; a.ln_bias = ln->fbias; a.ln_eps = ln->eps; }
   a.stats_out = stats_out;
   if (splitk > 1) { a.splitk = splitk; a.partial = partial; }
-  int pick = 0;
-  hipError_t e = ia2p_launch_gemm(a, false, (hipStream_t)stream, &pick);
-  if (stats_slots && pick >= 0 && pick < IA2P_GEMM_NVARIANT) *stats_slots = (splitk > 1 && !ia2p_splitk_inkernel(M, N, splitk)) ? 1 : (N + IA2P_GEMM_TILES[pick].bn - 1) / IA2P_GEMM_TILES[pick].bn;
+  int pick = 0, combined = 0;
+  hipError_t e = ia2p_launch_gemm(a, false, (hipStream_t)stream, &pick, &combined);
+  if (stats_slots && pick >= 0 && pick < IA2P_GEMM_NVARIANT) *stats_slots = (splitk > 1 && !combined) ? 1 : (N + IA2P_GEMM_TILES[pick].bn - 1) / IA2P_GEMM_TILES[pick].bn;
   RET_HIP(e, "gemm_ex");
 }
 ia2p_status ia2p_gemm_splitk(void* stream, const void* A, const void* W, const void* bias, const void* residual, void* C, int M, int N, int K,

@@ -19,8 +19,9 @@
 #include "common.h"
 
 // ---- kernel launchers (gemm.hip, attention.hip, norm.hip, misc.hip) ------------------------------------------
-hipError_t ia2p_launch_gemm(const GemmArgs& a, bool conv, hipStream_t s, int* picked);
-hipError_t ia2p_launch_gemm_variant(const GemmArgs& a, bool conv, int variant, hipStream_t s, bool with_reduce = true);
+hipError_t ia2p_launch_gemm(const GemmArgs& a, bool conv, hipStream_t s, int* picked, int* combined = nullptr);
+// *combined (optional): 1 when a K-split launch finishes inside the launch (ticket counters attached), 0 when its slabs wait for ia2p_launch_splitk_reduce
+hipError_t ia2p_launch_gemm_variant(const GemmArgs& a, bool conv, int variant, hipStream_t s, bool with_reduce = true, int* combined = nullptr);
 hipError_t ia2p_launch_splitk_reduce(const GemmArgs& a, hipStream_t s);
 bool ia2p_splitk_inkernel(int M, int N, int splitk);
 void ia2p_gemm_candidates(int M, int N, int K, bool conv, bool geglu, size_t max_slab_bytes, double slack, std::vector<GemmPlan>* out);

@@ -118,12 +118,39 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* hpartia
 // reduce launch costs more than the last arriver's serial slab read. Measured on one box (profiles/r02e_splitk_inkernel_ab.txt): every K-split
 // in-launch: batch 8 +0.6 ms / step, batch 1 -0.16 ms; large slabs are summed faster by a whole-chip reduce launch than by 160 lone workgroups.
 // IA2P_SPLITK_INKERNEL = byte threshold on splitk*M*N*4 (0: never, default 8 MiB).
+static long long g_sk_limit = -1;     // bytes of splitk*M*N*4 up to which a K split combines inside the launch; < 0: IA2P_SPLITK_INKERNEL or the default
+extern "C" void ia2p_debug_set_splitk_inkernel(long long bytes) { g_sk_limit = bytes; }
 bool ia2p_splitk_inkernel(int M, int N, int splitk) {
-  static const size_t limit = getenv("IA2P_SPLITK_INKERNEL") ? (size_t)atoll(getenv("IA2P_SPLITK_INKERNEL")) : ((size_t)8 << 20);
+  static const size_t env_limit = getenv("IA2P_SPLITK_INKERNEL") ? (size_t)atoll(getenv("IA2P_SPLITK_INKERNEL")) : ((size_t)8 << 20);
+  const size_t limit = g_sk_limit >= 0 ? (size_t)g_sk_limit : env_limit;
   return splitk > 1 && (size_t)splitk * M * N * sizeof(float) <= limit;
 }
 static int g_force_splitk = -1;    // test/tuning hook
 extern "C" void ia2p_debug_set_gemm_splitk(int s) { g_force_splitk = s; }
+
+// Ticket counters of the in-launch K-split combine: one int per output tile, zero between launches (the last arriver of a tile resets its
+// counter). One buffer per (device, stream): launches on one stream are ordered, so two K-split launches can only share counters when they cannot
+// run at the same time -- contexts, executors and serving threads that work on different streams never see each other's tickets.
+int ia2p_sk_counter_capacity() { return 1 << 18; }
+int* ia2p_sk_counters(hipStream_t s, int tiles) {
+  if (tiles > ia2p_sk_counter_capacity()) return nullptr;
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, int*> pool;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = pool.find({dev, s});
+  if (it != pool.end()) return it->second;
+  int* p = nullptr;
+  const size_t bytes = (size_t)ia2p_sk_counter_capacity() * sizeof(int);
+  if (hipMalloc((void**)&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess) {      // (hipMemset: synchronous with respect to the host, done before the first launch)
+    (void)hipGetLastError();
+    if (p) (void)hipFree(p);
+    p = nullptr;                      // remembered: this stream's K-splits are finished by reduce launches
+  }
+  pool[{dev, s}] = p;
+  return p;
+}
 
 // ---- tile / split-K choice: a small analytic cost model, calibrated on MI355X against the in-place timings of ~5400
 // candidate launches that ia2p_autotune logged (IA2P_TUNE_LOG=1) for three workloads (batch 8 and 2 at 512^2, batch 4 at
@@ -280,12 +307,20 @@ hipError_t ia2p_launch_splitk_reduce(const GemmArgs& a0, hipStream_t s) {
   return hipGetLastError();
 }
 
+// The ONE place that decides how a K-split launch is finished: counters attached -> the last-arriving K-slice of every tile combines inside the launch;
+// no counters (policy, no buffer for this stream, too many tiles) -> the slices leave their slabs and splitk_reduce_kernel finishes, launched here
+// (with_reduce) or by the caller, who learns which way it went through *combined.
 template <bool CONV>
-static hipError_t launch_any(const GemmArgs& a, int v, hipStream_t s, bool with_reduce) {
-  if (a.splitk > 1 && !a.partial) return hipErrorInvalidValue;
+static hipError_t launch_any(const GemmArgs& a0, int v, hipStream_t s, bool with_reduce, int* combined) {
+  if (a0.splitk > 1 && !a0.partial) return hipErrorInvalidValue;
   hipError_t e;
   if (v < 0 || v >= IA2P_GEMM_NVARIANT) return hipErrorInvalidValue;
-  if (a.geglu && IA2P_GEMM_TILES[v].bn % 32) return hipErrorInvalidValue;   // a (value, gate) block of 32 packed columns must not straddle tiles
+  if (a0.geglu && IA2P_GEMM_TILES[v].bn % 32) return hipErrorInvalidValue;   // a (value, gate) block of 32 packed columns must not straddle tiles
+  GemmArgs a = a0;
+  a.sk_counters = nullptr;
+  if (a.splitk > 1 && ia2p_splitk_inkernel(a.M, a.N, a.splitk))
+    a.sk_counters = ia2p_sk_counters(s, ((a.M + IA2P_GEMM_TILES[v].bm - 1) / IA2P_GEMM_TILES[v].bm) * ((a.N + IA2P_GEMM_TILES[v].bn - 1) / IA2P_GEMM_TILES[v].bn));
+  if (combined) *combined = a.sk_counters != nullptr;
   switch (v) {
 #define IA2P_TILE_CASE(ID, BM_, BN_, ST_)                                                                                    \
   case ID:                                                                                                                   \
@@ -324,18 +359,18 @@ static hipError_t launch_any(const GemmArgs& a, int v, hipStream_t s, bool with_
     // workgroup per CU; BK = 32 rings (64-byte rows halve the request efficiency). The template still takes WGM and BK.
     default: return hipErrorInvalidValue;
   }
-  if (e != hipSuccess || a.splitk <= 1 || !with_reduce || ia2p_splitk_inkernel(a.M, a.N, a.splitk)) return e;
+  if (e != hipSuccess || a.splitk <= 1 || !with_reduce || a.sk_counters) return e;
   return ia2p_launch_splitk_reduce(a, s);
 }
 
 // launch with an explicit tile variant (a.splitk / a.partial as the caller set them)
 // with_reduce = false: a K-split launch leaves its slabs for a separate ia2p_launch_splitk_reduce (the executor times the two apart)
-hipError_t ia2p_launch_gemm_variant(const GemmArgs& a, bool conv, int variant, hipStream_t s, bool with_reduce) {
-  return conv ? launch_any<true>(a, variant, s, with_reduce) : launch_any<false>(a, variant, s, with_reduce);
+hipError_t ia2p_launch_gemm_variant(const GemmArgs& a, bool conv, int variant, hipStream_t s, bool with_reduce, int* combined) {
+  return conv ? launch_any<true>(a, variant, s, with_reduce, combined) : launch_any<false>(a, variant, s, with_reduce, combined);
 }
 // *picked (optional) receives the variant id. a.splitk / a.partial must follow ia2p_gemm_plan (the caller owns the slabs).
-hipError_t ia2p_launch_gemm(const GemmArgs& a, bool conv, hipStream_t s, int* picked) {
+hipError_t ia2p_launch_gemm(const GemmArgs& a, bool conv, hipStream_t s, int* picked, int* combined) {
   const GemmPlan pl = ia2p_gemm_plan(a.M, a.N, a.K, conv, a.geglu != 0);
   if (picked) *picked = pl.variant;
-  return ia2p_launch_gemm_variant(a, conv, pl.variant, s, true);
+  return ia2p_launch_gemm_variant(a, conv, pl.variant, s, true, combined);
 }

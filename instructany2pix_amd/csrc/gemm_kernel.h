@@ -12,6 +12,8 @@
 #include <type_traits>
 
 bool ia2p_splitk_inkernel(int M, int N, int splitk);
+int ia2p_sk_counter_capacity();
+int* ia2p_sk_counters(hipStream_t s, int tiles);
 
 #define GLDS16(gptr, ldsptr)                                                                         \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),            \
@@ -570,16 +572,66 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   for (int ch = 0; ch < EC::NCHUNK; ++ch) {
     if (ch || from_slabs) __syncthreads();          // the previous chunk has been read out
     const int row0 = bm0 + ch * CR;
-    if (!from_slabs) acc_to_tile(ch);
-    else {                            // tile chunk = sum of the K-slice slabs, slab 0 first
+    acc_to_tile(ch);
+    if (from_slabs) {
+      // tile chunk = sum of the K-slice slabs in slab order (slab 0 first), whoever arrived last. This slice's own partial sums are still in its
+      // accumulators (now in the LDS tile: the very fp32 values its slab holds), so only the OTHER slabs are read back -- with every load of a
+      // thread in flight at once: one workgroup alone reads at the latency of its round trips, not at a bandwidth (a dependent loop over the slabs
+      // took ~16 serial trips per thread and cost more than the whole-chip reduce launch it replaced: profiles/r02e_splitk_inkernel_ab.txt).
+      __syncthreads();
       constexpr int GPR = BN / 4;
-      for (int idx = tid; idx < CR * GPR; idx += NT) {
-        const int r = idx / GPR, g = idx - r * GPR;
-        const int m = min(row0 + r, hM - 1), n = min(bn0 + g * 4, hN - 4);
-        const float* src = p.partial + (size_t)m * hN + n;
-        f4 v = *(const f4*)src;
-        for (int sl = 1; sl < nsplit; ++sl) { const f4 w = *(const f4*)(src + (size_t)sl * hM * hN); v[0] += w[0]; v[1] += w[1]; v[2] += w[2]; v[3] += w[3]; }
-        *(f4*)(tile + (size_t)r * PITCH + ((g ^ (r & 7)) << 2)) = v;
+      constexpr int PER = (CR * GPR + NT - 1) / NT;                     // float4 positions per thread
+      const size_t slab_elems = (size_t)hM * hN;
+      auto combine = [&](auto no_tag) {
+        constexpr int NO = decltype(no_tag)::value;                     // slabs of OTHER slices (nsplit - 1)
+        constexpr int BUDGET = EC::NCHUNK == 1 ? 32 : 8;                // 16-B loads in flight per lane (two chunks: the second chunk's accumulators are live -- more spills)
+        constexpr int UC = PER < BUDGET / NO ? PER : BUDGET / NO;
+#pragma unroll 1
+        for (int i0 = 0; i0 < PER; i0 += UC) {
+          f4 oth[NO][UC];
+          int off[UC];
+#pragma unroll
+          for (int u = 0; u < UC; ++u) {
+            const int idx = min(tid + (i0 + u) * NT, CR * GPR - 1);
+            const int r = idx / GPR, g = idx - r * GPR;
+            off[u] = r * PITCH + ((g ^ (r & 7)) << 2);
+            const float* src = p.partial + (size_t)min(row0 + r, hM - 1) * hN + min(bn0 + g * 4, hN - 4);
+#pragma unroll
+            for (int j = 0; j < NO; ++j) oth[j][u] = *(const f4*)(src + (size_t)(j < split ? j : j + 1) * slab_elems);     // (clamped addresses, never branched around)
+          }
+#pragma unroll
+          for (int u = 0; u < UC; ++u) {
+            if (i0 + u < PER && tid + (i0 + u) * NT < CR * GPR) {
+              const f4 own = *(const f4*)(tile + off[u]);
+              f4 v = split == 0 ? own : oth[0][u];
+#pragma unroll
+              for (int k = 1; k <= NO; ++k) {                            // slab k of the ordered sum: own partial, or the (k - (k > split))-th other slab
+                f4 w = own;
+                if (k != split) w = k > split ? oth[k - 1][u] : oth[k < NO ? k : NO - 1][u];
+                v[0] += w[0]; v[1] += w[1]; v[2] += w[2]; v[3] += w[3];
+              }
+              *(f4*)(tile + off[u]) = v;
+            }
+          }
+        }
+      };
+      if (nsplit == 2) combine(std::integral_constant<int, 1>{});
+      else if (nsplit == 3) combine(std::integral_constant<int, 2>{});
+      else if (nsplit == 4) combine(std::integral_constant<int, 3>{});
+      else {                          // wider splits (rare): plain ordered loop
+        for (int idx = tid; idx < CR * GPR; idx += NT) {
+          const int r = idx / GPR, g = idx - r * GPR;
+          const int o = r * PITCH + ((g ^ (r & 7)) << 2);
+          const float* src = p.partial + (size_t)min(row0 + r, hM - 1) * hN + min(bn0 + g * 4, hN - 4);
+          const f4 own = *(const f4*)(tile + o);
+          f4 v = split == 0 ? own : *(const f4*)src;
+          for (int sl = 1; sl < nsplit; ++sl) {
+            f4 w = own;
+            if (sl != split) w = *(const f4*)(src + (size_t)sl * slab_elems);
+            v[0] += w[0]; v[1] += w[1]; v[2] += w[2]; v[3] += w[3];
+          }
+          *(f4*)(tile + o) = v;
+        }
       }
     }
     __syncthreads();
@@ -797,20 +849,8 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
             (!a.rowvec || (a.rowvec_ld % 8 == 0 && al16(a.rowvec)))) ? 1 : 0;
   if (a.geglu && !b.vec8) return hipErrorInvalidValue;
   b.c_wt = ((ia2p_wt_mask() & 1) && (size_t)a.M * a.ldc * 2 < (size_t)0x7ffffff0) ? 1 : 0;      // same box: -0.14 ms per step at batch 8
-  b.sk_counters = nullptr;
-  if (ia2p_splitk_inkernel(a.M, a.N, a.splitk)) {
-    // ticket counters of the in-launch K-split combine: one int per output tile, zero between launches (the last arriver resets its tile's)
-    constexpr int NCNT = 1 << 20;
-    static int* cnt[64] = {nullptr};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev >= 0 && dev < 64 && tiles <= NCNT) {
-      if (!cnt[dev]) {
-        if (hipMalloc((void**)&cnt[dev], NCNT * sizeof(int)) != hipSuccess || hipMemset(cnt[dev], 0, NCNT * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); cnt[dev] = nullptr; }
-      }
-      b.sk_counters = cnt[dev];
-    }
-  }
+  // b.sk_counters: as the caller (launch_any, gemm.hip) attached them -- null: the K-slices only write their slabs and a splitk_reduce_kernel launch finishes
+  if (b.sk_counters && tiles > ia2p_sk_counter_capacity()) return hipErrorInvalidValue;
   b.group_w = ia2p_tile_group_w(tiles, (a.N + BN - 1) / BN, smem, BM, BN);
   const int extra = (!PP && a.pf && a.pf_bytes >= 4096) ? a.pf_blocks : 0;
   hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, NSTAGE, CONV, WGM, BK, PP, WGN>), dim3(tiles * (a.splitk > 1 ? a.splitk : 1) + extra), dim3(WGM * WGN * 64), smem, s,

@@ -24,7 +24,9 @@ def init_distributed(backend: str = None) -> Tuple[int, int, int]:
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
+        if "MASTER_PORT" not in os.environ:
+            # every launcher sets it (torchrun; bench.py's own launcher picks a free port); a fixed default would collide between jobs on one box
+            raise RuntimeError("WORLD_SIZE > 1 but MASTER_PORT is not set: start the ranks with a launcher (torchrun, or `bench.py --gpus N`)")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:       # IA2P_DIST_BACKEND=gloo lets two ranks share one GPU in tests (RCCL wants one GPU per rank)
             backend = os.environ.get("IA2P_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
@@ -74,6 +76,16 @@ def max_over_ranks(value: float, device="cpu") -> float:
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_floats(value: float, device="cpu") -> list:
+    """every rank's value, in rank order, on every rank (per-rank step times: a straggler must be visible in the result line)"""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(value)]
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
 
 
 def gather_batches(local: torch.Tensor) -> torch.Tensor:

@@ -64,3 +64,48 @@ def test_shard_range_covers_everything():
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
     with pytest.raises(ValueError):
         shard_range(8, 2, 2)
+
+
+def test_bench_gpus2_launches_its_own_ranks_gloo_stub():
+    """`python bench.py --gpus 2` with no launcher in the environment starts two rank processes itself (free rendezvous port), rendezvous over gloo,
+    broadcasts, brackets the timed region with barriers, takes the max over ranks and relays ONE line from rank 0 that says what it saw.
+    The step is the sleeping stub (IA2P_BENCH_STUB: no GPU here); rank 1 is 25 % slower by construction, so `ms_per_step` must be rank 1's."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(IA2P_DIST_BACKEND="gloo", IA2P_BENCH_STUB="20")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["warmup"] == 1 and d["data"] == "stub" and "STUB" in d["metric"]
+    c = d["config"]
+    assert c["ranks"] == 2 and c["dist_backend"] == "gloo" and c["self_launched"] is True
+    assert c["weight_broadcast"]["bytes"] == 4 << 16 and c["weight_broadcast"]["seconds"] >= 0
+    pr = c["per_rank_ms_per_step"]
+    assert len(pr) == 2 and pr[1] > pr[0] * 1.1                       # the straggler is visible ...
+    assert abs(d["ms_per_step"] - max(pr)) < 0.2 * max(pr)            # ... and sets the step time
+    assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"] + 1e-9      # whole-job steps/s = ranks x steps / max-over-ranks time
+
+
+def test_bench_self_launch_fails_when_a_rank_fails():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(IA2P_DIST_BACKEND="gloo", IA2P_BENCH_STUB="not-a-number")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_refuses_a_world_size_that_is_not_what_was_asked():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, IA2P_BENCH_STUB="5", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)

@@ -79,18 +79,60 @@ def test_gemm_tile_choice_never_changes_the_bits(L, M, N, K):
         assert torch.equal(o, outs[0])
 
 
-@pytest.mark.parametrize("M,N,K,S", [(256, 1280, 5120, 8), (256, 1280, 1280, 4), (2048, 1280, 11520, 3), (77, 192, 640, 5), (300, 64, 128, 2)])
+@pytest.mark.parametrize("M,N,K,S", [(256, 1280, 5120, 8), (256, 1280, 1280, 4), (2048, 1280, 11520, 3), (2048, 1280, 5120, 3), (77, 192, 640, 5), (300, 64, 128, 2)])
 def test_gemm_splitk_deterministic(L, M, N, K, S):
+    """A K split gives the same bits however it is finished: by the last-arriving K-slice inside the launch (ticket counters, own partial sums
+    from its accumulators, the other slabs read back in slab order) or by the separate splitk_reduce_kernel launch; and again on a second run."""
     f = _ffi()
     A, W, b, R = rnd(M, K, seed=41), rnd(N, K, seed=42, scale=K ** -0.5), rnd(N, seed=43), rnd(M, N, seed=44)
-    out, out2 = torch.empty(M, N, dtype=torch.half, device="cuda"), torch.empty(M, N, dtype=torch.half, device="cuda")
-    part = torch.empty(S * M * N, dtype=torch.float32, device="cuda")
-    run(L, "ia2p_gemm_splitk", f.ptr(A), f.ptr(W), f.ptr(b), f.ptr(R), f.ptr(out), M, N, K, S, C.c_void_p(part.data_ptr()))
     ref = A.float() @ W.float().t() + b.float() + R.float()
-    assert rel_l2(out, ref) < 1e-3, rel_l2(out, ref)
-    part.fill_(float("nan"))                         # slabs are fully rewritten; summation order is fixed -> same bits
-    run(L, "ia2p_gemm_splitk", f.ptr(A), f.ptr(W), f.ptr(b), f.ptr(R), f.ptr(out2), M, N, K, S, C.c_void_p(part.data_ptr()))
-    assert torch.equal(out, out2)
+    part = torch.empty(S * M * N, dtype=torch.float32, device="cuda")
+    outs = {}
+    try:
+        for route, limit in (("in-launch", 1 << 40), ("reduce launch", 0)):
+            L.ia2p_debug_set_splitk_inkernel(limit)
+            for tile in (-1, 0, 4, 8, 12):          # auto, 128x128, 64x64, 128x160 (two epilogue chunks), ping-pong 256x128
+                L.ia2p_debug_set_gemm_tile(tile)
+                out, out2 = torch.empty(M, N, dtype=torch.half, device="cuda"), torch.empty(M, N, dtype=torch.half, device="cuda")
+                run(L, "ia2p_gemm_splitk", f.ptr(A), f.ptr(W), f.ptr(b), f.ptr(R), f.ptr(out), M, N, K, S, C.c_void_p(part.data_ptr()))
+                assert rel_l2(out, ref) < 1e-3, (route, tile, rel_l2(out, ref))
+                part.fill_(float("nan"))                 # slabs are fully rewritten; summation order is fixed -> same bits
+                run(L, "ia2p_gemm_splitk", f.ptr(A), f.ptr(W), f.ptr(b), f.ptr(R), f.ptr(out2), M, N, K, S, C.c_void_p(part.data_ptr()))
+                assert torch.equal(out, out2), (route, tile)
+                outs[(route, tile)] = out
+    finally:
+        L.ia2p_debug_set_splitk_inkernel(-1)
+        L.ia2p_debug_set_gemm_tile(-1)
+    first = outs[("in-launch", -1)]
+    for key, o in outs.items():
+        assert torch.equal(o, first), key
+
+
+def test_gemm_splitk_in_launch_back_to_back_reuses_slabs_and_counters(L):
+    """stress of the in-launch hand-off: the same slab region and ticket counters serve launches with different data back to back (stale lines of
+    the previous launch's slabs may sit in L1 / L2 of the reading CU); every result must equal the reduce-launch route bit for bit"""
+    f = _ffi()
+    M, N, K, S = 2048, 1280, 5120, 3
+    part = torch.empty(S * M * N, dtype=torch.float32, device="cuda")
+    W = rnd(N, K, seed=61, scale=K ** -0.5)
+    As = [rnd(M, K, seed=70 + i) for i in range(6)]
+    try:
+        L.ia2p_debug_set_splitk_inkernel(0)
+        refs = []
+        for A in As:
+            o = torch.empty(M, N, dtype=torch.half, device="cuda")
+            run(L, "ia2p_gemm_splitk", f.ptr(A), f.ptr(W), None, None, f.ptr(o), M, N, K, S, C.c_void_p(part.data_ptr()))
+            refs.append(o)
+        L.ia2p_debug_set_splitk_inkernel(1 << 40)
+        outs = [torch.empty(M, N, dtype=torch.half, device="cuda") for _ in As]
+        for rep in range(5):
+            for A, o in zip(As, outs):          # no synchronisation between the launches
+                f.check(L.ia2p_gemm_splitk(f.current_stream(), f.ptr(A), f.ptr(W), None, None, f.ptr(o), M, N, K, S, C.c_void_p(part.data_ptr())))
+            torch.cuda.synchronize()
+            for i, (o, r) in enumerate(zip(outs, refs)):
+                assert torch.equal(o, r), (rep, i)
+    finally:
+        L.ia2p_debug_set_splitk_inkernel(-1)
 
 
 def test_gemm_no_bias_inplace_residual(L):
