@@ -112,16 +112,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* hpartia
   }
 }
 
-// K-split launches combine their slabs inside the GEMM launch (last-arriving slice of a tile); IA2P_SPLITK_INKERNEL=0: separate
-// splitk_reduce_kernel launches instead (A/B switch, read once)
-// Which K-split launches combine inside the launch: those whose slabs are small (latency-bound launches: batch 1, tiny contractions), where the
-// reduce launch costs more than the last arriver's serial slab read. Measured on one box (profiles/r02e_splitk_inkernel_ab.txt): every K-split
-// in-launch: batch 8 +0.6 ms / step, batch 1 -0.16 ms; large slabs are summed faster by a whole-chip reduce launch than by 160 lone workgroups.
-// IA2P_SPLITK_INKERNEL = byte threshold on splitk*M*N*4 (0: never, default 8 MiB).
+// K-split launches combine their slabs inside the GEMM launch (last-arriving slice of a tile); IA2P_SPLITK_INKERNEL = byte threshold on
+// splitk*M*N*4 up to which they do (0: never -- separate splitk_reduce_kernel launches, the A/B switch; default: always).
+// Round 2 combined only slab sets <= 8 MiB: the last arriver read the slabs in a dependent loop (~16 serial round trips per thread) and 160 of them
+// cost more than a whole-chip reduce launch (+0.6 ms / step at batch 8, profiles/r02e_splitk_inkernel_ab.txt). With the own partial sums kept on chip
+// and every load of the other slabs in flight at once the in-launch route is level with the reduce launch at batch 8 (same box, same plans:
+// 21.05-21.11 vs 21.10-21.16 ms / step; FF-out launches +4.3 us each against 78 reduce launches of 13.7 us, profiles/r03a_splitk_inkernel_ktable.txt)
+// and ahead at batch 1, so every K split now finishes in its own launch: no reduce launches in a step.
 static long long g_sk_limit = -1;     // bytes of splitk*M*N*4 up to which a K split combines inside the launch; < 0: IA2P_SPLITK_INKERNEL or the default
 extern "C" void ia2p_debug_set_splitk_inkernel(long long bytes) { g_sk_limit = bytes; }
 bool ia2p_splitk_inkernel(int M, int N, int splitk) {
-  static const size_t env_limit = getenv("IA2P_SPLITK_INKERNEL") ? (size_t)atoll(getenv("IA2P_SPLITK_INKERNEL")) : ((size_t)8 << 20);
+  static const size_t env_limit = getenv("IA2P_SPLITK_INKERNEL") ? (size_t)atoll(getenv("IA2P_SPLITK_INKERNEL")) : ((size_t)1 << 46);
   const size_t limit = g_sk_limit >= 0 ? (size_t)g_sk_limit : env_limit;
   return splitk > 1 && (size_t)splitk * M * N * sizeof(float) <= limit;
 }

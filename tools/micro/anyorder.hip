@@ -33,12 +33,12 @@ __global__ void work_k(int ticks, unsigned* sink) {
 }
 
 // chain step: wait (optional) -> spin -> publish (optional)
-__global__ void chain_k(const unsigned* wait_flags, unsigned* my_flags, unsigned epoch, int ticks, int skew_ticks, int kidx, float* payload, unsigned* timeouts) {
+__global__ void chain_k(const unsigned* wait_flags, unsigned wait_epoch, unsigned* my_flags, unsigned epoch, int ticks, int skew_ticks, int kidx, float* payload, unsigned* timeouts) {
   const int b = blockIdx.x;
   if (wait_flags) {
     if (threadIdx.x == 0) {
       unsigned spins = 0;
-      while (__hip_atomic_load((const gu32*)(wait_flags + b * 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+      while (__hip_atomic_load((const gu32*)(wait_flags + b * 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != wait_epoch) {
         __builtin_amdgcn_s_sleep(1);
         if (++spins > (1u << 17)) { atomicAdd(timeouts, 1u); break; }
       }
@@ -107,14 +107,14 @@ extern "C" int anyorder_run(int verbose) {
     unsigned* tmo; CK(hipMalloc(&tmo, 64)); CK(hipMemset(tmo, 0, 64));
     unsigned epoch = 0;
     for (int wg : {256, 512}) for (int work : {500, 1500}) for (int skew : {0, 300}) {
-      float t_ord = time_ms([&] { for (int i = 0; i < N; ++i) hipLaunchKernelGGL(chain_k, dim3(wg), dim3(256), 0, s, (const unsigned*)nullptr, (unsigned*)nullptr, 0u, work, skew, i, payload, tmo); }, s);
-      float t_pub = time_ms([&] { for (int i = 0; i < N; ++i) { ++epoch; hipLaunchKernelGGL(chain_k, dim3(wg), dim3(256), 0, s, (const unsigned*)nullptr, flags + (i & 1) * NW * 32, epoch, work, skew, i, payload, tmo); } }, s);
+      float t_ord = time_ms([&] { for (int i = 0; i < N; ++i) hipLaunchKernelGGL(chain_k, dim3(wg), dim3(256), 0, s, (const unsigned*)nullptr, 0u, (unsigned*)nullptr, 0u, work, skew, i, payload, tmo); }, s);
+      float t_pub = time_ms([&] { for (int i = 0; i < N; ++i) { ++epoch; hipLaunchKernelGGL(chain_k, dim3(wg), dim3(256), 0, s, (const unsigned*)nullptr, 0u, flags + (i & 1) * NW * 32, epoch, work, skew, i, payload, tmo); } }, s);
       float t_any = time_ms([&] {
         for (int i = 0; i < N; ++i) {
           ++epoch;
           const unsigned* wf = i ? flags + ((i - 1) & 1) * NW * 32 : nullptr;
           // first kernel of the chain is an ordered launch (everything before it must be complete); the rest may start early
-          hipExtLaunchKernelGGL(chain_k, dim3(wg), dim3(256), 0, s, nullptr, nullptr, i ? hipExtAnyOrderLaunch : 0, wf, flags + (i & 1) * NW * 32, epoch, work, skew, i, payload, tmo);
+          hipExtLaunchKernelGGL(chain_k, dim3(wg), dim3(256), 0, s, nullptr, nullptr, i ? hipExtAnyOrderLaunch : 0, wf, epoch - 1, flags + (i & 1) * NW * 32, epoch, work, skew, i, payload, tmo);
         } }, s);
       // NOTE: flag[k] is overwritten by kernel k+2 while kernel k+1 may still poll it for `epoch(k)` -- epochs are distinct per kernel and kernel k+2's
       // workgroup i publishes only after kernel k+1's workgroup i has seen epoch(k), so the two-deep flag ring is safe for this per-workgroup chain.
