@@ -211,6 +211,50 @@ def stub_main(args):
         torch.distributed.destroy_process_group()
 
 
+
+def box_probe(dev):
+    """How fast is THIS box? Boxes of the pool differ by up to 9 % on identical code, more than a round's gain, so every line carries
+    a calibrated yardstick measured in the same process: (i) a fixed L2-warm 4096^3 fp16 GEMM on the library's own kernel (random data), (ii) a 1 GiB
+    device copy, (iii) the back-to-back time of a one-tile GEMM launch = the dependent-launch floor every one of the step's ~800 launches pays, and
+    (iv) the K -> 0 intercept of the dominant contraction's shape (2048 x 3840 with a residual, K = 64). Divide two boxes' step times by their probes."""
+    import torch
+    from instructany2pix_amd import _ffi
+    L = _ffi.lib()
+    g = torch.Generator(device=dev).manual_seed(5)
+    rnd = lambda *s: (torch.rand(*s, generator=g, device=dev) * 2 - 1).half()
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+
+    def timed_gemm(M, N, K, reps, residual=False):
+        A, W, out = rnd(M, K), rnd(N, K) * (K ** -0.5), torch.empty(M, N, dtype=torch.half, device=dev)
+        R = rnd(M, N) if residual else None
+        call = lambda: _ffi.check(L.ia2p_gemm(_ffi.current_stream(), _ffi.ptr(A), _ffi.ptr(W), None, _ffi.ptr(R), _ffi.ptr(out), M, N, K, 0))
+        for _ in range(5):
+            call()
+        e0, e1 = ev(), ev()
+        e0.record()
+        for _ in range(reps):
+            call()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e3            # us per launch
+
+    us = timed_gemm(4096, 4096, 4096, 30)
+    src, dst = torch.empty(1 << 30, dtype=torch.uint8, device=dev), torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+    dst.copy_(src)
+    e0, e1 = ev(), ev()
+    e0.record()
+    for _ in range(5):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    copy_gbs = 5 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del src, dst
+    return {"gemm_4096_tflops": 2.0 * 4096 ** 3 / (us * 1e-6) / 1e12, "copy_1gib_gbs": copy_gbs, "launch_floor_us": timed_gemm(128, 128, 64, 300),
+            "k0_intercept_us_2048x3840": timed_gemm(2048, 3840, 64, 200, residual=True),
+            "note": "same process, before the timed region; gemm = ia2p_gemm 4096^3 fp16 on random data, L2-warm, 30 launches; copy = torch 1 GiB d2d "
+                    "(read + write bytes); launch_floor = back-to-back one-tile GEMM launches; k0_intercept = back-to-back 2048x3840x64 launches with a residual"}
+
+
 class Workload:
     """one denoise loop on resident inputs: UNet evaluation at B_eff + fused (CFG +) DDIM update, ping-ponging two latent buffers"""
 
@@ -282,7 +326,7 @@ class Workload:
         return table, regions
 
 
-def roofline_block(table, regions, nprof, B_eff, hw, use_ip, ms_per_step):
+def roofline_block(table, regions, nprof, B_eff, hw, use_ip, ms_per_step, probe=None):
     tot_ms = sum(v["ms"] for k, v in table.items() if k != "ddim_step_kernel")
     gemm = {k: v for k, v in table.items() if v["flops"] > 0 and (k.startswith("gemm_f16_kernel") or k.startswith("attention"))}
     dom = max(gemm, key=lambda k: gemm[k]["ms"])
@@ -293,12 +337,18 @@ def roofline_block(table, regions, nprof, B_eff, hw, use_ip, ms_per_step):
     if pmc:                     # HBM-side bytes per launch of this kernel, from separate rocprofv3 --pmc passes (tools/pmc_traffic.py)
         k = json.load(open(pmc[-1]))["kernels"].get(dom)
         if k:
-            traffic, traffic_src = k["traffic_bytes_per_launch"], os.path.basename(pmc[-1])
+            traffic, traffic_src = k["traffic_bytes_per_launch"], f"static: profiles/{os.path.basename(pmc[-1])} (separate rocprofv3 --pmc passes on the builder's box, tools/pmc_traffic.py; NOT measured in this run)"
     out = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
            "traffic": traffic, "traffic_unit": "bytes/launch (L2<->fabric, Infinity-Cache hits included)", "traffic_source": traffic_src,
            "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
            "launches_per_step": d["launches"] / nprof, "avg_launch_us": 1e3 * d["ms"] / d["launches"],
            "flops_per_launch": d["flops"] / d["launches"], "share_of_step": d["ms"] / tot_ms}
+    launches = sum(v["launches"] for k, v in table.items() if k != "ddim_step_kernel") / nprof + 1
+    out["launches_per_step_all_kernels"] = launches
+    if probe:       # what the step spends on per-launch fixed cost: launches x measured dependent-launch floor (box_probe), as a share of the step
+        out["fixed_share"] = {"launches_per_step": launches, "launch_floor_us": probe["launch_floor_us"], "share_of_step": launches * probe["launch_floor_us"] * 1e-3 / ms_per_step,
+                              "k0_intercept_us_2048x3840": probe["k0_intercept_us_2048x3840"],
+                              "note": "launch_floor = back-to-back one-tile GEMM launches on this box; the K -> 0 intercept of a full-width launch (C store + residual read included) is the larger figure"}
     step_tf = STEP_TFLOP.get((B_eff, hw, use_ip))
     if step_tf is None:
         step_tf = sum(v["flops"] for v in table.values()) / nprof / 1e12
@@ -342,6 +392,7 @@ def main():
     ap.add_argument("--unet", choices=["base", "refiner"], default="base", help="refiner = the second engine config (non-headline; use --ctx 77)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-box-probe", action="store_true", help="skip the calibrated box-speed probe (4096^3 GEMM, 1 GiB copy, launch floor)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the non-headline BASELINE shapes (configs[1], configs[4])")
     ap.add_argument("--no-autotune", action="store_true", help="use the built-in cost model instead of measured kernel plans")
     ap.add_argument("--plans", default=None, help="import this kernel plan table instead of measuring (profiler runs: keeps the tuning launches out of the trace)")
@@ -395,6 +446,12 @@ def main():
     torch.cuda.synchronize()
     log(f"[rank {rank}] weights ready in {time.time() - t0:.1f}s (arena {unet.arena.numel() / 1e9:.2f} GB, of which {unet.arena_raw.numel() / 1e9:.2f} GB travel; "
         f"{world} rank(s){', backend ' + backend if backend else ''})")
+
+    probe = None
+    if rank == 0 and not args.no_box_probe:
+        probe = box_probe(dev)
+        log(f"[box probe] 4096^3 GEMM {probe['gemm_4096_tflops']:.0f} TFLOP/s, 1 GiB copy {probe['copy_1gib_gbs']:.0f} GB/s, launch floor {probe['launch_floor_us']:.2f} us, "
+            f"K->0 intercept {probe['k0_intercept_us_2048x3840']:.2f} us")
 
     B, hw, L = args.batch, args.latent, args.ctx
     wl = Workload(unet, cfg, B, hw, L, args.guidance, dev, cfg_id=3)
@@ -462,6 +519,8 @@ def main():
                    "runs_ms_per_step": runs, "median_ms_per_step": statistics.median(runs), "steps_per_s_median": 1e3 / statistics.median(runs)},
     }
 
+    if probe:
+        res["box_probe"] = probe
     if rank == 0:      # secondary number, not `value`: the same loop with the request's context K/V projected once (what the pipelines do)
         unet.cache_context_kv = True
         wl.run(1)
@@ -472,7 +531,7 @@ def main():
     if rank == 0 and not args.no_roofline:
         nprof = 3
         table, regions = wl.profile(nprof)
-        res["roofline"] = roofline_block(table, regions, nprof, B, hw, use_ip, statistics.median(runs))
+        res["roofline"] = roofline_block(table, regions, nprof, B, hw, use_ip, statistics.median(runs), probe)
         log_table(table, nprof)
         if args.kernel_table:
             os.makedirs(os.path.dirname(os.path.abspath(args.kernel_table)), exist_ok=True)
@@ -482,9 +541,13 @@ def main():
     if rank == 0 and world == 1 and default_cfg and not args.no_secondary:
         sec = {}
         for name, (b2, hw2, L2, g2, cid) in {"configs[1]: 512x512, batch 1, 77-token text-only context": (1, 64, 77, 0.0, 2),
-                                              "configs[4]: 768x768, 4 requests with classifier-free guidance 10 (B_eff 8), 81-token contexts": (8, 96, 81, 10.0, 5)}.items():
-            if L2 > 77:
-                unet.load_ip_adapter_weights([], scale=1.0, num_tokens=L2 - 77)
+                                              "configs[4]: 768x768, 4 requests with classifier-free guidance 10 (B_eff 8), 81-token contexts": (8, 96, 81, 10.0, 5),
+                                              # the reference's own default request (pipeline.py:303, serve.py:80): 1024^2, inversion at batch 1 / guided sampling at B_eff 2
+                                              "reference default, inversion: 1024x1024, batch 1, 77-token context (IP processors installed: the last 4 text tokens are split off)": (1, 128, 77, 0.0, 6),
+                                              "reference default, guided sampling: 1024x1024, 1 request with classifier-free guidance 10 (B_eff 2), 81-token contexts": (2, 128, 81, 10.0, 7)}.items():
+            inv_quirk = "inversion" in name
+            if L2 > 77 or inv_quirk:
+                unet.load_ip_adapter_weights([], scale=1.0, num_tokens=4)
             else:
                 unet.set_attn_processor(AttnProcessor2_0())
             w2 = Workload(unet, cfg, b2, hw2, L2, g2, dev, cfg_id=cid)
@@ -497,10 +560,10 @@ def main():
             entry = {"ms_per_step": ms2, "steps_per_s": 1e3 / ms2, "runs_ms_per_step": r2, "B_eff": b2, "latent": hw2, "context_tokens": L2, "guidance": g2}
             if not args.no_roofline:
                 t2, rg2 = w2.profile(3)
-                rb = roofline_block(t2, rg2, 3, b2, hw2, L2 > 77, ms2)
-                entry["roofline"] = {k: rb[k] for k in ("kernel", "achieved", "frac", "whole_step", "conv_blocks", "hbm_kernels")}
+                rb = roofline_block(t2, rg2, 3, b2, hw2, L2 > 77, ms2, probe)
+                entry["roofline"] = {k: rb[k] for k in ("kernel", "achieved", "frac", "whole_step", "conv_blocks", "hbm_kernels", "launches_per_step_all_kernels", "fixed_share") if k in rb}
                 if b2 == 1:
-                    wbytes = 5.135e9           # compulsory weight bytes of a text-only evaluation
+                    wbytes = 5.817e9 if inv_quirk else 5.135e9           # compulsory weight bytes of an evaluation with / without the IP-Adapter projections
                     entry["weight_streaming"] = {"bytes": wbytes, "bound_ms_at_6290": wbytes / HBM_COPY_GBS / 1e6, "frac_of_bound": wbytes / HBM_COPY_GBS / 1e6 / ms2}
             sec[name] = entry
             log(f"[secondary] {name}: {ms2:.2f} ms/step")

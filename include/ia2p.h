@@ -87,6 +87,8 @@ ia2p_status ia2p_finalize_weights(ia2p_ctx* ctx);      /* verifies every UNet pa
  * tensors) present and derives the tail locally. */
 size_t ia2p_arena_raw_bytes(ia2p_ctx* ctx);
 ia2p_status ia2p_adopt_arena(ia2p_ctx* ctx, int with_ip_adapter);
+/* the same with the fold kernels ordered on `stream` -- the stream the broadcast that filled the head was enqueued on -- and synchronised there */
+ia2p_status ia2p_adopt_arena_on(ia2p_ctx* ctx, int with_ip_adapter, void* stream);
 /* IP-Adapter plugin state: set_ip_adapter (ip_adapter.py:120-142) / set_scale (:211-214) / disable (:153-154). */
 ia2p_status ia2p_set_ip_adapter(ia2p_ctx* ctx, int enabled, int num_tokens, float scale);
 
@@ -97,6 +99,15 @@ size_t ia2p_workspace_bytes(ia2p_ctx* ctx, int B, int h, int w, int L);
 ia2p_status ia2p_unet_forward(ia2p_ctx* ctx, void* stream, const void* sample, float timestep, const void* context, int L,
                               const void* text_embeds, const void* time_ids, void* out, int B, int h, int w,
                               void* workspace, size_t workspace_bytes);
+/* Per-request knobs inside ONE evaluation (batched serving of independent edit requests). timesteps: device, float [B], one
+ * timestep per batch element (diffusers' UNet2DConditionModel.forward accepts a [B] timestep tensor; the reference always passes a scalar,
+ * pnp_pipeline.py:253-260 / sdxl_pipeline.py:832-839, because it serves one request at a time). ip_scales: device, float [B], or NULL --
+ * the IP-Adapter scale of each batch element (reference: one `set_scale` value per call, ip_adapter.py:211-214; used at
+ * attention_processor.py:397). Exactly one of context / kv (ia2p_project_context) is non-NULL. Batch element b gets the bits it gets in a
+ * uniform batch of the same size evaluated at (timesteps[b], ip_scales[b]). */
+ia2p_status ia2p_unet_forward_v(ia2p_ctx* ctx, void* stream, const void* sample, const float* timesteps, const float* ip_scales,
+                                const void* context, const void* kv, int L, const void* text_embeds, const void* time_ids, void* out,
+                                int B, int h, int w, void* workspace, size_t workspace_bytes);
 
 /* ---- context K/V hoisted out of the step (optional) ------------------------------------------------------------------
  * The K/V projections of every cross-attention layer (reference attention_processor.py:358-359,379-380) depend only on the context and the
@@ -130,6 +141,10 @@ unsigned long long ia2p_plan_generation(void);   /* changes whenever the table d
 /* out = c_x * x + c_e * (eps_u + g * (eps_c - eps_u)); eps_c may be NULL (no guidance); out2 may be NULL. */
 ia2p_status ia2p_ddim_step(void* stream, const void* x, const void* eps_u, const void* eps_c, float g, float c_x, float c_e,
                            void* out, void* out2, int64_t n);
+/* the same update with per-request coefficients: coef = device float [B][3] = {g, c_x, c_e} of batch element b (`per` elements each), so that
+ * requests with their own guidance scale (reference pipeline.py:303 `cfg`) at their own step of their own schedule share one launch */
+ia2p_status ia2p_ddim_step_v(void* stream, const void* x, const void* eps_u, const void* eps_c, const float* coef, void* out, void* out2,
+                             int B, int64_t per);
 /* out = (1 - m) * (c0 * init + c1 * noise) + m * x with m = mask[b, 0, :, :] ([B,1,h,w], shared by the C channels): the per-step
  * blend of the inpainting loop behind `pipe_inpainting` (reference pipeline.py:132-139, gdino/lib.py:89-102; diffusers
  * StableDiffusionXLInpaintPipeline, 4-channel UNet branch). c0 = sqrt(abar_next), c1 = sqrt(1 - abar_next) re-noise the known

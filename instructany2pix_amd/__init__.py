@@ -6,7 +6,7 @@ Importing this package touches no GPU and no native code; the HIP library (libia
 from .config import UNetConfig, sdxl_base, sdxl_refiner, tiny
 
 __all__ = ["InstructAny2PixPrior", "prior_config", "MODALITY", "HipGPT2Model", "DDPMScheduler", "HipCLIPTextModel", "SDXLTextEncoders", "UNetConfig", "sdxl_base", "sdxl_refiner", "tiny", "StableDiffusionXLImg2ImgPipeline", "EulerDiscreteScheduler", "InstructAny2PixPipeline", "HipUNet2DConditionModel", "DDIMScheduler",
-           "SDXLDDIMPipeline", "StableDiffusionXLPipeline", "IPAdapterXL", "ImageProjModel", "HipAutoencoderKL"]
+           "SDXLDDIMPipeline", "StableDiffusionXLPipeline", "IPAdapterXL", "ImageProjModel", "HipAutoencoderKL", "EditRequest"]
 
 
 def __getattr__(name):          # lazy: keep `import instructany2pix_amd` free of torch/ctypes work
@@ -31,6 +31,8 @@ def __getattr__(name):          # lazy: keep `import instructany2pix_amd` free o
     elif name in ("HipCLIPTextModel", "SDXLTextEncoders"):
         from . import clip
         v = getattr(clip, name)
+    elif name == "EditRequest":
+        from .batch import EditRequest as v
     elif name == "HipAutoencoderKL":
         from .vae import HipAutoencoderKL as v
     else:

@@ -54,10 +54,12 @@ SIGNATURES = {
     "ia2p_load_tensor": (_I, [_P, C.c_char_p, _P, C.POINTER(_I64), _I, _P]),
     "ia2p_finalize_weights": (_I, [_P]),
     "ia2p_adopt_arena": (_I, [_P, _I]),
+    "ia2p_adopt_arena_on": (_I, [_P, _I, _P]),
     "ia2p_arena_raw_bytes": (_SZ, [_P]),
     "ia2p_set_ip_adapter": (_I, [_P, _I, _I, _F]),
     "ia2p_workspace_bytes": (_SZ, [_P, _I, _I, _I, _I]),
     "ia2p_unet_forward": (_I, [_P, _P, _P, _F, _P, _I, _P, _P, _P, _I, _I, _I, _P, _SZ]),
+    "ia2p_unet_forward_v": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P, _SZ]),
     "ia2p_context_kv_bytes": (_SZ, [_P, _I, _I]),
     "ia2p_project_context": (_I, [_P, _P, _P, _I, _I, _P, _SZ, _P, _SZ]),
     "ia2p_unet_forward_kv": (_I, [_P, _P, _P, _F, _P, _I, _P, _P, _P, _I, _I, _I, _P, _SZ]),
@@ -67,6 +69,7 @@ SIGNATURES = {
     "ia2p_plan_clear": (None, []),
     "ia2p_plan_generation": (C.c_ulonglong, []),
     "ia2p_ddim_step": (_I, [_P, _P, _P, _P, _F, _F, _F, _P, _P, _I64]),
+    "ia2p_ddim_step_v": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I64]),
     "ia2p_mask_blend": (_I, [_P, _P, _P, _P, _P, _F, _F, _P, _P, _I, _I, _I64]),
     "ia2p_groupnorm_silu": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P]),
     "ia2p_layernorm": (_I, [_P, _P, _P, _P, _P, _I, _I, _F]),

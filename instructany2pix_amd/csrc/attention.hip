@@ -19,12 +19,13 @@
 template <int MODE>      // 0: one key segment; 1: two segments, the second <= 64 keys (IP-Adapter image tokens), merged accumulator; 2: generic two segments
 __global__ __launch_bounds__(256, 2) void attention_f16_kernel(const half_t* aQ, half_t* aO, int aldq, int aldo, int aB, int aheads, int aNq, int anseg, float ascale,
                                                             int axcd, const half_t* aK0, const half_t* aV0, int an0, int ald0, int arpb0, float aw0,
-                                                            const half_t* aK1, const half_t* aV1, int an1, int ald1, int arpb1, float aw1) {
+                                                            const half_t* aK1, const half_t* aV1, int an1, int ald1, int arpb1, float aw1, const float* aw1b) {
   // scalar arguments (the first 16 dwords are preloaded into SGPRs: build.py PRELOAD), re-assembled into the descriptor the body uses
   AttnArgs p;
   p.Q = aQ; p.O = aO; p.ldq = aldq; p.ldo = aldo; p.B = aB; p.heads = aheads; p.Nq = aNq; p.nseg = anseg; p.scale_log2e = ascale; p.xcd_map = axcd;
   p.seg[0].K = aK0; p.seg[0].V = aV0; p.seg[0].nkeys = an0; p.seg[0].ld = ald0; p.seg[0].rows_per_batch = arpb0; p.seg[0].weight = aw0;
   p.seg[1].K = aK1; p.seg[1].V = aV1; p.seg[1].nkeys = an1; p.seg[1].ld = ald1; p.seg[1].rows_per_batch = arpb1; p.seg[1].weight = aw1;
+  p.w1_b = aw1b;
   // up to 4 key tiles (256 keys) of K and of V resident at once: one load phase + one barrier per 256 keys
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   char* sK = smem;
@@ -85,7 +86,7 @@ hipError_t ia2p_launch_attention(const AttnArgs& a, hipStream_t s) {
 #define IA2P_ATTN_LAUNCH(MODE)                                                                                                         \
   hipLaunchKernelGGL(attention_f16_kernel<MODE>, grid, dim3(256), 65536, s, b.Q, b.O, b.ldq, b.ldo, b.B, b.heads, b.Nq, b.nseg, b.scale_log2e, b.xcd_map, \
                      b.seg[0].K, b.seg[0].V, b.seg[0].nkeys, b.seg[0].ld, b.seg[0].rows_per_batch, b.seg[0].weight,                    \
-                     b.seg[1].K, b.seg[1].V, b.seg[1].nkeys, b.seg[1].ld, b.seg[1].rows_per_batch, b.seg[1].weight)
+                     b.seg[1].K, b.seg[1].V, b.seg[1].nkeys, b.seg[1].ld, b.seg[1].rows_per_batch, b.seg[1].weight, b.w1_b)
   if (mode == 0) IA2P_ATTN_LAUNCH(0);
   else if (mode == 1) IA2P_ATTN_LAUNCH(1);
   else IA2P_ATTN_LAUNCH(2);

@@ -143,7 +143,8 @@ __device__ __forceinline__ void attn_core(const AttnArgs& p, int b, int hd, cons
   constexpr int NSEG = MODE == 0 ? 1 : 2;
 #pragma unroll 1
   for (int sg = 0; sg < NSEG; ++sg) {
-    const AttnSeg seg = sg == 0 ? p.seg[0] : p.seg[1];   // (a runtime index into the by-value argument would push it to scratch)
+    AttnSeg seg = sg == 0 ? p.seg[0] : p.seg[1];         // (a runtime index into the by-value argument would push it to scratch)
+    if (sg == 1 && p.w1_b) seg.weight = p.w1_b[b];       // per-request IP-Adapter scale
     const half_t* Kb = seg.K + (size_t)b * seg.rows_per_batch * seg.ld + hd * 64;
     const half_t* Vb = seg.V + (size_t)b * seg.rows_per_batch * seg.ld + hd * 64;
     const bool ip_tile = MODE == 1 && sg == 1;           // one tile of <= 64 keys with its own softmax, merged into `o`

@@ -158,4 +158,6 @@ struct AttnArgs {
   float scale_log2e;     // (1/sqrt(64)) * log2(e)
   int xcd_map;           // 1: contiguous (batch, head, query block) range per XCD (set by the launcher)
   AttnSeg seg[2];
+  const float* w1_b;     // optional, device: weight of segment 1 PER BATCH ELEMENT (overrides seg[1].weight) -- requests with different IP-Adapter
+                         // scales (reference ip_adapter.py:211-214 `set_scale`, one value per call there) share one evaluation
 };

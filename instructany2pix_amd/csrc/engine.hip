@@ -463,6 +463,7 @@ struct Fwd {
   T2 temb_all;
   float* gn_partial;
   T2 kv_text, kv_ip;   // [B*Lt, kv_rows], [B*Li, kv_rows]
+  const float* ip_scales = nullptr;   // device [B] or null: per-request IP-Adapter scale (else the context's one value)
 };
 
 struct RegionScope { RunCtx* c; int prev; RegionScope(RunCtx* c_, int r) : c(c_), prev(c_->region) { c->region = r; } ~RegionScope() { c->region = prev; } };
@@ -577,6 +578,7 @@ static T2 run_transformer(Fwd& f, const Transformer& t, T2 x, int H, int Wd) {
       const half_t* ki = (c->dry || !Li) ? nullptr : f.kv_ip.p + b.kv_col;
       a.seg[0].K = kt; a.seg[0].V = c->dry ? nullptr : kt + C; a.seg[0].nkeys = Lt; a.seg[0].ld = ldkv; a.seg[0].rows_per_batch = Lt; a.seg[0].weight = 1.f;
       a.seg[1].K = ki; a.seg[1].V = ki ? ki + C : nullptr; a.seg[1].nkeys = Li; a.seg[1].ld = ldkv; a.seg[1].rows_per_batch = Li; a.seg[1].weight = c->ip_scale;
+      a.w1_b = Li ? f.ip_scales : nullptr;
       // a 128 x 64 tile of to_q is 128 queries x one head: projection and attention run as one launch when tiles do not straddle batch elements
       // (and the context fits 3 key tiles: its K / V ride in registers through the projection loop); small problems keep the finer 64 x 64 split
       const bool fuse = c->xattn_fuse && HW % 128 == 0 && C == t.heads * 64 && (Lt + 63) / 64 + (Li + 63) / 64 <= 3 && (long)(M / 128) * t.heads >= c->xattn_min_tiles;
@@ -623,12 +625,13 @@ static void project_context(ia2p_ctx* c, const half_t* context, int L, int B, ha
 // kv_cached != nullptr: the context projections were computed before (ia2p_project_context) and are read from there
 static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep, const half_t* context, int L,
                                const half_t* text_embeds, const half_t* time_ids, half_t* out, int B, int h, int w,
-                               const half_t* kv_cached = nullptr) {
+                               const half_t* kv_cached = nullptr, const float* timesteps = nullptr, const float* ip_scales = nullptr) {
   const ia2p_unet_config& g = c->cfg;
   const int n = g.n_blocks;
   const int T = g.time_embed_dim, Tp = g.time_proj_dim, Ain = g.projection_class_embeddings_input_dim, Ad = g.addition_time_embed_dim;
   const int pooled = Ain - g.num_time_ids * Ad;
   Fwd f{c, B, h, w, L, context, T2{(size_t)-1, nullptr}, nullptr, T2{(size_t)-1, nullptr}, T2{(size_t)-1, nullptr}};
+  f.ip_scales = ip_scales;
 
   // GroupNorm partial sums (fp32) live at the front of the workspace
   T2 gnp = wsalloc(c, (size_t)B * 64 * g.norm_num_groups * 2 * 2);
@@ -639,7 +642,7 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
   f.temb_all = wsalloc(c, (size_t)B * c->temb_total);
   {
     ProfScope ps(c, PK_EMBED, 0, 0);
-    CHECK_LAUNCH(c, ia2p_launch_embed(timestep, text_embeds, time_ids, tsin.p, addin.p, B, Tp, pooled, Ad, g.num_time_ids, c->stream), "embed");
+    CHECK_LAUNCH(c, ia2p_launch_embed(timestep, timesteps, text_embeds, time_ids, tsin.p, addin.p, B, Tp, pooled, Ad, g.num_time_ids, c->stream), "embed");
     // skinny linears hold <= 16 rows per launch: larger batches go in row chunks
     auto lin = [&](const half_t* X, int ldx, size_t w, size_t b, const half_t* add, int ldadd, half_t* o, int ldo, int N, int K, int si, int so, const char* what) {
       for (int r0 = 0; r0 < B; r0 += 16) {
@@ -874,10 +877,13 @@ ia2p_status ia2p_finalize_weights(ia2p_ctx* c) {
 size_t ia2p_arena_raw_bytes(ia2p_ctx* c) { return c ? c->arena_raw_elems * sizeof(half_t) : 0; }
 // The head of the arena ([0, ia2p_arena_raw_bytes): parameters as loaded) was filled elsewhere -- an RCCL broadcast from the rank that read the
 // checkpoint; the derived tail (LayerNorm folds) is recomputed here from it, so 2.5 GB of it never cross xGMI.
-ia2p_status ia2p_adopt_arena(ia2p_ctx* c, int with_ip_adapter) {
+// The fold kernels must run AFTER the broadcast that filled the head: they are enqueued on the caller's stream (the one the collective was
+// ordered on) and that stream is synchronised before returning, so forwards on any other stream afterwards see finished folds.
+ia2p_status ia2p_adopt_arena_on(ia2p_ctx* c, int with_ip_adapter, void* stream) {
   const ia2p_status st = rc_adopt(c, with_ip_adapter != 0);
-  return st == IA2P_OK ? fold_all(c, nullptr, true) : st;
+  return st == IA2P_OK ? fold_all(c, (hipStream_t)stream, true) : st;
 }
+ia2p_status ia2p_adopt_arena(ia2p_ctx* c, int with_ip_adapter) { return ia2p_adopt_arena_on(c, with_ip_adapter, nullptr); }
 
 ia2p_status ia2p_set_ip_adapter(ia2p_ctx* c, int enabled, int num_tokens, float scale) {
   if (!c) return IA2P_ERR_INVALID;
@@ -910,14 +916,15 @@ size_t ia2p_workspace_bytes(ia2p_ctx* c, int B, int h, int w, int L) {
 }
 
 static ia2p_status unet_forward_impl(ia2p_ctx* c, void* stream, const void* sample, float timestep, const void* context, const void* kv, int L,
-                                     const void* text_embeds, const void* time_ids, void* out, int B, int h, int w, void* ws, size_t ws_bytes) {
+                                     const void* text_embeds, const void* time_ids, void* out, int B, int h, int w, void* ws, size_t ws_bytes,
+                                     const float* timesteps = nullptr, const float* ip_scales = nullptr) {
   if (!c || !sample || (!context && !kv) || !text_embeds || !time_ids || !out || !ws) return fail(c, IA2P_ERR_INVALID, "unet_forward: null argument");
   if (!c->finalized) return fail(c, IA2P_ERR_STATE, "unet_forward before weights were finalized");
   ia2p_status st = check_fwd_shape(c, B, h, w, L);
   if (st != IA2P_OK) return st;
   if (!zero_page()) return fail(c, IA2P_ERR_HIP, "cannot allocate zero page");
-  if (c->fold_dirty) {            // a tensor was reloaded after finalize (hot swap, strict=False load): re-derive the folds, stream-ordered
-    st = fold_all(c, (hipStream_t)stream, false);
+  if (c->fold_dirty) {            // a tensor was reloaded after finalize (hot swap, strict=False load): re-derive the folds on this stream and wait
+    st = fold_all(c, (hipStream_t)stream, true);       // (rare; the wait keeps a following forward on ANOTHER stream from reading half-written folds)
     if (st != IA2P_OK) return st;
   }
   const uintptr_t base = ((uintptr_t)ws + 255) & ~(uintptr_t)255;
@@ -937,7 +944,7 @@ static ia2p_status unet_forward_impl(ia2p_ctx* c, void* stream, const void* samp
   c->ws_base = (char*)base;
   c->tail_pf = c->arena + c->embed_lo; c->tail_pf_bytes = (c->embed_hi - c->embed_lo) * sizeof(half_t);   // the next step starts with these
   st = run_forward(c, (const half_t*)sample, timestep, (const half_t*)context, L, (const half_t*)text_embeds, (const half_t*)time_ids, (half_t*)out, B, h, w,
-                   (const half_t*)kv);
+                   (const half_t*)kv, timesteps, ip_scales);
   if (c->failed && st == IA2P_OK) st = IA2P_ERR_HIP;
   if (c->failed && c->err == "workspace too small") st = IA2P_ERR_NOMEM;
   return st;
@@ -946,6 +953,18 @@ ia2p_status ia2p_unet_forward(ia2p_ctx* c, void* stream, const void* sample, flo
                               const void* text_embeds, const void* time_ids, void* out, int B, int h, int w, void* ws, size_t ws_bytes) {
   if (!context) return fail(c, IA2P_ERR_INVALID, "unet_forward: null argument");
   return unet_forward_impl(c, stream, sample, timestep, context, nullptr, L, text_embeds, time_ids, out, B, h, w, ws, ws_bytes);
+}
+
+// Per-request knobs inside ONE evaluation: `timesteps` (device, float [B]) gives every batch element its own timestep -- diffusers' UNet accepts
+// a [B] timestep tensor; the reference always passes one scalar (pnp_pipeline.py:253-260, sdxl_pipeline.py:832-839) because it serves one
+// request at a time -- and `ip_scales` (device, float [B], or NULL) its own IP-Adapter scale (reference: one `set_scale` value per call,
+// ip_adapter.py:211-214, attention_processor.py:397). Exactly one of `context` / `kv` (ia2p_project_context) is non-NULL. Batch element b gets
+// the same bits as in a uniform batch of the same size evaluated at (timesteps[b], ip_scales[b]) (tests/test_batch_gpu.py).
+ia2p_status ia2p_unet_forward_v(ia2p_ctx* c, void* stream, const void* sample, const float* timesteps, const float* ip_scales, const void* context, const void* kv,
+                                int L, const void* text_embeds, const void* time_ids, void* out, int B, int h, int w, void* ws, size_t ws_bytes) {
+  if (!timesteps || (!context) == (!kv)) return fail(c, IA2P_ERR_INVALID, "unet_forward_v: timesteps and exactly one of context / kv are required");
+  if (ip_scales && c && !c->ip_enabled) return fail(c, IA2P_ERR_STATE, "unet_forward_v: per-request IP-Adapter scales without an installed adapter");
+  return unet_forward_impl(c, stream, sample, 0.f, context, kv, L, text_embeds, time_ids, out, B, h, w, ws, ws_bytes, timesteps, ip_scales);
 }
 
 // ---- context K/V hoisted out of the step: the projections depend on (context, weights) only, constant over a request's steps
@@ -961,7 +980,7 @@ ia2p_status ia2p_project_context(ia2p_ctx* c, void* stream, const void* context,
   if (kv_bytes < need) return fail(c, IA2P_ERR_NOMEM, "project_context: kv buffer holds %zu bytes, needs %zu", kv_bytes, need);
   if (!zero_page()) return fail(c, IA2P_ERR_HIP, "cannot allocate zero page");
   if (c->fold_dirty) {
-    const ia2p_status fs = fold_all(c, (hipStream_t)stream, false);
+    const ia2p_status fs = fold_all(c, (hipStream_t)stream, true);
     if (fs != IA2P_OK) return fs;
   }
   const uintptr_t base = ((uintptr_t)ws + 255) & ~(uintptr_t)255;
@@ -1020,6 +1039,14 @@ ia2p_status ia2p_ddim_step(void* stream, const void* x, const void* eu, const vo
   if (!x || !eu || !out || n < 0) return fail(nullptr, IA2P_ERR_INVALID, "ddim_step: null argument");
   hipError_t e = ia2p_launch_ddim_step((const half_t*)x, (const half_t*)eu, (const half_t*)ec, g, c_x, c_e, (half_t*)out, (half_t*)out2, (long)n, (hipStream_t)stream);
   return e == hipSuccess ? IA2P_OK : fail(nullptr, IA2P_ERR_HIP, "ddim_step: %s", hipGetErrorString(e));
+}
+
+// The same update with per-request coefficients: coef (device, float [B][3]) = {guidance g, c_x, c_e} of batch element b, `per` elements each --
+// requests with their own guidance scale (reference pipeline.py:303 `cfg`) at their own step of their own schedule share one launch.
+ia2p_status ia2p_ddim_step_v(void* stream, const void* x, const void* eu, const void* ec, const float* coef, void* out, void* out2, int B, int64_t per) {
+  if (!x || !eu || !out || !coef || B < 0 || per < 1) return fail(nullptr, IA2P_ERR_INVALID, "ddim_step_v: bad argument");
+  hipError_t e = ia2p_launch_ddim_step((const half_t*)x, (const half_t*)eu, (const half_t*)ec, 0.f, 0.f, 0.f, (half_t*)out, (half_t*)out2, (long)B * per, (hipStream_t)stream, coef, (long)per);
+  return e == hipSuccess ? IA2P_OK : fail(nullptr, IA2P_ERR_HIP, "ddim_step_v: %s", hipGetErrorString(e));
 }
 
 ia2p_status ia2p_mask_blend(void* stream, const void* x, const void* init, const void* noise, const void* mask, float c0, float c1,

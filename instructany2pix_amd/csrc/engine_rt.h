@@ -33,7 +33,7 @@ hipError_t ia2p_launch_groupnorm(const half_t* x, int ldx, half_t* y, int ldy, c
                                  float* partial, int B, int HW, int C, int G, float eps, int silu, hipStream_t s, const half_t* x2 = nullptr, int ldx2 = 0, int Ca = 0);
 hipError_t ia2p_launch_layernorm(const half_t* x, int ldx, half_t* y, int ldy, const half_t* gamma, const half_t* beta,
                                  int M, int C, float eps, hipStream_t s);
-hipError_t ia2p_launch_embed(float t, const half_t* text_embeds, const half_t* time_ids, half_t* tsin, half_t* addin,
+hipError_t ia2p_launch_embed(float t, const float* ts, const half_t* text_embeds, const half_t* time_ids, half_t* tsin, half_t* addin,
                              int B, int Tp, int P, int Ad, int nids, hipStream_t s);
 hipError_t ia2p_launch_linear_small(const half_t* X, int ldx, const half_t* W, const half_t* bias, const half_t* addend, int ldadd,
                                     half_t* out, int ldo, int M, int N, int K, int silu_in, int silu_out, hipStream_t s);
@@ -41,7 +41,7 @@ hipError_t ia2p_launch_conv_in(const half_t* x, const half_t* w, const half_t* b
 hipError_t ia2p_launch_conv_out(const half_t* x, int ldx, const half_t* w, const half_t* bias, half_t* y, int B, int C, int H, int W, int Co, hipStream_t s);
 hipError_t ia2p_launch_concat(const half_t* a, int lda, int Ca, const half_t* b, int ldb, int Cb, half_t* y, long M, hipStream_t s);
 hipError_t ia2p_launch_ddim_step(const half_t* x, const half_t* eps_u, const half_t* eps_c, float g, float c_x, float c_e,
-                                 half_t* out, half_t* out2, long n, hipStream_t s);
+                                 half_t* out, half_t* out2, long n, hipStream_t s, const float* coef = nullptr, long per = 1);
 hipError_t ia2p_launch_mask_blend(const half_t* x, const half_t* init, const half_t* noise, const half_t* mask, float c0, float c1,
                                   half_t* out, half_t* out2, int B, int C, long HW, hipStream_t s);
 hipError_t ia2p_launch_cat_rows(const half_t* a, int Ka, const half_t* b, int Kb, const half_t* bias_a, const half_t* bias_b, half_t* dst, half_t* bias_dst, int rows, hipStream_t s);

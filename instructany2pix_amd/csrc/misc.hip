@@ -8,9 +8,12 @@
 // ---- sinusoidal embeddings (diffusers Timesteps(flip_sin_to_cos=True, freq_shift=0)) ------------------
 // tsin[b, :]   = [cos(t f_i), sin(t f_i)], i < Tp/2
 // addin[b, :]  = [text_embeds[b, :P], sinusoid(time_ids[b,0]), ..., sinusoid(time_ids[b,5])]
-__global__ void embed_kernel(float t, const half_t* text_embeds, const half_t* time_ids, half_t* tsin, half_t* addin,
+// ts (optional, device [B]): one timestep per batch element (diffusers' UNet takes a [B] timestep tensor; requests at different steps of
+// their schedules then share one evaluation); null: the scalar t for all
+__global__ void embed_kernel(float t0, const float* ts, const half_t* text_embeds, const half_t* time_ids, half_t* tsin, half_t* addin,
                              int B, int Tp, int P, int Ad, int nids) {
   const int b = blockIdx.x;
+  const float t = ts ? ts[b] : t0;
   const int Ain = P + nids * Ad;
   for (int i = threadIdx.x; i < Tp; i += blockDim.x) {
     const int half_ = Tp / 2, k = i % half_;
@@ -286,9 +289,12 @@ __global__ void concat_kernel(const half_t* a, int lda, int Ca, const half_t* b,
 // eps = eps_u + g (eps_c - eps_u)          reference ddim/sdxl_pipeline.py:842-844
 // out = c_x * x + c_e * eps                 sampling: DDIMScheduler.step (eta 0); inversion: pnp_pipeline.py:73-85
 // out2 (optional) receives a second copy (the cat([latents]*2) input of the next CFG evaluation, :826)
+// coef (optional, device [B][3] = {g, c_x, c_e} per batch element of `per` elements each): requests with their own guidance scale and their own
+// position in their own schedule share one launch; null: the scalars for all. Same arithmetic either way (fp32, one rounding).
 __global__ void ddim_step_kernel(const half_t* x, const half_t* eps_u, const half_t* eps_c, float g, float c_x, float c_e,
-                                 half_t* out, half_t* out2, long n) {
+                                 half_t* out, half_t* out2, long n, const float* coef, long per) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    if (coef) { const float* c = coef + 3 * (i / per); g = c[0]; c_x = c[1]; c_e = c[2]; }
     float e = (float)eps_u[i];
     if (eps_c) e = e + g * ((float)eps_c[i] - e);
     const half_t o = (half_t)(c_x * (float)x[i] + c_e * e);
@@ -601,9 +607,9 @@ __global__ __launch_bounds__(256) void ip_attn_map_kernel(const half_t* Q, int l
 // ---- host launchers -------------------------------------------------------------------------------------------------------
 static inline int grid_for(long n, int block) { long g = (n + block - 1) / block; return (int)(g > 4096 ? 4096 : (g < 1 ? 1 : g)); }
 
-hipError_t ia2p_launch_embed(float t, const half_t* text_embeds, const half_t* time_ids, half_t* tsin, half_t* addin,
+hipError_t ia2p_launch_embed(float t, const float* ts, const half_t* text_embeds, const half_t* time_ids, half_t* tsin, half_t* addin,
                              int B, int Tp, int P, int Ad, int nids, hipStream_t s) {
-  hipLaunchKernelGGL(embed_kernel, dim3(B), dim3(256), 0, s, t, text_embeds, time_ids, tsin, addin, B, Tp, P, Ad, nids);
+  hipLaunchKernelGGL(embed_kernel, dim3(B), dim3(256), 0, s, t, ts, text_embeds, time_ids, tsin, addin, B, Tp, P, Ad, nids);
   return hipGetLastError();
 }
 hipError_t ia2p_launch_linear_small(const half_t* X, int ldx, const half_t* W, const half_t* bias, const half_t* addend, int ldadd,
@@ -658,8 +664,8 @@ hipError_t ia2p_launch_concat(const half_t* a, int lda, int Ca, const half_t* b,
   return hipGetLastError();
 }
 hipError_t ia2p_launch_ddim_step(const half_t* x, const half_t* eps_u, const half_t* eps_c, float g, float c_x, float c_e,
-                                 half_t* out, half_t* out2, long n, hipStream_t s) {
-  hipLaunchKernelGGL(ddim_step_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, x, eps_u, eps_c, g, c_x, c_e, out, out2, n);
+                                 half_t* out, half_t* out2, long n, hipStream_t s, const float* coef, long per) {
+  hipLaunchKernelGGL(ddim_step_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, x, eps_u, eps_c, g, c_x, c_e, out, out2, n, coef, per > 0 ? per : 1);
   return hipGetLastError();
 }
 hipError_t ia2p_launch_mask_blend(const half_t* x, const half_t* init, const half_t* noise, const half_t* mask, float c0, float c1,

@@ -43,8 +43,11 @@ def polar_intrtpolate(x, y, alpha):
 
 
 def to_8bit_image(image):
-    """What the reference's hand-over between its pipelines does to an image tensor in [-1, 1]: `postprocess(output_type="pil")`
+    """What the reference's hand-over between its pipelines does to an image TENSOR IN [-1, 1] (what `vae_decode` hooks return here; a hook that
+    returns PIL images or [0, 1] tensors is rejected): `postprocess(output_type="pil")`
     (`(x / 2 + 0.5).clamp(0, 1)`, `* 255`, round, uint8) followed by the img2img pipeline's `preprocess` (`/ 255`, `2 x - 1`)."""
+    if not torch.is_tensor(image) or not image.is_floating_point():
+        raise TypeError("to_8bit_image expects the decode hook's float tensor in [-1, 1]")
     q = ((image.float() / 2 + 0.5).clamp(0, 1) * 255.0).round()
     return (q / 255.0 * 2.0 - 1.0).to(image.dtype)
 
@@ -75,6 +78,7 @@ class InstructAny2PixPipeline:
         if refiner_handoff not in ("image", "latent"):
             raise ValueError("refiner_handoff must be 'image' or 'latent'")
         self.refiner_handoff = refiner_handoff
+        self._warned_handoff = False
         # the embedding prior (reference :97-98,:120-122 `self.model`): prior.py::InstructAny2PixPrior on the HIP kernels, or None when
         # the conditioner supplies `y` itself
         self.model = prior
@@ -123,6 +127,15 @@ class InstructAny2PixPipeline:
                                              output_type="latent")
         return images, latent_inv
 
+    # ---- N independent requests as one batch per evaluation, sharded over the ranks (batch.py) ---------------------------------------------------
+    def denoise_batch(self, requests, group: int = 4, shard: bool = True):
+        """`denoise` for a list of `batch.EditRequest`s with their own `num_inference_steps` / `cfg` / `scale` / `alpha`: grouped `group` at a time
+        (B_eff = 2 x group in the guided loop), contiguous shards per rank when a process group is up, results all-gathered in request order.
+        -> (sampled latents [N,4,h,w], inverted latents [N,4,h,w])."""
+        from .batch import denoise_batch
+        self.pipe_inversion.unet = self.pipe.unet
+        return denoise_batch(self, requests, group=group, shard=shard)
+
     # ---- reference keyword surface ----------------------------------------------------------------------------------
     def __call__(self, inst, mm_data, alpha=0.7, h=[0.0, 0.4, 1.0], norm=20.0, refinement=0.5, llm_only=False, num_inference_steps=25,
                  use_cache=False, debug=False, diffusion_mode="default", subject_strength=0.0, cfg=10, scale=1.0) -> Any:
@@ -160,6 +173,13 @@ class InstructAny2PixPipeline:
                       negative_prompt_embeds=c["refiner_negative_prompt_embeds"], negative_pooled_prompt_embeds=c["refiner_negative_pooled_prompt_embeds"],
                       noise=c.get("refiner_noise"), output_type="latent")
             vae_route = self.refiner_handoff == "image" and self.pipe._vae_decode is not None and self.piperf._vae_encode is not None
+            if self.refiner_handoff == "image" and not vae_route and not self._warned_handoff:
+                # the reference's route was asked for (decode, 8-bit image, posterior SAMPLE from the global RNG) but cannot be taken: say so once --
+                # the latent route has different numerics and draws nothing from the RNG
+                import warnings
+                warnings.warn("refiner_handoff='image' needs vae_decode= on the base pipeline and vae_encode= on the refiner pipeline; handing the "
+                              "latents over directly instead (pass refiner_handoff='latent' to choose this route explicitly)", RuntimeWarning, stacklevel=2)
+                self._warned_handoff = True
             if vae_route:
                 # the reference hands a decoded 8-bit image over and the refiner pipeline re-encodes it with the shared VAE
                 # (`retrieve_latents(vae.encode(image)) * scaling_factor`: a posterior SAMPLE, global RNG)

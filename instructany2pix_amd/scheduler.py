@@ -117,6 +117,20 @@ def fused_update(x, eps_u, eps_c, guidance, c_x, c_e, out, out2=None):
     return out
 
 
+def fused_update_v(x, eps_u, eps_c, coef, out, out2=None):
+    """The same update with per-request coefficients (ia2p_ddim_step_v): coef = float32 device tensor [B, 3] = (guidance, c_x, c_e) of every
+    batch element of x [B, ...]; requests with their own guidance scale at their own step of their own schedule share one launch."""
+    for t in (x, eps_u, out):
+        assert t.dtype == torch.float16 and t.is_cuda and t.is_contiguous(), "latents must be contiguous fp16 device tensors"
+    B = x.shape[0]
+    per = x.numel() // B
+    assert coef.dtype == torch.float32 and coef.is_cuda and coef.is_contiguous() and tuple(coef.shape) == (B, 3)
+    assert eps_u.numel() == x.numel() and out.numel() == x.numel() and (eps_c is None or eps_c.numel() == x.numel())
+    L = _ffi.lib()
+    _ffi.check(L.ia2p_ddim_step_v(_ffi.current_stream(), _ffi.ptr(x), _ffi.ptr(eps_u), _ffi.ptr(eps_c), _ffi.ptr(coef), _ffi.ptr(out), _ffi.ptr(out2), B, per))
+    return out
+
+
 class EulerDiscreteScheduler:
     """Euler (first-order, sigma-space) sampler of the SDXL refiner: the scheduler `StableDiffusionXLImg2ImgPipeline.
     from_pretrained("stabilityai/stable-diffusion-xl-refiner-1.0")` instantiates for `self.piperf` (reference

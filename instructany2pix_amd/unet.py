@@ -98,7 +98,7 @@ class HipUNet2DConditionModel:
     def adopt_arena(self, with_ip_adapter: bool = True):
         """The arena HEAD was produced elsewhere (RCCL broadcast of `arena_raw` from rank 0): mark parameters present and derive the
         tail (LayerNorm folds) locally with the same kernel rank 0 used, so ranks hold bit-identical arenas."""
-        _ffi.check(self._lib.ia2p_adopt_arena(self._ctx, int(with_ip_adapter)), self._ctx)
+        _ffi.check(self._lib.ia2p_adopt_arena_on(self._ctx, int(with_ip_adapter), _ffi.current_stream()), self._ctx)   # ordered behind the broadcast
         self._weights_gen += 1
 
     # ---- operator-plugin API (reference ip_adapter.py:120-154) ----------------------------------------------------
@@ -178,7 +178,11 @@ class HipUNet2DConditionModel:
         return self._workspace
 
     def __call__(self, sample, timestep, encoder_hidden_states=None, cross_attention_kwargs=None, added_cond_kwargs=None,
-                 return_dict: bool = False, out: Optional[torch.Tensor] = None, _tune_reps: Optional[int] = None, **unused):
+                 return_dict: bool = False, out: Optional[torch.Tensor] = None, _tune_reps: Optional[int] = None,
+                 ip_scales: Optional[torch.Tensor] = None, **unused):
+        """`timestep`: a number / 0-dim tensor as the reference passes it, or a [B] tensor -- one timestep per batch element, as diffusers' UNet
+        accepts (`ia2p_unet_forward_v`); `ip_scales` (or cross_attention_kwargs={"ip_scales": ...}): optional [B] tensor, the IP-Adapter scale of
+        every batch element (the reference sets one value per call, ip_adapter.py:211-214). Both let independent requests share one evaluation."""
         if encoder_hidden_states is None or added_cond_kwargs is None:
             raise ValueError("encoder_hidden_states and added_cond_kwargs (text_embeds, time_ids) are required (text_time UNet)")
         if "text_embeds" not in added_cond_kwargs or "time_ids" not in added_cond_kwargs:
@@ -200,6 +204,28 @@ class HipUNet2DConditionModel:
         ws = self.workspace_for(B, h, w, L)
         if out is None:
             out = torch.empty(B, self.config.out_channels, h, w, dtype=torch.float16, device=self.device)
+        if ip_scales is None and cross_attention_kwargs:
+            ip_scales = cross_attention_kwargs.get("ip_scales")
+        per_sample = (torch.is_tensor(timestep) and timestep.numel() > 1) or ip_scales is not None
+        if per_sample:
+            if _tune_reps is not None:
+                raise ValueError("autotune takes a scalar timestep")
+            ts = timestep if torch.is_tensor(timestep) else torch.full((B,), float(timestep))
+            ts = ts.to(device=self.device, dtype=torch.float32).reshape(-1).contiguous()
+            if ts.numel() == 1:
+                ts = ts.expand(B).contiguous()
+            if ts.numel() != B:
+                raise ValueError(f"timestep tensor has {ts.numel()} elements for a batch of {B}")
+            sc = None
+            if ip_scales is not None:
+                sc = torch.as_tensor(ip_scales).to(device=self.device, dtype=torch.float32).reshape(-1).contiguous()
+                if sc.numel() != B:
+                    raise ValueError(f"ip_scales has {sc.numel()} elements for a batch of {B}")
+            kv = self._context_kv(ctx_in, ctx, B, L, ws) if self.cache_context_kv else None
+            _ffi.check(self._lib.ia2p_unet_forward_v(self._ctx, _ffi.current_stream(), _ffi.ptr(sample), _ffi.ptr(ts), _ffi.ptr(sc) if sc is not None else None,
+                                                     None if kv is not None else _ffi.ptr(ctx), _ffi.ptr(kv) if kv is not None else None, L, _ffi.ptr(te), _ffi.ptr(tid),
+                                                     _ffi.ptr(out), B, h, w, _ffi.ptr(ws), ws.numel()), self._ctx)
+            return (out,) if not return_dict else SimpleNamespace(sample=out)
         t = float(timestep.item()) if torch.is_tensor(timestep) else float(timestep)
         args = (self._ctx, _ffi.current_stream(), _ffi.ptr(sample), t, _ffi.ptr(ctx), L, _ffi.ptr(te), _ffi.ptr(tid), _ffi.ptr(out), B, h, w,
                 _ffi.ptr(ws), ws.numel())

@@ -225,14 +225,23 @@ def iter_safetensors(path: str, specs: "List[Spec] | None" = None, prefix: str =
             raise FileNotFoundError(f"no .safetensors checkpoint under {path}")
         if len(files) > 1 and not idx:
             plain = [f for f in files if os.path.basename(f) == "diffusion_pytorch_model.safetensors"]
-            files = plain or files[:1]
+            if not plain:       # several variants (fp16 / non-ema / ...) and nothing says which one is meant: do not pick silently
+                raise ValueError(f"{path} holds several .safetensors variants ({[os.path.basename(f) for f in files]}) and no "
+                                 f"diffusion_pytorch_model.safetensors: pass the file to load")
+            files = plain
         path = files[0]
     if path.endswith(".index.json"):
         shards = sorted(set(json.load(open(path))["weight_map"].values()))
         files = [os.path.join(os.path.dirname(path), f) for f in shards]
     else:
         files = [path]
-    handles = [safe_open(f, framework="pt", device="cpu") for f in files]
+    import contextlib
+    with contextlib.ExitStack() as stack:          # the mmaps / file handles close when the generator is exhausted or closed
+        handles = [stack.enter_context(safe_open(f, framework="pt", device="cpu")) for f in files]
+        yield from _iter_open_safetensors(handles, prefix, specs)
+
+
+def _iter_open_safetensors(handles, prefix, specs):
     where = {}
     for h in handles:
         for k in h.keys():

@@ -147,3 +147,81 @@ def test_cfg5_768px_guided_two_steps_vs_oracle(full):
             r, c = traj_metrics(steps[i][sel], x)
             # guidance 10 amplifies the fp16 difference of the two UNet outputs tenfold before it enters the update
             assert r < 3e-2 and c > 0.999, (i, r, c)
+
+
+def test_cfg3_last_timestep_and_10_step_trajectory(full):
+    """BASELINE configs[2] beyond its first evaluation: (i) the LAST timestep of the 50-step schedule (t = 1: the time embedding at the other end of
+    its range), requests 0 and 5 of the batch-8 evaluation against the oracle; (ii) the first 10 steps of the 50-step DDIM sampling loop
+    (no guidance, as bench.py's Workload runs it) for the whole batch on the HIP path, request 0's trajectory against the oracle loop step by step."""
+    from bench import make_inputs
+    from instructany2pix_amd.scheduler import DDIMScheduler, fused_update
+    cfg, hip, ref, ip_procs, oracle = full
+    _set_ip(hip, ref, ip_procs, 1.0)
+    lat, ctx, pooled, tid = make_inputs(cfg, 8, 64, 81, DEV, cfg_id=3)
+    added = dict(text_embeds=pooled, time_ids=tid)
+    out = hip(lat, 1, encoder_hidden_states=ctx, added_cond_kwargs=added)[0]
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    sel = [0, 5]
+    f = lambda t_: t_[sel].float().cpu()
+    with torch.no_grad():
+        want = ref(f(lat), 1, f(ctx), added_cond_kwargs=dict(text_embeds=f(pooled), time_ids=f(tid)))[0]
+    for i, r in enumerate(sel):
+        e = rel_l2(out[r], want[i])
+        assert e < 5e-3, (r, e)
+        assert float((out[r].float().cpu() - want[i]).abs().max()) < 2e-2 * float(want[i].abs().max()), r
+    # ---- 10 steps of the loop
+    sch = DDIMScheduler()
+    sch.set_timesteps(50)
+    x, y, eps = lat.clone(), torch.empty_like(lat), torch.empty_like(lat)
+    hip_traj = []
+    for i in range(10):
+        t = int(sch.timesteps[i])
+        hip(x, t, encoder_hidden_states=ctx, added_cond_kwargs=added, out=eps)
+        c_x, c_e = sch.step_coeffs(t)
+        fused_update(x, eps, None, 1.0, c_x, c_e, y)
+        x, y = y, x
+        hip_traj.append(x[0].clone())
+    torch.cuda.synchronize()
+    rs = oracle.DDIMSchedulerRef()
+    rs.set_timesteps(50)
+    g = lambda t_: t_[0:1].float().cpu()
+    xr, added_r = g(lat), dict(text_embeds=g(pooled), time_ids=g(tid))
+    with torch.no_grad():
+        for i in range(10):
+            t = int(rs.timesteps[i])
+            xr = rs.step(ref(xr, t, g(ctx), added_cond_kwargs=added_r)[0], t, xr)
+            r, c = traj_metrics(hip_traj[i], xr[0])
+            assert r < 3e-2 and c > 0.999, (i, r, c)
+
+
+def test_cfg5_768px_guided_first_step_all_four_requests(full):
+    """BASELINE configs[4]: the first guided step (t = 981, guidance 10, B_eff = 8) of ALL four 768x768 requests against the oracle."""
+    from bench import make_inputs
+    from instructany2pix_amd.scheduler import DDIMScheduler, fused_update
+    cfg, hip, ref, ip_procs, oracle = full
+    _set_ip(hip, ref, ip_procs, 1.0)
+    lat, ctx, pooled, tid = make_inputs(cfg, 4, 96, 81, DEV, cfg_id=5)
+    _, nctx, npooled, _ = make_inputs(cfg, 4, 96, 81, DEV, cfg_id=15)
+    sch = DDIMScheduler()
+    sch.set_timesteps(50)
+    t = int(sch.timesteps[0])
+    model_in = torch.cat([lat, lat], 0)
+    eps = hip(model_in, t, encoder_hidden_states=torch.cat([nctx, ctx], 0),
+              added_cond_kwargs=dict(text_embeds=torch.cat([npooled, pooled], 0), time_ids=torch.cat([tid, tid], 0)))[0]
+    c_x, c_e = sch.step_coeffs(t)
+    nxt = torch.empty_like(lat)
+    fused_update(lat, eps[:4].contiguous(), eps[4:].contiguous(), 10.0, c_x, c_e, nxt)
+    torch.cuda.synchronize()
+    rs = oracle.DDIMSchedulerRef()
+    rs.set_timesteps(50)
+    c = lambda t_: t_.float().cpu()
+    with torch.no_grad():
+        for r in range(4):           # one request (its two guidance halves) at a time: bounds the oracle's host memory
+            s = slice(r, r + 1)
+            eu, ec = ref(torch.cat([c(lat[s]), c(lat[s])], 0), t, torch.cat([c(nctx[s]), c(ctx[s])], 0),
+                         added_cond_kwargs=dict(text_embeds=torch.cat([c(npooled[s]), c(pooled[s])], 0), time_ids=torch.cat([c(tid[s]), c(tid[s])], 0)))[0].chunk(2)
+            want = rs.step(oracle.cfg_combine(eu, ec, 10.0), t, c(lat[s]))
+            rel, cos = traj_metrics(nxt[s], want)
+            assert rel < 3e-2 and cos > 0.999, (r, rel, cos)
+            assert rel_l2(eps[r], eu[0]) < 5e-3 and rel_l2(eps[4 + r], ec[0]) < 5e-3, r       # the two UNet outputs themselves, before guidance amplifies their difference
