@@ -170,6 +170,15 @@ ia2p_status ia2p_gemm(void* stream, const void* A, const void* W, const void* bi
  *                      *stats_slots = number of slots written; stats_out must hold (N/64 + 1) * M float2
  *       splitk > 1   : K split as in ia2p_gemm_splitk (partial: splitk*M*N floats); 0/1 = the library's unsplit choice */
 typedef struct { const float* stats; int slots; const float* colsum; const float* fbias; float eps; } ia2p_ln_fold;
+/* GEGLU feed-forward of a BasicTransformerBlock (diffusers FeedForward: ff.net.0 GEGLU + ff.net.2): H = geglu(X W1p^T + b1p) [M, 4C]
+ * (W1p / b1p packed by ia2p_pack_geglu), out = H W2^T + b2 + R. chained != 0: ONE launch, second-GEMM tiles waiting on per-128-row-panel counters of
+ * the first instead of on a kernel boundary (csrc/chain.hip), where the library's plans for the two shapes have a chained kernel -- *was_chained
+ * (optional) says whether it did. Same bits as two launches. splitk > 1: K split of the second GEMM (partial: splitk*M*C floats). */
+ia2p_status ia2p_ffn(void* stream, const void* X, const void* W1p, const void* b1p, const void* W2, const void* b2, const void* R, void* H, void* out,
+                     int M, int C, int chained, int splitk, float* partial, int* was_chained);
+/* chained launches bound every spin: a wait that gave up (never on this hardware: the dispatcher hands out workgroups in block order) sets a flag
+ * per (device, stream). Returns it (0 = all waits were satisfied) and clears it; call after synchronising the stream. */
+int ia2p_chain_errors(void* stream);
 ia2p_status ia2p_fold_layernorm(void* stream, const void* W, const void* gamma, const void* beta, const void* bias, void* Wf,
                                 float* colsum, float* fbias, int N, int K);
 ia2p_status ia2p_gemm_ex(void* stream, const void* A, const void* W, const void* bias, const void* residual, void* C, int M, int N, int K,

@@ -75,6 +75,8 @@ SIGNATURES = {
     "ia2p_layernorm": (_I, [_P, _P, _P, _P, _P, _I, _I, _F]),
     "ia2p_gemm": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I]),
     "ia2p_gemm_splitk": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "ia2p_ffn": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
+    "ia2p_chain_errors": (_I, [_P]),
     "ia2p_fold_layernorm": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I]),
     "ia2p_gemm_ex": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
     "ia2p_debug_set_gemm_splitk": (None, [_I]),

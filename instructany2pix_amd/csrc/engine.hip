@@ -52,7 +52,7 @@ struct Stage {            // one down/up block
 const char* prof_name(int k) {
   static char buf[PK_NCLASS][64];
   static const char* const other[] = {"attention_f16_kernel", "gn_stats_kernel+gn_apply_kernel", "layernorm_kernel",
-                                      "embed_kernel+linear_small_kernel", "conv_in_kernel", "conv_out_kernel", "concat_kernel", "splitk_reduce_kernel", "qproj_xattn_kernel"};
+                                      "embed_kernel+linear_small_kernel", "conv_in_kernel", "conv_out_kernel", "concat_kernel", "splitk_reduce_kernel", "qproj_xattn_kernel", "gemm_chain2_kernel"};
   if (k >= PK_ATTN) return other[k - PK_ATTN];
   const GemmTile t = IA2P_GEMM_TILES[(k % PK_CONV0) % IA2P_GEMM_NVARIANT];
   if (t.bm == 256) snprintf(buf[k], sizeof buf[k], "gemm_f16_kernel<%d, %d, %d, %s, 4, 64, 1, 2>", t.bm, t.bn, t.stages, k >= PK_CONV0 ? "true" : "false");
@@ -410,9 +410,9 @@ static void run_gemm(RunCtx* c, GemmArgs& a, bool conv, const char* what, double
   if (stat_slots) *stat_slots = (pl.splitk > 1 && !combined) ? 1 : (a.N + IA2P_GEMM_TILES[pl.variant].bn - 1) / IA2P_GEMM_TILES[pl.variant].bn;
 }
 
-void op_gemm(RunCtx* c, const half_t* A, int lda, const half_t* W, const half_t* bias, const half_t* residual, int ldr,
-             half_t* C, int ldc, int M, int N, int K, int geglu, int rpb, int bstride, int roff, int ldw,
-             const LnIn* ln, float* stats_out, int* stat_slots, int act) {
+static GemmArgs gemm_args(RunCtx* c, const half_t* A, int lda, const half_t* W, const half_t* bias, const half_t* residual, int ldr,
+                          half_t* C, int ldc, int M, int N, int K, int geglu, int rpb, int bstride, int roff, int ldw,
+                          const LnIn* ln, float* stats_out, int act) {
   GemmArgs a;
   memset(&a, 0, sizeof a);
   a.pad = 1;
@@ -424,8 +424,42 @@ void op_gemm(RunCtx* c, const half_t* A, int lda, const half_t* W, const half_t*
   a.rows_per_batch = 1;
   a.m_fastest = (long)M * K <= (long)N * K ? 1 : 0;
   a.acc_scale = c->ep_acc_scale; a.bias_scale = c->ep_bias_scale; c->ep_acc_scale = c->ep_bias_scale = 1.f;
+  return a;
+}
+static double gemm_bytes(int M, int N, int K, int geglu, bool residual) { return 2.0 * ((double)M * K + (double)N * K + (double)M * (geglu ? N / 2 : N) + (residual ? (double)M * N : 0)); }
+void op_gemm(RunCtx* c, const half_t* A, int lda, const half_t* W, const half_t* bias, const half_t* residual, int ldr,
+             half_t* C, int ldc, int M, int N, int K, int geglu, int rpb, int bstride, int roff, int ldw,
+             const LnIn* ln, float* stats_out, int* stat_slots, int act) {
+  GemmArgs a = gemm_args(c, A, lda, W, bias, residual, ldr, C, ldc, M, N, K, geglu, rpb, bstride, roff, ldw, ln, stats_out, act);
   set_prefetch(c, a, W, (size_t)N * K * sizeof(half_t));
-  run_gemm(c, a, false, "gemm", 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * (geglu ? N / 2 : N) + (residual ? (double)M * N : 0)), stat_slots);
+  run_gemm(c, a, false, "gemm", 2.0 * M * N * K, gemm_bytes(M, N, K, geglu, residual != nullptr), stat_slots);
+}
+// GEGLU feed-forward: ff.net.0 (a: K = C, N = 8 C packed, GEGLU epilogue -> H [M, 4 C]) then ff.net.2 (b: reads H, + bias + residual). With c->chain
+// and plans that have a chained kernel the two run as ONE launch (chain.hip); else as two. Same bits either way.
+static void run_ffn(RunCtx* c, GemmArgs& a, GemmArgs& b, int* stat_slots_b) {
+  set_prefetch(c, a, a.W, (size_t)a.N * a.K * sizeof(half_t));
+  set_prefetch(c, b, b.W, (size_t)b.N * b.K * sizeof(half_t));
+  const double fa = 2.0 * a.M * (double)a.N * a.K, fb = 2.0 * b.M * (double)b.N * b.K;
+  const double ba = gemm_bytes(a.M, a.N, a.K, 1, false), bb = gemm_bytes(b.M, b.N, b.K, 0, true);
+  if (c->tuning && !c->dry && !c->failed) { tune_site(c, a, false); tune_site(c, b, false); }
+  const GemmPlan pa = ia2p_gemm_plan(a.M, a.N, a.K, false, true), pb = ia2p_gemm_plan(b.M, b.N, b.K, false, false);
+  GemmArgs bt = b;
+  bt.splitk = pb.splitk > 1 ? pb.splitk : 0;
+  bt.partial = bt.splitk ? (float*)1 : nullptr;            // (placeholder for the shape check; the slabs are allocated below)
+  const bool chained = c->chain && !c->tuning && pa.splitk <= 1 && (pb.splitk <= 1 || ia2p_splitk_inkernel(b.M, b.N, pb.splitk)) && ia2p_chain2_ok(a, pa.variant, bt, pb.variant);
+  if (!chained) {
+    run_gemm(c, a, false, "ff.net.0", fa, ba);
+    run_gemm(c, b, false, "ff.net.2", fb, bb, stat_slots_b);
+    return;
+  }
+  T2 slab{(size_t)-1, nullptr};
+  if (pb.splitk > 1) { b.splitk = pb.splitk; slab = wsalloc(c, (size_t)pb.splitk * b.M * b.N * 2); b.partial = (float*)slab.p; }
+  {
+    ProfScope ps(c, PK_CHAIN, fa + fb, ba + bb);
+    CHECK_LAUNCH(c, ia2p_launch_gemm_chain2(a, pa.variant, b, pb.variant, c->stream), "ff.net.0 -> ff.net.2 (one launch)");
+  }
+  wsfree(c, slab);
+  if (stat_slots_b) *stat_slots_b = (b.N + IA2P_GEMM_TILES[pb.variant].bn - 1) / IA2P_GEMM_TILES[pb.variant].bn;
 }
 void op_conv3(RunCtx* c, const half_t* X, int B, int Hs, int Ws, int Cin, const half_t* W, const half_t* bias, int Co,
               int stride, int up, const half_t* rowvec, int rowvec_ld, const half_t* residual, half_t* Y, int pad_lo, const half_t* X2, int Cin2,
@@ -595,14 +629,14 @@ static T2 run_transformer(Fwd& f, const Transformer& t, T2 x, int H, int Wd) {
     }
     op_gemm(c, att.p, C, W_(c, b.wo2), W_(c, b.bo2), tk.p, C, tk.p, C, M, C, C, 0, 0, 0, 0, 0, nullptr, st, &slots);
     // GEGLU feed-forward
-    if (fold) {
+    if (!fold) op_ln(c, tk.p, lnb.p, b.ln3g, b.ln3b, M, C);
+    {
       const LnIn ln{st, slots, F_(b.cs3), F_(b.lb3), eps};
-      op_gemm(c, tk.p, C, W_(c, b.fff1), W_(c, b.bff1), nullptr, 0, ff.p, 4 * C, M, 8 * C, C, 1, 0, 0, 0, 0, &ln);
-    } else {
-      op_ln(c, tk.p, lnb.p, b.ln3g, b.ln3b, M, C);
-      op_gemm(c, lnb.p, C, W_(c, b.wff1), W_(c, b.bff1), nullptr, 0, ff.p, 4 * C, M, 8 * C, C, 1);
+      GemmArgs g1 = fold ? gemm_args(c, tk.p, C, W_(c, b.fff1), W_(c, b.bff1), nullptr, 0, ff.p, 4 * C, M, 8 * C, C, 1, 0, 0, 0, 0, &ln, nullptr, 0)
+                         : gemm_args(c, lnb.p, C, W_(c, b.wff1), W_(c, b.bff1), nullptr, 0, ff.p, 4 * C, M, 8 * C, C, 1, 0, 0, 0, 0, nullptr, nullptr, 0);
+      GemmArgs g2 = gemm_args(c, ff.p, 4 * C, W_(c, b.wff2), W_(c, b.bff2), tk.p, C, tk.p, C, M, C, 4 * C, 0, 0, 0, 0, 0, nullptr, st, 0);
+      run_ffn(c, g1, g2, &slots);
     }
-    op_gemm(c, ff.p, 4 * C, W_(c, b.wff2), W_(c, b.bff2), tk.p, C, tk.p, C, M, C, 4 * C, 0, 0, 0, 0, 0, nullptr, st, &slots);
   }
   wsfree(c, stt); wsfree(c, lnb); wsfree(c, qkv); wsfree(c, att); wsfree(c, ff);
   (void)ctxd;
@@ -1090,6 +1124,30 @@ ia2p_status ia2p_gemm(void* stream, const void* A, const void* W, const void* bi
   a.m_fastest = M <= N;
   hipError_t e = ia2p_launch_gemm(a, false, (hipStream_t)stream, nullptr);
   RET_HIP(e, "gemm");
+}
+// GEGLU feed-forward of a BasicTransformerBlock as an operator: H = geglu(X . W1p^T + b1p) [M, 4 C] (packed weights: ia2p_pack_geglu), out = H . W2^T + b2 + R.
+// chained != 0: the two GEMMs run as ONE launch with per-row-panel hand-off (chain.hip) when the library's plans for the two shapes have a chained
+// kernel (else, and with chained == 0, as two launches); *was_chained tells which. Same bits either way. splitk / partial: K split of the second GEMM
+// (partial: splitk * M * C floats) or 0.
+ia2p_status ia2p_ffn(void* stream, const void* X, const void* W1p, const void* b1p, const void* W2, const void* b2, const void* R, void* H, void* out,
+                     int M, int C, int chained, int splitk, float* partial, int* was_chained) {
+  if (!X || !W1p || !b1p || !W2 || !H || !out) return fail(nullptr, IA2P_ERR_INVALID, "ffn: null argument");
+  if (C % 64 || (splitk > 1 && (!partial || splitk > 4 * C / 64))) return fail(nullptr, IA2P_ERR_SHAPE, "ffn: C=%d must be a multiple of 64, splitk=%d needs slabs", C, splitk);
+  RunCtx rc;
+  GemmArgs a = gemm_args(&rc, (const half_t*)X, C, (const half_t*)W1p, (const half_t*)b1p, nullptr, 0, (half_t*)H, 4 * C, M, 8 * C, C, 1, 0, 0, 0, 0, nullptr, nullptr, 0);
+  GemmArgs b = gemm_args(&rc, (const half_t*)H, 4 * C, (const half_t*)W2, (const half_t*)b2, (const half_t*)R, C, (half_t*)out, C, M, C, 4 * C, 0, 0, 0, 0, 0, nullptr, nullptr, 0);
+  a.m_fastest = a.M <= a.N; b.m_fastest = b.M <= b.N;
+  if (splitk > 1) { b.splitk = splitk; b.partial = partial; }
+  const GemmPlan pa = ia2p_gemm_plan(a.M, a.N, a.K, false, true), pb = ia2p_gemm_plan(b.M, b.N, b.K, false, false);
+  const bool ch = chained && (splitk <= 1 || ia2p_splitk_inkernel(M, C, splitk)) && ia2p_chain2_ok(a, pa.variant, b, pb.variant);
+  if (was_chained) *was_chained = ch;
+  hipError_t e;
+  if (ch) e = ia2p_launch_gemm_chain2(a, pa.variant, b, pb.variant, (hipStream_t)stream);
+  else {
+    e = ia2p_launch_gemm_variant(a, false, pa.variant, (hipStream_t)stream);
+    if (e == hipSuccess) e = ia2p_launch_gemm_variant(b, false, pb.variant, (hipStream_t)stream);
+  }
+  RET_HIP(e, "ffn");
 }
 ia2p_status ia2p_fold_layernorm(void* stream, const void* W, const void* gamma, const void* beta, const void* bias, void* Wf, float* colsum,
                                 float* fbias, int N, int K) {

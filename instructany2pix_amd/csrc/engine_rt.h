@@ -23,6 +23,9 @@ hipError_t ia2p_launch_gemm(const GemmArgs& a, bool conv, hipStream_t s, int* pi
 // *combined (optional): 1 when a K-split launch finishes inside the launch (ticket counters attached), 0 when its slabs wait for ia2p_launch_splitk_reduce
 hipError_t ia2p_launch_gemm_variant(const GemmArgs& a, bool conv, int variant, hipStream_t s, bool with_reduce = true, int* combined = nullptr);
 hipError_t ia2p_launch_splitk_reduce(const GemmArgs& a, hipStream_t s);
+// chain.hip: two dependent GEMMs (b.A == a.C, row-panel-local) as ONE launch; va / vb = tile variants of the plans
+bool ia2p_chain2_ok(const GemmArgs& a, int va, const GemmArgs& b, int vb);
+hipError_t ia2p_launch_gemm_chain2(const GemmArgs& a, int va, const GemmArgs& b, int vb, hipStream_t s);
 bool ia2p_splitk_inkernel(int M, int N, int splitk);
 void ia2p_gemm_candidates(int M, int N, int K, bool conv, bool geglu, size_t max_slab_bytes, double slack, std::vector<GemmPlan>* out);
 hipError_t ia2p_launch_attention(const AttnArgs& a, hipStream_t s);
@@ -113,7 +116,7 @@ struct ProfRec { hipEvent_t e0, e1; int k; double flops, bytes; int region; };
 // profile regions of a UNet evaluation: what part of the network a launch belongs to (bench.py: conv-block roofline)
 enum { PR_OTHER = 0, PR_CONV_BLOCK = 1, PR_TRANSFORMER = 2, PR_NREGION };
 // profile classes = device kernel names as rocprofv3 prints them (template arguments included)
-enum { PK_GEMM0 = 0, PK_CONV0 = 24, PK_ATTN = 48, PK_GN, PK_LN, PK_EMBED, PK_CONV_IN, PK_CONV_OUT, PK_CONCAT, PK_REDUCE, PK_QXATTN, PK_NCLASS };
+enum { PK_GEMM0 = 0, PK_CONV0 = 24, PK_ATTN = 48, PK_GN, PK_LN, PK_EMBED, PK_CONV_IN, PK_CONV_OUT, PK_CONCAT, PK_REDUCE, PK_QXATTN, PK_CHAIN, PK_NCLASS };
 const char* prof_name(int k);
 
 // state shared by the executors (conditional UNet, VAE): weights, workspace, prefetch plan, per-kernel timing
@@ -142,6 +145,7 @@ struct RunCtx {
   bool cat_free = true;      // up path: torch.cat([hidden, skip]) never materialised (needs sc_fuse; IA2P_CAT_FREE=0: concat_kernel, for A/B runs)
   bool sc_fuse = true;       // ResnetBlock2D: conv2 + conv_shortcut as one implicit GEMM (IA2P_SC_FUSE=0: separate 1x1 launch + residual, for A/B runs)
   bool xattn_fuse = true;    // to_q + cross-attention as one launch where the shape allows (IA2P_XATTN_FUSE=0: two launches, for A/B runs)
+  bool chain = false;        // feed-forward pair (ff.net.0 -> ff.net.2) as ONE launch with per-row-panel hand-off (chain.hip; IA2P_CHAIN=1)
   bool ln_fold = true;       // LayerNorms folded into their consumer GEMMs (IA2P_LN_FOLD=0: separate layernorm_kernel launches, for A/B runs)
   bool prof = false;
   // autotune pass (ia2p_autotune): every GEMM / conv site of an unmeasured shape times its candidate plans in place
@@ -161,6 +165,7 @@ struct RunCtx {
   RunCtx() {
     if (const char* e = getenv("IA2P_PREFETCH")) prefetch = atoi(e) != 0;
     if (const char* e = getenv("IA2P_LN_FOLD")) ln_fold = atoi(e) != 0;
+    if (const char* e = getenv("IA2P_CHAIN")) chain = atoi(e) != 0;
     if (const char* e = getenv("IA2P_XATTN_FUSE")) xattn_fuse = atoi(e) != 0;
     if (const char* e = getenv("IA2P_SC_FUSE")) sc_fuse = atoi(e) != 0;
     if (const char* e = getenv("IA2P_CAT_FREE")) cat_free = atoi(e) != 0;

@@ -132,9 +132,11 @@ extern "C" void ia2p_debug_set_gemm_splitk(int s) { g_force_splitk = s; }
 // Ticket counters of the in-launch K-split combine: one int per output tile, zero between launches (the last arriver of a tile resets its
 // counter). One buffer per (device, stream): launches on one stream are ordered, so two K-split launches can only share counters when they cannot
 // run at the same time -- contexts, executors and serving threads that work on different streams never see each other's tickets.
-int ia2p_sk_counter_capacity() { return 1 << 18; }
-int* ia2p_sk_counters(hipStream_t s, int tiles) {
-  if (tiles > ia2p_sk_counter_capacity()) return nullptr;
+// Layout of a pool buffer (ints): [0, SK) K-split tickets | [SK, SK + 1024) chain arrival counters | [.., + 1024) chain "consumers done" counters |
+// [.., + 1) chain give-up flag (+ padding) | last 1024: spare
+static constexpr int POOL_INTS = 1 << 18, POOL_SK = POOL_INTS - 4096;
+int ia2p_sk_counter_capacity() { return POOL_SK; }
+static int* pool_buffer(hipStream_t s) {
   static std::mutex mu;
   static std::map<std::pair<int, hipStream_t>, int*> pool;
   int dev = 0;
@@ -143,14 +145,22 @@ int* ia2p_sk_counters(hipStream_t s, int tiles) {
   auto it = pool.find({dev, s});
   if (it != pool.end()) return it->second;
   int* p = nullptr;
-  const size_t bytes = (size_t)ia2p_sk_counter_capacity() * sizeof(int);
+  const size_t bytes = (size_t)POOL_INTS * sizeof(int);
   if (hipMalloc((void**)&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess) {      // (hipMemset: synchronous with respect to the host, done before the first launch)
     (void)hipGetLastError();
     if (p) (void)hipFree(p);
-    p = nullptr;                      // remembered: this stream's K-splits are finished by reduce launches
+    p = nullptr;                      // remembered: this stream's K-splits are finished by reduce launches, its chains run as separate launches
   }
   pool[{dev, s}] = p;
   return p;
+}
+int* ia2p_sk_counters(hipStream_t s, int tiles) { return tiles > POOL_SK ? nullptr : pool_buffer(s); }
+// chained launches: arrival counters (<= 1024 row panels), their "done" twins and the give-up flag of this (device, stream)
+bool ia2p_chain_words(hipStream_t s, int** cnt, int** done, unsigned** err) {
+  int* p = pool_buffer(s);
+  if (!p) return false;
+  *cnt = p + POOL_SK; *done = p + POOL_SK + 1024; *err = (unsigned*)(p + POOL_SK + 2048);
+  return true;
 }
 
 // ---- tile / split-K choice: a small analytic cost model, calibrated on MI355X against the in-place timings of ~5400

@@ -14,6 +14,7 @@
 bool ia2p_splitk_inkernel(int M, int N, int splitk);
 int ia2p_sk_counter_capacity();
 int* ia2p_sk_counters(hipStream_t s, int tiles);
+bool ia2p_chain_words(hipStream_t s, int** cnt, int** done, unsigned** err);
 
 #define GLDS16(gptr, ldsptr)                                                                         \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),            \
@@ -60,6 +61,55 @@ struct EpiCfg {
   static constexpr int SMEM = STAGE_BYTES > TILE_BYTES + extra(CR) ? STAGE_BYTES : TILE_BYTES + extra(CR);
 };
 
+// How a tile body is embedded in its launch. Plain launches: bid = blockIdx.x, no hooks. Chained launches (chain.hip: two dependent GEMMs in ONE
+// launch, the consumer's tiles waiting on per-row-panel counters of the producer instead of on a kernel boundary): the producer's tiles signal, the
+// consumer's tiles wait.
+struct TileCtl {
+  int bid;                 // block id inside THIS GEMM's grid (tiles x K-slices, then its prefetch workgroups)
+  const int* dep_cnt;      // consumer: arrival counters of the producer, one per `dep_rows` output rows (null: no dependency)
+  int dep_target;          //   arrivals that complete a panel (the producer's tile columns)
+  int dep_rows;
+  int* dep_done;           //   consumers that have passed the wait, per panel: the last of `dep_consumers` resets both words for the next launch
+  int dep_consumers;
+  int* sig_cnt;            // producer: the counter of the panel this tile belongs to gets +1 once the tile's C rows are written through
+  int sig_rows;
+  unsigned* err;           // bounded spins give up into this word (never hang the GPU); the host checks it
+};
+typedef __attribute__((address_space(1))) int gi32;
+
+// consumer side of the hand-off (cdna_hip_programming.md Guideline 16, R1 consume): ONE lane polls ONE word relaxed, then ONE agent-scope acquire drops
+// this CU's stale lines; the other waves load behind the workgroup barrier. The producer's rows were stored write-through and drained before its add.
+__device__ __forceinline__ void tile_wait_panel(const TileCtl& c, int row0, int tid) {
+  if (tid == 0) {
+    const int panel = row0 / c.dep_rows;
+    unsigned spins = 0;
+    while (__hip_atomic_load((const gi32*)(c.dep_cnt + panel), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < c.dep_target) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1u << 22)) { __hip_atomic_fetch_or((__attribute__((address_space(1))) unsigned*)c.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // ~seconds: give up, flag it
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+}
+// a consumer tile leaves: the last of a panel's consumers re-arms the panel for the next launch (every consumer of the panel passed its wait long ago;
+// the next chained launch on the stream starts behind this kernel's end). Off the tile's critical path: nothing waits for the returned value but the exit.
+__device__ __forceinline__ void tile_release_panel(const TileCtl& c, int row0, int tid) {
+  if (tid == 0) {
+    const int panel = row0 / c.dep_rows;
+    if (__hip_atomic_fetch_add((gi32*)(c.dep_done + panel), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == c.dep_consumers - 1) {
+      __hip_atomic_store((gi32*)(c.dep_cnt + panel), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store((gi32*)(c.dep_done + panel), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+// producer side (R1 publish): every storing wave drains its write-through stores, the workgroup meets, ONE lane adds
+__device__ __forceinline__ void tile_signal_panel(const TileCtl& c, int row0, int tid) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) __hip_atomic_fetch_add((gi32*)(c.sig_cnt + row0 / c.sig_rows), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // PP = 1 ("ping-pong", 8 waves = WGM 4, 3-stage ring, ONE workgroup per CU): waves 0-3 own the upper half of the tile rows, waves 4-7 the
 // lower half, and the two groups run half a k-step apart -- while one group reads its fragments from LDS the other issues its MFMAs, with a
 // workgroup barrier between the half-steps. Eight waves behind one barrier per k-step would all read, then all multiply (the LDS and the
@@ -69,7 +119,7 @@ struct EpiCfg {
 // into the Q fragments of the attention core (attention_core.h, MODE = XA - 1) and writes the cross-attention output instead.
 template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int BK = 64, int PP = 0, int WGN = 2, int XA = 0>
 __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* hW, const half_t* hzero, int hM, int hN, int hK, int hlda, int hldw, int hrpb, int hbstride,
-                                               int hroff, int hsplitk, int hgroup_w, const GemmArgs& p, const AttnArgs* xa) {
+                                               int hroff, int hsplitk, int hgroup_w, const GemmArgs& p, const AttnArgs* xa, const TileCtl& ctl) {
   // The leading 16 dwords of the argument list are what the prologue needs; built with -amdgpu-kernarg-preload-count=16 the command processor
   // hands them over in SGPRs, so the first tile loads go out without waiting for a cold read of the argument block (which costs every launch
   // ~1 us: tools/micro/launch_floor2.hip). The rest of GemmArgs (epilogue, conv geometry) arrives while those loads fly.   // >= 2 waves/SIMD: big tiles must fit 256 registers
@@ -94,7 +144,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
 
   // ---- tile of this workgroup; blocks b, b+8, ... share an XCD (its L2): give each XCD a contiguous tile range
   const int tiles_m = (hM + BM - 1) / BM, tiles_n = (hN + BN - 1) / BN;
-  int bid = blockIdx.x;
+  int bid = ctl.bid;
   const int nsplit = hsplitk > 1 ? hsplitk : 1;
   const int split = bid / (tiles_m * tiles_n);          // >= nsplit: prefetch workgroup
   if (split < nsplit) bid -= split * tiles_m * tiles_n;
@@ -135,6 +185,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   } else if (p.m_fastest) { tn = bid / tiles_m; tm = bid - tn * tiles_m; }
   else                    { tm = bid / tiles_n; tn = bid - tm * tiles_n; }
   const int bm0 = tm * BM, bn0 = tn * BN;
+  if (ctl.dep_cnt) tile_wait_panel(ctl, bm0, tid);        // chained launch: this tile's A rows come from tiles of the same launch
 
   // ---- staging addresses. Piece `pi` covers tile rows pi*8 .. pi*8+7; lane -> (row pi*8 + lane/8, LDS chunk lane%8),
   //      which must hold global chunk (lane%8) ^ swz(row), swz(row) = (row>>1)&7.
@@ -423,7 +474,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   if (PP && p.pf) {
     const long nwg = (long)tiles_m * tiles_n * nsplit;
     const long per = ((p.pf_bytes + nwg - 1) / nwg + 255) & ~255L;
-    const long lo = (long)blockIdx.x * per, hi = min(lo + per, p.pf_bytes & ~15L);
+    const long lo = (long)ctl.bid * per, hi = min(lo + per, p.pf_bytes & ~15L);
     const char* src = (const char*)p.pf;
     constexpr long SW = NWAVE * 64 * 16;
     if (lo < hi)
@@ -554,12 +605,12 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
         }
       }
     }
-    if (!p.sk_counters) { if (PP) asm volatile("" ::"v"(pfacc)); return; }      // finished by a separate splitk_reduce_kernel launch (A/B switch)
+    if (!p.sk_counters) { if (PP) asm volatile("" ::"v"(pfacc)); if (ctl.dep_cnt) tile_release_panel(ctl, bm0, tid); return; }      // finished by a separate splitk_reduce_kernel launch (A/B switch)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // EVERY storing wave drains its write-through stores ...
     __syncthreads();                                       // ... before ONE lane signals for the workgroup
     if (tid == 0) *sk_flag = __hip_atomic_fetch_add(p.sk_counters + (tm * tiles_n + tn), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    if (*sk_flag != nsplit - 1) { if (PP) asm volatile("" ::"v"(pfacc)); return; }
+    if (*sk_flag != nsplit - 1) { if (PP) asm volatile("" ::"v"(pfacc)); if (ctl.dep_cnt) tile_release_panel(ctl, bm0, tid); return; }
     if (tid == 0) {
       __hip_atomic_store(p.sk_counters + (tm * tiles_n + tn), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch (launches are stream-ordered)
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // drop this CU's stale lines before the plain loads below
@@ -805,6 +856,8 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
     }
   }
   if (PP) asm volatile("" ::"v"(pfacc));
+  if (ctl.sig_cnt) tile_signal_panel(ctl, bm0, tid);      // chained launch: this tile's rows are written (write-through): count it into its row panel
+  if (ctl.dep_cnt) tile_release_panel(ctl, bm0, tid);
 #ifdef IA2P_CLOCK_STAMP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the C stores of this wave have left
   __syncthreads();
@@ -815,7 +868,8 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
 template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int BK = 64, int PP = 0, int WGN = 2>
 __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_f16_kernel(const half_t* hA, const half_t* hW, const half_t* hzero, int hM, int hN, int hK, int hlda, int hldw, int hrpb, int hbstride,
                                                                          int hroff, int hsplitk, int hgroup_w, const GemmArgs p) {
-  gemm_tile_body<BM, BN, NSTAGE, CONV, WGM, BK, PP, WGN, 0>(hA, hW, hzero, hM, hN, hK, hlda, hldw, hrpb, hbstride, hroff, hsplitk, hgroup_w, p, nullptr);
+  const TileCtl ctl{(int)blockIdx.x, nullptr, 0, 1, nullptr, 0, nullptr, 1, nullptr};
+  gemm_tile_body<BM, BN, NSTAGE, CONV, WGM, BK, PP, WGN, 0>(hA, hW, hzero, hM, hN, hK, hlda, hldw, hrpb, hbstride, hroff, hsplitk, hgroup_w, p, nullptr, ctl);
 }
 
 // grouped tile order: panel width (in tiles) such that the contiguous tile range an XCD works on is a compact block; 0 = plain order
@@ -827,6 +881,17 @@ static inline int ia2p_tile_group_w(int tiles, int tiles_n, int smem, int BM, in
   static const double gscale = getenv("IA2P_TILE_GROUP_SCALE") ? atof(getenv("IA2P_TILE_GROUP_SCALE")) : 1.0;
   const int w = (int)(gscale * std::sqrt(resident * BM / BN) + 0.5);
   return std::max(1, std::min(w, tiles_n));
+}
+
+// launcher-side fields of a launch description: epilogue access width, write-through C, grouped tile order
+static inline void ia2p_gemm_prepare(GemmArgs& b, int smem, int BM, int BN) {
+  // 16-byte epilogue accesses need 8-element row strides and 16-byte-aligned bases; otherwise the epilogue falls back to 8-byte pieces
+  auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+  b.vec8 = (b.ldc % 8 == 0 && al16(b.C) && (!b.bias || al16(b.bias)) && (!b.residual || (b.ldr % 8 == 0 && al16(b.residual))) &&
+            (!b.rowvec || (b.rowvec_ld % 8 == 0 && al16(b.rowvec)))) ? 1 : 0;
+  b.c_wt = ((ia2p_wt_mask() & 1) && (size_t)b.M * b.ldc * 2 < (size_t)0x7ffffff0) ? 1 : 0;      // same box: -0.14 ms per step at batch 8
+  const int tiles_n = (b.N + BN - 1) / BN;
+  b.group_w = ia2p_tile_group_w(((b.M + BM - 1) / BM) * tiles_n, tiles_n, smem, BM, BN);
 }
 
 template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int BK = 64, int PP = 0, int WGN = 2>
@@ -843,15 +908,10 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
   }
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   GemmArgs b = a;
-  // 16-byte epilogue accesses need 8-element row strides and 16-byte-aligned bases; otherwise the epilogue falls back to 8-byte pieces
-  auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
-  b.vec8 = (a.ldc % 8 == 0 && al16(a.C) && (!a.bias || al16(a.bias)) && (!a.residual || (a.ldr % 8 == 0 && al16(a.residual))) &&
-            (!a.rowvec || (a.rowvec_ld % 8 == 0 && al16(a.rowvec)))) ? 1 : 0;
+  ia2p_gemm_prepare(b, smem, BM, BN);
   if (a.geglu && !b.vec8) return hipErrorInvalidValue;
-  b.c_wt = ((ia2p_wt_mask() & 1) && (size_t)a.M * a.ldc * 2 < (size_t)0x7ffffff0) ? 1 : 0;      // same box: -0.14 ms per step at batch 8
   // b.sk_counters: as the caller (launch_any, gemm.hip) attached them -- null: the K-slices only write their slabs and a splitk_reduce_kernel launch finishes
   if (b.sk_counters && tiles > ia2p_sk_counter_capacity()) return hipErrorInvalidValue;
-  b.group_w = ia2p_tile_group_w(tiles, (a.N + BN - 1) / BN, smem, BM, BN);
   const int extra = (!PP && a.pf && a.pf_bytes >= 4096) ? a.pf_blocks : 0;
   hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, NSTAGE, CONV, WGM, BK, PP, WGN>), dim3(tiles * (a.splitk > 1 ? a.splitk : 1) + extra), dim3(WGM * WGN * 64), smem, s,
                      b.A, b.W, b.zero, b.M, b.N, b.K, b.lda, b.ldw, b.rpb, b.bstride, b.roff, b.splitk, b.group_w, b);

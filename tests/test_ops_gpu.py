@@ -506,3 +506,62 @@ def test_ddim_step_cfg(L):
     ref = (cx * x.float() + ce * (eu.float() + g * (ec.float() - eu.float()))).half()   # one rounding, like the kernel
     assert (out.float() - ref.float()).abs().max() <= 2e-3 * ref.float().abs().max()
     assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize("M,C,S", [(2048, 1280, 3), (2048, 1280, 1), (256, 1280, 4), (8192, 640, 1), (1024, 320, 2)])
+def test_ffn_chain_one_launch_equals_two_launches(L, M, C, S):
+    """The GEGLU feed-forward as ONE launch (second-GEMM tiles wait on per-128-row-panel counters of the first, csrc/chain.hip) gives the bits of
+    the two launches, launch after launch with the counters re-armed in between, and no wait ever gives up."""
+    f = _ffi()
+    X, R = rnd(M, C, seed=81), rnd(M, C, seed=82)
+    W1, b1 = rnd(8 * C, C, seed=83, scale=C ** -0.5), rnd(8 * C, seed=84, scale=0.1)
+    W2, b2 = rnd(C, 4 * C, seed=85, scale=(4 * C) ** -0.5), rnd(C, seed=86, scale=0.1)
+    W1p, b1p = torch.empty_like(W1), torch.empty_like(b1)
+    run(L, "ia2p_pack_geglu", f.ptr(W1), f.ptr(W1p), 8 * C, C)
+    run(L, "ia2p_pack_geglu", f.ptr(b1), f.ptr(b1p), 8 * C, 1)
+    part = torch.empty(max(S, 1) * M * C, dtype=torch.float32, device="cuda")
+    H = torch.empty(M, 4 * C, dtype=torch.half, device="cuda")
+    was = C_int()
+    outs = {}
+    for tile_a in (8, 0):                     # FF-in on 128x160 and on 128x128; FF-out on 128x128
+        for chained in (0, 1):
+            o = torch.empty(M, C, dtype=torch.half, device="cuda")
+            reps = 4 if chained else 1
+            for _ in range(reps):
+                o.fill_(float("nan")); H.fill_(float("nan"))
+                _force_plans(L, M, C, tile_a, S)
+                f.check(L.ia2p_ffn(f.current_stream(), f.ptr(X), f.ptr(W1p), f.ptr(b1p), f.ptr(W2), f.ptr(b2), f.ptr(R), f.ptr(H), f.ptr(o), M, C, chained, S,
+                                   ctypes_ptr(part), ctypes_byref(was)))
+                torch.cuda.synchronize()
+                assert was.value == chained, (tile_a, chained, was.value)
+                assert L.ia2p_chain_errors(f.current_stream()) == 0
+                if (tile_a, chained) in outs:
+                    assert torch.equal(o, outs[(tile_a, chained)])
+                outs[(tile_a, chained)] = o.clone()
+    L.ia2p_plan_clear()
+    h = X.float() @ W1.float().t() + b1.float()
+    a, g = h.chunk(2, dim=-1)
+    ref = (a * F.gelu(g)).half().float() @ W2.float().t() + b2.float() + R.float()
+    assert rel_l2(outs[(8, 1)], ref) < 2e-3
+    assert torch.equal(outs[(8, 0)], outs[(8, 1)]) and torch.equal(outs[(0, 0)], outs[(0, 1)]) and torch.equal(outs[(8, 1)], outs[(0, 1)])
+
+
+def C_int():
+    import ctypes
+    return ctypes.c_int(0)
+
+
+def ctypes_ptr(t):
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def ctypes_byref(x):
+    import ctypes
+    return ctypes.byref(x)
+
+
+def _force_plans(L, M, C, tile_a, S):
+    """pin the two plans of the feed-forward pair through the plan table (what ia2p_autotune fills): FF-in on `tile_a`, FF-out on 128x128 with K split S"""
+    txt = f"{M},{8 * C},{C},0,1,{tile_a},1;{M},{C},{4 * C},0,0,0,{max(S, 1)};"
+    assert L.ia2p_plan_import(txt.encode()) == 2
