@@ -22,16 +22,17 @@ struct ChainArgs {
   int target;        // first-GEMM tiles per panel
   int consumers;     // second-GEMM workgroups per panel (tiles x K-slices)
   unsigned* err;
+  int diag;          // IA2P_CHAIN_DIAG (timing diagnostics, results may be wrong)
 };
 
 template <int ABN, int AST, int BBN, int BST>       // both tiles are 128 rows high (one row panel), 4 waves
 __global__ __launch_bounds__(256, 2) void gemm_chain2_kernel(const half_t* hA, const half_t* hW, const half_t* hzero, int hM, int hN, int hK, int hlda, int hldw, int hrpb, int hbstride,
                                                              int hroff, int hsplitk, int hgroup_w, const GemmArgs pa, const GemmArgs pb, const ChainArgs ch) {
   if ((int)blockIdx.x < ch.nA) {
-    const TileCtl ctl{(int)blockIdx.x, nullptr, 0, 1, nullptr, 0, ch.cnt, 128, ch.err};
+    const TileCtl ctl{(int)blockIdx.x, nullptr, 0, 1, nullptr, 0, ch.cnt, 128, ch.err, ch.diag};
     gemm_tile_body<128, ABN, AST, false, 2, 64, 0, 2, 0>(hA, hW, hzero, hM, hN, hK, hlda, hldw, hrpb, hbstride, hroff, hsplitk, hgroup_w, pa, nullptr, ctl);
   } else {
-    const TileCtl ctl{(int)blockIdx.x - ch.nA, ch.cnt, ch.target, 128, ch.done, ch.consumers, nullptr, 1, ch.err};
+    const TileCtl ctl{(int)blockIdx.x - ch.nA, ch.cnt, ch.target, 128, ch.done, ch.consumers, nullptr, 1, ch.err, ch.diag};
     gemm_tile_body<128, BBN, BST, false, 2, 64, 0, 2, 0>(pb.A, pb.W, pb.zero, pb.M, pb.N, pb.K, pb.lda, pb.ldw, pb.rpb, pb.bstride, pb.roff, pb.splitk, pb.group_w, pb, nullptr, ctl);
   }
 }
@@ -76,6 +77,8 @@ static hipError_t launch_pair(const GemmArgs& a0, const GemmArgs& b0, hipStream_
   ch.nA = tiles_a + pfa;
   ch.target = tiles_na;
   ch.consumers = tiles_nb * nsb;
+  static const int diag = getenv("IA2P_CHAIN_DIAG") ? atoi(getenv("IA2P_CHAIN_DIAG")) : 0;
+  ch.diag = diag;
   hipLaunchKernelGGL((gemm_chain2_kernel<ABN, AST, BBN, BST>), dim3(ch.nA + tiles_b * nsb + pfb), dim3(256), smem, s, a.A, a.W, a.zero, a.M, a.N, a.K, a.lda, a.ldw, a.rpb, a.bstride,
                      a.roff, a.splitk, a.group_w, a, b, ch);
   return hipGetLastError();

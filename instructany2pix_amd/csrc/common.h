@@ -130,6 +130,13 @@ struct GemmArgs {
   // producer side: row statistics of THIS launch's fp16 output, for the folded LayerNorm of the next contraction.
   // stats_out[(slot * M + m) * 2 + {0, 1}], slot = tile_n (or 0 for a K-split launch: the reduce kernel writes it)
   float* stats_out;
+  // producer side of a GroupNorm: per-column {sum, sum of squares} of THIS launch's fp16 output, per image -- what gn_stats_kernel used to get from a
+  // second pass over the tensor. Every tile writes the column sums of its rows to gn_cols[tile_m][N] (float2, scratch); the tile that arrives last
+  // at its image's ticket folds the image's tiles in tile order (fp64) into gn_tot[image][N] (double2). Needs gn_hw % BM == 0 (a tile lies in one image).
+  float* gn_cols;
+  double* gn_tot;
+  int* gn_tickets;       // one arrival counter per image, zero between launches
+  int gn_hw;             // rows per image
 };
 
 struct GemmPlan { int variant; int splitk; };

@@ -309,7 +309,12 @@ T2 wsalloc(RunCtx* c, size_t elems) {
   if (off == (size_t)-1) { if (!c->failed) fail(c, IA2P_ERR_NOMEM, "workspace too small"); return T2{off, nullptr}; }
   return T2{off, c->dry ? nullptr : (half_t*)(c->ws_base + off)};
 }
-void wsfree(RunCtx* c, T2 t) { if (t.off != (size_t)-1) c->ws.release(t.off); }
+void wsfree(RunCtx* c, T2 t) {
+  if (t.off == (size_t)-1) return;
+  auto it = c->gn_tot.find(t.off);
+  if (it != c->gn_tot.end()) { c->ws.release(it->second.first); c->gn_tot.erase(it); }      // the tensor's GroupNorm statistics go with it
+  c->ws.release(t.off);
+}
 
 hipEvent_t get_event(RunCtx* c) {
   if (!c->evpool.empty()) { hipEvent_t e = c->evpool.back(); c->evpool.pop_back(); return e; }
@@ -398,10 +403,32 @@ static void run_gemm(RunCtx* c, GemmArgs& a, bool conv, const char* what, double
   }
   struct Rel { RunCtx* c; T2 t; ~Rel() { wsfree(c, t); } } rel{c, slab};
   int combined = pl.splitk > 1 && ia2p_splitk_inkernel(a.M, a.N, pl.splitk);     // (dry pass: the policy's answer; the launcher reports what it really did)
+  // GroupNorm statistics of the output from this launch's epilogue (asked for by the caller through gn_next_*): totals live as long as the output
+  const int gn_hw = c->gn_next_hw;
+  const size_t gn_off = c->gn_next_off;
+  c->gn_next_hw = 0; c->gn_next_off = (size_t)-1;
+  T2 gcols{(size_t)-1, nullptr};
+  const long gn_wgs = (long)(a.M / IA2P_GEMM_TILES[pl.variant].bm) * ((a.N + IA2P_GEMM_TILES[pl.variant].bn - 1) / IA2P_GEMM_TILES[pl.variant].bn) * (pl.splitk > 1 ? pl.splitk : 1);
+  if (gn_hw > 0 && gn_off != (size_t)-1 && c->gn_epi && (c->gn_epi != 2 || gn_wgs <= 512) && !c->tuning && !a.geglu && (pl.splitk <= 1 || combined) &&
+      ia2p_gn_epilogue_ok(pl.variant, a.M, gn_hw) && a.ldc % 8 == 0 && a.N % 8 == 0) {
+    const int tiles_m = a.M / IA2P_GEMM_TILES[pl.variant].bm;
+    T2 tot = wsalloc(c, (size_t)(a.M / gn_hw) * a.N * 8);          // double2 per image and column
+    gcols = wsalloc(c, (size_t)tiles_m * a.N * 4);                  // float2 per tile row and column (scratch of this launch)
+    if (tot.off != (size_t)-1 && gcols.off != (size_t)-1) {
+      a.gn_cols = (float*)gcols.p; a.gn_tot = (double*)tot.p; a.gn_hw = gn_hw;
+      a.gn_tickets = c->dry ? nullptr : ia2p_gn_tickets(c->stream);
+      if (!c->dry && !a.gn_tickets) { a.gn_cols = nullptr; a.gn_tot = nullptr; }
+      auto old = c->gn_tot.find(gn_off);
+      if (old != c->gn_tot.end()) { c->ws.release(old->second.first); c->gn_tot.erase(old); }      // (an output written in place keeps one table)
+      if (c->dry || a.gn_cols) c->gn_tot[gn_off] = {tot.off, (double*)tot.p};
+      else c->ws.release(tot.off);
+    }
+  }
   {
     ProfScope ps(c, (conv ? PK_CONV0 : PK_GEMM0) + pl.variant, flops, bytes);
     CHECK_LAUNCH(c, ia2p_launch_gemm_variant(a, conv, pl.variant, c->stream, false, &combined), what);
   }
+  if (gcols.off != (size_t)-1) c->ws.release(gcols.off);
   if (pl.splitk > 1 && !combined) {
     ProfScope ps(c, PK_REDUCE, 0, (double)pl.splitk * a.M * a.N * 4 + 2.0 * a.M * a.N);
     CHECK_LAUNCH(c, ia2p_launch_splitk_reduce(a, c->stream), what);
@@ -466,24 +493,37 @@ void op_conv3(RunCtx* c, const half_t* X, int B, int Hs, int Ws, int Cin, const 
               const half_t* X3, int Cin3) {
   GemmArgs a;
   memset(&a, 0, sizeof a);
-  if ((X2 && (stride != 1 || up || pad_lo != 1 || Cin2 % 64)) || (X3 && (!X2 || Cin3 % 64))) { fail(c, IA2P_ERR_SHAPE, "conv3x3 with appended 1x1 blocks: stride 1, no upsampling, Cin2 / Cin3 % 64 == 0"); return; }
+  // (appended blocks are described by their channel counts: in a dry pass the pointers are null, the shapes -- hence plans and slabs -- must not change)
+  if ((Cin2 > 0 && (stride != 1 || up || pad_lo != 1 || Cin2 % 64)) || (Cin3 > 0 && (Cin2 <= 0 || Cin3 % 64)) || Cin2 < 0 || Cin3 < 0 ||
+      (!c->dry && ((Cin2 > 0) != (X2 != nullptr) || (Cin3 > 0) != (X3 != nullptr)))) { fail(c, IA2P_ERR_SHAPE, "conv3x3 with appended 1x1 blocks: stride 1, no upsampling, Cin2 / Cin3 % 64 == 0"); return; }
   a.pad = pad_lo;           // zero rows/cols before the image; one row/col of zeros after it in every mode
   const int Hv = Hs << up, Wv = Ws << up;
   a.Ho = (Hv + pad_lo + 1 - 3) / stride + 1; a.Wo = (Wv + pad_lo + 1 - 3) / stride + 1;
-  a.A = X; a.W = W; a.C = Y; a.zero = zero_page(); a.M = B * a.Ho * a.Wo; a.N = Co; a.K = 9 * Cin + (X2 ? Cin2 : 0) + (X3 ? Cin3 : 0); a.ldw = a.K; a.lda = Cin; a.ldc = Co;
-  a.A2 = X2; a.lda2 = Cin2; a.Cin2 = X2 ? Cin2 : 0;
-  a.A3 = X3; a.lda3 = Cin3; a.Cin3 = X3 ? Cin3 : 0;
+  a.A = X; a.W = W; a.C = Y; a.zero = zero_page(); a.M = B * a.Ho * a.Wo; a.N = Co; a.K = 9 * Cin + Cin2 + Cin3; a.ldw = a.K; a.lda = Cin; a.ldc = Co;
+  a.A2 = X2; a.lda2 = Cin2; a.Cin2 = Cin2;
+  a.A3 = X3; a.lda3 = Cin3; a.Cin3 = Cin3;
   a.Hs = Hs; a.Ws = Ws; a.stride = stride; a.up = up; a.Cin = Cin;
   a.bias = bias; a.rowvec = rowvec; a.rowvec_ld = rowvec_ld; a.rows_per_batch = a.Ho * a.Wo; a.residual = residual; a.ldr = Co;
   a.m_fastest = 0;
   a.acc_scale = c->ep_acc_scale; a.bias_scale = c->ep_bias_scale; c->ep_acc_scale = c->ep_bias_scale = 1.f;
   set_prefetch(c, a, W, (size_t)Co * a.K * sizeof(half_t));
-  run_gemm(c, a, true, "conv3x3", 2.0 * a.M * (double)Co * a.K, 2.0 * ((double)B * Hs * Ws * Cin + (double)Co * a.K + (double)a.M * Co + (residual ? (double)a.M * Co : 0) + (X2 ? (double)a.M * (Cin2 + (X3 ? Cin3 : 0)) : 0)));
+  run_gemm(c, a, true, "conv3x3", 2.0 * a.M * (double)Co * a.K, 2.0 * ((double)B * Hs * Ws * Cin + (double)Co * a.K + (double)a.M * Co + (residual ? (double)a.M * Co : 0) + (double)a.M * (Cin2 + Cin3)));
 }
-void op_gn(RunCtx* c, const half_t* x, half_t* y, size_t g, size_t b, int B, int HW, int C, float eps, int silu, float* partial, const half_t* x2, int Ca) {
-  ProfScope ps(c, PK_GN, 8.0 * B * HW * C, 4.0 * B * HW * C);
-  if (x2) CHECK_LAUNCH(c, ia2p_launch_groupnorm(x, Ca, y, C, W_(c, g), W_(c, b), partial, B, HW, C, c->groups, eps, silu, c->stream, x2, C - Ca, Ca), "groupnorm");
-  else CHECK_LAUNCH(c, ia2p_launch_groupnorm(x, C, y, C, W_(c, g), W_(c, b), partial, B, HW, C, c->groups, eps, silu, c->stream), "groupnorm");
+void op_gn(RunCtx* c, const half_t* x, half_t* y, size_t g, size_t b, int B, int HW, int C, float eps, int silu, float* partial, const half_t* x2, int Ca,
+           size_t x_off, size_t x2_off) {
+  // statistics from the producers' epilogues when EVERY source tensor carries them; else the classic statistics pass over the tensor(s)
+  const double *t1 = nullptr, *t2 = nullptr;
+  bool have = false;
+  if (c->gn_epi && x_off != (size_t)-1) {
+    auto i1 = c->gn_tot.find(x_off);
+    auto i2 = x2 || x2_off != (size_t)-1 ? c->gn_tot.find(x2_off) : c->gn_tot.end();
+    const bool two = x2 != nullptr || x2_off != (size_t)-1;
+    if (i1 != c->gn_tot.end() && (!two || i2 != c->gn_tot.end())) { have = true; t1 = i1->second.second; t2 = two ? i2->second.second : nullptr; }
+  }
+  ProfScope ps(c, PK_GN, 8.0 * B * HW * C, (have ? 4.0 : 4.0) * B * HW * C);
+  if (!have) { t1 = t2 = nullptr; }
+  if (x2) CHECK_LAUNCH(c, ia2p_launch_groupnorm(x, Ca, y, C, W_(c, g), W_(c, b), partial, B, HW, C, c->groups, eps, silu, c->stream, x2, C - Ca, Ca, t1, t2), "groupnorm");
+  else CHECK_LAUNCH(c, ia2p_launch_groupnorm(x, C, y, C, W_(c, g), W_(c, b), partial, B, HW, C, c->groups, eps, silu, c->stream, nullptr, 0, 0, t1, nullptr), "groupnorm");
 }
 void op_ln(RunCtx* c, const half_t* x, half_t* y, size_t g, size_t b, int M, int C) {
   ProfScope ps(c, PK_LN, 8.0 * M * C, 4.0 * M * C);
@@ -504,17 +544,20 @@ struct RegionScope { RunCtx* c; int prev; RegionScope(RunCtx* c_, int r) : c(c_)
 
 // x2 != null: the block input is [x (cx channels) | x2 (cin - cx channels)], never concatenated (up path: hidden state | skip) -- GroupNorm reads the two
 // tensors, and the shortcut rides in conv2 as two appended K-blocks. Only with the fused shortcut (c->sc_fuse); the caller concatenates otherwise.
-static T2 run_resnet(Fwd& f, const Resnet& r, T2 x, int H, int Wd, const half_t* x2 = nullptr, int cx = 0) {
+static T2 run_resnet(Fwd& f, const Resnet& r, T2 x, int H, int Wd, const T2* x2t = nullptr, int cx = 0) {
+  const half_t* x2 = x2t ? x2t->p : nullptr;
+  const bool two = x2t != nullptr;
   ia2p_ctx* c = f.c;
   RegionScope rs(c, PR_CONV_BLOCK);
   const int HW = H * Wd, M = f.B * HW;
   T2 n1 = wsalloc(c, (size_t)M * r.cin);
-  op_gn(c, x.p, n1.p, r.n1g, r.n1b, f.B, HW, r.cin, c->cfg.norm_eps, 1, f.gn_partial, x2, cx);
+  op_gn(c, x.p, n1.p, r.n1g, r.n1b, f.B, HW, r.cin, c->cfg.norm_eps, 1, f.gn_partial, x2, cx, x.off, two ? x2t->off : (size_t)-1);
   T2 hh = wsalloc(c, (size_t)M * r.cout);
+  c->gn_next_hw = HW; c->gn_next_off = hh.off;               // norm2 reads conv1's output: statistics from conv1's epilogue
   op_conv3(c, n1.p, f.B, H, Wd, r.cin, W_(c, r.w1), W_(c, r.b1), r.cout, 1, 0, c->dry ? nullptr : f.temb_all.p + r.temb_off, c->temb_total, nullptr, hh.p);
   wsfree(c, n1);
   T2 n2 = wsalloc(c, (size_t)M * r.cout);
-  op_gn(c, hh.p, n2.p, r.n2g, r.n2b, f.B, HW, r.cout, c->cfg.norm_eps, 1, f.gn_partial);
+  op_gn(c, hh.p, n2.p, r.n2g, r.n2b, f.B, HW, r.cout, c->cfg.norm_eps, 1, f.gn_partial, nullptr, 0, hh.off);
   wsfree(c, hh);
   T2 xs{(size_t)-1, nullptr};
   const half_t* resid = x.p;
@@ -525,7 +568,8 @@ static T2 run_resnet(Fwd& f, const Resnet& r, T2 x, int H, int Wd, const half_t*
     resid = xs.p;
   }
   T2 out = wsalloc(c, (size_t)M * r.cout);
-  if (cat && x2) op_conv3(c, n2.p, f.B, H, Wd, r.cout, W_(c, r.wcat), W_(c, r.bcat), r.cout, 1, 0, nullptr, 0, nullptr, out.p, 1, x.p, cx, x2, r.cin - cx);
+  c->gn_next_hw = HW; c->gn_next_off = out.off;              // whatever GroupNorm reads the block's output next (transformer norm, next norm1, up-path skip, conv_norm_out)
+  if (cat && two) op_conv3(c, n2.p, f.B, H, Wd, r.cout, W_(c, r.wcat), W_(c, r.bcat), r.cout, 1, 0, nullptr, 0, nullptr, out.p, 1, x.p, cx, x2, r.cin - cx);
   else if (cat) op_conv3(c, n2.p, f.B, H, Wd, r.cout, W_(c, r.wcat), W_(c, r.bcat), r.cout, 1, 0, nullptr, 0, nullptr, out.p, 1, x.p, r.cin);
   else op_conv3(c, n2.p, f.B, H, Wd, r.cout, W_(c, r.w2), W_(c, r.b2), r.cout, 1, 0, nullptr, 0, c->dry ? nullptr : resid, out.p);
   wsfree(c, n2);
@@ -567,7 +611,7 @@ static T2 run_transformer(Fwd& f, const Transformer& t, T2 x, int H, int Wd) {
   const int Li = c->ip_enabled ? c->ip_tokens : 0;
   const float sl2e = 0.125f * 1.4426950408889634f;
   T2 n = wsalloc(c, (size_t)M * C);
-  op_gn(c, x.p, n.p, t.ng, t.nb, f.B, HW, C, 1e-6f, 0, f.gn_partial);
+  op_gn(c, x.p, n.p, t.ng, t.nb, f.B, HW, C, 1e-6f, 0, f.gn_partial, nullptr, 0, x.off);
   // The three LayerNorms of a block never run as kernels: every GEMM that writes the token stream `tk` also emits per-row
   // {sum, sum of squares} partials of its fp16 output (`st`), and the GEMM that consumes LN(tk) reads raw `tk` against the
   // gamma-folded weights and finishes the normalisation in its epilogue (LnIn; GemmArgs.ln_* in common.h).
@@ -641,6 +685,7 @@ static T2 run_transformer(Fwd& f, const Transformer& t, T2 x, int H, int Wd) {
   wsfree(c, stt); wsfree(c, lnb); wsfree(c, qkv); wsfree(c, att); wsfree(c, ff);
   (void)ctxd;
   T2 out = wsalloc(c, (size_t)M * C);
+  c->gn_next_hw = HW; c->gn_next_off = out.off;              // the next ResnetBlock2D's norm1 (or an up-path concat) reads this
   op_gemm(c, tk.p, C, W_(c, t.wout), W_(c, t.bout), x.p, C, out.p, C, M, C, C);
   wsfree(c, tk);
   return out;
@@ -666,6 +711,7 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
   const int pooled = Ain - g.num_time_ids * Ad;
   Fwd f{c, B, h, w, L, context, T2{(size_t)-1, nullptr}, nullptr, T2{(size_t)-1, nullptr}, T2{(size_t)-1, nullptr}};
   f.ip_scales = ip_scales;
+  c->gn_tot.clear(); c->gn_next_hw = 0; c->gn_next_off = (size_t)-1;      // (the workspace was just reset)
 
   // GroupNorm partial sums (fp32) live at the front of the workspace
   T2 gnp = wsalloc(c, (size_t)B * 64 * g.norm_num_groups * 2 * 2);
@@ -730,6 +776,7 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
     if (st.resample) {
       const int Ho = (H - 1) / 2 + 1, Wo = (Wd - 1) / 2 + 1;
       T2 d = wsalloc(c, (size_t)B * Ho * Wo * st.rc);
+      c->gn_next_hw = Ho * Wo; c->gn_next_off = d.off;
       op_conv3(c, x.p, B, H, Wd, st.rc, W_(c, st.rw), W_(c, st.rb), st.rc, 2, 0, nullptr, 0, nullptr, d.p);
       H = Ho; Wd = Wo; x = d;
       skips.push_back(x); skip_c.push_back(st.rc);
@@ -753,7 +800,7 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
       T2 r;
       if (c->sc_fuse && c->cat_free && st.res[j].shortcut && cx % 64 == 0 && cs % 64 == 0) {
         // torch.cat([hidden, skip]) never materialised: GroupNorm and the appended shortcut blocks of conv2 read the two tensors
-        r = run_resnet(f, st.res[j], x, H, Wd, sk.p, cx);
+        r = run_resnet(f, st.res[j], x, H, Wd, &sk, cx);
         wsfree(c, x); wsfree(c, sk);
       } else {
         T2 cat = wsalloc(c, (size_t)M * st.res[j].cin);
@@ -770,6 +817,7 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
     }
     if (st.resample) {
       T2 u = wsalloc(c, (size_t)B * (2 * H) * (2 * Wd) * st.rc);
+      c->gn_next_hw = 4 * H * Wd; c->gn_next_off = u.off;
       op_conv3(c, x.p, B, H, Wd, st.rc, W_(c, st.rw), W_(c, st.rb), st.rc, 1, 1, nullptr, 0, nullptr, u.p);
       wsfree(c, x);
       H *= 2; Wd *= 2; x = u;
@@ -779,7 +827,7 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
   // ---- out
   const int c0 = g.block_out_channels[0];
   T2 no = wsalloc(c, (size_t)B * H * Wd * c0);
-  op_gn(c, x.p, no.p, c->ngo, c->nbo, B, H * Wd, c0, g.norm_eps, 1, f.gn_partial);
+  op_gn(c, x.p, no.p, c->ngo, c->nbo, B, H * Wd, c0, g.norm_eps, 1, f.gn_partial, nullptr, 0, x.off);
   wsfree(c, x);
   {
     ProfScope ps(c, PK_CONV_OUT, 2.0 * B * H * Wd * 9.0 * c0 * g.out_channels, 2.0 * ((double)B * H * Wd * (c0 + g.out_channels) + 9.0 * c0 * g.out_channels));

@@ -33,7 +33,8 @@ bool ia2p_qproj_xattn_ok(const GemmArgs& a, const AttnArgs& x);
 hipError_t ia2p_launch_qproj_xattn(const GemmArgs& a, const AttnArgs& x, hipStream_t s);   // qxattn.hip: to_q tile -> attention core, one launch
 int ia2p_gn_chunks(int B, int HW);
 hipError_t ia2p_launch_groupnorm(const half_t* x, int ldx, half_t* y, int ldy, const half_t* gamma, const half_t* beta,
-                                 float* partial, int B, int HW, int C, int G, float eps, int silu, hipStream_t s, const half_t* x2 = nullptr, int ldx2 = 0, int Ca = 0);
+                                 float* partial, int B, int HW, int C, int G, float eps, int silu, hipStream_t s, const half_t* x2 = nullptr, int ldx2 = 0, int Ca = 0,
+                                 const double* tot1 = nullptr, const double* tot2 = nullptr);
 hipError_t ia2p_launch_layernorm(const half_t* x, int ldx, half_t* y, int ldy, const half_t* gamma, const half_t* beta,
                                  int M, int C, float eps, hipStream_t s);
 hipError_t ia2p_launch_embed(float t, const float* ts, const half_t* text_embeds, const half_t* time_ids, half_t* tsin, half_t* addin,
@@ -161,11 +162,22 @@ struct RunCtx {
   double r_ms[PR_NREGION], r_fl[PR_NREGION], r_by[PR_NREGION];
   int64_t r_n[PR_NREGION];
   float ep_acc_scale = 1.f, ep_bias_scale = 1.f;   // epilogue scales of the NEXT op_gemm / op_conv3 call (reset by it): range extension, vae_engine.hip
+  // GroupNorm statistics from producer epilogues (GemmArgs.gn_*): the NEXT op_gemm / op_conv3 call emits them for its output when gn_next_hw > 0
+  // (rows per image; reset by the call) and registers the totals under the output's workspace offset; op_gn looks its sources up there.
+  int gn_epi = 0;            // IA2P_GN_EPI: 0 (default) every GroupNorm runs its own statistics pass (gn_stats_kernel); 1 producers emit the statistics from their
+                             // epilogues wherever they can; 2 only producers whose workgroups all fit the chip at once (<= 512). Built, parity-tested, measured and
+                             // left OFF: the pass it removes is a launch-floor-sized read served by L2 / Infinity Cache, what it adds (column pass, write-through drain,
+                             // ticket round trip, the last tile's acquire + fold) sits at the END of the producer's workgroups and costs as much -- same box, same
+                             // plans: batch 8 +0.06 ms (1) / +-0 (2), batch 1 +0.07 / +0.03, 1024^2 B_eff 2 +0.2 / +0.04 ms per step (profiles/r03c_gn_epilogue_ab.txt)
+  int gn_next_hw = 0;
+  size_t gn_next_off = (size_t)-1;
+  std::unordered_map<size_t, std::pair<size_t, double*>> gn_tot;   // tensor offset -> (offset, pointer) of its [B][C] double2 totals in the workspace
   bool fold_dirty = false;   // a LayerNorm-fold source tensor was (re)loaded after the last fold: re-fold before the next forward
   RunCtx() {
     if (const char* e = getenv("IA2P_PREFETCH")) prefetch = atoi(e) != 0;
     if (const char* e = getenv("IA2P_LN_FOLD")) ln_fold = atoi(e) != 0;
     if (const char* e = getenv("IA2P_CHAIN")) chain = atoi(e) != 0;
+    if (const char* e = getenv("IA2P_GN_EPI")) gn_epi = atoi(e);
     if (const char* e = getenv("IA2P_XATTN_FUSE")) xattn_fuse = atoi(e) != 0;
     if (const char* e = getenv("IA2P_SC_FUSE")) sc_fuse = atoi(e) != 0;
     if (const char* e = getenv("IA2P_CAT_FREE")) cat_free = atoi(e) != 0;
@@ -210,7 +222,10 @@ void op_gemm(RunCtx* c, const half_t* A, int lda, const half_t* W, const half_t*
              const LnIn* ln = nullptr, float* stats_out = nullptr, int* stat_slots = nullptr, int act = 0);
 void op_conv3(RunCtx* c, const half_t* X, int B, int Hs, int Ws, int Cin, const half_t* W, const half_t* bias, int Co,
               int stride, int up, const half_t* rowvec, int rowvec_ld, const half_t* residual, half_t* Y, int pad_lo = 1, const half_t* X2 = nullptr, int Cin2 = 0, const half_t* X3 = nullptr, int Cin3 = 0);
-void op_gn(RunCtx* c, const half_t* x, half_t* y, size_t g, size_t b, int B, int HW, int C, float eps, int silu, float* partial, const half_t* x2 = nullptr, int Ca = 0);
+void op_gn(RunCtx* c, const half_t* x, half_t* y, size_t g, size_t b, int B, int HW, int C, float eps, int silu, float* partial, const half_t* x2 = nullptr, int Ca = 0,
+           size_t x_off = (size_t)-1, size_t x2_off = (size_t)-1);
+bool ia2p_gn_epilogue_ok(int variant, int M, int hw);
+int* ia2p_gn_tickets(hipStream_t s);
 void op_ln(RunCtx* c, const half_t* x, half_t* y, size_t g, size_t b, int M, int C);
 
 // ---- weight arena plumbing shared by the three contexts

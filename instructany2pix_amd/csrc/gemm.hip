@@ -155,6 +155,14 @@ static int* pool_buffer(hipStream_t s) {
   return p;
 }
 int* ia2p_sk_counters(hipStream_t s, int tiles) { return tiles > POOL_SK ? nullptr : pool_buffer(s); }
+// GroupNorm statistics from a GEMM epilogue: per-image arrival counters (<= 1024 images) of this (device, stream)
+int* ia2p_gn_tickets(hipStream_t s) { int* p = pool_buffer(s); return p ? p + POOL_SK + 3072 : nullptr; }
+// a tile must lie inside one image: the variant's tile height divides the rows per image
+bool ia2p_gn_epilogue_ok(int variant, int M, int hw) {
+  if (variant < 0 || variant >= IA2P_GEMM_NVARIANT || hw <= 0) return false;
+  const int bm = IA2P_GEMM_TILES[variant].bm;
+  return hw >= bm && hw % bm == 0 && M % hw == 0 && M / hw <= 1024;
+}
 // chained launches: arrival counters (<= 1024 row panels), their "done" twins and the give-up flag of this (device, stream)
 bool ia2p_chain_words(hipStream_t s, int** cnt, int** done, unsigned** err) {
   int* p = pool_buffer(s);

@@ -74,6 +74,8 @@ struct TileCtl {
   int* sig_cnt;            // producer: the counter of the panel this tile belongs to gets +1 once the tile's C rows are written through
   int sig_rows;
   unsigned* err;           // bounded spins give up into this word (never hang the GPU); the host checks it
+  int diag;                // timing diagnostics only (IA2P_CHAIN_DIAG; results may be WRONG): 1 producer signals without draining its stores, 2 long poll sleep,
+                           // 4 consumer skips the acquire, 8 consumer does not wait at all
 };
 typedef __attribute__((address_space(1))) int gi32;
 
@@ -83,12 +85,14 @@ __device__ __forceinline__ void tile_wait_panel(const TileCtl& c, int row0, int 
   if (tid == 0) {
     const int panel = row0 / c.dep_rows;
     unsigned spins = 0;
-    while (__hip_atomic_load((const gi32*)(c.dep_cnt + panel), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < c.dep_target) {
-      __builtin_amdgcn_s_sleep(2);
+    while (!(c.diag & 8) && __hip_atomic_load((const gi32*)(c.dep_cnt + panel), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < c.dep_target) {
+      if (c.diag & 2) __builtin_amdgcn_s_sleep(32); else __builtin_amdgcn_s_sleep(2);
       if (++spins > (1u << 22)) { __hip_atomic_fetch_or((__attribute__((address_space(1))) unsigned*)c.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // ~seconds: give up, flag it
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!(c.diag & 4)) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
   }
   __syncthreads();
 }
@@ -105,7 +109,7 @@ __device__ __forceinline__ void tile_release_panel(const TileCtl& c, int row0, i
 }
 // producer side (R1 publish): every storing wave drains its write-through stores, the workgroup meets, ONE lane adds
 __device__ __forceinline__ void tile_signal_panel(const TileCtl& c, int row0, int tid) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (!(c.diag & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) __hip_atomic_fetch_add((gi32*)(c.sig_cnt + row0 / c.sig_rows), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -619,6 +623,10 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
     __syncthreads();
     from_slabs = true;
   }
+  // GroupNorm statistics of the output (p.gn_cols): thread (column quad c4, row slice gsl) sums the ROUNDED values of its columns over the tile rows
+  constexpr int GQ = BN / 4, GNSL = NT / GQ;
+  const int gc4 = tid % GQ, gsl = tid / GQ;
+  f4 gsum = {0.f, 0.f, 0.f, 0.f}, gsq = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
   for (int ch = 0; ch < EC::NCHUNK; ++ch) {
     if (ch || from_slabs) __syncthreads();          // the previous chunk has been read out
@@ -789,6 +797,12 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
             if (live[u]) store_c8((size_t)(row0 + r) * p.ldc + bn0 + cl, o);
+            if (p.gn_cols && tid + (k * U + u) * NT < TOTAL) {      // the value as stored (fp16) goes back into the tile slot it came from (only this thread touches it)
+              const f4 w0 = live[u] ? (f4){(float)o[0], (float)o[1], (float)o[2], (float)o[3]} : (f4){0.f, 0.f, 0.f, 0.f};
+              const f4 w1 = live[u] ? (f4){(float)o[4], (float)o[5], (float)o[6], (float)o[7]} : (f4){0.f, 0.f, 0.f, 0.f};
+              *(f4*)(tile + (size_t)r * PITCH + (((2 * gg[u]) ^ (r & 7)) << 2)) = w0;
+              *(f4*)(tile + (size_t)r * PITCH + (((2 * gg[u] + 1) ^ (r & 7)) << 2)) = w1;
+            }
             st1[u] = st2[u] = 0.f;
             if (p.stats_out && live[u]) {
 #pragma unroll
@@ -853,6 +867,64 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
           }
         }
       }
+      if (p.gn_cols) {                 // column pass over the rounded chunk: rows gsl, gsl + GNSL, ... of column quad gc4 (fixed order: deterministic)
+        __syncthreads();
+        if (gsl < GNSL) {
+          for (int r = gsl; r < CR; r += GNSL) {
+            const f4 v = tl(r, gc4);
+            gsum[0] += v[0]; gsum[1] += v[1]; gsum[2] += v[2]; gsum[3] += v[3];
+            gsq[0] = fmaf(v[0], v[0], gsq[0]); gsq[1] = fmaf(v[1], v[1], gsq[1]); gsq[2] = fmaf(v[2], v[2], gsq[2]); gsq[3] = fmaf(v[3], v[3], gsq[3]);
+          }
+        }
+      }
+    }
+  }
+  if (p.gn_cols && !p.geglu) {
+    // ---- GroupNorm statistics, producer side: column sums of this tile -> gn_cols; the last tile of the image folds the image's tiles (in tile order, fp64)
+    //      into gn_tot. Hand-off as for the K-split slabs: write-through stores, every wave drains, ONE lane draws the ticket; the folding workgroup takes
+    //      an agent-scope acquire (cdna_hip_programming.md Guideline 16).
+    __syncthreads();                  // every column pass is through: the tile memory is free
+    float* red = tile;                // [GNSL][BN] {sum, sum of squares}
+    if (gsl < GNSL) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) *(float2*)(red + ((size_t)(gsl * BN + gc4 * 4 + e) << 1)) = make_float2(gsum[e], gsq[e]);
+    }
+    __syncthreads();
+    if (tid < BN && bn0 + tid < hN) {
+      float a = 0.f, q = 0.f;
+#pragma unroll
+      for (int sl = 0; sl < GNSL; ++sl) { const float2 v = *(const float2*)(red + ((size_t)(sl * BN + tid) << 1)); a += v.x; q += v.y; }
+      typedef unsigned u2v __attribute__((__vector_size__(2 * sizeof(unsigned))));
+      const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc((void*)p.gn_cols, 0, (int)min((size_t)tiles_m * hN * 8, (size_t)0x7ffffff0), 0x00020000);
+      const float2 v = make_float2(a, q);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, v), gr, (int)(((size_t)tm * hN + bn0 + tid) * 8), 0, 16);      // sc1: write-through
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int img = bm0 / p.gn_hw, tpi = p.gn_hw / BM;
+    if (tid == 0) *sk_flag = __hip_atomic_fetch_add(p.gn_tickets + img, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (*sk_flag == tpi * tiles_n - 1) {
+      if (tid == 0) {
+        __hip_atomic_store(p.gn_tickets + img, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();
+      for (int col = tid; col < hN; col += NT) {
+        const float2* src = (const float2*)p.gn_cols + (size_t)img * tpi * hN + col;
+        double a = 0.0, q = 0.0;
+        for (int t0 = 0; t0 < tpi; t0 += 8) {
+          float2 v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = src[(size_t)min(t0 + u, tpi - 1) * hN];      // all loads of a round in flight (clamped, never branched around)
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (t0 + u < tpi) { a += (double)v[u].x; q += (double)v[u].y; }
+        }
+        p.gn_tot[((size_t)img * hN + col) * 2] = a;
+        p.gn_tot[((size_t)img * hN + col) * 2 + 1] = q;
+      }
     }
   }
   if (PP) asm volatile("" ::"v"(pfacc));
@@ -868,7 +940,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
 template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int BK = 64, int PP = 0, int WGN = 2>
 __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_f16_kernel(const half_t* hA, const half_t* hW, const half_t* hzero, int hM, int hN, int hK, int hlda, int hldw, int hrpb, int hbstride,
                                                                          int hroff, int hsplitk, int hgroup_w, const GemmArgs p) {
-  const TileCtl ctl{(int)blockIdx.x, nullptr, 0, 1, nullptr, 0, nullptr, 1, nullptr};
+  const TileCtl ctl{(int)blockIdx.x, nullptr, 0, 1, nullptr, 0, nullptr, 1, nullptr, 0};
   gemm_tile_body<BM, BN, NSTAGE, CONV, WGM, BK, PP, WGN, 0>(hA, hW, hzero, hM, hN, hK, hlda, hldw, hrpb, hbstride, hroff, hsplitk, hgroup_w, p, nullptr, ctl);
 }
 
@@ -910,6 +982,7 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
   GemmArgs b = a;
   ia2p_gemm_prepare(b, smem, BM, BN);
   if (a.geglu && !b.vec8) return hipErrorInvalidValue;
+  if (a.gn_cols && (!b.vec8 || a.geglu || !a.gn_tot || !a.gn_tickets || a.gn_hw < BM || a.gn_hw % BM || a.M % a.gn_hw)) return hipErrorInvalidValue;   // (callers ask ia2p_gn_epilogue_ok first)
   // b.sk_counters: as the caller (launch_any, gemm.hip) attached them -- null: the K-slices only write their slabs and a splitk_reduce_kernel launch finishes
   if (b.sk_counters && tiles > ia2p_sk_counter_capacity()) return hipErrorInvalidValue;
   const int extra = (!PP && a.pf && a.pf_bytes >= 4096) ? a.pf_blocks : 0;
