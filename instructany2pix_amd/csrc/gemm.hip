@@ -373,6 +373,10 @@ static hipError_t launch_any(const GemmArgs& a0, int v, hipStream_t s, bool with
       static_assert(IA2P_GEMM_TILES[12].bm == 256 && IA2P_GEMM_TILES[12].bn == 128 && IA2P_GEMM_TILES[12].stages == 3, "tile table");
       e = launch_cfg<256, 128, 3, CONV, 4, 64, 1>(a, s);
       break;
+    case 18:
+      static_assert(IA2P_GEMM_TILES[18].bm == 256 && IA2P_GEMM_TILES[18].bn == 160 && IA2P_GEMM_TILES[18].stages == 3, "tile table");
+      e = launch_cfg<256, 160, 3, CONV, 4, 64, 1>(a, s);
+      break;
 #undef IA2P_TILE_CASE
     // Measured and dropped in round 1 (tools/gemm_bench.py): 8-wave 256x128 (2- and 3-stage) and 256x320 at one
     // workgroup per CU; BK = 32 rings (64-byte rows halve the request efficiency). The template still takes WGM and BK.

@@ -45,9 +45,19 @@ template <int BK> __device__ __forceinline__ int lds_swz(int row) { return BK ==
 
 // LDS budget of the staged epilogue: the fp32 tile is read out in NCHUNK row chunks so that chunk + row constants (+ statistics partials) stay
 // within what two co-resident workgroups can hold (<= 80 KiB each), or within the stage buffers when those are larger
-template <int BM, int BN, int NSTAGE, int WGM, int BK, int WGN = 2>
+// weight-tile staging pieces (1 KiB = RPP rows) per wave. Even split where the pieces divide by the waves (surplus rows would read the zero page);
+// the ping-pong tile may split UNEVENLY -- its first wave group takes one piece more per wave than its second -- so that no LDS goes to padding rows
+// (256 x 160: 20 pieces = 4 x 3 + 4 x 2; three stages of (256 + 160) rows are 156 KiB, with padding to 192 rows they would not fit the CU's 160 KiB)
+template <int BN, int BK, int NWAVE, int PP>
+struct BStage {
+  static constexpr int RPP = 1024 / (2 * BK), P = BN / RPP, HI = (P + NWAVE - 1) / NWAVE;
+  static constexpr bool UNEVEN = PP != 0 && P % NWAVE != 0 && P == (NWAVE / 2) * (2 * HI - 1);
+  static constexpr int BNL = UNEVEN ? BN : HI * NWAVE * RPP;     // weight rows held in LDS
+};
+
+template <int BM, int BN, int NSTAGE, int WGM, int BK, int WGN = 2, int PP = 0>
 struct EpiCfg {
-  static constexpr int BNL = ((BN / (1024 / (2 * BK)) + WGM * WGN - 1) / (WGM * WGN)) * (WGM * WGN) * (1024 / (2 * BK));   // weight rows staged (>= BN)
+  static constexpr int BNL = BStage<BN, BK, WGM * WGN, PP>::BNL;   // weight rows staged (>= BN)
   static constexpr int STAGE_BYTES = NSTAGE * (BM + BNL) * 2 * BK;
   static constexpr int PITCH = ((BN / 4 + 7) & ~7) * 4;        // floats per fp32 tile row: whole groups of 8 chunks (the XOR swizzle stays inside a group)
   static constexpr bool POW2 = ((BN / 8) & (BN / 8 - 1)) == 0;
@@ -132,8 +142,10 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   constexpr int WM = BM / WGM, WN = BN / WGN;    // wave tile (waves arranged WGM x WGN; WGN = 1: narrow tiles, one wave per 128-byte column block)
   constexpr int MR = WM / 16, NR = WN / 16;
   constexpr int ROWB = 2 * BK, CPR = ROWB / 16, RPP = 1024 / ROWB;   // row bytes, chunks per row, rows per 1-KiB staging piece
-  constexpr int A_PW = BM / RPP / NWAVE, B_PW = (BN / RPP + NWAVE - 1) / NWAVE;    // staging pieces per wave (B rounded up: the surplus rows read the zero page)
-  constexpr int BNL = B_PW * NWAVE * RPP;                            // weight rows held in LDS (>= BN)
+  using BS = BStage<BN, BK, NWAVE, PP>;
+  constexpr int A_PW = BM / RPP / NWAVE, B_PW = BS::HI;             // staging pieces per wave (B rounded up: the surplus rows read the zero page -- or,
+  constexpr bool B_UNEVEN = BS::UNEVEN;                              //  ping-pong tile, the second wave group takes one piece less per wave: BStage)
+  constexpr int BNL = BS::BNL;                                       // weight rows held in LDS (>= BN)
   static_assert(BM % (RPP * NWAVE) == 0 && BN % 16 == 0 && WN % 16 == 0 && WM % 16 == 0, "tile / wave layout");
   constexpr int STAGE = (BM + BNL) * ROWB;
   constexpr int KSUB = BK / 32;                                       // 32-deep MFMA sub-steps per k-tile
@@ -221,9 +233,12 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   }
   const half_t* w_ptr[B_PW];
   int w_inc[B_PW];
+  // this wave's weight pieces: [b_pi0, b_pi0 + b_npw)
+  const int b_npw = B_UNEVEN && wave >= NWAVE / 2 ? B_PW - 1 : B_PW;
+  const int b_pi0 = B_UNEVEN ? (wave < NWAVE / 2 ? wave * B_PW : (NWAVE / 2) * B_PW + (wave - NWAVE / 2) * (B_PW - 1)) : wave * B_PW;
 #pragma unroll
   for (int i = 0; i < B_PW; ++i) {
-    const int pi = wave * B_PW + i;
+    const int pi = min(b_pi0 + i, BNL / RPP - 1);
     const int n = bn0 + pi * RPP + srow;
     const int gch = cpos ^ lds_swz<BK>(pi * RPP + srow);
     if (n < hN && pi * RPP + srow < BN) { w_ptr[i] = hW + (size_t)n * hldw + gch * 8; w_inc[i] = BK; }
@@ -252,7 +267,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
 
   auto stage = [&](int kt, int buf) {
     char* sA = smem + buf * STAGE + wave * (A_PW * 1024);
-    char* sB = smem + buf * STAGE + BM * ROWB + wave * (B_PW * 1024);
+    char* sB = smem + buf * STAGE + BM * ROWB + b_pi0 * 1024;
     if (CONV) {
       if (tap_fresh) {        // (wave-uniform) new filter tap: re-derive the gathered pixel of each row once per Cin/64 k-steps
         if (tap < 9) {
@@ -296,7 +311,8 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
       for (int i = 0; i < A_PW; ++i) { GLDS16(a_ptr[i], sA + i * 1024); a_ptr[i] += a_inc[i]; }   // running pointers: no per-step multiply
     }
 #pragma unroll
-    for (int i = 0; i < B_PW; ++i) { GLDS16(w_ptr[i], sB + i * 1024); w_ptr[i] += w_inc[i]; }
+    for (int i = 0; i < B_PW; ++i)
+      if (!B_UNEVEN || i < b_npw) { GLDS16(w_ptr[i], sB + i * 1024); w_ptr[i] += w_inc[i]; }      // (wave-uniform)
   };
 
   // ---- fragment read offsets (wave tile origin is a multiple of 16, so swz(row) = (lane>>1)&7)
@@ -351,7 +367,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
     // Barrier sequence b0, b1, ...; interval I_n lies between b_n and b_n+1. Group 0 reads tile t in I_2t and multiplies it in I_2t+1; group 1
     // reads it in I_2t+1 and multiplies it in I_2t+2. Every wave waits for its DMA pieces of tile t before b_2t; the slot of tile t-1 is free
     // after b_2t (group 1 finished reading it in I_2t-1), so tile t+2 is issued into it in I_2t: two tiles stay in flight.
-    static_assert(MR * NR <= 16, "ping-pong keeps the fragments of a whole k-tile in registers across a barrier");
+    static_assert(MR * NR <= 20, "ping-pong keeps the fragments of a whole k-tile in registers across a barrier");
     const int grp = wave >> 2;
     h8 af[KSUB][MR], wf[KSUB][NR];
     auto rd = [&](int slot) {
@@ -376,12 +392,13 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
     };
     // One loop per group (straight-line bodies: a shared loop with per-group arms makes the compiler shuffle the 128 fragment / accumulator
     // registers between the arms every iteration). Both loops pass exactly two barriers per k-tile.
-    auto top = [&](int t) {      // b_2t: tile t has landed for every wave (tile t+1 may still be in flight)
+    auto top = [&](int t, auto lps_tag) {      // b_2t: tile t has landed for every wave (tile t+1 may still be in flight: this wave's lps_tag pieces of it)
       __builtin_amdgcn_sched_barrier(0);
-      if (t + 1 < nk) wait_vm_barrier<LPS>();
+      if (t + 1 < nk) wait_vm_barrier<decltype(lps_tag)::value>();
       else wait_vm_barrier<0>();
       __builtin_amdgcn_sched_barrier(0);
     };
+    constexpr int LPS0 = LPS, LPS1 = B_UNEVEN ? LPS - 1 : LPS;       // pieces per k-tile of a wave of group 0 / group 1
     auto mid = [&]() {           // b_2t+1
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -392,7 +409,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
     // a group issues its DMA pieces of tile t+2 behind the fragment reads of its READ half-step
     if (grp == 0) {
       for (int t = 0; t < nk; ++t) {
-        top(t);
+        top(t, std::integral_constant<int, LPS0>{});
         rd(slot_r);
         __builtin_amdgcn_sched_barrier(0);
         if (t + NSTAGE - 1 < nk) stage(t + NSTAGE - 1, slot_s);
@@ -402,7 +419,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
       }
     } else {
       for (int t = 0; t < nk; ++t) {
-        top(t);
+        top(t, std::integral_constant<int, LPS1>{});
         if (t > 0) mm();
         mid();
         rd(slot_r);
@@ -496,7 +513,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   //      free) stage buffers once: written in the MFMA layout (16-B chunks XOR-swizzled by row & 7: conflict-free ds_write_b128), read back
   //      row-major, 8 columns per thread, so that bias / time-embedding row / folded-LayerNorm constants / residual are 16-B loads and C is
   //      written in whole 128-B lines; everything is still applied to the fp32 accumulator and rounded once.
-  using EC = EpiCfg<BM, BN, NSTAGE, WGM, BK, WGN>;
+  using EC = EpiCfg<BM, BN, NSTAGE, WGM, BK, WGN, PP>;
   constexpr int PITCH = EC::PITCH;
   constexpr int NT = NWAVE * 64, CR = EC::CR;                           // threads, tile rows per chunk
   float* tile = (float*)smem;
@@ -968,7 +985,7 @@ static inline void ia2p_gemm_prepare(GemmArgs& b, int smem, int BM, int BN) {
 
 template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int BK = 64, int PP = 0, int WGN = 2>
 static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
-  constexpr int smem = EpiCfg<BM, BN, NSTAGE, WGM, BK, WGN>::SMEM;
+  constexpr int smem = EpiCfg<BM, BN, NSTAGE, WGM, BK, WGN, PP>::SMEM;
   // the attribute is per DEVICE: one flag per device id (several contexts on several GPUs in one process)
   static bool attr_set[64] = {false};
   int dev = 0;
