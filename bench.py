@@ -341,6 +341,10 @@ def roofline_block(table, regions, nprof, B_eff, hw, use_ip, ms_per_step, probe=
     out = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS,
            "traffic": traffic, "traffic_unit": "bytes/launch (L2<->fabric, Infinity-Cache hits included)", "traffic_source": traffic_src,
            "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
+           # the PMC figure counts what the launch moved, including the NEXT contraction's weights its trailing workgroups prefetched: priced apart
+           "prefetch_bytes_per_launch": d.get("prefetch_bytes", 0.0) / d["launches"],
+           "traffic_over_algorithmic": (traffic / (d["bytes"] / d["launches"])) if traffic else None,
+           "traffic_minus_prefetch_over_algorithmic": ((traffic - d.get("prefetch_bytes", 0.0) / d["launches"]) / (d["bytes"] / d["launches"])) if traffic else None,
            "launches_per_step": d["launches"] / nprof, "avg_launch_us": 1e3 * d["ms"] / d["launches"],
            "flops_per_launch": d["flops"] / d["launches"], "share_of_step": d["ms"] / tot_ms}
     launches = sum(v["launches"] for k, v in table.items() if k != "ddim_step_kernel") / nprof + 1

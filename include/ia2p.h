@@ -237,6 +237,9 @@ void ia2p_debug_gemm_plan(int M, int N, int K, int conv, int geglu, int* variant
 ia2p_status ia2p_profile_enable(ia2p_ctx* ctx, int on);   /* also clears the sums */
 int ia2p_profile_classes(void);
 /* sums since enable for class k: launches, milliseconds, algorithmic flops and bytes */
+/* bytes of the NEXT contraction's weights that the launches of class k streamed with their trailing prefetch workgroups (counted in the class's
+ * HBM-side traffic by the PMC counters, but not its own operands) */
+ia2p_status ia2p_profile_read_prefetch(ia2p_ctx* ctx, int k, double* bytes);
 ia2p_status ia2p_profile_read(ia2p_ctx* ctx, int k, char* name, int name_len, int64_t* launches, double* ms, double* flops, double* bytes);
 /* the same sums by REGION of the UNet evaluation: 0 = other (embeddings), 1 = conv blocks (conv_in / conv_out, the ResnetBlock2Ds with their
  * GroupNorm+SiLU and 1x1 shortcuts, resample convolutions, skip concatenation -- SURVEY.md §8d "conv blocks"), 2 = transformer blocks */

@@ -117,6 +117,7 @@ SIGNATURES = {
     "ia2p_profile_enable": (_I, [_P, _I]),
     "ia2p_profile_classes": (_I, []),
     "ia2p_profile_read_region": (_I, [_P, _I, C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "ia2p_profile_read_prefetch": (_I, [_P, _I, _P]),
     "ia2p_profile_read": (_I, [_P, _I, C.c_char_p, _I, C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 

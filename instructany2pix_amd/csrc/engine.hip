@@ -426,6 +426,7 @@ static void run_gemm(RunCtx* c, GemmArgs& a, bool conv, const char* what, double
   }
   {
     ProfScope ps(c, (conv ? PK_CONV0 : PK_GEMM0) + pl.variant, flops, bytes);
+    ps.pf = a.pf ? (double)a.pf_bytes : 0.0;
     CHECK_LAUNCH(c, ia2p_launch_gemm_variant(a, conv, pl.variant, c->stream, false, &combined), what);
   }
   if (gcols.off != (size_t)-1) c->ws.release(gcols.off);
@@ -1345,7 +1346,7 @@ ia2p_status ia2p_profile_enable(ia2p_ctx* c, int on) {
   if (!c) return IA2P_ERR_INVALID;
   for (auto& r : c->recs) { c->evpool.push_back(r.e0); c->evpool.push_back(r.e1); }
   c->recs.clear();
-  for (int k = 0; k < PK_NCLASS; ++k) { c->p_ms[k] = c->p_fl[k] = c->p_by[k] = 0; c->p_n[k] = 0; }
+  for (int k = 0; k < PK_NCLASS; ++k) { c->p_ms[k] = c->p_fl[k] = c->p_by[k] = c->p_pf[k] = 0; c->p_n[k] = 0; }
   for (int k = 0; k < PR_NREGION; ++k) { c->r_ms[k] = c->r_fl[k] = c->r_by[k] = 0; c->r_n[k] = 0; }
   c->prof = on != 0;
   return IA2P_OK;
@@ -1356,7 +1357,7 @@ static void prof_fold(ia2p_ctx* c) {
     float t = 0.f;
     (void)hipEventSynchronize(r.e1);
     (void)hipEventElapsedTime(&t, r.e0, r.e1);
-    c->p_ms[r.k] += t; c->p_fl[r.k] += r.flops; c->p_by[r.k] += r.bytes; c->p_n[r.k] += 1;
+    c->p_ms[r.k] += t; c->p_fl[r.k] += r.flops; c->p_by[r.k] += r.bytes; c->p_pf[r.k] += r.pf; c->p_n[r.k] += 1;
     const int g = r.region >= 0 && r.region < PR_NREGION ? r.region : PR_OTHER;
     c->r_ms[g] += t; c->r_fl[g] += r.flops; c->r_by[g] += r.bytes; c->r_n[g] += 1;
     c->evpool.push_back(r.e0); c->evpool.push_back(r.e1);
@@ -1370,6 +1371,14 @@ ia2p_status ia2p_profile_read_region(ia2p_ctx* c, int region, int64_t* launches,
   if (ms) *ms = c->r_ms[region];
   if (flops) *flops = c->r_fl[region];
   if (bytes) *bytes = c->r_by[region];
+  return IA2P_OK;
+}
+// bytes of next-contraction weights that the launches of class k streamed with their trailing prefetch workgroups (part of the class's HBM-side
+// traffic that is NOT its own operands: bench.py separates the two when it prices the PMC figure)
+ia2p_status ia2p_profile_read_prefetch(ia2p_ctx* c, int k, double* bytes) {
+  if (!c || k < 0 || k >= PK_NCLASS || !bytes) return IA2P_ERR_INVALID;
+  prof_fold(c);
+  *bytes = c->p_pf[k];
   return IA2P_OK;
 }
 ia2p_status ia2p_profile_read(ia2p_ctx* c, int k, char* name, int name_len, int64_t* launches, double* ms, double* flops, double* bytes) {

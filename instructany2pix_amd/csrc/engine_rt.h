@@ -113,7 +113,7 @@ struct Arena {            // deterministic first-fit allocator over [0, cap)
   }
 };
 
-struct ProfRec { hipEvent_t e0, e1; int k; double flops, bytes; int region; };
+struct ProfRec { hipEvent_t e0, e1; int k; double flops, bytes; int region; double pf; };
 // profile regions of a UNet evaluation: what part of the network a launch belongs to (bench.py: conv-block roofline)
 enum { PR_OTHER = 0, PR_CONV_BLOCK = 1, PR_TRANSFORMER = 2, PR_NREGION };
 // profile classes = device kernel names as rocprofv3 prints them (template arguments included)
@@ -156,7 +156,7 @@ struct RunCtx {
   size_t tune_slab_bytes = 0, tune_flush_bytes = 0;
   std::vector<ProfRec> recs;
   std::vector<hipEvent_t> evpool;
-  double p_ms[PK_NCLASS], p_fl[PK_NCLASS], p_by[PK_NCLASS];
+  double p_ms[PK_NCLASS], p_fl[PK_NCLASS], p_by[PK_NCLASS], p_pf[PK_NCLASS];     // p_pf: bytes of the NEXT contraction's weights the class's launches prefetched
   int64_t p_n[PK_NCLASS];
   int region = PR_OTHER;     // region the executor is in (tags the profile records)
   double r_ms[PR_NREGION], r_fl[PR_NREGION], r_by[PR_NREGION];
@@ -182,7 +182,7 @@ struct RunCtx {
     if (const char* e = getenv("IA2P_SC_FUSE")) sc_fuse = atoi(e) != 0;
     if (const char* e = getenv("IA2P_CAT_FREE")) cat_free = atoi(e) != 0;
     if (const char* e = getenv("IA2P_XATTN_MIN_TILES")) xattn_min_tiles = atoi(e);
-    for (int k = 0; k < PK_NCLASS; ++k) { p_ms[k] = p_fl[k] = p_by[k] = 0; p_n[k] = 0; }
+    for (int k = 0; k < PK_NCLASS; ++k) { p_ms[k] = p_fl[k] = p_by[k] = p_pf[k] = 0; p_n[k] = 0; }
     for (int k = 0; k < PR_NREGION; ++k) { r_ms[k] = r_fl[k] = r_by[k] = 0; r_n[k] = 0; }
   }
   ~RunCtx() {
@@ -199,11 +199,11 @@ void wsfree(RunCtx* c, T2 t);
 hipEvent_t get_event(RunCtx* c);
 
 struct ProfScope {
-  RunCtx* c; int k; double fl, by; hipEvent_t e0, e1; bool on;
+  RunCtx* c; int k; double fl, by; hipEvent_t e0, e1; bool on; double pf = 0;
   ProfScope(RunCtx* c_, int k_, double fl_, double by_) : c(c_), k(k_), fl(fl_), by(by_), on(c_ && c_->prof && !c_->dry) {
     if (on) { e0 = get_event(c); e1 = get_event(c); (void)hipEventRecord(e0, c->stream); }
   }
-  ~ProfScope() { if (on) { (void)hipEventRecord(e1, c->stream); c->recs.push_back(ProfRec{e0, e1, k, fl, by, c->region}); } }
+  ~ProfScope() { if (on) { (void)hipEventRecord(e1, c->stream); c->recs.push_back(ProfRec{e0, e1, k, fl, by, c->region, pf}); } }
   void set_class(int kk) { k = kk; }
 };
 #define CHECK_LAUNCH(c, expr, what)                                                             \

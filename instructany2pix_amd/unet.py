@@ -287,7 +287,9 @@ class HipUNet2DConditionModel:
             n, ms, fl, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
             _ffi.check(self._lib.ia2p_profile_read(self._ctx, k, name, 96, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)), self._ctx)
             if n.value:
-                res[name.value.decode()] = dict(launches=n.value, ms=ms.value, flops=fl.value, bytes=by.value)
+                pf = C.c_double()
+                _ffi.check(self._lib.ia2p_profile_read_prefetch(self._ctx, k, C.byref(pf)), self._ctx)
+                res[name.value.decode()] = dict(launches=n.value, ms=ms.value, flops=fl.value, bytes=by.value, prefetch_bytes=pf.value)
         return res
 
 

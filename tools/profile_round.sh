@@ -5,16 +5,16 @@
 TAG=${1:-rXX}
 R=$GRAFT_REPO_ROOT
 cd $R
-python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-roofline --save-plans $R/gpurun_out/${TAG}_plans_cfg3.txt > /dev/null 2> $R/gpurun_out/${TAG}_plans.err
+python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-roofline --no-box-probe --save-plans $R/gpurun_out/${TAG}_plans_cfg3.txt > /dev/null 2> $R/gpurun_out/${TAG}_plans.err
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace -d $R/gpurun_out/pmc_${TAG}_$c --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-roofline --plans $R/gpurun_out/${TAG}_plans_cfg3.txt > $R/gpurun_out/pmc_${TAG}_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace -d $R/gpurun_out/pmc_${TAG}_$c --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-roofline --no-box-probe --plans $R/gpurun_out/${TAG}_plans_cfg3.txt > $R/gpurun_out/pmc_${TAG}_$c.log 2>&1
 done
 cd $R
 python3 tools/pmc_traffic.py gpurun_out/pmc_${TAG}_FETCH_SIZE gpurun_out/pmc_${TAG}_WRITE_SIZE profiles/${TAG}_pmc_traffic.json > gpurun_out/${TAG}_pmc_traffic.txt 2>&1
 cp profiles/${TAG}_pmc_traffic.json gpurun_out/
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG} --output-format csv -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary --no-roofline --plans $R/gpurun_out/${TAG}_plans_cfg3.txt > $R/gpurun_out/prof_${TAG}.log 2>&1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG} --output-format csv -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary --no-roofline --no-box-probe --plans $R/gpurun_out/${TAG}_plans_cfg3.txt > $R/gpurun_out/prof_${TAG}.log 2>&1
 cd $R
 find gpurun_out/prof_${TAG} -name "*kernel_stats.csv" -exec python3 tools/demangle_stats.py {} gpurun_out/${TAG}_kernel_stats_bench_cfg3.csv \;
 python3 bench.py --steps 50 --warmup 3 --plans gpurun_out/${TAG}_plans_cfg3.txt --no-secondary --kernel-table gpurun_out/${TAG}_kernel_table.json > gpurun_out/${TAG}_bench_cfg3.json 2> gpurun_out/${TAG}_bench_cfg3.err
