@@ -348,7 +348,6 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
     }
   }
   };
-  if (PP) load_ln();
   const int nk = kt1 - kt0;
   constexpr int LPS = A_PW + B_PW;   // LDS-DMA pieces this wave issues per k-tile
   // NSTAGE-deep LDS ring: tiles kt+1 .. kt+NSTAGE-2 stay in flight across the barrier of step kt (counted vmcnt,
@@ -356,8 +355,8 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < nk) stage(s, s);
-  if (!PP) load_ln();
-  else asm volatile("" : "+v"(ln_s1), "+v"(ln_s2));
+  load_ln();               // behind the prologue DMA: the statistics' round trip overlaps the first tiles' (the ping-pong tile used to load them AHEAD of
+  if (PP) asm volatile("" : "+v"(ln_s1), "+v"(ln_s2));      //  its prologue -- a serial 1-2 us at every workgroup start; folded here, before the loop, they still cost it no registers)
   // fused cross-attention: the context K / V of this tile's (batch element, head) travel to registers while the projection runs
   AttnKvRegs kvr;       // loaded inside the k-loop, behind the first tile     // folds now; the counted wait leaves the prologue DMA in flight
 #ifdef IA2P_CLOCK_STAMP     // diagnostic build only (tools/micro/gemm_clock.hip): in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz around the k-loop
@@ -489,24 +488,6 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
     o[0] = __builtin_amdgcn_s_memtime() - stamp_c0; o[1] = r1 - stamp_r0; o[2] = stamp_entry; o[3] = stamp_r0; o[4] = r1;
   }
 #endif
-  // Ping-pong tile: no separate prefetch workgroups (a workgroup holds a whole CU's LDS, so they would queue up behind the tiles): every
-  // tile workgroup touches its slice of the next contraction's weights here; the loads fly during the epilogue.
-  unsigned pfacc = 0;
-  if (PP && p.pf) {
-    const long nwg = (long)tiles_m * tiles_n * nsplit;
-    const long per = ((p.pf_bytes + nwg - 1) / nwg + 255) & ~255L;
-    const long lo = (long)ctl.bid * per, hi = min(lo + per, p.pf_bytes & ~15L);
-    const char* src = (const char*)p.pf;
-    constexpr long SW = NWAVE * 64 * 16;
-    if (lo < hi)
-      for (long o = lo + tid * 16; o < hi; o += 8 * SW) {      // 8 independent loads in flight per thread (clamped, never branched around)
-        unsigned v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = *(const unsigned*)(src + min(o + u * SW, hi - 16));
-#pragma unroll
-        for (int u = 0; u < 8; ++u) pfacc ^= v[u];
-      }
-  }
   // ---- epilogue, staged through LDS. The MFMA layout gives a lane 4 consecutive columns of ONE row (acc[i][j][r] = C[bm0+wm0+16i+(lane&15)]
   //      [bn0+wn0+16j+4(lane>>4)+r]): stored from there, a wave-instruction touches 16 rows x 32 B -- quarter cache lines, and so does every
   //      residual read (profiles/r01g_gemm_loop_ablation.txt: 15 us of a 34 us launch at K -> 0). Instead the fp32 tile goes through the (now
@@ -536,6 +517,32 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
       *(f4*)(ln_lb + tid * 4) = *(const f4*)(p.ln_bias + bn0 + tid * 4);
     }
   }
+  // Ping-pong tile: no separate prefetch workgroups (a workgroup holds a whole CU's LDS, so they would queue up behind the tiles): every
+  // tile workgroup touches its slice of the next contraction's weights. The loads are issued HERE -- behind the epilogue's own constant loads,
+  // whose wait would otherwise (vmcnt retires in order) also wait for these HBM-cold lines -- and nothing consumes them before the kernel's
+  // end, so they fly during the whole epilogue (round 2 XOR-ed them together right away: a 2-3 us stall of every workgroup ahead of its epilogue).
+  unsigned pfacc = 0, pfv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (PP && p.pf) {
+    const long nwg = (long)tiles_m * tiles_n * nsplit;
+    const long per = ((p.pf_bytes + nwg - 1) / nwg + 255) & ~255L;
+    const long lo = (long)ctl.bid * per, hi = min(lo + per, p.pf_bytes & ~15L);
+    const char* src = (const char*)p.pf;
+    constexpr long SW = NWAVE * 64 * 16;
+    if (lo < hi)
+      for (long o = lo + tid * 16; o < hi; o += 8 * SW) {      // 8 independent loads in flight per thread (clamped, never branched around)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pfacc ^= pfv[u];            // the PREVIOUS round's lines (zeros the first time): nothing waits for the loads just issued
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pfv[u] = *(const unsigned*)(src + min(o + u * SW, hi - 16));
+#ifdef IA2P_PP_EAGER_PF      // A/B builds: consume at once, as round 2 did
+#pragma unroll
+        for (int u = 0; u < 8; ++u) asm volatile("" : "+v"(pfv[u]));
+#endif
+      }
+  }
+  auto pf_sink = [&]() {              // keep the loads alive up to here
+    if (PP) asm volatile("" ::"v"(pfacc), "v"(pfv[0]), "v"(pfv[1]), "v"(pfv[2]), "v"(pfv[3]), "v"(pfv[4]), "v"(pfv[5]), "v"(pfv[6]), "v"(pfv[7]));
+  };
   const float e_as = p.acc_scale == 0.f ? 1.f : p.acc_scale, e_bs = p.bias_scale == 0.f ? 1.f : p.bias_scale;
   const bool fast = p.vec8 != 0 && (hN & 7) == 0;     // 16-byte accesses everywhere (every shape of the executors); else 8-byte pieces
   // C stores: plain, or write-through (`sc1`) when the launcher asks for it
@@ -626,12 +633,12 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
         }
       }
     }
-    if (!p.sk_counters) { if (PP) asm volatile("" ::"v"(pfacc)); if (ctl.dep_cnt) tile_release_panel(ctl, bm0, tid); return; }      // finished by a separate splitk_reduce_kernel launch (A/B switch)
+    if (!p.sk_counters) { pf_sink(); if (ctl.dep_cnt) tile_release_panel(ctl, bm0, tid); return; }      // finished by a separate splitk_reduce_kernel launch (A/B switch)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // EVERY storing wave drains its write-through stores ...
     __syncthreads();                                       // ... before ONE lane signals for the workgroup
     if (tid == 0) *sk_flag = __hip_atomic_fetch_add(p.sk_counters + (tm * tiles_n + tn), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    if (*sk_flag != nsplit - 1) { if (PP) asm volatile("" ::"v"(pfacc)); if (ctl.dep_cnt) tile_release_panel(ctl, bm0, tid); return; }
+    if (*sk_flag != nsplit - 1) { pf_sink(); if (ctl.dep_cnt) tile_release_panel(ctl, bm0, tid); return; }
     if (tid == 0) {
       __hip_atomic_store(p.sk_counters + (tm * tiles_n + tn), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch (launches are stream-ordered)
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // drop this CU's stale lines before the plain loads below
@@ -750,6 +757,8 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
 #pragma unroll
             for (int e = 0; e < 8; ++e) { va[e] += (float)ba[u][e]; vg[e] += (float)bg[u][e]; }
           }
+          // (packed fp32 -- v_pk_fma_f32 on element pairs, the same operations -- was built and measured: +0.1 ms per step, same box, A/B builds;
+          //  the compiler's own mix of scalar and packed instructions is the faster one. Round 3)
           h8 o;
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = (half_t)(va[e] * gelu_erf_f(vg[e]));
@@ -944,7 +953,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
       }
     }
   }
-  if (PP) asm volatile("" ::"v"(pfacc));
+  pf_sink();
   if (ctl.sig_cnt) tile_signal_panel(ctl, bm0, tid);      // chained launch: this tile's rows are written (write-through): count it into its row panel
   if (ctl.dep_cnt) tile_release_panel(ctl, bm0, tid);
 #ifdef IA2P_CLOCK_STAMP

@@ -13,12 +13,16 @@
 #include <vector>
 
 bool ia2p_splitk_inkernel(int, int, int) { return false; }
+int ia2p_sk_counter_capacity() { return 1 << 18; }
+int* ia2p_sk_counters(hipStream_t, int) { return nullptr; }
+bool ia2p_chain_words(hipStream_t, int**, int**, unsigned**) { return false; }
 
 template <int BM, int BN, int ST, int WGM, int PP>
-static void run(const char* name, int M, int N, int K, const half_t* A, const half_t* W, half_t* C, const half_t* zero, unsigned long long* stamps) {
+static void run(const char* name, int M, int N, int K, const half_t* A, const half_t* W, half_t* C, const half_t* zero, unsigned long long* stamps, int geglu = 0) {
   GemmArgs a;
   memset(&a, 0, sizeof a);
-  a.pad = 1; a.A = A; a.W = W; a.C = C; a.zero = zero; a.M = M; a.N = N; a.K = K; a.lda = K; a.ldw = K; a.ldc = N; a.rows_per_batch = 1;
+  a.pad = 1; a.A = A; a.W = W; a.C = C; a.zero = zero; a.M = M; a.N = N; a.K = K; a.lda = K; a.ldw = K; a.ldc = geglu ? N / 2 : N; a.rows_per_batch = 1;
+  a.geglu = geglu; if (geglu) a.bias = W;        // (any N readable halves: timing only)
   a.partial = (float*)stamps; a.acc_scale = a.bias_scale = 1.f;
   const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -69,5 +73,9 @@ int main() {
   run<256, 128, 3, 4, 1>("256x128x3 pp K=5120", M, 3840, 5120, A, W, C, zero, stamps);
   run<128, 128, 2, 2, 0>("128x128x2 K=5120", M, 3840, 5120, A, W, C, zero, stamps);
   run<64, 64, 2, 2, 0>("64x64x2 (out-proj)", M, 1280, 1280, A, W, C, zero, stamps);
+  run<256, 160, 3, 4, 1>("256x160x3 pp (FF-in*)", M, 10240, 1280, A, W, C, zero, stamps);
+  run<256, 160, 3, 4, 1>("256x160x3 pp GEGLU", M, 10240, 1280, A, W, C, zero, stamps, 1);
+  run<128, 160, 2, 2, 0>("128x160x2 GEGLU", M, 10240, 1280, A, W, C, zero, stamps, 1);
+  run<256, 160, 3, 4, 1>("256x160x3 pp (QKV)", M, 3840, 1280, A, W, C, zero, stamps);
   return 0;
 }
