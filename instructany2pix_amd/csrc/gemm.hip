@@ -192,7 +192,7 @@ static double plan_cost_us(int M, int N, int K, bool conv, const GemmTile& t, in
   const int conc = (int)std::min<long>(occ, worst);         // co-resident workgroups there
   const long batches = (worst + conc - 1) / conc;
   const double per_cu = std::max(1.0, 0.6 * tiles / 256.0 + 0.4 * worst);
-  const bool pingpong = t.bm == 256;    // 8 waves in two half-step-shifted groups: one workgroup behaves like two co-resident ones
+  const bool pingpong = t.pp != 0;      // 8 waves in two half-step-shifted groups: one workgroup behaves like two co-resident ones
   const double t_mfma = per_cu * (2.0 * t.bm * t.bn * 64) / (MFMA_EFF * (conc == 1 && !pingpong ? LONE_EFF : 1.0) * CU_FLOPS_PER_US);
   const double t_fill = per_cu * ((t.bm + t.bn) * 128.0) / FILL_B_PER_US;
   const double t_lat = batches * LAT_US / (t.stages - 1) * (pingpong ? 0.5 : 1.0);
@@ -376,6 +376,10 @@ static hipError_t launch_any(const GemmArgs& a0, int v, hipStream_t s, bool with
     case 18:
       static_assert(IA2P_GEMM_TILES[18].bm == 256 && IA2P_GEMM_TILES[18].bn == 160 && IA2P_GEMM_TILES[18].stages == 3, "tile table");
       e = launch_cfg<256, 160, 3, CONV, 4, 64, 1>(a, s);
+      break;
+    case 19:
+      static_assert(IA2P_GEMM_TILES[19].bm == 128 && IA2P_GEMM_TILES[19].bn == 160 && IA2P_GEMM_TILES[19].stages == 3 && IA2P_GEMM_TILES[19].pp, "tile table");
+      e = launch_cfg<128, 160, 3, CONV, 4, 64, 1>(a, s);
       break;
 #undef IA2P_TILE_CASE
     // Measured and dropped in round 1 (tools/gemm_bench.py): 8-wave 256x128 (2- and 3-stage) and 256x320 at one
