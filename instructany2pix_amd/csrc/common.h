@@ -39,6 +39,17 @@ __device__ __forceinline__ float erf_as_f(float x) {
   return copysignf(r, x);
 }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erf_as_f(x * 0.70710678118654752440f)); }
+// Exact-erf GELU of the GEGLU gate through a table of the normal CDF in LDS: Phi(x) on [-8, 8) in steps of 1/32 (513 float2 entries {Phi(x_i), Phi(x_i+1) - Phi(x_i)},
+// built in double precision on the host, gemm.hip), linear interpolation -- |error of Phi| <= h^2/8 max|Phi''| = 3e-5, i.e. below a tenth of an fp16 ulp of
+// the product it scales. 8 VALU slots and one LDS read per gate instead of ~20 slots (v_rcp, v_exp, a 5-term polynomial): the GEGLU epilogue is VALU-bound
+// (20 480 gates per 256 x 160 tile; 5 of the 8 us between the k-loop's end and the last store, profiles/r03f_gemm_inkernel_clock.txt).
+constexpr int IA2P_PHI_LUT_N = 513;
+__device__ __forceinline__ float gelu_lut_f(float g, const float2* lut) {
+  const float f = fmaf(__builtin_amdgcn_fmed3f(g, -8.0f, 7.99f), 32.0f, 256.0f);
+  const float fl = floorf(f);
+  const float2 e = lut[(int)fl];
+  return g * fmaf(f - fl, e.y, e.x);
+}
 __device__ __forceinline__ float quick_gelu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x)); }
 __device__ __forceinline__ float gelu_tanh_f(float x) { return 0.5f * x * (1.0f + tanhf(0.79788456080286535588f * (x + 0.044715f * x * x * x))); }   // "gelu_new" (GPT-2)
 // Write-through (`sc1`) stores for tensors the NEXT kernel reads: the bytes leave the L2 while the kernel still runs, so the end-of-kernel
@@ -99,6 +110,7 @@ struct GemmArgs {
   const half_t* residual;  // [M, ldr] or null (may alias C)
   int ldr;
   int geglu;             // 1: W/bias rows interleaved in 16-row (a,g) pairs; out[m, n/2] = a * gelu(g)
+  const float* phi_lut;  // set by the launcher for GEGLU launches: the normal-CDF table of gelu_lut_f (device memory, IA2P_PHI_LUT_N float2)
   int m_fastest;         // tile order: 1 = consecutive blocks walk M (weights panel shared), 0 = walk N
   int vec8;              // set by the launcher: strides / bases allow 16-byte epilogue accesses
   int c_wt;              // set by the launcher: C leaves through write-through (sc1) stores, so the end-of-kernel write-back has nothing left to do

@@ -155,6 +155,31 @@ static int* pool_buffer(hipStream_t s) {
   return p;
 }
 int* ia2p_sk_counters(hipStream_t s, int tiles) { return tiles > POOL_SK ? nullptr : pool_buffer(s); }
+// normal-CDF table of the GEGLU gate activation (gelu_lut_f, common.h): IA2P_PHI_LUT_N entries {Phi(x_i), Phi(x_i+1) - Phi(x_i)}, x_i = (i - 256) / 32,
+// computed in double precision (0.5 erfc(-x / sqrt 2)), one copy per device
+const float* ia2p_phi_lut() {
+  static std::mutex mu;
+  static float* tab[64] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!tab[dev]) {
+    std::vector<float> h(2 * IA2P_PHI_LUT_N);
+    auto phi = [](double x) { return 0.5 * std::erfc(-x * 0.70710678118654752440); };
+    for (int i = 0; i < IA2P_PHI_LUT_N; ++i) {
+      const double a = phi((i - 256) / 32.0), b = phi((i - 255) / 32.0);
+      h[2 * i] = (float)a; h[2 * i + 1] = (float)(b - a);
+    }
+    float* d = nullptr;
+    if (hipMalloc((void**)&d, h.size() * sizeof(float)) != hipSuccess || hipMemcpy(d, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+      (void)hipGetLastError();
+      if (d) (void)hipFree(d);
+      return nullptr;
+    }
+    tab[dev] = d;
+  }
+  return tab[dev];
+}
 // GroupNorm statistics from a GEMM epilogue: per-image arrival counters (<= 1024 images) of this (device, stream)
 int* ia2p_gn_tickets(hipStream_t s) { int* p = pool_buffer(s); return p ? p + POOL_SK + 3072 : nullptr; }
 // a tile must lie inside one image: the variant's tile height divides the rows per image

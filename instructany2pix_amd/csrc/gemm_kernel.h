@@ -14,6 +14,7 @@
 bool ia2p_splitk_inkernel(int M, int N, int splitk);
 int ia2p_sk_counter_capacity();
 int* ia2p_sk_counters(hipStream_t s, int tiles);
+const float* ia2p_phi_lut();
 bool ia2p_chain_words(hipStream_t s, int** cnt, int** done, unsigned** err);
 
 #define GLDS16(gptr, ldsptr)                                                                         \
@@ -61,7 +62,9 @@ struct EpiCfg {
   static constexpr int STAGE_BYTES = NSTAGE * (BM + BNL) * 2 * BK;
   static constexpr int PITCH = ((BN / 4 + 7) & ~7) * 4;        // floats per fp32 tile row: whole groups of 8 chunks (the XOR swizzle stays inside a group)
   static constexpr bool POW2 = ((BN / 8) & (BN / 8 - 1)) == 0;
-  static constexpr int extra(int cr) { return (2 * BM + 2 * BN + 4) * 4 + (POW2 ? 0 : cr * (BN / 8) * 8); }
+  static constexpr int LUT_BYTES = BN % 32 == 0 ? ((IA2P_PHI_LUT_N * 8 + 15) & ~15) : 0;          // GEGLU-capable widths: the normal-CDF table of the gate activation
+  static constexpr int extra_nolut(int cr) { return (2 * BM + 2 * BN + 4) * 4 + (POW2 ? 0 : cr * (BN / 8) * 8); }
+  static constexpr int extra(int cr) { return extra_nolut(cr) + LUT_BYTES; }
   static constexpr int LIMIT = STAGE_BYTES > 80 * 1024 ? STAGE_BYTES : 80 * 1024;
   static constexpr int NCHUNK = (BM * PITCH * 4 + extra(BM) <= LIMIT) ? 1 : 2;
   static_assert(WGM % NCHUNK == 0, "a chunk holds whole wave rows");
@@ -503,6 +506,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   float* ln_lb = ln_cs + BN;
   int* sk_flag = (int*)(ln_lb + BN);                                    // K-split: the ticket this workgroup drew, broadcast to its waves
   float2* part = (float2*)(ln_lb + BN + 4);                             // row-statistics partials (tile widths whose 8-column groups per row are not a power of two)
+  const float2* phi = (const float2*)(smem + EC::TILE_BYTES + EC::extra_nolut(CR));      // GEGLU: normal-CDF table (gelu_lut_f), copied in below
   __syncthreads();                    // every wave has finished reading the stage buffers
   if (p.ln_stats) {
     if (tid < BM) {
@@ -649,8 +653,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   }
   // GroupNorm statistics of the output (p.gn_cols): thread (column quad c4, row slice gsl) sums the ROUNDED values of its columns over the tile rows
   constexpr int GQ = BN / 4, GNSL = NT / GQ;
-  const int gc4 = tid % GQ, gsl = tid / GQ;
-  f4 gsum = {0.f, 0.f, 0.f, 0.f}, gsq = {0.f, 0.f, 0.f, 0.f};
+  float gcol_a = 0.f, gcol_q = 0.f;        // thread c < BN: {sum, sum of squares} of tile column c over the chunks done so far (two registers live across the chunks)
 #pragma unroll 1
   for (int ch = 0; ch < EC::NCHUNK; ++ch) {
     if (ch || from_slabs) __syncthreads();          // the previous chunk has been read out
@@ -717,6 +720,9 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
         }
       }
     }
+    if (p.geglu && ch == 0 && EC::LUT_BYTES) {
+      for (int i = tid; i < IA2P_PHI_LUT_N; i += NT) ((float2*)phi)[i] = ((const float2*)p.phi_lut)[i];
+    }
     __syncthreads();
     if (p.geglu) {                    // packed columns: 32-wide blocks [16 values | 16 gates]; out[m][n/2] = a * gelu(g)
       constexpr int GPR = BN / 16;    // groups of 8 OUTPUT columns per row
@@ -761,7 +767,13 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
           //  the compiler's own mix of scalar and packed instructions is the faster one. Round 3)
           h8 o;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) o[e] = (half_t)(va[e] * gelu_erf_f(vg[e]));
+          for (int e = 0; e < 8; ++e) {
+#ifdef IA2P_GEGLU_ERF        // A/B builds: the arithmetic form (Abramowitz & Stegun 7.1.26)
+            o[e] = (half_t)(va[e] * gelu_erf_f(vg[e]));
+#else
+            o[e] = (half_t)(va[e] * gelu_lut_f(vg[e], phi));
+#endif
+          }
           if (live[u]) store_c8((size_t)(row0 + r) * p.ldc + (bn0 >> 1) + (g >> 1) * 16 + (g & 1) * 8, o);
         }
       }
@@ -893,14 +905,27 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
           }
         }
       }
-      if (p.gn_cols) {                 // column pass over the rounded chunk: rows gsl, gsl + GNSL, ... of column quad gc4 (fixed order: deterministic)
-        __syncthreads();
+      if (p.gn_cols) {                 // column pass over the rounded chunk: thread (column quad gc4, row slice gsl) sums rows gsl, gsl + GNSL, ... (fixed order: deterministic),
+        __syncthreads();               // the slices meet in LDS (the chunk has been read out by then) and thread c < BN adds them up in slice order
+        const int gc4 = tid % GQ, gsl = tid / GQ;
+        f4 gsum = {0.f, 0.f, 0.f, 0.f}, gsq = {0.f, 0.f, 0.f, 0.f};
         if (gsl < GNSL) {
           for (int r = gsl; r < CR; r += GNSL) {
             const f4 v = tl(r, gc4);
             gsum[0] += v[0]; gsum[1] += v[1]; gsum[2] += v[2]; gsum[3] += v[3];
             gsq[0] = fmaf(v[0], v[0], gsq[0]); gsq[1] = fmaf(v[1], v[1], gsq[1]); gsq[2] = fmaf(v[2], v[2], gsq[2]); gsq[3] = fmaf(v[3], v[3], gsq[3]);
           }
+        }
+        __syncthreads();               // every column pass is through: the tile memory is free
+        float* red = tile;             // [GNSL][BN] {sum, sum of squares}
+        if (gsl < GNSL) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) *(float2*)(red + ((size_t)(gsl * BN + gc4 * 4 + e) << 1)) = make_float2(gsum[e], gsq[e]);
+        }
+        __syncthreads();
+        if (tid < BN) {
+#pragma unroll
+          for (int sl = 0; sl < GNSL; ++sl) { const float2 v = *(const float2*)(red + ((size_t)(sl * BN + tid) << 1)); gcol_a += v.x; gcol_q += v.y; }
         }
       }
     }
@@ -909,20 +934,10 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
     // ---- GroupNorm statistics, producer side: column sums of this tile -> gn_cols; the last tile of the image folds the image's tiles (in tile order, fp64)
     //      into gn_tot. Hand-off as for the K-split slabs: write-through stores, every wave drains, ONE lane draws the ticket; the folding workgroup takes
     //      an agent-scope acquire (cdna_hip_programming.md Guideline 16).
-    __syncthreads();                  // every column pass is through: the tile memory is free
-    float* red = tile;                // [GNSL][BN] {sum, sum of squares}
-    if (gsl < GNSL) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) *(float2*)(red + ((size_t)(gsl * BN + gc4 * 4 + e) << 1)) = make_float2(gsum[e], gsq[e]);
-    }
-    __syncthreads();
     if (tid < BN && bn0 + tid < hN) {
-      float a = 0.f, q = 0.f;
-#pragma unroll
-      for (int sl = 0; sl < GNSL; ++sl) { const float2 v = *(const float2*)(red + ((size_t)(sl * BN + tid) << 1)); a += v.x; q += v.y; }
       typedef unsigned u2v __attribute__((__vector_size__(2 * sizeof(unsigned))));
       const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc((void*)p.gn_cols, 0, (int)min((size_t)tiles_m * hN * 8, (size_t)0x7ffffff0), 0x00020000);
-      const float2 v = make_float2(a, q);
+      const float2 v = make_float2(gcol_a, gcol_q);
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, v), gr, (int)(((size_t)tm * hN + bn0 + tid) * 8), 0, 16);      // sc1: write-through
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -988,6 +1003,7 @@ static inline void ia2p_gemm_prepare(GemmArgs& b, int smem, int BM, int BN) {
   b.vec8 = (b.ldc % 8 == 0 && al16(b.C) && (!b.bias || al16(b.bias)) && (!b.residual || (b.ldr % 8 == 0 && al16(b.residual))) &&
             (!b.rowvec || (b.rowvec_ld % 8 == 0 && al16(b.rowvec)))) ? 1 : 0;
   b.c_wt = ((ia2p_wt_mask() & 1) && (size_t)b.M * b.ldc * 2 < (size_t)0x7ffffff0) ? 1 : 0;      // same box: -0.14 ms per step at batch 8
+  b.phi_lut = b.geglu ? ia2p_phi_lut() : nullptr;
   const int tiles_n = (b.N + BN - 1) / BN;
   b.group_w = ia2p_tile_group_w(((b.M + BM - 1) / BM) * tiles_n, tiles_n, smem, BM, BN);
 }
@@ -1008,6 +1024,7 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
   GemmArgs b = a;
   ia2p_gemm_prepare(b, smem, BM, BN);
   if (a.geglu && !b.vec8) return hipErrorInvalidValue;
+  if (a.geglu && !b.phi_lut) return hipErrorOutOfMemory;
   if (a.gn_cols && (!b.vec8 || a.geglu || !a.gn_tot || !a.gn_tickets || a.gn_hw < BM || a.gn_hw % BM || a.M % a.gn_hw)) return hipErrorInvalidValue;   // (callers ask ia2p_gn_epilogue_ok first)
   // b.sk_counters: as the caller (launch_any, gemm.hip) attached them -- null: the K-slices only write their slabs and a splitk_reduce_kernel launch finishes
   if (b.sk_counters && tiles > ia2p_sk_counter_capacity()) return hipErrorInvalidValue;

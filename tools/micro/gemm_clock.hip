@@ -16,6 +16,7 @@ bool ia2p_splitk_inkernel(int, int, int) { return false; }
 int ia2p_sk_counter_capacity() { return 1 << 18; }
 int* ia2p_sk_counters(hipStream_t, int) { return nullptr; }
 bool ia2p_chain_words(hipStream_t, int**, int**, unsigned**) { return false; }
+const float* ia2p_phi_lut() { static float* d = nullptr; if (!d) { hipMalloc(&d, 2 * IA2P_PHI_LUT_N * sizeof(float)); hipMemset(d, 0, 2 * IA2P_PHI_LUT_N * sizeof(float)); } return d; }   // (timing only)
 
 template <int BM, int BN, int ST, int WGM, int PP>
 static void run(const char* name, int M, int N, int K, const half_t* A, const half_t* W, half_t* C, const half_t* zero, unsigned long long* stamps, int geglu = 0) {
