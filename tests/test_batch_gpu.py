@@ -114,3 +114,20 @@ def test_per_sample_entry_points_equal_their_scalar_forms():
         fused_update(x[b:b + 1].contiguous(), eu[b:b + 1].contiguous(), ec[b:b + 1].contiguous(), float(coef[b, 0]), float(coef[b, 1]), float(coef[b, 2]), o1[b:b + 1])
     assert torch.equal(o1, o2)
     assert torch.equal(o2[1], x[1])            # (g, 1, 0): a request that has finished its schedule keeps its latents bit for bit
+
+
+def test_denoise_batch_sharded_over_two_ranks():
+    """world_size 2 on one GPU (gloo): contiguous request shards per rank, groups of 2, all-gather in request order == the single-process result, bit for bit"""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tests", "dist_batch_two_ranks.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0 and "BATCH_DIST_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
