@@ -726,7 +726,10 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
     __syncthreads();
     if (p.geglu) {                    // packed columns: 32-wide blocks [16 values | 16 gates]; out[m][n/2] = a * gelu(g)
       constexpr int GPR = BN / 16;    // groups of 8 OUTPUT columns per row
-      constexpr int TOTAL = CR * GPR, U = EC::NCHUNK == 1 ? 2 : 1, ITER = (TOTAL + NT * U - 1) / (NT * U);
+#ifndef IA2P_GEGLU_U
+#define IA2P_GEGLU_U 1        // groups in flight per thread in the two-chunk tiles (build-time knob for A/B builds)
+#endif
+      constexpr int TOTAL = CR * GPR, U = EC::NCHUNK == 1 ? 2 : IA2P_GEGLU_U, ITER = (TOTAL + NT * U - 1) / (NT * U);
 #pragma unroll 1
       for (int k = 0; k < ITER; ++k) {
         f4 a0[U], a1[U], g0[U], g1[U];
