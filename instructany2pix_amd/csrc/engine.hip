@@ -735,8 +735,11 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
     lin(tsin.p, Tp, c->te1w, c->te1b, nullptr, 0, e1.p, T, T, Tp, 0, 1, "time_embedding.linear_1");
     lin(e1.p, T, c->te2w, c->te2b, nullptr, 0, emb0.p, T, T, T, 0, 0, "time_embedding.linear_2");
     lin(addin.p, Ain, c->ae1w, c->ae1b, nullptr, 0, a1.p, T, T, Ain, 0, 1, "add_embedding.linear_1");
-    lin(a1.p, T, c->ae2w, c->ae2b, emb0.p, T, emb.p, T, T, T, 0, 0, "add_embedding.linear_2");
-    lin(emb.p, T, c->tw_all, c->tb_all, nullptr, 0, f.temb_all.p, c->temb_total, c->temb_total, T, 1, 0, "time_emb_proj (stacked)");
+    // `emb` is only ever consumed through SiLU (every ResnetBlock2D: time_emb_proj(nonlinearity(temb))), so the last embedding linear stores
+    // SiLU(emb) -- applied to the fp32 sum, rounded once -- and the stacked projection reads it as is: the activation used to be recomputed inside that
+    // kernel by every one of its 3 440 output-column waves (64 SiLUs per wave-iteration against 256 FMAs)
+    lin(a1.p, T, c->ae2w, c->ae2b, emb0.p, T, emb.p, T, T, T, 0, 1, "add_embedding.linear_2 (+ SiLU)");
+    lin(emb.p, T, c->tw_all, c->tb_all, nullptr, 0, f.temb_all.p, c->temb_total, c->temb_total, T, 0, 0, "time_emb_proj (stacked)");
   }
   wsfree(c, tsin); wsfree(c, addin); wsfree(c, e1); wsfree(c, emb0); wsfree(c, a1); wsfree(c, emb);
 
