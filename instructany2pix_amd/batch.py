@@ -129,7 +129,9 @@ def sample_batch(unet, scheduler_config, latents, cond_ctx, uncond_ctx, cond_poo
 @torch.no_grad()
 def denoise_batch(pipeline, requests: List[EditRequest], group: int = 4, shard: bool = True):
     """N independent edit requests through the hot segment, batched and (with an initialised process group) sharded over the ranks.
-    Returns (sampled latents [N,4,h,w], inverted latents [N,4,h,w]) in request order on every rank."""
+    Returns (sampled latents [N,4,h,w], inverted latents [N,4,h,w]) in request order on every rank.
+    `group` requests share one launch sequence (B_eff = 2 * group under guidance): 4 is the headline shape; with a queue of requests 8 is 16 %
+    cheaper per image (2.05 vs 2.44 ms per image-step, profiles/r03j_two_stream_probe.txt) at twice the latency of a group."""
     from .pipeline import polar_intrtpolate
     N = len(requests)
     if N == 0:
