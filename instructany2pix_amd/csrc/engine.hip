@@ -721,6 +721,22 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
   T2 tsin = wsalloc(c, (size_t)B * Tp), addin = wsalloc(c, (size_t)B * Ain), e1 = wsalloc(c, (size_t)B * T), emb0 = wsalloc(c, (size_t)B * T);
   T2 a1 = wsalloc(c, (size_t)B * T), emb = wsalloc(c, (size_t)B * T);
   f.temb_all = wsalloc(c, (size_t)B * c->temb_total);
+  // side stream: only where something runs beside it (the in-step context projection), never in profiled / tuning / dry passes (their accounting is per stream)
+  bool forked = false;
+  hipStream_t main_stream = c->stream;
+  if (c->embed_overlap && !c->dry && !c->prof && !c->tuning && !c->failed && c->kv_rows > 0 && !kv_cached) {
+    hipError_t e = hipSuccess;
+    if (!c->side) {
+      e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+    }
+    if (e == hipSuccess) e = hipEventRecord(c->ev_fork, main_stream);      // behind everything the caller queued: inputs ready, the previous pass done with the workspace
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->side, c->ev_fork, 0);
+    if (e != hipSuccess) return fail(c, IA2P_ERR_HIP, "embedding side stream: %s", hipGetErrorString(e));
+    forked = true;
+    c->stream = c->side;
+  }
   {
     ProfScope ps(c, PK_EMBED, 0, 0);
     CHECK_LAUNCH(c, ia2p_launch_embed(timestep, timesteps, text_embeds, time_ids, tsin.p, addin.p, B, Tp, pooled, Ad, g.num_time_ids, c->stream), "embed");
@@ -741,7 +757,11 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
     lin(a1.p, T, c->ae2w, c->ae2b, emb0.p, T, emb.p, T, T, T, 0, 1, "add_embedding.linear_2 (+ SiLU)");
     lin(emb.p, T, c->tw_all, c->tb_all, nullptr, 0, f.temb_all.p, c->temb_total, c->temb_total, T, 0, 0, "time_emb_proj (stacked)");
   }
-  wsfree(c, tsin); wsfree(c, addin); wsfree(c, e1); wsfree(c, emb0); wsfree(c, a1); wsfree(c, emb);
+  if (forked) {
+    hipError_t e = hipEventRecord(c->ev_join, c->side);
+    c->stream = main_stream;
+    if (e != hipSuccess) return fail(c, IA2P_ERR_HIP, "embedding side stream: %s", hipGetErrorString(e));
+  }
 
   // ---- context K/V for every cross-attention layer in one GEMM each (text rows / image-token rows of ctx);
   //      per layer: reference attention_processor.py:358-359 (to_k/to_v) and :379-380 (to_k_ip/to_v_ip)
@@ -768,6 +788,12 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
                  2.0 * ((double)B * H * Wd * (g.in_channels + g.block_out_channels[0]) + 64.0 * g.block_out_channels[0]));
     CHECK_LAUNCH(c, ia2p_launch_conv_in(sample, W_(c, c->conv_in_w), W_(c, c->conv_in_b), x.p, B, g.in_channels, H, Wd, g.block_out_channels[0], c->stream), "conv_in");
   }
+  if (forked) {       // join: the first ResnetBlock2D reads temb_all
+    hipError_t e = hipStreamWaitEvent(main_stream, c->ev_join, 0);
+    if (e != hipSuccess) return fail(c, IA2P_ERR_HIP, "embedding side stream: %s", hipGetErrorString(e));
+  }
+  // the chain's scratch goes back only here in EVERY pass (sizing, profiled, forked alike: one workspace layout), so nothing on the caller's stream reuses it before the join
+  wsfree(c, tsin); wsfree(c, addin); wsfree(c, e1); wsfree(c, emb0); wsfree(c, a1); wsfree(c, emb);
   skips.push_back(x); skip_c.push_back(g.block_out_channels[0]);
   for (int i = 0; i < n; ++i) {
     const Stage& st = c->down[i];

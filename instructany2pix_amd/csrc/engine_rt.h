@@ -148,6 +148,12 @@ struct RunCtx {
   bool xattn_fuse = true;    // to_q + cross-attention as one launch where the shape allows (IA2P_XATTN_FUSE=0: two launches, for A/B runs)
   bool chain = false;        // feed-forward pair (ff.net.0 -> ff.net.2) as ONE launch with per-row-panel hand-off (chain.hip; IA2P_CHAIN=1)
   bool ln_fold = true;       // LayerNorms folded into their consumer GEMMs (IA2P_LN_FOLD=0: separate layernorm_kernel launches, for A/B runs)
+  // The embedding chain (7 skinny dependent launches, ~100 us) is independent of the context K/V projection and conv_in: IA2P_EMBED_OVERLAP=1 runs it on a
+  // side stream of the context, forked off the caller's stream and joined before the first ResnetBlock2D. Measured and left OFF: 20.31 vs 19.60 ms/step
+  // (same box, 2 x 2 runs, tools/ab_embed_overlap.sh) -- one fork / join per step costs seven times what the chain takes in line
+  bool embed_overlap = false;
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool prof = false;
   // autotune pass (ia2p_autotune): every GEMM / conv site of an unmeasured shape times its candidate plans in place
   bool tuning = false;
@@ -177,6 +183,7 @@ struct RunCtx {
     if (const char* e = getenv("IA2P_PREFETCH")) prefetch = atoi(e) != 0;
     if (const char* e = getenv("IA2P_LN_FOLD")) ln_fold = atoi(e) != 0;
     if (const char* e = getenv("IA2P_CHAIN")) chain = atoi(e) != 0;
+    if (const char* e = getenv("IA2P_EMBED_OVERLAP")) embed_overlap = atoi(e) != 0;
     if (const char* e = getenv("IA2P_GN_EPI")) gn_epi = atoi(e);
     if (const char* e = getenv("IA2P_XATTN_FUSE")) xattn_fuse = atoi(e) != 0;
     if (const char* e = getenv("IA2P_SC_FUSE")) sc_fuse = atoi(e) != 0;
@@ -188,6 +195,9 @@ struct RunCtx {
   ~RunCtx() {
     for (auto& r : recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto e : evpool) (void)hipEventDestroy(e);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+    if (side) (void)hipStreamDestroy(side);
   }
 };
 

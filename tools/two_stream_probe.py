@@ -54,6 +54,14 @@ def main():
     a = [ms_per_step(one.run, args.steps) for _ in range(3)]
     print(f"one stream,  B={B}:            {min(a):.3f} ms/step (runs {', '.join('%.3f' % v for v in a)})", flush=True)
 
+    s0 = torch.cuda.Stream(dev)
+    s0.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s0):
+        one.run(3)
+        a2 = [ms_per_step(one.run, args.steps) for _ in range(3)]
+    print(f"one stream (a created stream instead of the default one), B={B}: {min(a2):.3f} ms/step", flush=True)
+    torch.cuda.synchronize()
+
     h = B // 2
     wa, wb = bench.Workload(u1, cfg, h, 64, 81, 0.0, dev, cfg_id=3), bench.Workload(u2, cfg, h, 64, 81, 0.0, dev, cfg_id=3)
     u1.autotune(wa.lat, wa.ts[0], wa.ctx, wa.added)
