@@ -1,11 +1,9 @@
 #!/bin/bash
-# same-box A/B of an environment switch on cfg 3 (and optionally cfg 2): usage inside gpurun: bash tools/ab_env.sh VAR [b1]
-VAR=$1
-cd $GRAFT_REPO_ROOT
-python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary --no-roofline --repeats 1 --save-plans gpurun_out/ab_plans.txt > /dev/null 2>&1
-for i in 1 2; do for v in 0 1; do
-env $VAR=$v python3 bench.py --steps 30 --warmup 3 --repeats 3 --no-cpu-baseline --no-secondary --no-roofline --plans gpurun_out/ab_plans.txt 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('B8 $VAR=$v', d['timing']['runs_ms_per_step'])"
+# A/B of a process environment setting on the headline step, same box, interleaved: tools/ab_env.sh NAME VALUE_A VALUE_B [NAME2=... fixed]
+F="--no-roofline --no-cpu-baseline --no-secondary --no-box-probe --steps 50 --repeats 3"
+N=$1; A=$2; B=$3
+python bench.py $F --save-plans gpurun_out/p.txt 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('warm (unset)', round(d['ms_per_step'],3))"
+for i in 1 2; do
+for v in "$A" "$B"; do
+env $N=$v python bench.py $F --plans gpurun_out/p.txt 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$N=$v', round(d['ms_per_step'],3), [round(x,3) for x in d['timing']['runs_ms_per_step']])"
 done; done
-if [ "$2" = "b1" ]; then for v in 0 1; do
-env $VAR=$v python3 bench.py --batch 1 --ctx 77 --steps 30 --warmup 3 --repeats 3 --no-cpu-baseline --no-secondary --no-roofline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('B1 $VAR=$v', d['timing']['runs_ms_per_step'])"
-done; fi

@@ -78,5 +78,15 @@ int main() {
   run<256, 160, 3, 4, 1>("256x160x3 pp GEGLU", M, 10240, 1280, A, W, C, zero, stamps, 1);
   run<128, 160, 2, 2, 0>("128x160x2 GEGLU", M, 10240, 1280, A, W, C, zero, stamps, 1);
   run<256, 160, 3, 4, 1>("256x160x3 pp (QKV)", M, 3840, 1280, A, W, C, zero, stamps);
+  // batch-1 shapes (M = 256: 80-240 workgroups, at most one per CU): where does a latency-bound launch spend its time?
+  run<64, 64, 3, 2, 0>("64x64x3 M=256 out-proj", 256, 1280, 1280, A, W, C, zero, stamps);
+  run<64, 64, 4, 2, 0>("64x64x4 M=256 (swp)", 256, 1280, 1280, A, W, C, zero, stamps);
+  run<64, 64, 3, 2, 0>("64x64x3 M=256 QKV", 256, 3840, 1280, A, W, C, zero, stamps);
+  run<64, 64, 4, 2, 0>("64x64x4 M=256 QKV (swp)", 256, 3840, 1280, A, W, C, zero, stamps);
+  run<64, 64, 6, 2, 0>("64x64x6 M=256 (swp)", 256, 1280, 1280, A, W, C, zero, stamps);
+  run<64, 64, 6, 2, 0>("64x64x6 M=256 QKV (swp)", 256, 3840, 1280, A, W, C, zero, stamps);
+  run<64, 64, 6, 2, 0>("64x64x6 M=256 K=5120", 256, 1280, 5120, A, W, C, zero, stamps);
+  run<64, 64, 2, 2, 0>("64x64x2 M=256 K=5120", 256, 1280, 5120, A, W, C, zero, stamps);
+  run<64, 64, 4, 2, 0>("64x64x4 M=256 K=5120", 256, 1280, 5120, A, W, C, zero, stamps);
   return 0;
 }
