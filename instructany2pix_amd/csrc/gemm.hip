@@ -386,6 +386,8 @@ static hipError_t launch_any(const GemmArgs& a0, int v, hipStream_t s, bool with
     IA2P_TILE_CASE(13, 64, 64, 4)
     IA2P_TILE_CASE(14, 64, 64, 6)
     IA2P_TILE_CASE(15, 128, 64, 4)
+    IA2P_TILE_CASE(20, 32, 64, 3)
+    IA2P_TILE_CASE(21, 32, 128, 3)
     case 16:
       static_assert(IA2P_GEMM_TILES[16].bm == 128 && IA2P_GEMM_TILES[16].bn == 80 && IA2P_GEMM_TILES[16].stages == 2, "tile table");
       e = launch_cfg<128, 80, 2, CONV, 4, 64, 0, 1>(a, s);

@@ -41,7 +41,7 @@ def run(L, name, *args):
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("tile", [-1] + list(range(20)))        # every entry of IA2P_GEMM_TILES (csrc/common.h)
+@pytest.mark.parametrize("tile", [-1] + list(range(22)))        # every entry of IA2P_GEMM_TILES (csrc/common.h)
 @pytest.mark.parametrize("M,N,K", [(256, 320, 320), (2048, 1280, 1280), (616, 2560, 2048), (100, 64, 64), (37, 132, 128), (8192, 640, 2560)])
 def test_gemm_bias_residual(L, M, N, K, tile):
     f = _ffi()
@@ -68,7 +68,7 @@ def test_gemm_tile_choice_never_changes_the_bits(L, M, N, K):
     A, W, b, R = rnd(M, K, seed=51), rnd(N, K, seed=52, scale=K ** -0.5), rnd(N, seed=53), rnd(M, N, seed=54)
     outs = []
     try:
-        for tile in range(20):
+        for tile in range(22):
             out = torch.empty(M, N, dtype=torch.half, device="cuda")
             L.ia2p_debug_set_gemm_tile(tile)
             run(L, "ia2p_gemm", f.ptr(A), f.ptr(W), f.ptr(b), f.ptr(R), f.ptr(out), M, N, K, 0)
@@ -268,7 +268,7 @@ def test_conv3x3(L, B, H, W, Cin, Co, stride, up):
     assert rel_l2(y, ref) < 1e-3, rel_l2(y, ref)
 
 
-@pytest.mark.parametrize("tile", list(range(20)))
+@pytest.mark.parametrize("tile", list(range(22)))
 @pytest.mark.parametrize("B,H,W,Cin,Co,stride,up", [(1, 32, 32, 320, 320, 1, 0), (2, 12, 20, 128, 192, 2, 0), (1, 10, 14, 64, 320, 1, 1)])
 def test_conv3x3_every_tile(L, tile, B, H, W, Cin, Co, stride, up):
     L.ia2p_debug_set_gemm_tile(tile)

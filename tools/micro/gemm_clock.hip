@@ -88,6 +88,9 @@ int main() {
   run<64, 64, 3, 4, 0>("64x64x3 8 waves K=5120", 256, 1280, 5120, A, W, C, zero, stamps);
   run<128, 64, 3, 4, 0>("128x64x3 8 waves QKV", 256, 3840, 1280, A, W, C, zero, stamps);
   run<128, 64, 3, 2, 0>("128x64x3 4 waves QKV", 256, 3840, 1280, A, W, C, zero, stamps);
+  run<32, 64, 3, 2, 0>("32x64x3 M=256", 256, 1280, 1280, A, W, C, zero, stamps);
+  run<32, 64, 3, 2, 0>("32x64x3 QKV", 256, 3840, 1280, A, W, C, zero, stamps);
+  run<32, 64, 3, 2, 0>("32x64x3 K=5120", 256, 1280, 5120, A, W, C, zero, stamps);
   run<64, 64, 6, 2, 0>("64x64x6 M=256 (swp)", 256, 1280, 1280, A, W, C, zero, stamps);
   run<64, 64, 6, 2, 0>("64x64x6 M=256 QKV (swp)", 256, 3840, 1280, A, W, C, zero, stamps);
   run<64, 64, 6, 2, 0>("64x64x6 M=256 K=5120", 256, 1280, 5120, A, W, C, zero, stamps);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise an IA2P_TUNE_LOG=1 stderr capture: per contraction site the winner's TFLOP/s and the fastest candidates. usage: tune_log_table.py LOG [TOP]"""
 import re, sys, collections
-T = [(128,128,2),(128,128,3),(128,64,2),(128,64,3),(64,64,2),(64,64,3),(64,160,2),(64,160,3),(128,160,2),(128,160,3),(160,128,2),(160,160,2),(256,128,3),(64,64,4),(64,64,6),(128,64,4),(128,80,2),(128,80,4),(256,160,3),(128,160,3)]
+T = [(128,128,2),(128,128,3),(128,64,2),(128,64,3),(64,64,2),(64,64,3),(64,160,2),(64,160,3),(128,160,2),(128,160,3),(160,128,2),(160,160,2),(256,128,3),(64,64,4),(64,64,6),(128,64,4),(128,80,2),(128,80,4),(256,160,3),(128,160,3),(32,64,3),(32,128,3)]
 PP = (12, 18, 19)
 d = collections.OrderedDict()
 for l in open(sys.argv[1]):
