@@ -91,7 +91,7 @@ def test_gemm_splitk_deterministic(L, M, N, K, S):
     try:
         for route, limit in (("in-launch", 1 << 40), ("reduce launch", 0)):
             L.ia2p_debug_set_splitk_inkernel(limit)
-            for tile in (-1, 0, 4, 8, 12, 18, 19):      # auto, 128x128, 64x64, 128x160 (two epilogue chunks), ping-pong 256x128 and 256x160
+            for tile in (-1, 0, 4, 8, 12, 18, 19, 20, 21):      # auto, 128x128, 64x64, 128x160 (two epilogue chunks), ping-pong 256x128 / 256x160 / 128x160, 32-row tiles
                 L.ia2p_debug_set_gemm_tile(tile)
                 out, out2 = torch.empty(M, N, dtype=torch.half, device="cuda"), torch.empty(M, N, dtype=torch.half, device="cuda")
                 run(L, "ia2p_gemm_splitk", f.ptr(A), f.ptr(W), f.ptr(b), f.ptr(R), f.ptr(out), M, N, K, S, C.c_void_p(part.data_ptr()))
@@ -145,7 +145,7 @@ def test_gemm_no_bias_inplace_residual(L):
     assert rel_l2(X, ref) < 1e-3
 
 
-@pytest.mark.parametrize("tile", [-1, 0, 2, 4, 8, 10, 12, 18, 19])
+@pytest.mark.parametrize("tile", [-1, 0, 2, 4, 8, 10, 12, 18, 19, 20, 21])
 @pytest.mark.parametrize("M,C", [(256, 128), (2048, 1280), (130, 640)])
 def test_gemm_geglu(L, M, C, tile):
     f = _ffi()
@@ -183,7 +183,7 @@ def _ln_fold_setup(L, M, C_, N, seed, bias=True):
     return f, X, Wp, R, gamma, beta, W, b, Wf, cs, fb
 
 
-@pytest.mark.parametrize("tile", [-1, 0, 4, 6, 8, 11, 12])
+@pytest.mark.parametrize("tile", [-1, 0, 4, 6, 8, 11, 12, 20, 21])
 @pytest.mark.parametrize("M,C_,N,psplit,csplit", [(2048, 1280, 3840, 1, 1), (300, 256, 768, 1, 1), (256, 1280, 1280, 3, 2), (77, 128, 132, 2, 1)])
 def test_layernorm_folded_into_gemm(L, M, C_, N, psplit, csplit, tile):
     """producer GEMM emits row statistics, consumer GEMM reads the raw rows against gamma-folded weights: equals
@@ -311,7 +311,7 @@ def test_boundary_convs_reject_bad_shapes(L):
     assert L.ia2p_conv_out(f.current_stream(), f.ptr(x), f.ptr(x), f.ptr(x), f.ptr(x), 1, 64, 4, 4, 9) != 0              # Co > 8
 
 
-@pytest.mark.parametrize("tile", [-1, 0, 4, 6, 8, 12, 16])
+@pytest.mark.parametrize("tile", [-1, 0, 4, 6, 8, 12, 16, 20])
 @pytest.mark.parametrize("B,H,W,Cin,Cin2,Co", [(2, 16, 16, 1280, 640, 1280), (1, 32, 32, 320, 960, 320), (2, 9, 7, 128, 64, 192)])
 def test_conv3x3_with_appended_shortcut(L, B, H, W, Cin, Cin2, Co, tile):
     """conv2(h) + conv_shortcut(x) of a ResnetBlock2D as ONE implicit GEMM (K = 9 Cin + Cin2), every tile family incl. K-split plans"""
