@@ -313,7 +313,8 @@ void wsfree(RunCtx* c, T2 t) {
   if (t.off == (size_t)-1) return;
   auto it = c->gn_tot.find(t.off);
   if (it != c->gn_tot.end()) { c->ws.release(it->second.first); c->gn_tot.erase(it); }      // the tensor's GroupNorm statistics go with it
-  c->ws.release(t.off);
+  if (c->defer_free) c->defer_free->push_back(t.off);
+  else c->ws.release(t.off);
 }
 
 hipEvent_t get_event(RunCtx* c) {
@@ -539,6 +540,8 @@ struct Fwd {
   float* gn_partial;
   T2 kv_text, kv_ip;   // [B*Lt, kv_rows], [B*Li, kv_rows]
   const float* ip_scales = nullptr;   // device [B] or null: per-request IP-Adapter scale (else the context's one value)
+  bool kv_join = false;               // the context projection runs on the side stream: the first transformer waits for it
+  std::vector<size_t> kv_deferred;    // workspace blocks the projection released (handed back in front of the first transformer)
 };
 
 struct RegionScope { RunCtx* c; int prev; RegionScope(RunCtx* c_, int r) : c(c_), prev(c_->region) { c->region = r; } ~RegionScope() { c->region = prev; } };
@@ -611,6 +614,13 @@ static T2 run_transformer(Fwd& f, const Transformer& t, T2 x, int H, int Wd) {
   const int Lt = c->ip_enabled ? f.L - c->ip_tokens : f.L;
   const int Li = c->ip_enabled ? c->ip_tokens : 0;
   const float sl2e = 0.125f * 1.4426950408889634f;
+  if (f.kv_join) {                    // the context K / V come from the side stream
+    f.kv_join = false;
+    hipError_t e = hipStreamWaitEvent(c->stream, c->ev_join, 0);
+    if (e != hipSuccess) { fail(c, IA2P_ERR_HIP, "context projection side stream: %s", hipGetErrorString(e)); return x; }
+  }
+  for (size_t off : f.kv_deferred) c->ws.release(off);
+  f.kv_deferred.clear();
   T2 n = wsalloc(c, (size_t)M * C);
   op_gn(c, x.p, n.p, t.ng, t.nb, f.B, HW, C, 1e-6f, 0, f.gn_partial, nullptr, 0, x.off);
   // The three LayerNorms of a block never run as kernels: every GEMM that writes the token stream `tk` also emits per-row
@@ -714,6 +724,21 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
   f.ip_scales = ip_scales;
   c->gn_tot.clear(); c->gn_next_hw = 0; c->gn_next_off = (size_t)-1;      // (the workspace was just reset)
 
+  // in-step context projection on the side stream (below): the fork point is HERE, in front of the embedding chain, so that it runs beside it
+  const bool kv_defer = c->kv_overlap && c->kv_rows > 0 && !kv_cached;
+  const bool kv_fork = kv_defer && !c->dry && !c->prof && !c->tuning && !c->failed;
+  if (kv_fork) {
+    hipError_t e = hipSuccess;
+    if (!c->side) {
+      int lo = 0, hi = 0;
+      e = hipDeviceGetStreamPriorityRange(&lo, &hi);      // lo = least priority (numerically largest)
+      if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, lo);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+    }
+    if (e == hipSuccess) e = hipEventRecord(c->ev_fork, c->stream);      // behind everything the caller queued: inputs ready, the previous pass done with the workspace
+    if (e != hipSuccess) return fail(c, IA2P_ERR_HIP, "context projection side stream: %s", hipGetErrorString(e));
+  }
   // GroupNorm partial sums (fp32) live at the front of the workspace
   T2 gnp = wsalloc(c, (size_t)B * 64 * g.norm_num_groups * 2 * 2);
   f.gn_partial = (float*)gnp.p;
@@ -721,22 +746,6 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
   T2 tsin = wsalloc(c, (size_t)B * Tp), addin = wsalloc(c, (size_t)B * Ain), e1 = wsalloc(c, (size_t)B * T), emb0 = wsalloc(c, (size_t)B * T);
   T2 a1 = wsalloc(c, (size_t)B * T), emb = wsalloc(c, (size_t)B * T);
   f.temb_all = wsalloc(c, (size_t)B * c->temb_total);
-  // side stream: only where something runs beside it (the in-step context projection), never in profiled / tuning / dry passes (their accounting is per stream)
-  bool forked = false;
-  hipStream_t main_stream = c->stream;
-  if (c->embed_overlap && !c->dry && !c->prof && !c->tuning && !c->failed && c->kv_rows > 0 && !kv_cached) {
-    hipError_t e = hipSuccess;
-    if (!c->side) {
-      e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
-      if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
-      if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
-    }
-    if (e == hipSuccess) e = hipEventRecord(c->ev_fork, main_stream);      // behind everything the caller queued: inputs ready, the previous pass done with the workspace
-    if (e == hipSuccess) e = hipStreamWaitEvent(c->side, c->ev_fork, 0);
-    if (e != hipSuccess) return fail(c, IA2P_ERR_HIP, "embedding side stream: %s", hipGetErrorString(e));
-    forked = true;
-    c->stream = c->side;
-  }
   {
     ProfScope ps(c, PK_EMBED, 0, 0);
     CHECK_LAUNCH(c, ia2p_launch_embed(timestep, timesteps, text_embeds, time_ids, tsin.p, addin.p, B, Tp, pooled, Ad, g.num_time_ids, c->stream), "embed");
@@ -757,11 +766,7 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
     lin(a1.p, T, c->ae2w, c->ae2b, emb0.p, T, emb.p, T, T, T, 0, 1, "add_embedding.linear_2 (+ SiLU)");
     lin(emb.p, T, c->tw_all, c->tb_all, nullptr, 0, f.temb_all.p, c->temb_total, c->temb_total, T, 0, 0, "time_emb_proj (stacked)");
   }
-  if (forked) {
-    hipError_t e = hipEventRecord(c->ev_join, c->side);
-    c->stream = main_stream;
-    if (e != hipSuccess) return fail(c, IA2P_ERR_HIP, "embedding side stream: %s", hipGetErrorString(e));
-  }
+  wsfree(c, tsin); wsfree(c, addin); wsfree(c, e1); wsfree(c, emb0); wsfree(c, a1); wsfree(c, emb);
 
   // ---- context K/V for every cross-attention layer in one GEMM each (text rows / image-token rows of ctx);
   //      per layer: reference attention_processor.py:358-359 (to_k/to_v) and :379-380 (to_k_ip/to_v_ip)
@@ -773,7 +778,25 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
     } else {
       f.kv_text = wsalloc(c, (size_t)B * Lt * c->kv_rows);
       if (Li) f.kv_ip = wsalloc(c, (size_t)B * Li * c->kv_rows);
+      // The projection depends on nothing the step computes and nothing needs it before the first transformer: with c->kv_overlap it runs on a
+      // low-priority stream of the context BESIDE the embedding chain, conv_in and the first ResnetBlock2Ds (launches that leave most CUs idle
+      // or half filled) and is joined in front of the first transformer (kv_join). Whatever it releases (K-split slabs) goes back at the join
+      // only -- in every pass, so that the sizing pass and the run share one workspace layout.
+      hipStream_t main_stream = c->stream;
+      if (kv_defer) c->defer_free = &f.kv_deferred;
+      if (kv_fork) {
+        const hipError_t e = hipStreamWaitEvent(c->side, c->ev_fork, 0);
+        if (e != hipSuccess) return fail(c, IA2P_ERR_HIP, "context projection side stream: %s", hipGetErrorString(e));
+        c->stream = c->side;
+      }
       project_context(c, context, L, B, f.kv_text.p, f.kv_ip.p);
+      c->defer_free = nullptr;
+      if (kv_fork) {
+        hipError_t e = hipEventRecord(c->ev_join, c->side);
+        c->stream = main_stream;
+        if (e != hipSuccess) return fail(c, IA2P_ERR_HIP, "context projection side stream: %s", hipGetErrorString(e));
+        f.kv_join = true;
+      }
     }
   }
 
@@ -788,12 +811,6 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
                  2.0 * ((double)B * H * Wd * (g.in_channels + g.block_out_channels[0]) + 64.0 * g.block_out_channels[0]));
     CHECK_LAUNCH(c, ia2p_launch_conv_in(sample, W_(c, c->conv_in_w), W_(c, c->conv_in_b), x.p, B, g.in_channels, H, Wd, g.block_out_channels[0], c->stream), "conv_in");
   }
-  if (forked) {       // join: the first ResnetBlock2D reads temb_all
-    hipError_t e = hipStreamWaitEvent(main_stream, c->ev_join, 0);
-    if (e != hipSuccess) return fail(c, IA2P_ERR_HIP, "embedding side stream: %s", hipGetErrorString(e));
-  }
-  // the chain's scratch goes back only here in EVERY pass (sizing, profiled, forked alike: one workspace layout), so nothing on the caller's stream reuses it before the join
-  wsfree(c, tsin); wsfree(c, addin); wsfree(c, e1); wsfree(c, emb0); wsfree(c, a1); wsfree(c, emb);
   skips.push_back(x); skip_c.push_back(g.block_out_channels[0]);
   for (int i = 0; i < n; ++i) {
     const Stage& st = c->down[i];
@@ -855,6 +872,13 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
   }
   if (H != h || Wd != w) return fail(c, IA2P_ERR_SHAPE, "latent %dx%d does not survive the down/up path (needs divisibility by 2^%d)", h, w, n - 1);
   // ---- out
+  if (f.kv_join) {                    // a network without a transformer never joined the side stream: the pass must not end before it
+    f.kv_join = false;
+    const hipError_t e = hipStreamWaitEvent(c->stream, c->ev_join, 0);
+    if (e != hipSuccess) return fail(c, IA2P_ERR_HIP, "context projection side stream: %s", hipGetErrorString(e));
+  }
+  for (size_t off : f.kv_deferred) c->ws.release(off);
+  f.kv_deferred.clear();
   const int c0 = g.block_out_channels[0];
   T2 no = wsalloc(c, (size_t)B * H * Wd * c0);
   op_gn(c, x.p, no.p, c->ngo, c->nbo, B, H * Wd, c0, g.norm_eps, 1, f.gn_partial, nullptr, 0, x.off);

@@ -148,10 +148,14 @@ struct RunCtx {
   bool xattn_fuse = true;    // to_q + cross-attention as one launch where the shape allows (IA2P_XATTN_FUSE=0: two launches, for A/B runs)
   bool chain = false;        // feed-forward pair (ff.net.0 -> ff.net.2) as ONE launch with per-row-panel hand-off (chain.hip; IA2P_CHAIN=1)
   bool ln_fold = true;       // LayerNorms folded into their consumer GEMMs (IA2P_LN_FOLD=0: separate layernorm_kernel launches, for A/B runs)
-  // The embedding chain (7 skinny dependent launches, ~100 us) is independent of the context K/V projection and conv_in: IA2P_EMBED_OVERLAP=1 runs it on a
-  // side stream of the context, forked off the caller's stream and joined before the first ResnetBlock2D. Measured and left OFF: 20.31 vs 19.60 ms/step
-  // (same box, 2 x 2 runs, tools/ab_embed_overlap.sh) -- one fork / join per step costs seven times what the chain takes in line
-  bool embed_overlap = false;
+  // IA2P_KV_OVERLAP=1: the in-step context K / V projection (two GEMMs, 0.63 ms at batch 8) runs on a low-priority side stream of the context beside
+  // the start of the step (engine.hip run_forward) and is joined in front of the first transformer. Built, bit-identical, measured and left OFF:
+  // 20.16 vs 19.50 ms/step (same box, 2 x 2 runs). The kernel trace (profiles/r03m_kv_overlap_trace.txt) shows why: the chip has no idle share to
+  // give -- beside the background GEMM the embedding linears take 65-83 us instead of 8-27, conv_in 86 instead of 17, the first convolution 117
+  // instead of 68, the GEMM itself 560 instead of 489: the work is conserved, the interleaving costs. (The embedding chain on the side stream,
+  // tried first, cost the same +0.7 ms.) On this chip the step belongs on ONE queue.
+  bool kv_overlap = false;
+  std::vector<size_t>* defer_free = nullptr;      // while set, wsfree parks the blocks here instead of releasing them
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool prof = false;
@@ -183,7 +187,7 @@ struct RunCtx {
     if (const char* e = getenv("IA2P_PREFETCH")) prefetch = atoi(e) != 0;
     if (const char* e = getenv("IA2P_LN_FOLD")) ln_fold = atoi(e) != 0;
     if (const char* e = getenv("IA2P_CHAIN")) chain = atoi(e) != 0;
-    if (const char* e = getenv("IA2P_EMBED_OVERLAP")) embed_overlap = atoi(e) != 0;
+    if (const char* e = getenv("IA2P_KV_OVERLAP")) kv_overlap = atoi(e) != 0;
     if (const char* e = getenv("IA2P_GN_EPI")) gn_epi = atoi(e);
     if (const char* e = getenv("IA2P_XATTN_FUSE")) xattn_fuse = atoi(e) != 0;
     if (const char* e = getenv("IA2P_SC_FUSE")) sc_fuse = atoi(e) != 0;

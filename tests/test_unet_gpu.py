@@ -424,8 +424,9 @@ def test_load_unet_safetensors_gives_the_same_bits(tiny_models, tmp_path):
 def test_executor_switches_keep_parity(tiny_models, monkeypatch, B, h, w, L):
     """The measured-and-left-off structures of round 3 stay correct: the feed-forward pair as ONE launch (IA2P_CHAIN=1: the bits of two launches, no wait
     ever gives up) and GroupNorm statistics from the producers' epilogues (IA2P_GN_EPI=1 / 2: the statistics pass over the tensor replaced by
-    per-image column totals from the GEMM / conv epilogues -- a different fp32 summation order, so oracle tolerance, not bits); the embedding
-    chain on a side stream (IA2P_EMBED_OVERLAP=1: same kernels, same bits, run twice so that the second pass reuses the workspace behind the join)."""
+    per-image column totals from the GEMM / conv epilogues -- a different fp32 summation order, so oracle tolerance, not bits); the in-step
+    context projection on a low-priority side stream (IA2P_KV_OVERLAP=1) against in line: same kernels, same bits, run twice (the second pass
+    reuses the workspace behind the join)."""
     from instructany2pix_amd import _ffi
     from instructany2pix_amd.unet import HipUNet2DConditionModel
     cfg, sd, ipsd, hip, oracle = tiny_models
@@ -437,7 +438,7 @@ def test_executor_switches_keep_parity(tiny_models, monkeypatch, B, h, w, L):
     ref_net = oracle.build_unet(cfg, sd, ipsd, ip_scale=0.8)
     with torch.no_grad():
         ref = ref_net(x.float(), 501, ctx.float(), added_cond_kwargs=dict(text_embeds=te.float(), time_ids=tid.float()))[0]
-    for env, exact in ((dict(IA2P_CHAIN="1"), True), (dict(IA2P_EMBED_OVERLAP="1"), True), (dict(IA2P_GN_EPI="1"), False), (dict(IA2P_GN_EPI="2"), False), (dict(IA2P_CHAIN="1", IA2P_GN_EPI="1"), False)):
+    for env, exact in ((dict(IA2P_CHAIN="1"), True), (dict(IA2P_KV_OVERLAP="1"), True), (dict(IA2P_GN_EPI="1"), False), (dict(IA2P_GN_EPI="2"), False), (dict(IA2P_CHAIN="1", IA2P_GN_EPI="1"), False)):
         for k, v in env.items():
             monkeypatch.setenv(k, v)               # read when the context is created
         m = HipUNet2DConditionModel(cfg, DEV)
@@ -446,8 +447,11 @@ def test_executor_switches_keep_parity(tiny_models, monkeypatch, B, h, w, L):
         m.load_state_dict(sd)
         _install_ip(m, cfg, ipsd, 0.8)
         out = m(*args, **kw)[0]
-        if "IA2P_EMBED_OVERLAP" in env:
-            m.cache_context_kv = False      # the fork happens beside the in-step context projection
+        if "IA2P_KV_OVERLAP" in env:
+            hip.cache_context_kv = False    # the in-step context projection: in line by default, on the side stream in `m`
+            assert torch.equal(hip(*args, **kw)[0], base)
+            hip.cache_context_kv = True
+            m.cache_context_kv = False
             out = m(*args, **kw)[0].clone()
             assert torch.equal(m(*args, **kw)[0], out)
         torch.cuda.synchronize()
