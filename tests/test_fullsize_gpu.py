@@ -5,6 +5,7 @@ SDXL-base architecture (2.567 G parameters) + IP-Adapter, same seeded fp16-repre
   cfg 3  (configs[2])  latent [8,4,64,64], 81-token context (77 text + 4 image tokens)  -> every one of the 8 requests vs the oracle
   cfg 2  (configs[1])  latent [1,4,64,64], 77-token text-only context                    -> one evaluation + a 20-step DDIM trajectory
   cfg 5  (configs[4])  latent [4,4,96,96] with CFG (B_eff = 8), 81-token contexts        -> 2 guided steps, 2 of the 4 requests
+  cfg 3 / cfg 2 under MEASURED kernel plans (what bench.py times)                          -> one evaluation each vs the oracle
 Reference call sites: instructany2pix/ddim/pnp_pipeline.py:251-275 (inversion loop), ddim/sdxl_pipeline.py:824-857 (guided sampling
 loop), diffusion/ip_adapter/ip_adapter.py:289-356 (context assembly).
 
@@ -225,3 +226,40 @@ def test_cfg5_768px_guided_first_step_all_four_requests(full):
             rel, cos = traj_metrics(nxt[s], want)
             assert rel < 3e-2 and cos > 0.999, (r, rel, cos)
             assert rel_l2(eps[r], eu[0]) < 5e-3 and rel_l2(eps[4 + r], ec[0]) < 5e-3, r       # the two UNet outputs themselves, before guidance amplifies their difference
+
+
+def test_measured_plans_are_the_verified_configuration(full):
+    """bench.py times the step under MEASURED kernel plans (ia2p_autotune: tile variant and K split per contraction shape), the tests above run under
+    the cost model's plans. Tiles never change the bits, but a different K split sums fp32 partials in a different order -- so the configuration the
+    headline number is measured on is checked here too: cfg 3 (batch 8, 81 tokens) and cfg 2 (batch 1, 77 tokens: the 32-row tiles) autotuned exactly
+    as bench.py does, then one evaluation each against the oracle (requests 0 and 7 of the batch), and against the cost-model run of the same inputs."""
+    from bench import make_inputs
+    from instructany2pix_amd.unet import clear_plans, export_plans
+    cfg, hip, ref, ip_procs, oracle = full
+    try:
+        for B, L, cfg_id, sel in ((8, 81, 3, [0, 7]), (1, 77, 2, [0])):
+            clear_plans()
+            if L > 77:
+                _set_ip(hip, ref, ip_procs, 1.0)
+            else:
+                _set_text_only(hip, ref, oracle)
+            lat, ctx, pooled, tid = make_inputs(cfg, B, 64, L, DEV, cfg_id=cfg_id)
+            added = dict(text_embeds=pooled, time_ids=tid)
+            hip.cache_context_kv = False             # as the headline loop: the context projection inside the evaluation
+            base = hip(lat, 981, encoder_hidden_states=ctx, added_cond_kwargs=added)[0].clone()
+            n = hip.autotune(lat, 981, ctx, added)
+            assert n >= 20 and export_plans().count(";") >= 20, n
+            out = hip(lat, 981, encoder_hidden_states=ctx, added_cond_kwargs=added)[0]
+            torch.cuda.synchronize()
+            assert torch.isfinite(out).all()
+            assert rel_l2(out, base) < 2e-3, rel_l2(out, base)          # same arithmetic up to the K-split summation order
+            f = lambda t_: t_[sel].float().cpu()
+            with torch.no_grad():
+                want = ref(f(lat), 981, f(ctx), added_cond_kwargs=dict(text_embeds=f(pooled), time_ids=f(tid)))[0]
+            for i, r in enumerate(sel):
+                e = rel_l2(out[r], want[i])
+                assert e < 5e-3, (B, r, e)
+                assert float((out[r].float().cpu() - want[i]).abs().max()) < 2e-2 * float(want[i].abs().max()), (B, r)
+    finally:
+        clear_plans()
+        hip.cache_context_kv = True
