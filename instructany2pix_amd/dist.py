@@ -17,12 +17,23 @@ import torch
 import torch.distributed as dist
 
 
+def _world1_collectives() -> bool:
+    """IA2P_DIST_WORLD1=1: a ONE-rank process group is still initialised and the helpers below still issue their collectives (a 1-GPU box can
+    then exercise RCCL initialisation and every collective this module uses, with the product's dtypes, on the device:
+    tests/test_dist_gpu.py::test_rccl_one_rank_collectives)."""
+    return os.environ.get("IA2P_DIST_WORLD1", "") not in ("", "0")
+
+
+def _active() -> bool:
+    return dist.is_initialized() and (dist.get_world_size() > 1 or _world1_collectives())
+
+
 def init_distributed(backend: str = None) -> Tuple[int, int, int]:
     """(rank, world_size, local_rank) from the torchrun environment; world_size 1 needs no process group."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _world1_collectives()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:
             # every launcher sets it (torchrun; bench.py's own launcher picks a free port); a fixed default would collide between jobs on one box
@@ -48,7 +59,7 @@ def shard_range(n_requests: int, world: int, rank: int) -> Tuple[int, int]:
 def broadcast_flat(buf: torch.Tensor, src: int = 0, chunk_bytes: int = 1 << 30) -> torch.Tensor:
     """Broadcast one flat buffer in <=1 GiB pieces (a few large messages: ring broadcast over xGMI is per-link
     bound, so message count, not size, is what to keep small)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _active():
         return buf
     flat = buf.view(-1)
     step = max(1, chunk_bytes // flat.element_size())
@@ -66,12 +77,12 @@ def broadcast_weights(unet, src: int = 0, with_ip_adapter: bool = True):
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dist.barrier()
 
 
 def max_over_ranks(value: float, device="cpu") -> float:
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _active():
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -80,7 +91,7 @@ def max_over_ranks(value: float, device="cpu") -> float:
 
 def gather_floats(value: float, device="cpu") -> list:
     """every rank's value, in rank order, on every rank (per-rank step times: a straggler must be visible in the result line)"""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _active():
         return [float(value)]
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
@@ -90,7 +101,7 @@ def gather_floats(value: float, device="cpu") -> list:
 
 def gather_batches(local: torch.Tensor) -> torch.Tensor:
     """Concatenate equally-sized per-rank result batches along dim 0 on every rank."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _active():
         return local
     out = [torch.empty_like(local) for _ in range(dist.get_world_size())]
     dist.all_gather(out, local.contiguous())

@@ -26,3 +26,10 @@ def test_rccl_broadcast_and_shard():
     world = min(n, 8)
     r = _launch("dist_nccl_ranks.py", world, 29541)
     assert r.returncode == 0 and f"RCCL_OK world={world}" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_rccl_one_rank_collectives():
+    """RCCL on THIS box: a one-rank "nccl" process group, the full-size arena-head broadcast and every collective dist.py issues, on the device
+    (tests/dist_nccl_world1.py). The transport between GPUs needs the two-GPU test above."""
+    r = _launch("dist_nccl_world1.py", 1, 29547)
+    assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
