@@ -33,3 +33,21 @@ def test_rccl_one_rank_collectives():
     (tests/dist_nccl_world1.py). The transport between GPUs needs the two-GPU test above."""
     r = _launch("dist_nccl_world1.py", 1, 29547)
     assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_bench_gpus2_real_step_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` end to end on the REAL step (no stub): bench.py launches its own two ranks, rank 0 generates the weights, the
+    5.8 GB arena head travels (gloo transport here: both ranks share this box's one GPU, IA2P_FORCE_DEVICE=0), rank 0's measured plans are
+    imported by rank 1, barriers and max-over-ranks timing bracket the steps, rank 0 prints ONE line with n_gpus = ranks = 2."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", IA2P_DIST_BACKEND="gloo", IA2P_FORCE_DEVICE="0")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--repeats", "1", "--no-cpu-baseline",
+                        "--no-secondary", "--no-roofline", "--no-box-probe"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["ranks"] == 2 and d["config"]["dist_backend"] == "gloo" and d["config"]["self_launched"] is True
+    assert d["config"]["global_batch"] == 16 and len(d["config"]["per_rank_ms_per_step"]) == 2
+    assert d["config"]["weight_broadcast"]["bytes"] > 5e9 and d["value"] > 0 and d["ms_per_step"] > 0
