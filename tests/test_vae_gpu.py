@@ -1,6 +1,7 @@
 """VAE parity on the MI355X: HIP encode / decode through the C ABI vs the CPU oracle, whose
 architecture is pinned against the reference's in-tree ldm Encoder/Decoder (tests/golden/vae_ldm.npz, fixture G9).
-Tolerance: rel-L2 <= 1e-2 and max|d| <= 3e-2 * max|ref| (fp16 activations vs fp32 oracle, deep conv stack)."""
+Tolerance: rel-L2 <= 3e-3 and max|d| <= 3e-2 * max|ref| (fp16 activations with a 2^-7 stream scale vs the fp32 oracle the reference's upcast
+corresponds to; measured on the MI355X, round 3, tools/vae_err_probe.py: 2.6e-4 ... 1.3e-3 over every case of this file -- tighter than the UNet's 5e-3)."""
 import numpy as np
 import pytest
 import torch
@@ -37,19 +38,19 @@ def test_tiny_vae_decode_and_encode_vs_oracle(B, h, w):
     with torch.no_grad():
         rimg = ref.decode(z.float())
     assert img.shape == (B, 3, h * f, w * f) and torch.isfinite(img).all()
-    assert rel_l2(img, rimg) < 1e-2, rel_l2(img, rimg)
+    assert rel_l2(img, rimg) < 3e-3, rel_l2(img, rimg)
     assert float((img.float().cpu() - rimg).abs().max()) < 3e-2 * float(rimg.abs().max())
     x = torch.randn(B, 3, h * f, w * f, generator=g).half()
     dist = hip.encode(x.to(DEV)).latent_dist
     with torch.no_grad():
         rmom = ref.encode_moments(x.float())
-    assert rel_l2(dist.parameters, rmom) < 1e-2, rel_l2(dist.parameters, rmom)
+    assert rel_l2(dist.parameters, rmom) < 3e-3, rel_l2(dist.parameters, rmom)
     # sampling + scaling on the host, like `retrieve_latents(...) * scaling_factor`
     gen = torch.Generator().manual_seed(5)
     lat = hip.encode_to_latents(x.to(DEV), gen)
     import oracle
     noise = torch.randn(rmom[:, :4].shape, generator=torch.Generator().manual_seed(5))
-    assert rel_l2(lat, oracle.sample_latents(rmom, noise, cfg.scaling_factor)) < 1.5e-2
+    assert rel_l2(lat, oracle.sample_latents(rmom, noise, cfg.scaling_factor)) < 3e-3
 
 
 def test_vae_golden_ldm_weights(golden):
@@ -67,8 +68,8 @@ def test_vae_golden_ldm_weights(golden):
     hip.load_state_dict(sd)
     img = hip.decode(torch.from_numpy(d["z"]).to(DEV), return_dict=False)[0]
     mom = hip.encode(torch.from_numpy(d["img"]).to(DEV)).latent_dist.parameters
-    assert rel_l2(img, torch.from_numpy(d["dec_out"])) < 1e-2
-    assert rel_l2(mom, torch.from_numpy(d["enc_out"])) < 1e-2
+    assert rel_l2(img, torch.from_numpy(d["dec_out"])) < 3e-3
+    assert rel_l2(mom, torch.from_numpy(d["enc_out"])) < 3e-3
 
 
 def test_sdxl_vae_full_size_decode_vs_oracle():
@@ -83,11 +84,11 @@ def test_sdxl_vae_full_size_decode_vs_oracle():
     with torch.no_grad():
         rimg = ref.decode(z.float())
     assert img.shape == (1, 3, 256, 256)
-    assert rel_l2(img, rimg) < 1e-2, rel_l2(img, rimg)
+    assert rel_l2(img, rimg) < 3e-3, rel_l2(img, rimg)
     mom = hip.encode(img).latent_dist.parameters
     with torch.no_grad():
         rmom = ref.encode_moments(img.float().cpu())
-    assert rel_l2(mom, rmom) < 1e-2, rel_l2(mom, rmom)
+    assert rel_l2(mom, rmom) < 3e-3, rel_l2(mom, rmom)
 
 
 def test_vae_input_validation():
@@ -153,7 +154,7 @@ def test_image_to_image_hot_segment_with_vae():
         rlat = oracle.sample_loop(ref_net, sch, mixed, torch.cat([ctx.float(), p], 1), dict(text_embeds=pooled.float(), time_ids=tid), N, cfgs,
                                   torch.cat([nctx.float(), n_], 1), dict(text_embeds=npooled.float(), time_ids=tid))
         rout = rvae.decode(rlat / vcfg.scaling_factor)
-    assert rel_l2(base, rbase) < 1.5e-2
+    assert rel_l2(base, rbase) < 3e-3
     a, b = inv.float().cpu().flatten(), rinv.flatten()
     assert float((a - b).norm() / b.norm()) < 4e-2 and float(torch.dot(a, b) / (a.norm() * b.norm())) > 0.998
     a, b = out.float().cpu().flatten(), rout.flatten()
@@ -188,8 +189,8 @@ def test_vae_range_extension_replaces_the_fp32_upcast():
     ext.load_state_dict(big)
     assert ext.config.force_upcast is False
     img = ext.decode(z.to(DEV), return_dict=False)[0]
-    assert rel_l2(img, rimg) < 1e-2, rel_l2(img, rimg)
-    assert rel_l2(ext.encode(x.to(DEV)).latent_dist.parameters, rmom) < 1e-2
+    assert rel_l2(img, rimg) < 3e-3, rel_l2(img, rimg)
+    assert rel_l2(ext.encode(x.to(DEV)).latent_dist.parameters, rmom) < 3e-3
     plain = HipAutoencoderKL(dataclasses.replace(cfg, stream_scale=1.0), DEV)
     plain.load_state_dict(big)
     with pytest.raises(_ffi.IA2PError):
@@ -200,6 +201,6 @@ def test_vae_range_extension_replaces_the_fp32_upcast():
     ia, ib = a.decode(z.to(DEV), return_dict=False)[0], b.decode(z.to(DEV), return_dict=False)[0]
     with torch.no_grad():
         r0 = oracle.build_vae(cfg, sd).decode(z.float())
-    assert rel_l2(ia, r0) < 1e-2 and rel_l2(ib, r0) < 1e-2 and rel_l2(ia, ib) < 5e-3
+    assert rel_l2(ia, r0) < 3e-3 and rel_l2(ib, r0) < 3e-3 and rel_l2(ia, ib) < 5e-3
     with pytest.raises(ValueError):
         HipAutoencoderKL(dataclasses.replace(cfg, stream_scale=0.3), DEV)
