@@ -574,6 +574,9 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
     //      this tile is Q of 128 queries x one head. It goes through the fp32 LDS tile once (projection epilogue applied there, rounded to fp16
     //      exactly as the stand-alone GEMM would store it), comes back as the Q^T fragments of the attention core, and only O is written.
     static_assert(BM == 128 && BN == 64 && WGM == 2 && WGN == 2 && !CONV && !PP && EC::NCHUNK == 1, "fused cross-attention: 128 x 64 tiles, 4 waves");
+#ifdef IA2P_CLOCK_STAMP
+    unsigned long long* xo = p.partial ? (unsigned long long*)p.partial + 8 * blockIdx.x : nullptr;      // (diagnostic build, tools/micro/qx_clock.hip: the fused launch has no slabs, the field carries the stamp buffer)
+#endif
     acc_to_tile(0);
     __syncthreads();
     const int r31 = lane & 31, hh = lane >> 5;
@@ -608,9 +611,20 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
     f16v otot[2];
     attn_kv_store(ap, tid, kvr, smem, smem + 32768);     // only short contexts are fused (the launcher checks): their K / V are in registers by now
     __syncthreads();
+#ifdef IA2P_CLOCK_STAMP
+    if (tid == 0 && xo) xo[6] = __builtin_amdgcn_s_memrealtime();      // Q fragments built, K / V images in LDS
+#endif
     attn_core<XA - 1, true>(ap, b, hd, qf, smem, smem + 32768, tid, otot);
     __syncthreads();                  // every wave is through with the K / V images
+#ifdef IA2P_CLOCK_STAMP
+    if (tid == 0 && xo) xo[7] = __builtin_amdgcn_s_memrealtime();      // attention core done
+#endif
     attn_store_o(otot, ap.O, (size_t)ap.B * ap.Nq * ap.ldo, b, q0, hd, ap.Nq, ap.ldo, smem + wave * 4096, lane, (ap.xcd_map & 2) != 0);
+#ifdef IA2P_CLOCK_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0 && xo) xo[5] = __builtin_amdgcn_s_memrealtime();
+#endif
     return;
   }
   bool from_slabs = false;

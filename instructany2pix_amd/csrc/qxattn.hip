@@ -47,7 +47,10 @@ hipError_t ia2p_launch_qproj_xattn(const GemmArgs& a, const AttnArgs& x, hipStre
   }
   const int tiles_n = a.N / BN, tiles = (a.M / BM) * tiles_n;
   GemmArgs b = a;
-  b.vec8 = 1; b.splitk = 0; b.sk_counters = nullptr; b.partial = nullptr;
+  b.vec8 = 1; b.splitk = 0; b.sk_counters = nullptr;
+#ifndef IA2P_CLOCK_STAMP
+  b.partial = nullptr;
+#endif
   b.group_w = ia2p_tile_group_w(tiles, tiles_n, SMEM, BM, BN);
   AttnArgs y = x;
   y.xcd_map = ((ia2p_wt_mask() & 8) && (size_t)x.B * x.Nq * x.ldo * 2 < (size_t)0x7ffffff0) ? 2 : 0;      // bit 1: write-through O
