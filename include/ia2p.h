@@ -228,7 +228,9 @@ ia2p_status ia2p_linear_small(void* stream, const void* X, const void* W, const 
 
 void ia2p_debug_set_gemm_splitk(int splitk);  /* -1 auto (tests / tuning; engine path only) */
 void ia2p_debug_set_splitk_inkernel(long long bytes); /* slab-set size (splitk*M*N*4) up to which a K split combines inside the GEMM launch; < 0: IA2P_SPLITK_INKERNEL / default (tests, A/B runs) */
-void ia2p_debug_set_gemm_tile(int variant);   /* -1 auto; else index into IA2P_GEMM_TILES of csrc/common.h, 0..19 (tests / tuning) */
+void ia2p_debug_set_gemm_tile(int variant);   /* -1 auto; else index into IA2P_GEMM_TILES of csrc/common.h, 0..23 (tests / tuning) */
+/* the tile table (tests / tools): out[4] = {tile rows, tile columns, LDS ring stages, schedule: 0 plain, 1 ping-pong, 2 eight-phase}; 0, or -1 past the last variant */
+int ia2p_debug_gemm_tile_info(int variant, int* out);
 /* the tile variant and K-split the library picks for a problem (pure function of the shape; host-only, no GPU needed) */
 void ia2p_debug_gemm_plan(int M, int N, int K, int conv, int geglu, int* variant, int* splitk);
 

@@ -33,6 +33,12 @@
 // more co-resident blocks hide the per-k-step load latency).
 static int g_force_variant = -1;   // test/tuning hook (ia2p_debug_set_gemm_tile)
 extern "C" void ia2p_debug_set_gemm_tile(int v) { g_force_variant = v; }
+// the tile table, for tools and tests: out = {bm, bn, ring stages, schedule (0 plain, 1 ping-pong, 2 eight-phase)}; returns 0, or -1 past the last variant
+extern "C" int ia2p_debug_gemm_tile_info(int v, int* out) {
+  if (v < 0 || v >= IA2P_GEMM_NVARIANT || !out) return -1;
+  out[0] = IA2P_GEMM_TILES[v].bm; out[1] = IA2P_GEMM_TILES[v].bn; out[2] = IA2P_GEMM_TILES[v].stages; out[3] = IA2P_GEMM_TILES[v].pp;
+  return 0;
+}
 
 // tuning hook: IA2P_GEMM_RULES="MxNxK=variant;..." overrides the choice for exact shapes (in-situ A/B runs of bench.py)
 struct ShapeRule { int M, N, K, v; };
@@ -407,6 +413,14 @@ static hipError_t launch_any(const GemmArgs& a0, int v, hipStream_t s, bool with
     case 19:
       static_assert(IA2P_GEMM_TILES[19].bm == 128 && IA2P_GEMM_TILES[19].bn == 160 && IA2P_GEMM_TILES[19].stages == 3 && IA2P_GEMM_TILES[19].pp, "tile table");
       e = launch_cfg<128, 160, 3, CONV, 4, 64, 1>(a, s);
+      break;
+    case 22:
+      static_assert(IA2P_GEMM_TILES[22].bm == 256 && IA2P_GEMM_TILES[22].bn == 256 && IA2P_GEMM_TILES[22].stages == 2 && IA2P_GEMM_TILES[22].pp == 2, "tile table");
+      e = launch_cfg<256, 256, 2, CONV, 2, 64, 2, 4>(a, s);
+      break;
+    case 23:
+      static_assert(IA2P_GEMM_TILES[23].bm == 256 && IA2P_GEMM_TILES[23].bn == 128 && IA2P_GEMM_TILES[23].stages == 2 && IA2P_GEMM_TILES[23].pp == 2, "tile table");
+      e = launch_cfg<256, 128, 2, CONV, 2, 64, 2, 4>(a, s);
       break;
 #undef IA2P_TILE_CASE
     // Measured and dropped in round 1 (tools/gemm_bench.py): 8-wave 256x128 (2- and 3-stage) and 256x320 at one

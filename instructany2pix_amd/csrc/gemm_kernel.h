@@ -65,8 +65,8 @@ struct EpiCfg {
   static constexpr int LUT_BYTES = BN % 32 == 0 ? ((IA2P_PHI_LUT_N * 8 + 15) & ~15) : 0;          // GEGLU-capable widths: the normal-CDF table of the gate activation
   static constexpr int extra_nolut(int cr) { return (2 * BM + 2 * BN + 4) * 4 + (POW2 ? 0 : cr * (BN / 8) * 8); }
   static constexpr int extra(int cr) { return extra_nolut(cr) + LUT_BYTES; }
-  static constexpr int LIMIT = STAGE_BYTES > 80 * 1024 ? STAGE_BYTES : 80 * 1024;
-  static constexpr int NCHUNK = (BM * PITCH * 4 + extra(BM) <= LIMIT) ? 1 : 2;
+  static constexpr int LIMIT = PP == 2 ? 160 * 1024 : STAGE_BYTES > 80 * 1024 ? STAGE_BYTES : 80 * 1024;   // (the 8-phase tile owns its CU: the whole LDS)
+  static constexpr int NCHUNK = (PP != 2 && BM * PITCH * 4 + extra(BM) <= LIMIT) ? 1 : 2;     // (8-phase tile: always one chunk per row half, the way its waves hold the rows)
   static_assert(WGM % NCHUNK == 0, "a chunk holds whole wave rows");
   static constexpr int CR = BM / NCHUNK;
   static constexpr int TILE_BYTES = CR * PITCH * 4;
@@ -140,7 +140,8 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   // The leading 16 dwords of the argument list are what the prologue needs; built with -amdgpu-kernarg-preload-count=16 the command processor
   // hands them over in SGPRs, so the first tile loads go out without waiting for a cold read of the argument block (which costs every launch
   // ~1 us: tools/micro/launch_floor2.hip). The rest of GemmArgs (epilogue, conv geometry) arrives while those loads fly.   // >= 2 waves/SIMD: big tiles must fit 256 registers
-  static_assert(!PP || (WGM == 4 && NSTAGE == 3), "ping-pong schedule: 8 waves, 3-stage ring");
+  static_assert(PP != 1 || (WGM == 4 && NSTAGE == 3), "ping-pong schedule: 8 waves, 3-stage ring");
+  static_assert(PP != 2 || (WGM == 2 && WGN == 4 && NSTAGE == 2 && BK == 64 && BM == 256 && (BN == 256 || BN == 128) && XA == 0), "8-phase schedule: 256-row tiles, 2 x 4 waves, two k-tile buffers");
   constexpr int NWAVE = WGM * WGN;
   constexpr int WM = BM / WGM, WN = BN / WGN;    // wave tile (waves arranged WGM x WGN; WGN = 1: narrow tiles, one wave per 128-byte column block)
   constexpr int MR = WM / 16, NR = WN / 16;
@@ -209,12 +210,16 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   // ---- staging addresses. Piece `pi` covers tile rows pi*8 .. pi*8+7; lane -> (row pi*8 + lane/8, LDS chunk lane%8),
   //      which must hold global chunk (lane%8) ^ swz(row), swz(row) = (row>>1)&7.
   const int srow = lane / CPR, cpos = lane % CPR;
+  // staging piece i of this wave -> piece index inside the operand tile. 8-phase tile: an operand tile is staged as two half-tiles (rows [0, B/2) and
+  // [B/2, B)) in different phases of the k-loop, and EVERY wave carries an equal share of each half (one counted vmcnt per wave fits all)
+  constexpr int A_HP = PP == 2 ? A_PW / 2 : 1, B_HP = PP == 2 ? B_PW / 2 : 1;      // pieces per wave and half-tile
+  auto a_piece = [&](int i) { return PP == 2 ? (i / A_HP) * (BM / 2 / RPP) + wave * A_HP + i % A_HP : wave * A_PW + i; };
   const half_t* a_ptr[A_PW];
   int a_inc[A_PW];
   int a_y[A_PW], a_x[A_PW], a_pix[A_PW], a_ch[A_PW];
 #pragma unroll
   for (int i = 0; i < A_PW; ++i) {
-    const int pi = wave * A_PW + i;
+    const int pi = a_piece(i);
     const int m = bm0 + pi * RPP + srow;
     const int gch = cpos ^ lds_swz<BK>(pi * RPP + srow);
     if (!CONV) {
@@ -239,9 +244,10 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   // this wave's weight pieces: [b_pi0, b_pi0 + b_npw)
   const int b_npw = B_UNEVEN && wave >= NWAVE / 2 ? B_PW - 1 : B_PW;
   const int b_pi0 = B_UNEVEN ? (wave < NWAVE / 2 ? wave * B_PW : (NWAVE / 2) * B_PW + (wave - NWAVE / 2) * (B_PW - 1)) : wave * B_PW;
+  auto b_piece = [&](int i) { return PP == 2 ? (i / B_HP) * (BN / 2 / RPP) + wave * B_HP + i % B_HP : b_pi0 + i; };
 #pragma unroll
   for (int i = 0; i < B_PW; ++i) {
-    const int pi = min(b_pi0 + i, BNL / RPP - 1);
+    const int pi = min(b_piece(i), BNL / RPP - 1);
     const int n = bn0 + pi * RPP + srow;
     const int gch = cpos ^ lds_swz<BK>(pi * RPP + srow);
     if (n < hN && pi * RPP + srow < BN) { w_ptr[i] = hW + (size_t)n * hldw + gch * 8; w_inc[i] = BK; }
@@ -268,67 +274,94 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
     for (int i = 0; i < B_PW; ++i) w_ptr[i] += (size_t)kt0 * w_inc[i];
   }
 
-  auto stage = [&](int kt, int buf) {
-    char* sA = smem + buf * STAGE + wave * (A_PW * 1024);
-    char* sB = smem + buf * STAGE + BM * ROWB + b_pi0 * 1024;
-    if (CONV) {
-      if (tap_fresh) {        // (wave-uniform) new filter tap: re-derive the gathered pixel of each row once per Cin/64 k-steps
-        if (tap < 9) {
-          const int ky = tap / 3, kx = tap - ky * 3;
+  // new filter tap (wave-uniform): re-derive the gathered pixel of each row once per Cin/64 k-steps
+  auto conv_tap_setup = [&]() {
+    if (tap_fresh) {
+      if (tap < 9) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+        for (int i = 0; i < A_PW; ++i) {
+          const int iy = a_y[i] + ky, ix = a_x[i] + kx;
+          const bool ok = (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
+          a_ptr[i] = ok ? hA + (size_t)(a_pix[i] + (iy >> p.up) * p.Ws + (ix >> p.up)) * hlda + ci0 + a_ch[i] : hzero;
+          a_inc[i] = ok ? BK : 0;
+        }
+      } else {              // appended 1x1 block: the output pixel itself, from the second tensor (stride 1: pixel index = output row)
+        // (two copies of the loop, not a select between p.A2 and p.A3: a select between FIELDS of the by-value argument struct is compiled
+        //  as an indexed access and pushes the whole struct to scratch)
+        if (tap == 9) {
 #pragma unroll
           for (int i = 0; i < A_PW; ++i) {
-            const int iy = a_y[i] + ky, ix = a_x[i] + kx;
-            const bool ok = (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
-            a_ptr[i] = ok ? hA + (size_t)(a_pix[i] + (iy >> p.up) * p.Ws + (ix >> p.up)) * hlda + ci0 + a_ch[i] : hzero;
+            const int m = bm0 + a_piece(i) * RPP + srow;      // (re-derived: happens once or twice per launch)
+            const bool ok = m < hM;
+            a_ptr[i] = ok ? p.A2 + (size_t)m * p.lda2 + ci0 + a_ch[i] : hzero;
             a_inc[i] = ok ? BK : 0;
           }
-        } else {              // appended 1x1 block: the output pixel itself, from the second tensor (stride 1: pixel index = output row)
-          // (two copies of the loop, not a select between p.A2 and p.A3: a select between FIELDS of the by-value argument struct is compiled
-          //  as an indexed access and pushes the whole struct to scratch)
-          if (tap == 9) {
+        } else {
 #pragma unroll
-            for (int i = 0; i < A_PW; ++i) {
-              const int m = bm0 + (wave * A_PW + i) * RPP + srow;      // (re-derived: happens once or twice per launch)
-              const bool ok = m < hM;
-              a_ptr[i] = ok ? p.A2 + (size_t)m * p.lda2 + ci0 + a_ch[i] : hzero;
-              a_inc[i] = ok ? BK : 0;
-            }
-          } else {
-#pragma unroll
-            for (int i = 0; i < A_PW; ++i) {
-              const int m = bm0 + (wave * A_PW + i) * RPP + srow;
-              const bool ok = m < hM;
-              a_ptr[i] = ok ? p.A3 + (size_t)m * p.lda3 + ci0 + a_ch[i] : hzero;
-              a_inc[i] = ok ? BK : 0;
-            }
+          for (int i = 0; i < A_PW; ++i) {
+            const int m = bm0 + a_piece(i) * RPP + srow;
+            const bool ok = m < hM;
+            a_ptr[i] = ok ? p.A3 + (size_t)m * p.lda3 + ci0 + a_ch[i] : hzero;
+            a_inc[i] = ok ? BK : 0;
           }
         }
-        tap_fresh = false;
       }
-#pragma unroll
-      for (int i = 0; i < A_PW; ++i) { GLDS16(a_ptr[i], sA + i * 1024); a_ptr[i] += a_inc[i]; }
-      ci0 += BK;
-      if (tap < 10 && ci0 >= (tap < 9 ? cin_main : cin_extra)) { ci0 = 0; ++tap; tap_fresh = true; }      // (the last block runs to the end of K)
-    } else {
-#pragma unroll
-      for (int i = 0; i < A_PW; ++i) { GLDS16(a_ptr[i], sA + i * 1024); a_ptr[i] += a_inc[i]; }   // running pointers: no per-step multiply
+      tap_fresh = false;
     }
+  };
+  auto conv_tap_advance = [&]() {
+    ci0 += BK;
+    if (tap < 10 && ci0 >= (tap < 9 ? cin_main : cin_extra)) { ci0 = 0; ++tap; tap_fresh = true; }      // (the last block runs to the end of K)
+  };
+  // LDS-DMA of this wave's activation pieces [i0, i1) / weight pieces [i0, i1) of the next k-tile into ring slot `buf`; running pointers: no per-step multiply
+  auto issue_a = [&](int buf, auto i0_tag, auto i1_tag) {
 #pragma unroll
-    for (int i = 0; i < B_PW; ++i)
-      if (!B_UNEVEN || i < b_npw) { GLDS16(w_ptr[i], sB + i * 1024); w_ptr[i] += w_inc[i]; }      // (wave-uniform)
+    for (int i = decltype(i0_tag)::value; i < decltype(i1_tag)::value; ++i) { GLDS16(a_ptr[i], smem + buf * STAGE + a_piece(i) * 1024); a_ptr[i] += a_inc[i]; }
+  };
+  auto issue_b = [&](int buf, auto i0_tag, auto i1_tag) {
+#pragma unroll
+    for (int i = decltype(i0_tag)::value; i < decltype(i1_tag)::value; ++i)
+      if (!B_UNEVEN || i < b_npw) { GLDS16(w_ptr[i], smem + buf * STAGE + BM * ROWB + b_piece(i) * 1024); w_ptr[i] += w_inc[i]; }      // (wave-uniform)
+  };
+  using I0 = std::integral_constant<int, 0>;
+  auto stage = [&](int kt, int buf) {
+    if (CONV) conv_tap_setup();
+    issue_a(buf, I0{}, std::integral_constant<int, A_PW>{});
+    if (CONV) conv_tap_advance();
+    issue_b(buf, I0{}, std::integral_constant<int, B_PW>{});
+  };
+  // 8-phase tile: one HALF of an operand tile per call, in the order B0, A0, B1, A1 of a k-tile (A0 opens the k-tile for the conv gather, A1 closes it)
+  auto stage_part = [&](int buf, auto which_tag) {
+    constexpr int WHICH = decltype(which_tag)::value;
+    using AH = std::integral_constant<int, A_HP>;
+    using BH = std::integral_constant<int, B_HP>;
+    if constexpr (WHICH == 0) issue_b(buf, I0{}, BH{});
+    else if constexpr (WHICH == 1) { if (CONV) conv_tap_setup(); issue_a(buf, I0{}, AH{}); }
+    else if constexpr (WHICH == 2) issue_b(buf, BH{}, std::integral_constant<int, B_PW>{});
+    else { issue_a(buf, AH{}, std::integral_constant<int, A_PW>{}); if (CONV) conv_tap_advance(); }
   };
 
   // ---- fragment read offsets (wave tile origin is a multiple of 16, so swz(row) = (lane>>1)&7)
-  const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
+  // wave tile: MR x NR fragments of 16 x 16. Plain / ping-pong tiles: one contiguous WM x WN block. 8-phase tile: a 2 x 2 arrangement of quadrants, one
+  // in each half-tile of A and of B (rows wm0 + [0, WM/2) and BM/2 + wm0 + [0, WM/2), columns likewise), so that a whole half-tile is free for the
+  // next k-tile's DMA as soon as every wave has read ITS quadrant rows out of it
+  constexpr int MRH = MR / 2, NRH = NR / 2;
+  auto frag_row = [](int i) constexpr { return PP == 2 ? (i / (MR / 2)) * (BM / 2) + (i % (MR / 2)) * 16 : i * 16; };
+  auto frag_col = [](int j) constexpr { return PP == 2 ? (j / (NR / 2)) * (BN / 2) + (j % (NR / 2)) * 16 : j * 16; };
+  const int wm0 = (wave / WGN) * (PP == 2 ? WM / 2 : WM), wn0 = (wave % WGN) * (PP == 2 ? WN / 2 : WN);
   const int frow = lane & 15, fq = lane >> 4;
   const int fswz = lds_swz<BK>(frow);
   const int a_off = (wm0 + frow) * ROWB, w_off = BM * ROWB + (wn0 + frow) * ROWB;
 
   f4 acc[MR][NR];
+  auto zero_acc = [&]() {
 #pragma unroll
-  for (int i = 0; i < MR; ++i)
+    for (int i = 0; i < MR; ++i)
 #pragma unroll
-    for (int j = 0; j < NR; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NR; ++j) acc[i][j] = (f4){0.f, 0.f, 0.f, 0.f};
+  };
+  if constexpr (PP != 2) zero_acc();      // (8-phase tile: zeroed right before its loop -- 128 registers of zeros live across the prologue were spilled to scratch and reloaded)
 
   // ---- folded LayerNorm (consumer): thread r < BM collects the {sum, sum of squares} partials of tile row r. Issued behind the
   //      first tile loads, all slots in flight at once (slot order kept in the sums); turned into mean / rstd after the k-loop.
@@ -355,9 +388,15 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   constexpr int LPS = A_PW + B_PW;   // LDS-DMA pieces this wave issues per k-tile
   // NSTAGE-deep LDS ring: tiles kt+1 .. kt+NSTAGE-2 stay in flight across the barrier of step kt (counted vmcnt,
   // raw s_barrier -- cdna_hip_programming.md §5 "Pipelining across barriers"); ONE barrier per k-step.
+  if constexpr (PP == 2) {      // 8-phase tile: k-tile 0 whole, k-tile 1 up to its third half (the fourth is issued in the first phase of the loop)
+    stage_part(0, std::integral_constant<int, 0>{}); stage_part(0, std::integral_constant<int, 1>{});
+    stage_part(0, std::integral_constant<int, 2>{}); stage_part(0, std::integral_constant<int, 3>{});
+    if (nk > 1) { stage_part(1, std::integral_constant<int, 0>{}); stage_part(1, std::integral_constant<int, 1>{}); stage_part(1, std::integral_constant<int, 2>{}); }
+  } else {
 #pragma unroll
-  for (int s = 0; s < NSTAGE - 1; ++s)
-    if (s < nk) stage(s, s);
+    for (int s = 0; s < NSTAGE - 1; ++s)
+      if (s < nk) stage(s, s);
+  }
   load_ln();               // behind the prologue DMA: the statistics' round trip overlaps the first tiles' (the ping-pong tile used to load them AHEAD of
   if (PP) asm volatile("" : "+v"(ln_s1), "+v"(ln_s2));      //  its prologue -- a serial 1-2 us at every workgroup start; folded here, before the loop, they still cost it no registers)
   // fused cross-attention: the context K / V of this tile's (batch element, head) travel to registers while the projection runs
@@ -365,7 +404,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
 #ifdef IA2P_CLOCK_STAMP     // diagnostic build only (tools/micro/gemm_clock.hip): in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz around the k-loop
   const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  if constexpr (PP) {
+  if constexpr (PP == 1) {
     // Barrier sequence b0, b1, ...; interval I_n lies between b_n and b_n+1. Group 0 reads tile t in I_2t and multiplies it in I_2t+1; group 1
     // reads it in I_2t+1 and multiplies it in I_2t+2. Every wave waits for its DMA pieces of tile t before b_2t; the slot of tile t-1 is free
     // after b_2t (group 1 finished reading it in I_2t-1), so tile t+2 is issued into it in I_2t: two tiles stay in flight.
@@ -431,6 +470,119 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
       }
       mm();
     }
+  } else if constexpr (PP == 2) {
+    // ---- 8-phase schedule (cdna_hip_programming.md §5 "The 256^2 8-phase template"): a k-tile is multiplied in FOUR phases, one 64-row x (BN/8)-column
+    //      quadrant of the wave tile x K = 64 each; every phase = { fragment reads of the quadrant's new operand half, LDS-DMA of ONE half-tile of a later
+    //      k-tile } -> barrier -> MFMA cluster -> barrier. Waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave multiplies while its
+    //      partner reads and stages. Phase p of k-tile t (slot b = t & 1):
+    //        P1  read b0 (B half 0), a0 (A half 0)   stage A1(t+1) -> slot b^1    MFMA a0 x b0
+    //        P2  read b1 (B half 1)                  stage B0(t+2) -> slot b      MFMA a0 x b1
+    //        P3  read a1 (A half 1, into a0's regs)  stage A0(t+2) -> slot b      MFMA a1 x b1
+    //        P4  --                                  stage B1(t+2) -> slot b      MFMA a1 x b0      + counted vmcnt: k-tile t+1 has landed
+    //      Hazards (two groups one barrier apart). Write-after-read: a half-tile is re-staged >= 2 phases after its last fragment read (A0: P1 -> P3, B1: P2 -> P4,
+    //      A1: P3 -> next P1), or 1 phase after when the reads were retired BEFORE the reading phase's first barrier (B0: issued first in P1, lgkmcnt(8) before
+    //      the barrier, re-staged in P2). Read-after-write: the counted vmcnt of P4 leaves the three half-tiles issued in P2..P4 in flight and retires all of
+    //      k-tile t+1 (its last half, A1, was issued in P1); the first read of k-tile t+1 is one phase later, behind barriers both groups have passed.
+    static_assert(A_PW % 2 == 0 && B_PW % 2 == 0 && MR % 2 == 0 && NR % 2 == 0, "8-phase: even pieces / fragments per half");
+    constexpr int HLPS = A_HP + 2 * B_HP;        // this wave's LDS-DMA pieces of the three half-tiles B0, A0, B1 that stay in flight across P4
+    h8 af[KSUB][MRH], wf0[KSUB][NRH], wf1[KSUB][NRH];
+    auto rd_a = [&](int slot, auto half_tag) {
+      constexpr int H = decltype(half_tag)::value;
+      const char* base = smem + slot * STAGE;
+#pragma unroll
+      for (int kk = 0; kk < KSUB; ++kk) {
+        const int coff = ((kk * 4 + fq) ^ fswz) << 4;
+#pragma unroll
+        for (int i = 0; i < MRH; ++i) af[kk][i] = *(const h8*)(base + a_off + frag_row(H * MRH + i) * ROWB + coff);
+      }
+    };
+    auto rd_b = [&](int slot, auto half_tag, h8 (&wf)[KSUB][NRH]) {
+      constexpr int H = decltype(half_tag)::value;
+      const char* base = smem + slot * STAGE;
+#pragma unroll
+      for (int kk = 0; kk < KSUB; ++kk) {
+        const int coff = ((kk * 4 + fq) ^ fswz) << 4;
+#pragma unroll
+        for (int j = 0; j < NRH; ++j) wf[kk][j] = *(const h8*)(base + w_off + frag_col(H * NRH + j) * ROWB + coff);
+      }
+    };
+    auto mmq = [&](auto ah_tag, auto bh_tag, const h8 (&wf)[KSUB][NRH]) {
+      constexpr int AHf = decltype(ah_tag)::value, BHf = decltype(bh_tag)::value;
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < KSUB; ++kk)
+#pragma unroll
+        for (int i = 0; i < MRH; ++i)
+#pragma unroll
+          for (int j = 0; j < NRH; ++j)
+            acc[AHf * MRH + i][BHf * NRH + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][j], af[kk][i], acc[AHf * MRH + i][BHf * NRH + j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    };
+    using H0 = std::integral_constant<int, 0>;
+    using H1 = std::integral_constant<int, 1>;
+    using S_B0 = std::integral_constant<int, 0>;
+    using S_A0 = std::integral_constant<int, 1>;
+    using S_B1 = std::integral_constant<int, 2>;
+    using S_A1 = std::integral_constant<int, 3>;
+    auto bar1 = [&]() {            // first barrier of a phase, then this wave's fragment reads have to be in
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto bar2 = [&]() {
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_barrier" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // prologue (issued above): k-tile 0 whole (slot 0), k-tile 1 without its last half (slot 1)
+    zero_acc();
+    if (nk > 1) wait_vm_barrier<HLPS>(); else wait_vm_barrier<0>();
+    if (wave >= NWAVE / 2) bar2();                // the second wave group runs one barrier behind the first
+    auto ktile = [&](int t, auto slot_tag) {
+      constexpr int SL = decltype(slot_tag)::value;
+      // P1
+      rd_b(SL, H0{}, wf0);
+      __builtin_amdgcn_sched_barrier(0);          // issue order pinned: the B reads first (retired by the counted wait below)
+      rd_a(SL, H0{});
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 1 < nk) stage_part(SL ^ 1, S_A1{});
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(KSUB * MRH) : "memory");      // all but the A reads: half-tile B0 of this slot is free for P2's DMA
+      bar1();
+      mmq(H0{}, H0{}, wf0);
+      bar2();
+      // P2
+      rd_b(SL, H1{}, wf1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 2 < nk) stage_part(SL, S_B0{});
+      bar1();
+      mmq(H0{}, H1{}, wf1);
+      bar2();
+      // P3
+      rd_a(SL, H1{});
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 2 < nk) stage_part(SL, S_A0{});
+      bar1();
+      mmq(H1{}, H1{}, wf1);
+      bar2();
+      // P4
+      if (t + 2 < nk) {
+        stage_part(SL, S_B1{});
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HLPS) : "memory");
+      } else {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      bar1();
+      mmq(H1{}, H0{}, wf0);
+      bar2();
+    };
+    for (int t = 0; t < nk; t += 2) {
+      ktile(t, std::integral_constant<int, 0>{});
+      if (t + 1 < nk) ktile(t + 1, std::integral_constant<int, 1>{});
+    }
+    if (wave < NWAVE / 2) bar2();
   } else {
   int cur = 0, nxt = NSTAGE - 1;      // ring slots: `cur` is consumed this step, `nxt` is refilled
   for (int kt = 0; kt < nk; ++kt) {
@@ -557,7 +709,25 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   };
   auto tl = [&](int r, int c) -> f4 { return *(const f4*)(tile + (size_t)r * PITCH + ((c ^ (r & 7)) << 2)); };
   auto acc_to_tile = [&](int ch) {
-    if (wm0 / CR == ch) {
+    if constexpr (PP == 2) {        // 8-phase tile: chunk ch = half-tile ch of the rows; every wave holds MR / 2 fragment rows of it
+      static_assert(PP != 2 || (EC::NCHUNK == 2 && CR == BM / 2), "8-phase tile: one epilogue chunk per row half");
+      // (two explicit arms with compile-time fragment indices: written as `if (i / MRH == ch)` inside one unrolled loop, the compiler re-rolled it into
+      //  acc[ch * MRH + i] -- a runtime index, i.e. the accumulators in scratch)
+      auto half = [&](auto h_tag) {
+        constexpr int H = decltype(h_tag)::value;
+#pragma unroll
+        for (int i = 0; i < MRH; ++i) {
+          const int r = wm0 + i * 16 + frow;
+#pragma unroll
+          for (int j = 0; j < NR; ++j) {
+            const int c = (wn0 + frag_col(j)) / 4 + fq;
+            *(f4*)(tile + (size_t)r * PITCH + ((c ^ (r & 7)) << 2)) = acc[H * MRH + i][j];
+          }
+        }
+      };
+      if (ch == 0) half(std::integral_constant<int, 0>{});
+      else half(std::integral_constant<int, 1>{});
+    } else if (wm0 / CR == ch) {
 #pragma unroll
       for (int i = 0; i < MR; ++i) {
         const int r = wm0 - ch * CR + i * 16 + frow;
@@ -635,7 +805,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
     //      and runs the epilogue: no reduce launch, no spin (nobody waits for anybody).
     constexpr int GPR = BN / 4;
     const __amdgpu_buffer_rsrc_t slab = __builtin_amdgcn_make_buffer_rsrc((void*)(p.partial + (size_t)split * hM * hN), 0, (int)min((size_t)hM * hN * 4, (size_t)0x7ffffff0), 0x00020000);
-#pragma unroll 1
+#pragma unroll(PP == 2 ? 2 : 1)      // (8-phase tile: both chunks spelled out, so that the accumulator fragments of a chunk are compile-time register names)
     for (int ch = 0; ch < EC::NCHUNK; ++ch) {
       if (ch) __syncthreads();
       acc_to_tile(ch);
@@ -668,7 +838,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   // GroupNorm statistics of the output (p.gn_cols): thread (column quad c4, row slice gsl) sums the ROUNDED values of its columns over the tile rows
   constexpr int GQ = BN / 4, GNSL = NT / GQ;
   float gcol_a = 0.f, gcol_q = 0.f;        // thread c < BN: {sum, sum of squares} of tile column c over the chunks done so far (two registers live across the chunks)
-#pragma unroll 1
+#pragma unroll(PP == 2 ? 2 : 1)
   for (int ch = 0; ch < EC::NCHUNK; ++ch) {
     if (ch || from_slabs) __syncthreads();          // the previous chunk has been read out
     const int row0 = bm0 + ch * CR;

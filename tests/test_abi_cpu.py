@@ -75,10 +75,17 @@ def test_gemm_plan_is_a_pure_host_function_and_the_plan_table_round_trips(lib):
         lib.ia2p_debug_gemm_plan(M, N, K, conv, geglu, C.addressof(v), C.addressof(s))
         return v.value, s.value
     lib.ia2p_plan_clear()
-    bn = [128, 128, 64, 64, 64, 64, 160, 160, 160, 160, 128, 160, 128, 64, 64, 64, 80, 80]           # IA2P_GEMM_TILES[v].bn
-    for shape in [(2048, 1280, 1280), (8192, 640, 640), (64, 64, 64), (616, 166400, 2048), (37, 132, 128), (256, 1280, 5120)]:
+    tiles = []                                                               # IA2P_GEMM_TILES, as the library reports it
+    t = (C.c_int * 4)()
+    while lib.ia2p_debug_gemm_tile_info(len(tiles), t) == 0:
+        tiles.append(tuple(t))
+    from tests.test_ops_gpu import NTILES
+    assert len(tiles) == NTILES and lib.ia2p_debug_gemm_tile_info(-1, t) == -1
+    assert tiles[0] == (128, 128, 2, 0) and tiles[18] == (256, 160, 3, 1) and tiles[22] == (256, 256, 2, 2)
+    bn = [x[1] for x in tiles]
+    for shape in [(2048, 1280, 1280), (8192, 640, 640), (64, 64, 64), (616, 166400, 2048), (37, 132, 128), (256, 1280, 5120), (4096, 4096, 4096)]:
         v, s = plan(*shape)
-        assert 0 <= v < 22 and 1 <= s <= shape[2] // 64
+        assert 0 <= v < len(tiles) and 1 <= s <= shape[2] // 64
         assert plan(*shape) == (v, s)                                        # deterministic
     for M, C_ in [(2048, 1280), (8192, 640), (130, 64)]:
         v, s = plan(M, 8 * C_, C_, 0, 1)

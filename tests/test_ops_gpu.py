@@ -9,6 +9,7 @@ import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
+NTILES = 24      # entries of IA2P_GEMM_TILES (csrc/common.h); tests/test_abi_cpu.py checks it against the library's table
 
 
 @pytest.fixture(scope="module")
@@ -41,7 +42,7 @@ def run(L, name, *args):
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("tile", [-1] + list(range(22)))        # every entry of IA2P_GEMM_TILES (csrc/common.h)
+@pytest.mark.parametrize("tile", [-1] + list(range(NTILES)))        # every entry of IA2P_GEMM_TILES (csrc/common.h)
 @pytest.mark.parametrize("M,N,K", [(256, 320, 320), (2048, 1280, 1280), (616, 2560, 2048), (100, 64, 64), (37, 132, 128), (8192, 640, 2560)])
 def test_gemm_bias_residual(L, M, N, K, tile):
     f = _ffi()
@@ -68,7 +69,7 @@ def test_gemm_tile_choice_never_changes_the_bits(L, M, N, K):
     A, W, b, R = rnd(M, K, seed=51), rnd(N, K, seed=52, scale=K ** -0.5), rnd(N, seed=53), rnd(M, N, seed=54)
     outs = []
     try:
-        for tile in range(22):
+        for tile in range(NTILES):
             out = torch.empty(M, N, dtype=torch.half, device="cuda")
             L.ia2p_debug_set_gemm_tile(tile)
             run(L, "ia2p_gemm", f.ptr(A), f.ptr(W), f.ptr(b), f.ptr(R), f.ptr(out), M, N, K, 0)
@@ -91,7 +92,7 @@ def test_gemm_splitk_deterministic(L, M, N, K, S):
     try:
         for route, limit in (("in-launch", 1 << 40), ("reduce launch", 0)):
             L.ia2p_debug_set_splitk_inkernel(limit)
-            for tile in (-1, 0, 4, 8, 12, 18, 19, 20, 21):      # auto, 128x128, 64x64, 128x160 (two epilogue chunks), ping-pong 256x128 / 256x160 / 128x160, 32-row tiles
+            for tile in (-1, 0, 4, 8, 12, 18, 19, 20, 21, 22, 23):      # auto, 128x128, 64x64, 128x160 (two epilogue chunks), ping-pong 256x128 / 256x160 / 128x160, 32-row tiles, 8-phase 256x256 / 256x128
                 L.ia2p_debug_set_gemm_tile(tile)
                 out, out2 = torch.empty(M, N, dtype=torch.half, device="cuda"), torch.empty(M, N, dtype=torch.half, device="cuda")
                 run(L, "ia2p_gemm_splitk", f.ptr(A), f.ptr(W), f.ptr(b), f.ptr(R), f.ptr(out), M, N, K, S, C.c_void_p(part.data_ptr()))
@@ -268,7 +269,7 @@ def test_conv3x3(L, B, H, W, Cin, Co, stride, up):
     assert rel_l2(y, ref) < 1e-3, rel_l2(y, ref)
 
 
-@pytest.mark.parametrize("tile", list(range(22)))
+@pytest.mark.parametrize("tile", list(range(NTILES)))
 @pytest.mark.parametrize("B,H,W,Cin,Co,stride,up", [(1, 32, 32, 320, 320, 1, 0), (2, 12, 20, 128, 192, 2, 0), (1, 10, 14, 64, 320, 1, 1)])
 def test_conv3x3_every_tile(L, tile, B, H, W, Cin, Co, stride, up):
     L.ia2p_debug_set_gemm_tile(tile)
