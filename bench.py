@@ -142,21 +142,38 @@ def self_launch(n, argv):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), IA2P_BENCH_SELF_LAUNCHED="1")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out = procs[0].stdout.read().decode()
-    rcs = []
-    deadline = time.time() + 3600
-    for p in procs:
-        try:
-            rcs.append(p.wait(timeout=max(1.0, deadline - time.time())))
-        except subprocess.TimeoutExpired:
-            p.kill()
-            rcs.append(-9)
-    if any(rcs):
-        for p in procs:
+    # rank 0's stdout is drained by a thread (a blocking read here would sit until rank 0 exits -- and rank 0 sits in a collective until its timeout when a
+    # peer has died); the parent polls EVERY child: the first non-zero exit kills the others and fails the run within seconds
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.time() + float(os.environ.get("IA2P_BENCH_LAUNCH_TIMEOUT_S", "3600"))
+    rcs = [None] * n
+    failed = False
+    while any(rc is None for rc in rcs) and not failed:
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+        failed = any(rc not in (None, 0) for rc in rcs) or time.time() > deadline
+        if not failed and any(rc is None for rc in rcs):
+            time.sleep(0.05)
+    if failed:
+        for r, p in enumerate(procs):
             if p.poll() is None:
-                p.kill()
-        log(f"[bench] rank exit codes {rcs}: a rank failed, no result line")
+                p.kill()                       # (exact children of this process, by handle)
+        for r, p in enumerate(procs):
+            try:
+                rc = p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                rc = -9
+            if rcs[r] is None:
+                rcs[r] = f"killed({rc})"
+        why = "launch timeout" if time.time() > deadline else "a rank failed"
+        log(f"[bench] rank exit codes {rcs}: {why}; the other ranks were killed, no result line")
         return 1
+    reader.join(timeout=10)
+    out = b"".join(chunks).decode()
     lines = [l for l in out.splitlines() if l.startswith("{")]
     if not lines:
         log("[bench] rank 0 printed no result line")
@@ -194,6 +211,12 @@ def stub_main(args):
     D.broadcast_flat(buf, src=0, chunk_bytes=1 << 16)
     bcast_s = time.time() - t_b
     assert float(buf[-1]) == float((1 << 16) - 1), "weight broadcast did not arrive"
+    # test hook (tests/test_dist_cpu.py): ONE rank dies after the rendezvous and the broadcast while the others sit where a lost peer would leave them -- in a wait
+    # that does not end by itself (a collective with a long timeout); the launcher has to notice the death and end the job
+    if os.environ.get("IA2P_BENCH_STUB_DIE_RANK"):
+        if rank == int(os.environ["IA2P_BENCH_STUB_DIE_RANK"]):
+            raise SystemExit(3)
+        time.sleep(float(os.environ.get("IA2P_BENCH_STUB_HANG_S", "600")))
     wl.run(args.warmup)
     D.barrier()
     wall, _ = wl.timed(args.steps)

@@ -43,7 +43,11 @@ def init_distributed(backend: str = None) -> Tuple[int, int, int]:
             backend = os.environ.get("IA2P_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        # bounded collectives: a rank that lost a peer fails after IA2P_DIST_TIMEOUT_S (default 10 min; the weight broadcast of 5.8 GB takes seconds)
+        # instead of sitting in the collective for the backend's default half hour
+        import datetime
+        timeout = datetime.timedelta(seconds=float(os.environ.get("IA2P_DIST_TIMEOUT_S", "600")))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
     return rank, world, local
 
 

@@ -102,6 +102,37 @@ def test_bench_self_launch_fails_when_a_rank_fails():
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
+def test_bench_self_launch_fails_fast_when_one_rank_dies_after_rendezvous():
+    """Rank 1 exits AFTER the rendezvous and the weight broadcast; rank 0 is left in a wait that would last ten minutes (what a collective with a lost peer
+    looks like). The launcher polls every child: it must kill rank 0, report both exit codes and return non-zero within seconds, not after rank 0's wait."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(IA2P_DIST_BACKEND="gloo", IA2P_BENCH_STUB="5", IA2P_BENCH_STUB_DIE_RANK="1", IA2P_BENCH_STUB_HANG_S="600")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    took = time.time() - t0
+    assert r.returncode != 0
+    assert took < 30, f"launcher took {took:.0f} s to notice a dead rank"
+    assert "rank exit codes" in r.stderr and "3" in r.stderr and "killed" in r.stderr, r.stderr[-1500:]
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_self_launch_times_out():
+    """every rank alive but stuck: the launcher's own deadline (IA2P_BENCH_LAUNCH_TIMEOUT_S) ends the job"""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(IA2P_DIST_BACKEND="gloo", IA2P_BENCH_STUB="5", IA2P_BENCH_STUB_DIE_RANK="7", IA2P_BENCH_STUB_HANG_S="600", IA2P_BENCH_LAUNCH_TIMEOUT_S="12")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and time.time() - t0 < 60 and "launch timeout" in r.stderr, r.stderr[-1500:]
+
+
 def test_bench_refuses_a_world_size_that_is_not_what_was_asked():
     import subprocess
     import sys
