@@ -1172,19 +1172,24 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_f16_kernel(const half_
   gemm_tile_body<BM, BN, NSTAGE, CONV, WGM, BK, PP, WGN, 0>(hA, hW, hzero, hM, hN, hK, hlda, hldw, hrpb, hbstride, hroff, hsplitk, hgroup_w, p, nullptr, ctl);
 }
 
-// grouped tile order: panel width (in tiles) such that the contiguous tile range an XCD works on is a compact block; 0 = plain order
-static inline int ia2p_tile_group_w(int tiles, int tiles_n, int smem, int BM, int BN) {
-  static const int group_mode = getenv("IA2P_TILE_GROUP") ? atoi(getenv("IA2P_TILE_GROUP")) : 1;
+// grouped tile order: panel width (in tiles) such that the contiguous tile range an XCD works on is a compact block; 0 = plain order.
+// An XCD that holds r x c tiles fetches r activation row panels and c weight column panels: r a + c w bytes with r c fixed is least at c = sqrt(resident a / w).
+// a_over_w = bytes of one activation row panel over bytes of one weight column panel: BM / BN for a linear layer (both K deep), but a 3x3 convolution's
+// row panel holds only Cin channels of (BM + halo) pixels while its weight panel is 9 Cin deep -- ~ BM / (6 BN): narrow, tall blocks. Round 3 used BM / BN for
+// both and the M = 2048, K = 11520 ... 23040 convolutions fetched their 29 ... 59 MB of weights into nearly every XCD (PMC traffic 5.5 x algorithmic).
+static inline int ia2p_tile_group_w(int tiles, int tiles_n, int smem, double a_over_w) {
+  static const int group_mode = getenv("IA2P_TILE_GROUP") ? atoi(getenv("IA2P_TILE_GROUP")) : 2;      // 0 plain order, 1 round 3's BM / BN rule for everything, 2 byte-aware
   if (!group_mode) return 0;
   const int smem_per_cu = 160 * 1024 / smem;                                   // co-resident workgroups per CU by LDS
   const double resident = std::min<double>(tiles / 8.0, 32.0 * std::max(1, std::min(smem_per_cu, 2)));   // tiles an XCD holds at once
   static const double gscale = getenv("IA2P_TILE_GROUP_SCALE") ? atof(getenv("IA2P_TILE_GROUP_SCALE")) : 1.0;
-  const int w = (int)(gscale * std::sqrt(resident * BM / BN) + 0.5);
+  const int w = (int)(gscale * std::sqrt(resident * a_over_w) + 0.5);
   return std::max(1, std::min(w, tiles_n));
 }
+static inline int ia2p_tile_group_w(int tiles, int tiles_n, int smem, int BM, int BN) { return ia2p_tile_group_w(tiles, tiles_n, smem, (double)BM / BN); }
 
 // launcher-side fields of a launch description: epilogue access width, write-through C, grouped tile order
-static inline void ia2p_gemm_prepare(GemmArgs& b, int smem, int BM, int BN) {
+static inline void ia2p_gemm_prepare(GemmArgs& b, int smem, int BM, int BN, bool conv = false) {
   // 16-byte epilogue accesses need 8-element row strides and 16-byte-aligned bases; otherwise the epilogue falls back to 8-byte pieces
   auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
   b.vec8 = (b.ldc % 8 == 0 && al16(b.C) && (!b.bias || al16(b.bias)) && (!b.residual || (b.ldr % 8 == 0 && al16(b.residual))) &&
@@ -1192,7 +1197,11 @@ static inline void ia2p_gemm_prepare(GemmArgs& b, int smem, int BM, int BN) {
   b.c_wt = ((ia2p_wt_mask() & 1) && (size_t)b.M * b.ldc * 2 < (size_t)0x7ffffff0) ? 1 : 0;      // same box: -0.14 ms per step at batch 8
   b.phi_lut = b.geglu ? ia2p_phi_lut() : nullptr;
   const int tiles_n = (b.N + BN - 1) / BN;
-  b.group_w = ia2p_tile_group_w(((b.M + BM - 1) / BM) * tiles_n, tiles_n, smem, BM, BN);
+  double a_over_w = (double)BM / BN;
+  static const int group_mode = getenv("IA2P_TILE_GROUP") ? atoi(getenv("IA2P_TILE_GROUP")) : 2;
+  if (conv && group_mode >= 2 && b.K > 0)      // distinct activation bytes of a row panel: Cin channels of the tile's pixels plus their halo (~ 1.5 x), plus the appended 1x1 blocks
+    a_over_w = BM * (1.5 * b.Cin + (b.A2 ? b.Cin2 : 0) + (b.A3 ? b.Cin3 : 0)) / ((double)BN * b.K);
+  b.group_w = ia2p_tile_group_w(((b.M + BM - 1) / BM) * tiles_n, tiles_n, smem, a_over_w);
 }
 
 template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int BK = 64, int PP = 0, int WGN = 2>
@@ -1209,7 +1218,7 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
   }
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   GemmArgs b = a;
-  ia2p_gemm_prepare(b, smem, BM, BN);
+  ia2p_gemm_prepare(b, smem, BM, BN, CONV);
   if (a.geglu && !b.vec8) return hipErrorInvalidValue;
   if (a.geglu && !b.phi_lut) return hipErrorOutOfMemory;
   if (a.gn_cols && (!b.vec8 || a.geglu || !a.gn_tot || !a.gn_tickets || a.gn_hw < BM || a.gn_hw % BM || a.M % a.gn_hw)) return hipErrorInvalidValue;   // (callers ask ia2p_gn_epilogue_ok first)

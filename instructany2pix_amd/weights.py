@@ -170,7 +170,21 @@ def _fan_in(shape: Tuple[int, ...]) -> int:
     return max(f, 1)
 
 
-def _make(key: str, shape, kind: str, seed: int, device, dtype) -> torch.Tensor:
+HEAVY_SCALE = 60.0
+
+
+def heavy_tail_rows(rows: int) -> "torch.Tensor":
+    """Output channels of a residual branch's last layer that the "heavy" recipe scales x HEAVY_SCALE: 1 % of the rows, the SAME channels in every layer of a
+    given width (as in trained transformers, where a few fixed channels of the residual stream carry the outliers), so the branches add up in them."""
+    idx = [r for r in range(rows) if ((r * 2654435761) & 0xFFFFFFFF) % 100 == 0]
+    return torch.tensor(idx or [rows // 2], dtype=torch.long)
+
+
+def _make(key: str, shape, kind: str, seed: int, device, dtype, recipe: str = "tame") -> torch.Tensor:
+    """recipe "tame": N(0, 1 / fan_in) weights, residual branches x 0.3 (activations stay O(1) everywhere).
+    recipe "heavy": the same draw, but 1 % of the output channels of every residual branch's last layer (attn to_out.0, ff.net.2, resnet conv2,
+    proj_out -- kind "w_res") are scaled x HEAVY_SCALE = 60 (the same channels in every layer), so the residual stream carries outlier channels of a few hundred like a trained SDXL UNet's does:
+    the stand-in for the checkpoint nobody has here (tests/test_fullsize_heavy_gpu.py)."""
     g = torch.Generator(device=device)
     g.manual_seed((zlib.crc32(key.encode()) ^ (seed * 0x9E3779B1)) & 0x7FFFFFFF)
     r = torch.randn(shape, generator=g, device=device, dtype=torch.float32)
@@ -194,18 +208,22 @@ def _make(key: str, shape, kind: str, seed: int, device, dtype) -> torch.Tensor:
         r.mul_(0.05)
     else:
         raise ValueError(kind)
+    if recipe == "heavy" and kind == "w_res":
+        r[heavy_tail_rows(shape[0]).to(r.device)] *= HEAVY_SCALE
+    elif recipe not in ("tame", "heavy"):
+        raise ValueError(recipe)
     return r.to(dtype)
 
 
-def synthetic_state_dict(specs: List[Spec], seed: int = 7, device="cpu", dtype=torch.float16) -> "OrderedDict[str, torch.Tensor]":
-    """Seeded synthetic parameters. Each tensor depends only on (key, seed), so any subset can be
+def synthetic_state_dict(specs: List[Spec], seed: int = 7, device="cpu", dtype=torch.float16, recipe: str = "tame") -> "OrderedDict[str, torch.Tensor]":
+    """Seeded synthetic parameters. Each tensor depends only on (key, seed, recipe), so any subset can be
     regenerated independently and CPU/GPU processes agree when `device` is the same kind."""
-    return OrderedDict((k, _make(k, shp, kind, seed, device, dtype)) for k, shp, kind in specs)
+    return OrderedDict((k, _make(k, shp, kind, seed, device, dtype, recipe)) for k, shp, kind in specs)
 
 
-def iter_synthetic(specs: List[Spec], seed: int = 7, device="cpu", dtype=torch.float16) -> Iterator[Tuple[str, torch.Tensor]]:
+def iter_synthetic(specs: List[Spec], seed: int = 7, device="cpu", dtype=torch.float16, recipe: str = "tame") -> Iterator[Tuple[str, torch.Tensor]]:
     for k, shp, kind in specs:
-        yield k, _make(k, shp, kind, seed, device, dtype)
+        yield k, _make(k, shp, kind, seed, device, dtype, recipe)
 
 
 def iter_safetensors(path: str, specs: "List[Spec] | None" = None, prefix: str = "") -> Iterator[Tuple[str, torch.Tensor]]:

@@ -238,6 +238,118 @@ def test_layernorm_folded_into_geglu(L, M, C_):
         f.check(L.ia2p_gemm_ex(f.current_stream(), f.ptr(t), f.ptr(Wf), None, None, f.ptr(out), M, 8 * C_, C_, 1, None, None, None, 1, None))   # GEGLU without bias or fold
 
 
+@pytest.mark.parametrize("tile", [-1, 0, 12, 18, 22])
+@pytest.mark.parametrize("ratio", [10.0, 50.0])
+@pytest.mark.parametrize("geglu", [0, 1])
+def test_layernorm_fold_on_real_weight_shaped_rows(L, ratio, tile, geglu):
+    """The folded LayerNorm computes rstd * (acc - mean * colsum) from {sum x, sum x^2}: both steps cancel when |mean| >> std. Rows like a trained SDXL residual
+    stream's: per-row mean = ratio x the row's std (both signs), four x 100 outlier channels, a quarter of the rows with all three. Against fp32
+    LayerNorm -> Linear (-> GEGLU) in torch at the bound of the tame test, and no worse than the explicit fp16 LayerNorm kernel + plain GEMM."""
+    f = _ffi()
+    M, C_ = 1024, 1280
+    N = 8 * C_ if geglu else 3 * C_
+    g = torch.Generator().manual_seed(int(ratio) + 7 * geglu)
+    t = torch.randn(M, C_, generator=g)
+    sign = torch.where(torch.rand(M, 1, generator=g) < 0.5, -1.0, 1.0)
+    t[: M // 2] += ratio * sign[: M // 2]                                  # rows with |mean| / std = ratio
+    out_ch = torch.tensor([3, 640, 641, 1279])
+    t[M // 4: 3 * M // 4, out_ch] *= 100.0                                  # outlier channels (rows M/4 .. M/2 have both)
+    t = t.half().cuda()
+    gamma = (1.0 + 0.3 * torch.randn(C_, generator=g)).half().cuda()
+    beta = (0.2 * torch.randn(C_, generator=g)).half().cuda()
+    W = (torch.randn(N, C_, generator=g) * C_ ** -0.5).half().cuda()
+    b = (0.3 * torch.randn(N, generator=g)).half().cuda()
+    if geglu:
+        Wp, bp = torch.empty_like(W), torch.empty_like(b)
+        run(L, "ia2p_pack_geglu", f.ptr(W), f.ptr(Wp), N, C_)
+        run(L, "ia2p_pack_geglu", f.ptr(b), f.ptr(bp), N, 1)
+    else:
+        Wp, bp = W, b
+    Wf = torch.empty_like(W)
+    cs, fb = torch.empty(N, dtype=torch.float32, device="cuda"), torch.empty(N, dtype=torch.float32, device="cuda")
+    run(L, "ia2p_fold_layernorm", f.ptr(Wp), f.ptr(gamma), f.ptr(beta), f.ptr(bp), f.ptr(Wf), f.ptr(cs), f.ptr(fb), N, C_)
+    tf = t.float()
+    # row statistics as a producer epilogue writes them: {sum, sum of squares} of the fp16 row over 64-column slots, fp32
+    slots = C_ // 64
+    st = torch.stack([tf.view(M, slots, 64).sum(2), (tf * tf).view(M, slots, 64).sum(2)], dim=2).permute(1, 0, 2).contiguous()      # [slot][M][2]
+    ln = f.LnFoldC(st.data_ptr(), slots, cs.data_ptr(), fb.data_ptr(), 1e-5)
+    No = N // 2 if geglu else N
+    out = torch.empty(M, No, dtype=torch.half, device="cuda")
+    L.ia2p_debug_set_gemm_tile(tile)
+    try:
+        run(L, "ia2p_gemm_ex", f.ptr(t), f.ptr(Wf), None, None, f.ptr(out), M, N, C_, geglu, C.addressof(ln), None, None, 1, None)
+        y = torch.empty_like(t)
+        run(L, "ia2p_layernorm", f.ptr(t), f.ptr(y), f.ptr(gamma), f.ptr(beta), M, C_, 1e-5)
+        sep = torch.empty_like(out)
+        run(L, "ia2p_gemm", f.ptr(y), f.ptr(Wp), f.ptr(bp), None, f.ptr(sep), M, N, C_, geglu)
+    finally:
+        L.ia2p_debug_set_gemm_tile(-1)
+    h = F.layer_norm(tf.double(), (C_,), gamma.double(), beta.double(), 1e-5) @ W.double().t() + b.double()
+    if geglu:
+        a_, g_ = h.chunk(2, dim=-1)
+        h = a_ * F.gelu(g_)
+    ref = h.float()
+    assert torch.isfinite(out).all()
+    e_fold, e_sep = rel_l2(out, ref), rel_l2(sep, ref)
+    groups = {"shifted": slice(0, M // 4), "shifted + outliers": slice(M // 4, M // 2), "outliers": slice(M // 2, 3 * M // 4), "plain": slice(3 * M // 4, M)}
+    per = {k: rel_l2(out[v], ref[v]) for k, v in groups.items()}
+    assert e_fold < 2e-3, (ratio, tile, geglu, e_fold, per)
+    assert max(per.values()) < 3e-3, per                                   # every kind of row by itself, not just the average
+    assert e_fold <= 1.2 * e_sep + 1e-4, (e_fold, e_sep)
+
+
+def test_geglu_gate_table_range_and_special_values(L):
+    """The GEGLU gate goes through a normal-CDF table on [-8, 8) (csrc/common.h gelu_lut_f). Gates anywhere in [-12, 12] -- exactly +-8, the table's last cell,
+    beyond it on both sides -- and values times such gates against exact-erf GELU; NaN / +Inf in the value or the gate come out as NaN / Inf, never as a
+    finite number. One row of A selects one (value, gate) pair: W = identity-like rows, so acc = the chosen numbers exactly."""
+    f = _ffi()
+    K, M = 64, 64
+    gates = torch.tensor([-12.0, -9.5, -8.0, -7.99, -7.5, -4.0, -1.0, -0.03125, 0.0, 0.015625, 1.0, 3.0, 6.0, 7.96875, 7.99, 8.0, 9.5, 12.0])
+    gates = torch.cat([gates, torch.linspace(-12, 12, 64 - len(gates))])
+    vals = torch.linspace(-3.0, 3.0, 64)
+    # A[m] = e_m (one-hot, exact); W rows: 32 packed columns per block = [16 values | 16 gates]; value row j and gate row j both pick k = j
+    A = torch.eye(M, K).half().cuda()
+    N = 8 * 16                                                               # 4 blocks of (16 values + 16 gates)
+    W = torch.zeros(N, K)
+    bias = torch.zeros(N)
+    for blk in range(4):
+        for j in range(16):
+            c = blk * 16 + j                                                  # output column c gets value vals[m] * scale_c and gate gates[m]
+            W[blk * 32 + j, :] = vals                                        # value row: acc = vals[m]
+            W[blk * 32 + 16 + j, :] = gates                                  # gate row:  acc = gates[m]
+    W = W.half().cuda()
+    bias = bias.half().cuda()
+    out = torch.empty(M, N // 2, dtype=torch.half, device="cuda")
+    for tile in (0, 18, 22):
+        L.ia2p_debug_set_gemm_tile(tile)
+        try:
+            run(L, "ia2p_gemm", f.ptr(A), f.ptr(W), f.ptr(bias), None, f.ptr(out), M, N, K, 1)
+        finally:
+            L.ia2p_debug_set_gemm_tile(-1)
+        v, g_ = W[0].double().cpu(), W[16].double().cpu()                  # as rounded to fp16
+        ref = (v * F.gelu(g_)).float()
+        got = out[:, 0].float().cpu()
+        assert torch.equal(out, out[:, :1].expand_as(out)), tile              # every column computes the same thing
+        err = (got - ref).abs()
+        assert float((err / (ref.abs() + 1e-3)).max()) < 2e-3, (tile, got, ref)
+        assert float(got[g_ <= -9.0].abs().max()) == 0.0                      # far negative gates switch the value off entirely
+    # special values: NaN / Inf must propagate
+    for special, where in ((float("nan"), "gate"), (float("nan"), "value"), (float("inf"), "gate"), (float("inf"), "value")):
+        W2 = W.clone()
+        row = 16 if where == "gate" else 0
+        W2[row, 5] = special                                                 # A row 5 selects k = 5
+        run(L, "ia2p_gemm", f.ptr(A), f.ptr(W2), f.ptr(bias), None, f.ptr(out), M, N, K, 1)
+        got = out[5, 0].float().item()
+        v5 = float("nan") if (where == "value" and special != special) else (special if where == "value" else float(W[0, 5]))
+        g5 = special if where == "gate" else float(W[16, 5])
+        want = (torch.tensor(v5, dtype=torch.float64) * F.gelu(torch.tensor(g5, dtype=torch.float64))).item()
+        if want != want:
+            assert got != got, (special, where, got)
+        else:
+            assert got == want or (abs(want) == float("inf") and got == want), (special, where, got, want)
+        assert torch.isfinite(out[:, 1:].float()).all()                       # only the output column fed by the poisoned weight row is affected
+
+
 def test_gemm_rejects_bad_shapes(L):
     f = _ffi()
     A, W, out = rnd(64, 96), rnd(64, 96), torch.empty(64, 64, dtype=torch.half, device="cuda")
