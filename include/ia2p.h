@@ -171,14 +171,10 @@ ia2p_status ia2p_gemm(void* stream, const void* A, const void* W, const void* bi
  *       splitk > 1   : K split as in ia2p_gemm_splitk (partial: splitk*M*N floats); 0/1 = the library's unsplit choice */
 typedef struct { const float* stats; int slots; const float* colsum; const float* fbias; float eps; } ia2p_ln_fold;
 /* GEGLU feed-forward of a BasicTransformerBlock (diffusers FeedForward: ff.net.0 GEGLU + ff.net.2): H = geglu(X W1p^T + b1p) [M, 4C]
- * (W1p / b1p packed by ia2p_pack_geglu), out = H W2^T + b2 + R. chained != 0: ONE launch, second-GEMM tiles waiting on per-128-row-panel counters of
- * the first instead of on a kernel boundary (csrc/chain.hip), where the library's plans for the two shapes have a chained kernel -- *was_chained
- * (optional) says whether it did. Same bits as two launches. splitk > 1: K split of the second GEMM (partial: splitk*M*C floats). */
+ * (W1p / b1p packed by ia2p_pack_geglu), out = H W2^T + b2 + R, as two launches under the library's plans. splitk > 1: K split of the second GEMM
+ * (partial: splitk*M*C floats). */
 ia2p_status ia2p_ffn(void* stream, const void* X, const void* W1p, const void* b1p, const void* W2, const void* b2, const void* R, void* H, void* out,
-                     int M, int C, int chained, int splitk, float* partial, int* was_chained);
-/* chained launches bound every spin: a wait that gave up (never on this hardware: the dispatcher hands out workgroups in block order) sets a flag
- * per (device, stream). Returns it (0 = all waits were satisfied) and clears it; call after synchronising the stream. */
-int ia2p_chain_errors(void* stream);
+                     int M, int C, int splitk, float* partial);
 ia2p_status ia2p_fold_layernorm(void* stream, const void* W, const void* gamma, const void* beta, const void* bias, void* Wf,
                                 float* colsum, float* fbias, int N, int K);
 ia2p_status ia2p_gemm_ex(void* stream, const void* A, const void* W, const void* bias, const void* residual, void* C, int M, int N, int K,
@@ -229,6 +225,9 @@ ia2p_status ia2p_linear_small(void* stream, const void* X, const void* W, const 
 void ia2p_debug_set_gemm_splitk(int splitk);  /* -1 auto (tests / tuning; engine path only) */
 void ia2p_debug_set_splitk_inkernel(long long bytes); /* slab-set size (splitk*M*N*4) up to which a K split combines inside the GEMM launch; < 0: IA2P_SPLITK_INKERNEL / default (tests, A/B runs) */
 void ia2p_debug_set_gemm_tile(int variant);   /* -1 auto; else index into IA2P_GEMM_TILES of csrc/common.h, 0..23 (tests / tuning) */
+/* fused to_q + cross-attention: contexts created AFTER this call fuse launches of at least `tiles` 128-query x head tiles (-1: the built-in 128). Tests only:
+ * lets a tiny model take the fused path. */
+void ia2p_debug_set_xattn_min_tiles(int tiles);
 /* the tile table (tests / tools): out[4] = {tile rows, tile columns, LDS ring stages, schedule: 0 plain, 1 ping-pong, 2 eight-phase}; 0, or -1 past the last variant */
 int ia2p_debug_gemm_tile_info(int variant, int* out);
 /* the tile variant and K-split the library picks for a problem (pure function of the shape; host-only, no GPU needed) */

@@ -75,8 +75,7 @@ SIGNATURES = {
     "ia2p_layernorm": (_I, [_P, _P, _P, _P, _P, _I, _I, _F]),
     "ia2p_gemm": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I]),
     "ia2p_gemm_splitk": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "ia2p_ffn": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P]),
-    "ia2p_chain_errors": (_I, [_P]),
+    "ia2p_ffn": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "ia2p_fold_layernorm": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I]),
     "ia2p_gemm_ex": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
     "ia2p_debug_set_gemm_splitk": (None, [_I]),
@@ -92,6 +91,7 @@ SIGNATURES = {
     "ia2p_ip_attn_map": (_I, [_P, _P, _I, _P, _I, _P, _I, _I, _I, _I]),
     "ia2p_debug_set_gemm_tile": (None, [_I]),
     "ia2p_debug_gemm_tile_info": (_I, [_I, _P]),
+    "ia2p_debug_set_xattn_min_tiles": (None, [_I]),
     "ia2p_debug_set_splitk_inkernel": (None, [C.c_longlong]),
     "ia2p_debug_gemm_plan": (None, [_I, _I, _I, _I, _I, _P, _P]),
     "ia2p_clip_create": (_I, [C.POINTER(CLIPConfigC), C.POINTER(_P)]),

@@ -12,13 +12,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include", "ia2p.h")
 OUT = os.path.join(HERE, "libia2p_hip.so")
-SOURCES = ["gemm.hip", "chain.hip", "qxattn.hip", "attention.hip", "norm.hip", "misc.hip", "engine.hip", "vae_engine.hip", "clip_engine.hip"]
+SOURCES = ["gemm.hip", "qxattn.hip", "attention.hip", "norm.hip", "misc.hip", "engine.hip", "vae_engine.hip", "clip_engine.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"] + os.environ.get("IA2P_EXTRA_FLAGS", "").split()    # (A/B builds of compile-time knobs)
 # attention: MFMA results feed VALU softmax directly; the VGPR form avoids ~250 v_accvgpr_read/write per key tile
 # kernarg preload: the first 16 dwords of a kernel's (scalar) arguments arrive in SGPRs instead of through a cold read of the argument block
 PRELOAD = ["-mllvm", "-amdgpu-kernarg-preload-count=16"]
-FILE_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"] + PRELOAD, "qxattn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"] + PRELOAD, "gemm.hip": PRELOAD, "chain.hip": PRELOAD, "norm.hip": PRELOAD}
+FILE_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"] + PRELOAD, "qxattn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"] + PRELOAD, "gemm.hip": PRELOAD, "norm.hip": PRELOAD}
 
 
 def _stamp():

@@ -77,7 +77,7 @@ hipError_t ia2p_launch_attention(const AttnArgs& a, hipStream_t s) {
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
-  static const int xcd_map = getenv("IA2P_ATTN_XCD") ? atoi(getenv("IA2P_ATTN_XCD")) : 1;     // A/B switch
+  static const int xcd_map = ia2p_exp_env("IA2P_ATTN_XCD") ? atoi(ia2p_exp_env("IA2P_ATTN_XCD")) : 1;     // A/B switch
   AttnArgs b = a;
   b.xcd_map = (xcd_map ? 1 : 0) | (((ia2p_wt_mask() & 8) && (size_t)a.B * a.Nq * a.ldo * 2 < (size_t)0x7ffffff0) ? 2 : 0);
   // mode: 0 = one key segment; 1 = two segments with a second one of <= 64 keys and a non-zero first weight (the IP-Adapter call: merged

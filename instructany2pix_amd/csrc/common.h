@@ -69,6 +69,18 @@ __device__ __forceinline__ void store8_wt(__amdgpu_buffer_rsrc_t r, size_t byte_
   typedef unsigned u2v __attribute__((__vector_size__(2 * sizeof(unsigned))));
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, v), r, (int)byte_off, 0, IA2P_WT_AUX);
 }
+// Experiment knobs (A/B runs of a structure or a heuristic constant) are read from the environment only in builds made with -DIA2P_EXPERIMENTS
+// (IA2P_EXTRA_FLAGS=-DIA2P_EXPERIMENTS python -m instructany2pix_amd.build --force); the product library answers with the built-in default.
+// The eight runtime switches the product does read are listed in DESIGN.md §4 (IA2P_LN_FOLD, IA2P_XATTN_FUSE, IA2P_PREFETCH, IA2P_WT, IA2P_TILE_GROUP,
+// IA2P_SPLITK_INKERNEL, IA2P_TUNE_LOG, IA2P_TUNE_EXCLUDE).
+static inline const char* ia2p_exp_env(const char* name) {
+#ifdef IA2P_EXPERIMENTS
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
 // IA2P_WT: bit mask of the kernels that store write-through (1 GEMM C, 2 K-split reduce, 4 GroupNorm, 8 attention, 16 concat); A/B switch.
 // Same-box A/B at batch 8 (tools/ab_vals.sh): GEMM C -0.14 ms per step, GroupNorm -0.06, reduce / concat -0.02 each; attention +0.33 while O left
 // as 8-byte per-query pieces (partial lines: write-through pays for every one of them), -0.06 once O goes through LDS and leaves as whole lines.
@@ -142,13 +154,6 @@ struct GemmArgs {
   // producer side: row statistics of THIS launch's fp16 output, for the folded LayerNorm of the next contraction.
   // stats_out[(slot * M + m) * 2 + {0, 1}], slot = tile_n (or 0 for a K-split launch: the reduce kernel writes it)
   float* stats_out;
-  // producer side of a GroupNorm: per-column {sum, sum of squares} of THIS launch's fp16 output, per image -- what gn_stats_kernel used to get from a
-  // second pass over the tensor. Every tile writes the column sums of its rows to gn_cols[tile_m][N] (float2, scratch); the tile that arrives last
-  // at its image's ticket folds the image's tiles in tile order (fp64) into gn_tot[image][N] (double2). Needs gn_hw % BM == 0 (a tile lies in one image).
-  float* gn_cols;
-  double* gn_tot;
-  int* gn_tickets;       // one arrival counter per image, zero between launches
-  int gn_hw;             // rows per image
 };
 
 struct GemmPlan { int variant; int splitk; };

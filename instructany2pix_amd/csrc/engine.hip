@@ -49,10 +49,14 @@ struct Stage {            // one down/up block
   int rc;
 };
 
+static int g_xattn_min_tiles = -1;      // test hook: fusion threshold of contexts created from now on (< 0: the built-in 128)
+int ia2p_default_xattn_min_tiles() { return g_xattn_min_tiles; }
+extern "C" void ia2p_debug_set_xattn_min_tiles(int tiles) { g_xattn_min_tiles = tiles; }
+
 const char* prof_name(int k) {
   static char buf[PK_NCLASS][64];
   static const char* const other[] = {"attention_f16_kernel", "gn_stats_kernel+gn_apply_kernel", "layernorm_kernel",
-                                      "embed_kernel+linear_small_kernel", "conv_in_kernel", "conv_out_kernel", "concat_kernel", "splitk_reduce_kernel", "qproj_xattn_kernel", "gemm_chain2_kernel"};
+                                      "embed_kernel+linear_small_kernel", "conv_in_kernel", "conv_out_kernel", "concat_kernel", "splitk_reduce_kernel", "qproj_xattn_kernel"};
   if (k >= PK_ATTN) return other[k - PK_ATTN];
   const GemmTile t = IA2P_GEMM_TILES[(k % PK_CONV0) % IA2P_GEMM_NVARIANT];
   if (t.pp == 2) snprintf(buf[k], sizeof buf[k], "gemm_f16_kernel<%d, %d, %d, %s, 2, 64, 2, 4>", t.bm, t.bn, t.stages, k >= PK_CONV0 ? "true" : "false");
@@ -312,10 +316,7 @@ T2 wsalloc(RunCtx* c, size_t elems) {
 }
 void wsfree(RunCtx* c, T2 t) {
   if (t.off == (size_t)-1) return;
-  auto it = c->gn_tot.find(t.off);
-  if (it != c->gn_tot.end()) { c->ws.release(it->second.first); c->gn_tot.erase(it); }      // the tensor's GroupNorm statistics go with it
-  if (c->defer_free) c->defer_free->push_back(t.off);
-  else c->ws.release(t.off);
+  c->ws.release(t.off);
 }
 
 hipEvent_t get_event(RunCtx* c) {
@@ -331,8 +332,8 @@ static void set_prefetch(RunCtx* c, GemmArgs& a, const half_t* W, size_t bytes) 
   ++c->widx;
   if (nx.second > ((size_t)96 << 20)) return;           // larger than the Infinity Cache can usefully hold
   a.pf = nx.first; a.pf_bytes = (long)nx.second;
-  static const size_t pf_cap = getenv("IA2P_PF_BLOCKS") ? (size_t)atoi(getenv("IA2P_PF_BLOCKS")) : 128;            // tuning hooks: most prefetch workgroups per launch,
-  static const size_t pf_per = getenv("IA2P_PF_BLOCK_BYTES") ? (size_t)atol(getenv("IA2P_PF_BLOCK_BYTES")) : 131072;   // bytes per workgroup below that
+  static const size_t pf_cap = ia2p_exp_env("IA2P_PF_BLOCKS") ? (size_t)atoi(ia2p_exp_env("IA2P_PF_BLOCKS")) : 128;            // tuning hooks: most prefetch workgroups per launch,
+  static const size_t pf_per = ia2p_exp_env("IA2P_PF_BLOCK_BYTES") ? (size_t)atol(ia2p_exp_env("IA2P_PF_BLOCK_BYTES")) : 131072;   // bytes per workgroup below that
   a.pf_blocks = (int)std::max<size_t>(1, std::min<size_t>(pf_cap, (nx.second + pf_per - 1) / pf_per));
 }
 
@@ -344,7 +345,7 @@ static void set_prefetch(RunCtx* c, GemmArgs& a, const half_t* W, size_t bytes) 
 static void tune_site(RunCtx* c, const GemmArgs& a, bool conv) {
   if (ia2p_plan_lookup(a.M, a.N, a.K, conv, a.geglu != 0, nullptr)) return;
   std::vector<GemmPlan> cands;
-  ia2p_gemm_candidates(a.M, a.N, a.K, conv, a.geglu != 0, c->tune_slab_bytes, getenv("IA2P_TUNE_SLACK") ? atof(getenv("IA2P_TUNE_SLACK")) : 1.7, &cands);
+  ia2p_gemm_candidates(a.M, a.N, a.K, conv, a.geglu != 0, c->tune_slab_bytes, ia2p_exp_env("IA2P_TUNE_SLACK") ? atof(ia2p_exp_env("IA2P_TUNE_SLACK")) : 1.7, &cands);
   static const bool tune_log = getenv("IA2P_TUNE_LOG") != nullptr;      // every candidate's time, for calibrating the cost model
   hipEvent_t e0 = get_event(c), e1 = get_event(c);
   // Rounds over all candidates (round -1 untimed), so that clock / cache drift during the measurement hits every candidate alike;
@@ -405,33 +406,11 @@ static void run_gemm(RunCtx* c, GemmArgs& a, bool conv, const char* what, double
   }
   struct Rel { RunCtx* c; T2 t; ~Rel() { wsfree(c, t); } } rel{c, slab};
   int combined = pl.splitk > 1 && ia2p_splitk_inkernel(a.M, a.N, pl.splitk);     // (dry pass: the policy's answer; the launcher reports what it really did)
-  // GroupNorm statistics of the output from this launch's epilogue (asked for by the caller through gn_next_*): totals live as long as the output
-  const int gn_hw = c->gn_next_hw;
-  const size_t gn_off = c->gn_next_off;
-  c->gn_next_hw = 0; c->gn_next_off = (size_t)-1;
-  T2 gcols{(size_t)-1, nullptr};
-  const long gn_wgs = (long)(a.M / IA2P_GEMM_TILES[pl.variant].bm) * ((a.N + IA2P_GEMM_TILES[pl.variant].bn - 1) / IA2P_GEMM_TILES[pl.variant].bn) * (pl.splitk > 1 ? pl.splitk : 1);
-  if (gn_hw > 0 && gn_off != (size_t)-1 && c->gn_epi && (c->gn_epi != 2 || gn_wgs <= 512) && !c->tuning && !a.geglu && (pl.splitk <= 1 || combined) &&
-      ia2p_gn_epilogue_ok(pl.variant, a.M, gn_hw) && a.ldc % 8 == 0 && a.N % 8 == 0) {
-    const int tiles_m = a.M / IA2P_GEMM_TILES[pl.variant].bm;
-    T2 tot = wsalloc(c, (size_t)(a.M / gn_hw) * a.N * 8);          // double2 per image and column
-    gcols = wsalloc(c, (size_t)tiles_m * a.N * 4);                  // float2 per tile row and column (scratch of this launch)
-    if (tot.off != (size_t)-1 && gcols.off != (size_t)-1) {
-      a.gn_cols = (float*)gcols.p; a.gn_tot = (double*)tot.p; a.gn_hw = gn_hw;
-      a.gn_tickets = c->dry ? nullptr : ia2p_gn_tickets(c->stream);
-      if (!c->dry && !a.gn_tickets) { a.gn_cols = nullptr; a.gn_tot = nullptr; }
-      auto old = c->gn_tot.find(gn_off);
-      if (old != c->gn_tot.end()) { c->ws.release(old->second.first); c->gn_tot.erase(old); }      // (an output written in place keeps one table)
-      if (c->dry || a.gn_cols) c->gn_tot[gn_off] = {tot.off, (double*)tot.p};
-      else c->ws.release(tot.off);
-    }
-  }
   {
     ProfScope ps(c, (conv ? PK_CONV0 : PK_GEMM0) + pl.variant, flops, bytes);
     ps.pf = a.pf ? (double)a.pf_bytes : 0.0;
     CHECK_LAUNCH(c, ia2p_launch_gemm_variant(a, conv, pl.variant, c->stream, false, &combined), what);
   }
-  if (gcols.off != (size_t)-1) c->ws.release(gcols.off);
   if (pl.splitk > 1 && !combined) {
     ProfScope ps(c, PK_REDUCE, 0, (double)pl.splitk * a.M * a.N * 4 + 2.0 * a.M * a.N);
     CHECK_LAUNCH(c, ia2p_launch_splitk_reduce(a, c->stream), what);
@@ -464,32 +443,13 @@ void op_gemm(RunCtx* c, const half_t* A, int lda, const half_t* W, const half_t*
   set_prefetch(c, a, W, (size_t)N * K * sizeof(half_t));
   run_gemm(c, a, false, "gemm", 2.0 * M * N * K, gemm_bytes(M, N, K, geglu, residual != nullptr), stat_slots);
 }
-// GEGLU feed-forward: ff.net.0 (a: K = C, N = 8 C packed, GEGLU epilogue -> H [M, 4 C]) then ff.net.2 (b: reads H, + bias + residual). With c->chain
-// and plans that have a chained kernel the two run as ONE launch (chain.hip); else as two. Same bits either way.
+// GEGLU feed-forward: ff.net.0 (a: K = C, N = 8 C packed, GEGLU epilogue -> H [M, 4 C]) then ff.net.2 (b: reads H, + bias + residual): two launches.
+// (One launch with a per-row-panel hand-off between the two was built and measured in round 3: +0.45 ... +0.8 ms per step, docs/LOG.md; removed in round 4.)
 static void run_ffn(RunCtx* c, GemmArgs& a, GemmArgs& b, int* stat_slots_b) {
   set_prefetch(c, a, a.W, (size_t)a.N * a.K * sizeof(half_t));
   set_prefetch(c, b, b.W, (size_t)b.N * b.K * sizeof(half_t));
-  const double fa = 2.0 * a.M * (double)a.N * a.K, fb = 2.0 * b.M * (double)b.N * b.K;
-  const double ba = gemm_bytes(a.M, a.N, a.K, 1, false), bb = gemm_bytes(b.M, b.N, b.K, 0, true);
-  if (c->tuning && !c->dry && !c->failed) { tune_site(c, a, false); tune_site(c, b, false); }
-  const GemmPlan pa = ia2p_gemm_plan(a.M, a.N, a.K, false, true), pb = ia2p_gemm_plan(b.M, b.N, b.K, false, false);
-  GemmArgs bt = b;
-  bt.splitk = pb.splitk > 1 ? pb.splitk : 0;
-  bt.partial = bt.splitk ? (float*)1 : nullptr;            // (placeholder for the shape check; the slabs are allocated below)
-  const bool chained = c->chain && !c->tuning && pa.splitk <= 1 && (pb.splitk <= 1 || ia2p_splitk_inkernel(b.M, b.N, pb.splitk)) && ia2p_chain2_ok(a, pa.variant, bt, pb.variant);
-  if (!chained) {
-    run_gemm(c, a, false, "ff.net.0", fa, ba);
-    run_gemm(c, b, false, "ff.net.2", fb, bb, stat_slots_b);
-    return;
-  }
-  T2 slab{(size_t)-1, nullptr};
-  if (pb.splitk > 1) { b.splitk = pb.splitk; slab = wsalloc(c, (size_t)pb.splitk * b.M * b.N * 2); b.partial = (float*)slab.p; }
-  {
-    ProfScope ps(c, PK_CHAIN, fa + fb, ba + bb);
-    CHECK_LAUNCH(c, ia2p_launch_gemm_chain2(a, pa.variant, b, pb.variant, c->stream), "ff.net.0 -> ff.net.2 (one launch)");
-  }
-  wsfree(c, slab);
-  if (stat_slots_b) *stat_slots_b = (b.N + IA2P_GEMM_TILES[pb.variant].bn - 1) / IA2P_GEMM_TILES[pb.variant].bn;
+  run_gemm(c, a, false, "ff.net.0", 2.0 * a.M * (double)a.N * a.K, gemm_bytes(a.M, a.N, a.K, 1, false));
+  run_gemm(c, b, false, "ff.net.2", 2.0 * b.M * (double)b.N * b.K, gemm_bytes(b.M, b.N, b.K, 0, true), stat_slots_b);
 }
 void op_conv3(RunCtx* c, const half_t* X, int B, int Hs, int Ws, int Cin, const half_t* W, const half_t* bias, int Co,
               int stride, int up, const half_t* rowvec, int rowvec_ld, const half_t* residual, half_t* Y, int pad_lo, const half_t* X2, int Cin2,
@@ -512,21 +472,10 @@ void op_conv3(RunCtx* c, const half_t* X, int B, int Hs, int Ws, int Cin, const 
   set_prefetch(c, a, W, (size_t)Co * a.K * sizeof(half_t));
   run_gemm(c, a, true, "conv3x3", 2.0 * a.M * (double)Co * a.K, 2.0 * ((double)B * Hs * Ws * Cin + (double)Co * a.K + (double)a.M * Co + (residual ? (double)a.M * Co : 0) + (double)a.M * (Cin2 + Cin3)));
 }
-void op_gn(RunCtx* c, const half_t* x, half_t* y, size_t g, size_t b, int B, int HW, int C, float eps, int silu, float* partial, const half_t* x2, int Ca,
-           size_t x_off, size_t x2_off) {
-  // statistics from the producers' epilogues when EVERY source tensor carries them; else the classic statistics pass over the tensor(s)
-  const double *t1 = nullptr, *t2 = nullptr;
-  bool have = false;
-  if (c->gn_epi && x_off != (size_t)-1) {
-    auto i1 = c->gn_tot.find(x_off);
-    auto i2 = x2 || x2_off != (size_t)-1 ? c->gn_tot.find(x2_off) : c->gn_tot.end();
-    const bool two = x2 != nullptr || x2_off != (size_t)-1;
-    if (i1 != c->gn_tot.end() && (!two || i2 != c->gn_tot.end())) { have = true; t1 = i1->second.second; t2 = two ? i2->second.second : nullptr; }
-  }
-  ProfScope ps(c, PK_GN, 8.0 * B * HW * C, (have ? 4.0 : 4.0) * B * HW * C);
-  if (!have) { t1 = t2 = nullptr; }
-  if (x2) CHECK_LAUNCH(c, ia2p_launch_groupnorm(x, Ca, y, C, W_(c, g), W_(c, b), partial, B, HW, C, c->groups, eps, silu, c->stream, x2, C - Ca, Ca, t1, t2), "groupnorm");
-  else CHECK_LAUNCH(c, ia2p_launch_groupnorm(x, C, y, C, W_(c, g), W_(c, b), partial, B, HW, C, c->groups, eps, silu, c->stream, nullptr, 0, 0, t1, nullptr), "groupnorm");
+void op_gn(RunCtx* c, const half_t* x, half_t* y, size_t g, size_t b, int B, int HW, int C, float eps, int silu, float* partial, const half_t* x2, int Ca) {
+  ProfScope ps(c, PK_GN, 8.0 * B * HW * C, 4.0 * B * HW * C);
+  if (x2) CHECK_LAUNCH(c, ia2p_launch_groupnorm(x, Ca, y, C, W_(c, g), W_(c, b), partial, B, HW, C, c->groups, eps, silu, c->stream, x2, C - Ca, Ca), "groupnorm");
+  else CHECK_LAUNCH(c, ia2p_launch_groupnorm(x, C, y, C, W_(c, g), W_(c, b), partial, B, HW, C, c->groups, eps, silu, c->stream), "groupnorm");
 }
 void op_ln(RunCtx* c, const half_t* x, half_t* y, size_t g, size_t b, int M, int C) {
   ProfScope ps(c, PK_LN, 8.0 * M * C, 4.0 * M * C);
@@ -541,8 +490,6 @@ struct Fwd {
   float* gn_partial;
   T2 kv_text, kv_ip;   // [B*Lt, kv_rows], [B*Li, kv_rows]
   const float* ip_scales = nullptr;   // device [B] or null: per-request IP-Adapter scale (else the context's one value)
-  bool kv_join = false;               // the context projection runs on the side stream: the first transformer waits for it
-  std::vector<size_t> kv_deferred;    // workspace blocks the projection released (handed back in front of the first transformer)
 };
 
 struct RegionScope { RunCtx* c; int prev; RegionScope(RunCtx* c_, int r) : c(c_), prev(c_->region) { c->region = r; } ~RegionScope() { c->region = prev; } };
@@ -556,13 +503,12 @@ static T2 run_resnet(Fwd& f, const Resnet& r, T2 x, int H, int Wd, const T2* x2t
   RegionScope rs(c, PR_CONV_BLOCK);
   const int HW = H * Wd, M = f.B * HW;
   T2 n1 = wsalloc(c, (size_t)M * r.cin);
-  op_gn(c, x.p, n1.p, r.n1g, r.n1b, f.B, HW, r.cin, c->cfg.norm_eps, 1, f.gn_partial, x2, cx, x.off, two ? x2t->off : (size_t)-1);
+  op_gn(c, x.p, n1.p, r.n1g, r.n1b, f.B, HW, r.cin, c->cfg.norm_eps, 1, f.gn_partial, x2, cx);
   T2 hh = wsalloc(c, (size_t)M * r.cout);
-  c->gn_next_hw = HW; c->gn_next_off = hh.off;               // norm2 reads conv1's output: statistics from conv1's epilogue
   op_conv3(c, n1.p, f.B, H, Wd, r.cin, W_(c, r.w1), W_(c, r.b1), r.cout, 1, 0, c->dry ? nullptr : f.temb_all.p + r.temb_off, c->temb_total, nullptr, hh.p);
   wsfree(c, n1);
   T2 n2 = wsalloc(c, (size_t)M * r.cout);
-  op_gn(c, hh.p, n2.p, r.n2g, r.n2b, f.B, HW, r.cout, c->cfg.norm_eps, 1, f.gn_partial, nullptr, 0, hh.off);
+  op_gn(c, hh.p, n2.p, r.n2g, r.n2b, f.B, HW, r.cout, c->cfg.norm_eps, 1, f.gn_partial);
   wsfree(c, hh);
   T2 xs{(size_t)-1, nullptr};
   const half_t* resid = x.p;
@@ -573,7 +519,6 @@ static T2 run_resnet(Fwd& f, const Resnet& r, T2 x, int H, int Wd, const T2* x2t
     resid = xs.p;
   }
   T2 out = wsalloc(c, (size_t)M * r.cout);
-  c->gn_next_hw = HW; c->gn_next_off = out.off;              // whatever GroupNorm reads the block's output next (transformer norm, next norm1, up-path skip, conv_norm_out)
   if (cat && two) op_conv3(c, n2.p, f.B, H, Wd, r.cout, W_(c, r.wcat), W_(c, r.bcat), r.cout, 1, 0, nullptr, 0, nullptr, out.p, 1, x.p, cx, x2, r.cin - cx);
   else if (cat) op_conv3(c, n2.p, f.B, H, Wd, r.cout, W_(c, r.wcat), W_(c, r.bcat), r.cout, 1, 0, nullptr, 0, nullptr, out.p, 1, x.p, r.cin);
   else op_conv3(c, n2.p, f.B, H, Wd, r.cout, W_(c, r.w2), W_(c, r.b2), r.cout, 1, 0, nullptr, 0, c->dry ? nullptr : resid, out.p);
@@ -615,15 +560,8 @@ static T2 run_transformer(Fwd& f, const Transformer& t, T2 x, int H, int Wd) {
   const int Lt = c->ip_enabled ? f.L - c->ip_tokens : f.L;
   const int Li = c->ip_enabled ? c->ip_tokens : 0;
   const float sl2e = 0.125f * 1.4426950408889634f;
-  if (f.kv_join) {                    // the context K / V come from the side stream
-    f.kv_join = false;
-    hipError_t e = hipStreamWaitEvent(c->stream, c->ev_join, 0);
-    if (e != hipSuccess) { fail(c, IA2P_ERR_HIP, "context projection side stream: %s", hipGetErrorString(e)); return x; }
-  }
-  for (size_t off : f.kv_deferred) c->ws.release(off);
-  f.kv_deferred.clear();
   T2 n = wsalloc(c, (size_t)M * C);
-  op_gn(c, x.p, n.p, t.ng, t.nb, f.B, HW, C, 1e-6f, 0, f.gn_partial, nullptr, 0, x.off);
+  op_gn(c, x.p, n.p, t.ng, t.nb, f.B, HW, C, 1e-6f, 0, f.gn_partial);
   // The three LayerNorms of a block never run as kernels: every GEMM that writes the token stream `tk` also emits per-row
   // {sum, sum of squares} partials of its fp16 output (`st`), and the GEMM that consumes LN(tk) reads raw `tk` against the
   // gamma-folded weights and finishes the normalisation in its epilogue (LnIn; GemmArgs.ln_* in common.h).
@@ -697,7 +635,6 @@ static T2 run_transformer(Fwd& f, const Transformer& t, T2 x, int H, int Wd) {
   wsfree(c, stt); wsfree(c, lnb); wsfree(c, qkv); wsfree(c, att); wsfree(c, ff);
   (void)ctxd;
   T2 out = wsalloc(c, (size_t)M * C);
-  c->gn_next_hw = HW; c->gn_next_off = out.off;              // the next ResnetBlock2D's norm1 (or an up-path concat) reads this
   op_gemm(c, tk.p, C, W_(c, t.wout), W_(c, t.bout), x.p, C, out.p, C, M, C, C);
   wsfree(c, tk);
   return out;
@@ -723,23 +660,7 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
   const int pooled = Ain - g.num_time_ids * Ad;
   Fwd f{c, B, h, w, L, context, T2{(size_t)-1, nullptr}, nullptr, T2{(size_t)-1, nullptr}, T2{(size_t)-1, nullptr}};
   f.ip_scales = ip_scales;
-  c->gn_tot.clear(); c->gn_next_hw = 0; c->gn_next_off = (size_t)-1;      // (the workspace was just reset)
 
-  // in-step context projection on the side stream (below): the fork point is HERE, in front of the embedding chain, so that it runs beside it
-  const bool kv_defer = c->kv_overlap && c->kv_rows > 0 && !kv_cached;
-  const bool kv_fork = kv_defer && !c->dry && !c->prof && !c->tuning && !c->failed;
-  if (kv_fork) {
-    hipError_t e = hipSuccess;
-    if (!c->side) {
-      int lo = 0, hi = 0;
-      e = hipDeviceGetStreamPriorityRange(&lo, &hi);      // lo = least priority (numerically largest)
-      if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, lo);
-      if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
-      if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
-    }
-    if (e == hipSuccess) e = hipEventRecord(c->ev_fork, c->stream);      // behind everything the caller queued: inputs ready, the previous pass done with the workspace
-    if (e != hipSuccess) return fail(c, IA2P_ERR_HIP, "context projection side stream: %s", hipGetErrorString(e));
-  }
   // GroupNorm partial sums (fp32) live at the front of the workspace
   T2 gnp = wsalloc(c, (size_t)B * 64 * g.norm_num_groups * 2 * 2);
   f.gn_partial = (float*)gnp.p;
@@ -779,25 +700,9 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
     } else {
       f.kv_text = wsalloc(c, (size_t)B * Lt * c->kv_rows);
       if (Li) f.kv_ip = wsalloc(c, (size_t)B * Li * c->kv_rows);
-      // The projection depends on nothing the step computes and nothing needs it before the first transformer: with c->kv_overlap it runs on a
-      // low-priority stream of the context BESIDE the embedding chain, conv_in and the first ResnetBlock2Ds (launches that leave most CUs idle
-      // or half filled) and is joined in front of the first transformer (kv_join). Whatever it releases (K-split slabs) goes back at the join
-      // only -- in every pass, so that the sizing pass and the run share one workspace layout.
-      hipStream_t main_stream = c->stream;
-      if (kv_defer) c->defer_free = &f.kv_deferred;
-      if (kv_fork) {
-        const hipError_t e = hipStreamWaitEvent(c->side, c->ev_fork, 0);
-        if (e != hipSuccess) return fail(c, IA2P_ERR_HIP, "context projection side stream: %s", hipGetErrorString(e));
-        c->stream = c->side;
-      }
+      // (On a low-priority side stream beside the start of the step -- round 3, docs/LOG.md -- the projection cost +0.7 ms per step: the work is conserved, the
+      //  interleaving costs. The step belongs on ONE queue; the pipelines hoist the projection out of the loop anyway.)
       project_context(c, context, L, B, f.kv_text.p, f.kv_ip.p);
-      c->defer_free = nullptr;
-      if (kv_fork) {
-        hipError_t e = hipEventRecord(c->ev_join, c->side);
-        c->stream = main_stream;
-        if (e != hipSuccess) return fail(c, IA2P_ERR_HIP, "context projection side stream: %s", hipGetErrorString(e));
-        f.kv_join = true;
-      }
     }
   }
 
@@ -824,7 +729,6 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
     if (st.resample) {
       const int Ho = (H - 1) / 2 + 1, Wo = (Wd - 1) / 2 + 1;
       T2 d = wsalloc(c, (size_t)B * Ho * Wo * st.rc);
-      c->gn_next_hw = Ho * Wo; c->gn_next_off = d.off;
       op_conv3(c, x.p, B, H, Wd, st.rc, W_(c, st.rw), W_(c, st.rb), st.rc, 2, 0, nullptr, 0, nullptr, d.p);
       H = Ho; Wd = Wo; x = d;
       skips.push_back(x); skip_c.push_back(st.rc);
@@ -865,7 +769,6 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
     }
     if (st.resample) {
       T2 u = wsalloc(c, (size_t)B * (2 * H) * (2 * Wd) * st.rc);
-      c->gn_next_hw = 4 * H * Wd; c->gn_next_off = u.off;
       op_conv3(c, x.p, B, H, Wd, st.rc, W_(c, st.rw), W_(c, st.rb), st.rc, 1, 1, nullptr, 0, nullptr, u.p);
       wsfree(c, x);
       H *= 2; Wd *= 2; x = u;
@@ -873,16 +776,9 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
   }
   if (H != h || Wd != w) return fail(c, IA2P_ERR_SHAPE, "latent %dx%d does not survive the down/up path (needs divisibility by 2^%d)", h, w, n - 1);
   // ---- out
-  if (f.kv_join) {                    // a network without a transformer never joined the side stream: the pass must not end before it
-    f.kv_join = false;
-    const hipError_t e = hipStreamWaitEvent(c->stream, c->ev_join, 0);
-    if (e != hipSuccess) return fail(c, IA2P_ERR_HIP, "context projection side stream: %s", hipGetErrorString(e));
-  }
-  for (size_t off : f.kv_deferred) c->ws.release(off);
-  f.kv_deferred.clear();
   const int c0 = g.block_out_channels[0];
   T2 no = wsalloc(c, (size_t)B * H * Wd * c0);
-  op_gn(c, x.p, no.p, c->ngo, c->nbo, B, H * Wd, c0, g.norm_eps, 1, f.gn_partial, nullptr, 0, x.off);
+  op_gn(c, x.p, no.p, c->ngo, c->nbo, B, H * Wd, c0, g.norm_eps, 1, f.gn_partial);
   wsfree(c, x);
   {
     ProfScope ps(c, PK_CONV_OUT, 2.0 * B * H * Wd * 9.0 * c0 * g.out_channels, 2.0 * ((double)B * H * Wd * (c0 + g.out_channels) + 9.0 * c0 * g.out_channels));
@@ -1228,12 +1124,10 @@ ia2p_status ia2p_gemm(void* stream, const void* A, const void* W, const void* bi
   hipError_t e = ia2p_launch_gemm(a, false, (hipStream_t)stream, nullptr);
   RET_HIP(e, "gemm");
 }
-// GEGLU feed-forward of a BasicTransformerBlock as an operator: H = geglu(X . W1p^T + b1p) [M, 4 C] (packed weights: ia2p_pack_geglu), out = H . W2^T + b2 + R.
-// chained != 0: the two GEMMs run as ONE launch with per-row-panel hand-off (chain.hip) when the library's plans for the two shapes have a chained
-// kernel (else, and with chained == 0, as two launches); *was_chained tells which. Same bits either way. splitk / partial: K split of the second GEMM
-// (partial: splitk * M * C floats) or 0.
+// GEGLU feed-forward of a BasicTransformerBlock as an operator: H = geglu(X . W1p^T + b1p) [M, 4 C] (packed weights: ia2p_pack_geglu), out = H . W2^T + b2 + R,
+// as the executor runs it (two launches, the library's plans). splitk / partial: K split of the second GEMM (partial: splitk * M * C floats) or 0.
 ia2p_status ia2p_ffn(void* stream, const void* X, const void* W1p, const void* b1p, const void* W2, const void* b2, const void* R, void* H, void* out,
-                     int M, int C, int chained, int splitk, float* partial, int* was_chained) {
+                     int M, int C, int splitk, float* partial) {
   if (!X || !W1p || !b1p || !W2 || !H || !out) return fail(nullptr, IA2P_ERR_INVALID, "ffn: null argument");
   if (C % 64 || (splitk > 1 && (!partial || splitk > 4 * C / 64))) return fail(nullptr, IA2P_ERR_SHAPE, "ffn: C=%d must be a multiple of 64, splitk=%d needs slabs", C, splitk);
   RunCtx rc;
@@ -1242,14 +1136,8 @@ ia2p_status ia2p_ffn(void* stream, const void* X, const void* W1p, const void* b
   a.m_fastest = a.M <= a.N; b.m_fastest = b.M <= b.N;
   if (splitk > 1) { b.splitk = splitk; b.partial = partial; }
   const GemmPlan pa = ia2p_gemm_plan(a.M, a.N, a.K, false, true), pb = ia2p_gemm_plan(b.M, b.N, b.K, false, false);
-  const bool ch = chained && (splitk <= 1 || ia2p_splitk_inkernel(M, C, splitk)) && ia2p_chain2_ok(a, pa.variant, b, pb.variant);
-  if (was_chained) *was_chained = ch;
-  hipError_t e;
-  if (ch) e = ia2p_launch_gemm_chain2(a, pa.variant, b, pb.variant, (hipStream_t)stream);
-  else {
-    e = ia2p_launch_gemm_variant(a, false, pa.variant, (hipStream_t)stream);
-    if (e == hipSuccess) e = ia2p_launch_gemm_variant(b, false, pb.variant, (hipStream_t)stream);
-  }
+  hipError_t e = ia2p_launch_gemm_variant(a, false, pa.variant, (hipStream_t)stream);
+  if (e == hipSuccess) e = ia2p_launch_gemm_variant(b, false, pb.variant, (hipStream_t)stream);
   RET_HIP(e, "ffn");
 }
 ia2p_status ia2p_fold_layernorm(void* stream, const void* W, const void* gamma, const void* beta, const void* bias, void* Wf, float* colsum,

@@ -23,9 +23,6 @@ hipError_t ia2p_launch_gemm(const GemmArgs& a, bool conv, hipStream_t s, int* pi
 // *combined (optional): 1 when a K-split launch finishes inside the launch (ticket counters attached), 0 when its slabs wait for ia2p_launch_splitk_reduce
 hipError_t ia2p_launch_gemm_variant(const GemmArgs& a, bool conv, int variant, hipStream_t s, bool with_reduce = true, int* combined = nullptr);
 hipError_t ia2p_launch_splitk_reduce(const GemmArgs& a, hipStream_t s);
-// chain.hip: two dependent GEMMs (b.A == a.C, row-panel-local) as ONE launch; va / vb = tile variants of the plans
-bool ia2p_chain2_ok(const GemmArgs& a, int va, const GemmArgs& b, int vb);
-hipError_t ia2p_launch_gemm_chain2(const GemmArgs& a, int va, const GemmArgs& b, int vb, hipStream_t s);
 bool ia2p_splitk_inkernel(int M, int N, int splitk);
 void ia2p_gemm_candidates(int M, int N, int K, bool conv, bool geglu, size_t max_slab_bytes, double slack, std::vector<GemmPlan>* out);
 hipError_t ia2p_launch_attention(const AttnArgs& a, hipStream_t s);
@@ -33,8 +30,7 @@ bool ia2p_qproj_xattn_ok(const GemmArgs& a, const AttnArgs& x);
 hipError_t ia2p_launch_qproj_xattn(const GemmArgs& a, const AttnArgs& x, hipStream_t s);   // qxattn.hip: to_q tile -> attention core, one launch
 int ia2p_gn_chunks(int B, int HW);
 hipError_t ia2p_launch_groupnorm(const half_t* x, int ldx, half_t* y, int ldy, const half_t* gamma, const half_t* beta,
-                                 float* partial, int B, int HW, int C, int G, float eps, int silu, hipStream_t s, const half_t* x2 = nullptr, int ldx2 = 0, int Ca = 0,
-                                 const double* tot1 = nullptr, const double* tot2 = nullptr);
+                                 float* partial, int B, int HW, int C, int G, float eps, int silu, hipStream_t s, const half_t* x2 = nullptr, int ldx2 = 0, int Ca = 0);
 hipError_t ia2p_launch_layernorm(const half_t* x, int ldx, half_t* y, int ldy, const half_t* gamma, const half_t* beta,
                                  int M, int C, float eps, hipStream_t s);
 hipError_t ia2p_launch_embed(float t, const float* ts, const half_t* text_embeds, const half_t* time_ids, half_t* tsin, half_t* addin,
@@ -117,10 +113,11 @@ struct ProfRec { hipEvent_t e0, e1; int k; double flops, bytes; int region; doub
 // profile regions of a UNet evaluation: what part of the network a launch belongs to (bench.py: conv-block roofline)
 enum { PR_OTHER = 0, PR_CONV_BLOCK = 1, PR_TRANSFORMER = 2, PR_NREGION };
 // profile classes = device kernel names as rocprofv3 prints them (template arguments included)
-enum { PK_GEMM0 = 0, PK_CONV0 = 24, PK_ATTN = 48, PK_GN, PK_LN, PK_EMBED, PK_CONV_IN, PK_CONV_OUT, PK_CONCAT, PK_REDUCE, PK_QXATTN, PK_CHAIN, PK_NCLASS };
+enum { PK_GEMM0 = 0, PK_CONV0 = 24, PK_ATTN = 48, PK_GN, PK_LN, PK_EMBED, PK_CONV_IN, PK_CONV_OUT, PK_CONCAT, PK_REDUCE, PK_QXATTN, PK_NCLASS };
 const char* prof_name(int k);
 
 // state shared by the executors (conditional UNet, VAE): weights, workspace, prefetch plan, per-kernel timing
+int ia2p_default_xattn_min_tiles();      // < 0: the built-in threshold (engine.hip; test hook ia2p_debug_set_xattn_min_tiles)
 struct RunCtx {
   std::string err;
   std::unordered_map<std::string, Param> params;
@@ -142,22 +139,11 @@ struct RunCtx {
   bool prefetch = true;
   const half_t* tail_pf = nullptr;   // what the LAST contraction of a pass prefetches: the first weights of the next pass (embedding MLPs)
   size_t tail_pf_bytes = 0;
-  int xattn_min_tiles = 128; // ... and only when the fused launch has at least this many 128-query x head tiles (IA2P_XATTN_MIN_TILES; 40-tile launches lose 4 us each, 160-tile ones gain 1)
+  int xattn_min_tiles = 128; // ... and only when the fused launch has at least this many 128-query x head tiles (40-tile launches lose 4 us each, 160-tile ones gain 1)
   bool cat_free = true;      // up path: torch.cat([hidden, skip]) never materialised (needs sc_fuse; IA2P_CAT_FREE=0: concat_kernel, for A/B runs)
   bool sc_fuse = true;       // ResnetBlock2D: conv2 + conv_shortcut as one implicit GEMM (IA2P_SC_FUSE=0: separate 1x1 launch + residual, for A/B runs)
   bool xattn_fuse = true;    // to_q + cross-attention as one launch where the shape allows (IA2P_XATTN_FUSE=0: two launches, for A/B runs)
-  bool chain = false;        // feed-forward pair (ff.net.0 -> ff.net.2) as ONE launch with per-row-panel hand-off (chain.hip; IA2P_CHAIN=1)
   bool ln_fold = true;       // LayerNorms folded into their consumer GEMMs (IA2P_LN_FOLD=0: separate layernorm_kernel launches, for A/B runs)
-  // IA2P_KV_OVERLAP=1: the in-step context K / V projection (two GEMMs, 0.63 ms at batch 8) runs on a low-priority side stream of the context beside
-  // the start of the step (engine.hip run_forward) and is joined in front of the first transformer. Built, bit-identical, measured and left OFF:
-  // 20.16 vs 19.50 ms/step (same box, 2 x 2 runs). The kernel trace (profiles/r03m_kv_overlap_trace.txt) shows why: the chip has no idle share to
-  // give -- beside the background GEMM the embedding linears take 65-83 us instead of 8-27, conv_in 86 instead of 17, the first convolution 117
-  // instead of 68, the GEMM itself 560 instead of 489: the work is conserved, the interleaving costs. (The embedding chain on the side stream,
-  // tried first, cost the same +0.7 ms.) On this chip the step belongs on ONE queue.
-  bool kv_overlap = false;
-  std::vector<size_t>* defer_free = nullptr;      // while set, wsfree parks the blocks here instead of releasing them
-  hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool prof = false;
   // autotune pass (ia2p_autotune): every GEMM / conv site of an unmeasured shape times its candidate plans in place
   bool tuning = false;
@@ -172,36 +158,20 @@ struct RunCtx {
   double r_ms[PR_NREGION], r_fl[PR_NREGION], r_by[PR_NREGION];
   int64_t r_n[PR_NREGION];
   float ep_acc_scale = 1.f, ep_bias_scale = 1.f;   // epilogue scales of the NEXT op_gemm / op_conv3 call (reset by it): range extension, vae_engine.hip
-  // GroupNorm statistics from producer epilogues (GemmArgs.gn_*): the NEXT op_gemm / op_conv3 call emits them for its output when gn_next_hw > 0
-  // (rows per image; reset by the call) and registers the totals under the output's workspace offset; op_gn looks its sources up there.
-  int gn_epi = 0;            // IA2P_GN_EPI: 0 (default) every GroupNorm runs its own statistics pass (gn_stats_kernel); 1 producers emit the statistics from their
-                             // epilogues wherever they can; 2 only producers whose workgroups all fit the chip at once (<= 512). Built, parity-tested, measured and
-                             // left OFF: the pass it removes is a launch-floor-sized read served by L2 / Infinity Cache, what it adds (column pass, write-through drain,
-                             // ticket round trip, the last tile's acquire + fold) sits at the END of the producer's workgroups and costs as much -- same box, same
-                             // plans: batch 8 +0.06 ms (1) / +-0 (2), batch 1 +0.07 / +0.03, 1024^2 B_eff 2 +0.2 / +0.04 ms per step (profiles/r03c_gn_epilogue_ab.txt)
-  int gn_next_hw = 0;
-  size_t gn_next_off = (size_t)-1;
-  std::unordered_map<size_t, std::pair<size_t, double*>> gn_tot;   // tensor offset -> (offset, pointer) of its [B][C] double2 totals in the workspace
   bool fold_dirty = false;   // a LayerNorm-fold source tensor was (re)loaded after the last fold: re-fold before the next forward
   RunCtx() {
     if (const char* e = getenv("IA2P_PREFETCH")) prefetch = atoi(e) != 0;
     if (const char* e = getenv("IA2P_LN_FOLD")) ln_fold = atoi(e) != 0;
-    if (const char* e = getenv("IA2P_CHAIN")) chain = atoi(e) != 0;
-    if (const char* e = getenv("IA2P_KV_OVERLAP")) kv_overlap = atoi(e) != 0;
-    if (const char* e = getenv("IA2P_GN_EPI")) gn_epi = atoi(e);
     if (const char* e = getenv("IA2P_XATTN_FUSE")) xattn_fuse = atoi(e) != 0;
-    if (const char* e = getenv("IA2P_SC_FUSE")) sc_fuse = atoi(e) != 0;
-    if (const char* e = getenv("IA2P_CAT_FREE")) cat_free = atoi(e) != 0;
-    if (const char* e = getenv("IA2P_XATTN_MIN_TILES")) xattn_min_tiles = atoi(e);
+    if (const char* e = ia2p_exp_env("IA2P_SC_FUSE")) sc_fuse = atoi(e) != 0;
+    if (const char* e = ia2p_exp_env("IA2P_CAT_FREE")) cat_free = atoi(e) != 0;
+    if (ia2p_default_xattn_min_tiles() >= 0) xattn_min_tiles = ia2p_default_xattn_min_tiles();      // (test hook: ia2p_debug_set_xattn_min_tiles)
     for (int k = 0; k < PK_NCLASS; ++k) { p_ms[k] = p_fl[k] = p_by[k] = p_pf[k] = 0; p_n[k] = 0; }
     for (int k = 0; k < PR_NREGION; ++k) { r_ms[k] = r_fl[k] = r_by[k] = 0; r_n[k] = 0; }
   }
   ~RunCtx() {
     for (auto& r : recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     for (auto e : evpool) (void)hipEventDestroy(e);
-    if (ev_fork) (void)hipEventDestroy(ev_fork);
-    if (ev_join) (void)hipEventDestroy(ev_join);
-    if (side) (void)hipStreamDestroy(side);
   }
 };
 
@@ -236,10 +206,7 @@ void op_gemm(RunCtx* c, const half_t* A, int lda, const half_t* W, const half_t*
              const LnIn* ln = nullptr, float* stats_out = nullptr, int* stat_slots = nullptr, int act = 0);
 void op_conv3(RunCtx* c, const half_t* X, int B, int Hs, int Ws, int Cin, const half_t* W, const half_t* bias, int Co,
               int stride, int up, const half_t* rowvec, int rowvec_ld, const half_t* residual, half_t* Y, int pad_lo = 1, const half_t* X2 = nullptr, int Cin2 = 0, const half_t* X3 = nullptr, int Cin3 = 0);
-void op_gn(RunCtx* c, const half_t* x, half_t* y, size_t g, size_t b, int B, int HW, int C, float eps, int silu, float* partial, const half_t* x2 = nullptr, int Ca = 0,
-           size_t x_off = (size_t)-1, size_t x2_off = (size_t)-1);
-bool ia2p_gn_epilogue_ok(int variant, int M, int hw);
-int* ia2p_gn_tickets(hipStream_t s);
+void op_gn(RunCtx* c, const half_t* x, half_t* y, size_t g, size_t b, int B, int HW, int C, float eps, int silu, float* partial, const half_t* x2 = nullptr, int Ca = 0);
 void op_ln(RunCtx* c, const half_t* x, half_t* y, size_t g, size_t b, int M, int C);
 
 // ---- weight arena plumbing shared by the three contexts

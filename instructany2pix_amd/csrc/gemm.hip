@@ -45,7 +45,7 @@ struct ShapeRule { int M, N, K, v; };
 static const std::vector<ShapeRule>& shape_rules() {
   static std::vector<ShapeRule> rules = [] {
     std::vector<ShapeRule> r;
-    if (const char* e = getenv("IA2P_GEMM_RULES")) {
+    if (const char* e = ia2p_exp_env("IA2P_GEMM_RULES")) {
       const char* p = e;
       while (*p) {
         ShapeRule x;
@@ -138,8 +138,7 @@ extern "C" void ia2p_debug_set_gemm_splitk(int s) { g_force_splitk = s; }
 // Ticket counters of the in-launch K-split combine: one int per output tile, zero between launches (the last arriver of a tile resets its
 // counter). One buffer per (device, stream): launches on one stream are ordered, so two K-split launches can only share counters when they cannot
 // run at the same time -- contexts, executors and serving threads that work on different streams never see each other's tickets.
-// Layout of a pool buffer (ints): [0, SK) K-split tickets | [SK, SK + 1024) chain arrival counters | [.., + 1024) chain "consumers done" counters |
-// [.., + 1) chain give-up flag (+ padding) | last 1024: spare
+// Layout of a pool buffer (ints): [0, SK) K-split tickets | spare
 static constexpr int POOL_INTS = 1 << 18, POOL_SK = POOL_INTS - 4096;
 int ia2p_sk_counter_capacity() { return POOL_SK; }
 static int* pool_buffer(hipStream_t s) {
@@ -155,7 +154,7 @@ static int* pool_buffer(hipStream_t s) {
   if (hipMalloc((void**)&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess) {      // (hipMemset: synchronous with respect to the host, done before the first launch)
     (void)hipGetLastError();
     if (p) (void)hipFree(p);
-    p = nullptr;                      // remembered: this stream's K-splits are finished by reduce launches, its chains run as separate launches
+    p = nullptr;                      // remembered: this stream's K-splits are finished by reduce launches
   }
   pool[{dev, s}] = p;
   return p;
@@ -186,22 +185,6 @@ const float* ia2p_phi_lut() {
   }
   return tab[dev];
 }
-// GroupNorm statistics from a GEMM epilogue: per-image arrival counters (<= 1024 images) of this (device, stream)
-int* ia2p_gn_tickets(hipStream_t s) { int* p = pool_buffer(s); return p ? p + POOL_SK + 3072 : nullptr; }
-// a tile must lie inside one image: the variant's tile height divides the rows per image
-bool ia2p_gn_epilogue_ok(int variant, int M, int hw) {
-  if (variant < 0 || variant >= IA2P_GEMM_NVARIANT || hw <= 0) return false;
-  const int bm = IA2P_GEMM_TILES[variant].bm;
-  return hw >= bm && hw % bm == 0 && M % hw == 0 && M / hw <= 1024;
-}
-// chained launches: arrival counters (<= 1024 row panels), their "done" twins and the give-up flag of this (device, stream)
-bool ia2p_chain_words(hipStream_t s, int** cnt, int** done, unsigned** err) {
-  int* p = pool_buffer(s);
-  if (!p) return false;
-  *cnt = p + POOL_SK; *done = p + POOL_SK + 1024; *err = (unsigned*)(p + POOL_SK + 2048);
-  return true;
-}
-
 // ---- tile / split-K choice: a small analytic cost model, calibrated on MI355X against the in-place timings of ~5400
 // candidate launches that ia2p_autotune logged (IA2P_TUNE_LOG=1) for three workloads (batch 8 and 2 at 512^2, batch 4 at
 // 768^2). Per CU, the tiles it owns (a blend of the mean and the worst CU) cost, per k-step, the largest of

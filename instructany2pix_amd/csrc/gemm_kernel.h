@@ -15,7 +15,6 @@ bool ia2p_splitk_inkernel(int M, int N, int splitk);
 int ia2p_sk_counter_capacity();
 int* ia2p_sk_counters(hipStream_t s, int tiles);
 const float* ia2p_phi_lut();
-bool ia2p_chain_words(hipStream_t s, int** cnt, int** done, unsigned** err);
 
 #define GLDS16(gptr, ldsptr)                                                                         \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),            \
@@ -74,59 +73,6 @@ struct EpiCfg {
   static constexpr int SMEM = STAGE_BYTES > TILE_BYTES + extra(CR) ? STAGE_BYTES : TILE_BYTES + extra(CR);
 };
 
-// How a tile body is embedded in its launch. Plain launches: bid = blockIdx.x, no hooks. Chained launches (chain.hip: two dependent GEMMs in ONE
-// launch, the consumer's tiles waiting on per-row-panel counters of the producer instead of on a kernel boundary): the producer's tiles signal, the
-// consumer's tiles wait.
-struct TileCtl {
-  int bid;                 // block id inside THIS GEMM's grid (tiles x K-slices, then its prefetch workgroups)
-  const int* dep_cnt;      // consumer: arrival counters of the producer, one per `dep_rows` output rows (null: no dependency)
-  int dep_target;          //   arrivals that complete a panel (the producer's tile columns)
-  int dep_rows;
-  int* dep_done;           //   consumers that have passed the wait, per panel: the last of `dep_consumers` resets both words for the next launch
-  int dep_consumers;
-  int* sig_cnt;            // producer: the counter of the panel this tile belongs to gets +1 once the tile's C rows are written through
-  int sig_rows;
-  unsigned* err;           // bounded spins give up into this word (never hang the GPU); the host checks it
-  int diag;                // timing diagnostics only (IA2P_CHAIN_DIAG; results may be WRONG): 1 producer signals without draining its stores, 2 long poll sleep,
-                           // 4 consumer skips the acquire, 8 consumer does not wait at all
-};
-typedef __attribute__((address_space(1))) int gi32;
-
-// consumer side of the hand-off (cdna_hip_programming.md Guideline 16, R1 consume): ONE lane polls ONE word relaxed, then ONE agent-scope acquire drops
-// this CU's stale lines; the other waves load behind the workgroup barrier. The producer's rows were stored write-through and drained before its add.
-__device__ __forceinline__ void tile_wait_panel(const TileCtl& c, int row0, int tid) {
-  if (tid == 0) {
-    const int panel = row0 / c.dep_rows;
-    unsigned spins = 0;
-    while (!(c.diag & 8) && __hip_atomic_load((const gi32*)(c.dep_cnt + panel), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < c.dep_target) {
-      if (c.diag & 2) __builtin_amdgcn_s_sleep(32); else __builtin_amdgcn_s_sleep(2);
-      if (++spins > (1u << 22)) { __hip_atomic_fetch_or((__attribute__((address_space(1))) unsigned*)c.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // ~seconds: give up, flag it
-    }
-    if (!(c.diag & 4)) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-  }
-  __syncthreads();
-}
-// a consumer tile leaves: the last of a panel's consumers re-arms the panel for the next launch (every consumer of the panel passed its wait long ago;
-// the next chained launch on the stream starts behind this kernel's end). Off the tile's critical path: nothing waits for the returned value but the exit.
-__device__ __forceinline__ void tile_release_panel(const TileCtl& c, int row0, int tid) {
-  if (tid == 0) {
-    const int panel = row0 / c.dep_rows;
-    if (__hip_atomic_fetch_add((gi32*)(c.dep_done + panel), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == c.dep_consumers - 1) {
-      __hip_atomic_store((gi32*)(c.dep_cnt + panel), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store((gi32*)(c.dep_done + panel), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-// producer side (R1 publish): every storing wave drains its write-through stores, the workgroup meets, ONE lane adds
-__device__ __forceinline__ void tile_signal_panel(const TileCtl& c, int row0, int tid) {
-  if (!(c.diag & 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) __hip_atomic_fetch_add((gi32*)(c.sig_cnt + row0 / c.sig_rows), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // PP = 1 ("ping-pong", 8 waves = WGM 4, 3-stage ring, ONE workgroup per CU): waves 0-3 own the upper half of the tile rows, waves 4-7 the
 // lower half, and the two groups run half a k-step apart -- while one group reads its fragments from LDS the other issues its MFMAs, with a
 // workgroup barrier between the half-steps. Eight waves behind one barrier per k-step would all read, then all multiply (the LDS and the
@@ -136,7 +82,7 @@ __device__ __forceinline__ void tile_signal_panel(const TileCtl& c, int row0, in
 // into the Q fragments of the attention core (attention_core.h, MODE = XA - 1) and writes the cross-attention output instead.
 template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int BK = 64, int PP = 0, int WGN = 2, int XA = 0>
 __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* hW, const half_t* hzero, int hM, int hN, int hK, int hlda, int hldw, int hrpb, int hbstride,
-                                               int hroff, int hsplitk, int hgroup_w, const GemmArgs& p, const AttnArgs* xa, const TileCtl& ctl) {
+                                               int hroff, int hsplitk, int hgroup_w, const GemmArgs& p, const AttnArgs* xa) {
   // The leading 16 dwords of the argument list are what the prologue needs; built with -amdgpu-kernarg-preload-count=16 the command processor
   // hands them over in SGPRs, so the first tile loads go out without waiting for a cold read of the argument block (which costs every launch
   // ~1 us: tools/micro/launch_floor2.hip). The rest of GemmArgs (epilogue, conv geometry) arrives while those loads fly.   // >= 2 waves/SIMD: big tiles must fit 256 registers
@@ -164,7 +110,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
 
   // ---- tile of this workgroup; blocks b, b+8, ... share an XCD (its L2): give each XCD a contiguous tile range
   const int tiles_m = (hM + BM - 1) / BM, tiles_n = (hN + BN - 1) / BN;
-  int bid = ctl.bid;
+  int bid = blockIdx.x;
   const int nsplit = hsplitk > 1 ? hsplitk : 1;
   const int split = bid / (tiles_m * tiles_n);          // >= nsplit: prefetch workgroup
   if (split < nsplit) bid -= split * tiles_m * tiles_n;
@@ -205,7 +151,6 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   } else if (p.m_fastest) { tn = bid / tiles_m; tm = bid - tn * tiles_m; }
   else                    { tm = bid / tiles_n; tn = bid - tm * tiles_n; }
   const int bm0 = tm * BM, bn0 = tn * BN;
-  if (ctl.dep_cnt) tile_wait_panel(ctl, bm0, tid);        // chained launch: this tile's A rows come from tiles of the same launch
 
   // ---- staging addresses. Piece `pi` covers tile rows pi*8 .. pi*8+7; lane -> (row pi*8 + lane/8, LDS chunk lane%8),
   //      which must hold global chunk (lane%8) ^ swz(row), swz(row) = (row>>1)&7.
@@ -681,7 +626,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   if (PP && p.pf) {
     const long nwg = (long)tiles_m * tiles_n * nsplit;
     const long per = ((p.pf_bytes + nwg - 1) / nwg + 255) & ~255L;
-    const long lo = (long)ctl.bid * per, hi = min(lo + per, p.pf_bytes & ~15L);
+    const long lo = (long)blockIdx.x * per, hi = min(lo + per, p.pf_bytes & ~15L);
     const char* src = (const char*)p.pf;
     constexpr long SW = NWAVE * 64 * 16;
     if (lo < hi)
@@ -821,12 +766,12 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
         }
       }
     }
-    if (!p.sk_counters) { pf_sink(); if (ctl.dep_cnt) tile_release_panel(ctl, bm0, tid); return; }      // finished by a separate splitk_reduce_kernel launch (A/B switch)
+    if (!p.sk_counters) { pf_sink(); return; }      // finished by a separate splitk_reduce_kernel launch (A/B switch)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // EVERY storing wave drains its write-through stores ...
     __syncthreads();                                       // ... before ONE lane signals for the workgroup
     if (tid == 0) *sk_flag = __hip_atomic_fetch_add(p.sk_counters + (tm * tiles_n + tn), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    if (*sk_flag != nsplit - 1) { pf_sink(); if (ctl.dep_cnt) tile_release_panel(ctl, bm0, tid); return; }
+    if (*sk_flag != nsplit - 1) { pf_sink(); return; }
     if (tid == 0) {
       __hip_atomic_store(p.sk_counters + (tm * tiles_n + tn), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch (launches are stream-ordered)
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // drop this CU's stale lines before the plain loads below
@@ -835,9 +780,6 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
     __syncthreads();
     from_slabs = true;
   }
-  // GroupNorm statistics of the output (p.gn_cols): thread (column quad c4, row slice gsl) sums the ROUNDED values of its columns over the tile rows
-  constexpr int GQ = BN / 4, GNSL = NT / GQ;
-  float gcol_a = 0.f, gcol_q = 0.f;        // thread c < BN: {sum, sum of squares} of tile column c over the chunks done so far (two registers live across the chunks)
 #pragma unroll(PP == 2 ? 2 : 1)
   for (int ch = 0; ch < EC::NCHUNK; ++ch) {
     if (ch || from_slabs) __syncthreads();          // the previous chunk has been read out
@@ -1022,12 +964,6 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
             if (live[u]) store_c8((size_t)(row0 + r) * p.ldc + bn0 + cl, o);
-            if (p.gn_cols && tid + (k * U + u) * NT < TOTAL) {      // the value as stored (fp16) goes back into the tile slot it came from (only this thread touches it)
-              const f4 w0 = live[u] ? (f4){(float)o[0], (float)o[1], (float)o[2], (float)o[3]} : (f4){0.f, 0.f, 0.f, 0.f};
-              const f4 w1 = live[u] ? (f4){(float)o[4], (float)o[5], (float)o[6], (float)o[7]} : (f4){0.f, 0.f, 0.f, 0.f};
-              *(f4*)(tile + (size_t)r * PITCH + (((2 * gg[u]) ^ (r & 7)) << 2)) = w0;
-              *(f4*)(tile + (size_t)r * PITCH + (((2 * gg[u] + 1) ^ (r & 7)) << 2)) = w1;
-            }
             st1[u] = st2[u] = 0.f;
             if (p.stats_out && live[u]) {
 #pragma unroll
@@ -1092,72 +1028,9 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
           }
         }
       }
-      if (p.gn_cols) {                 // column pass over the rounded chunk: thread (column quad gc4, row slice gsl) sums rows gsl, gsl + GNSL, ... (fixed order: deterministic),
-        __syncthreads();               // the slices meet in LDS (the chunk has been read out by then) and thread c < BN adds them up in slice order
-        const int gc4 = tid % GQ, gsl = tid / GQ;
-        f4 gsum = {0.f, 0.f, 0.f, 0.f}, gsq = {0.f, 0.f, 0.f, 0.f};
-        if (gsl < GNSL) {
-          for (int r = gsl; r < CR; r += GNSL) {
-            const f4 v = tl(r, gc4);
-            gsum[0] += v[0]; gsum[1] += v[1]; gsum[2] += v[2]; gsum[3] += v[3];
-            gsq[0] = fmaf(v[0], v[0], gsq[0]); gsq[1] = fmaf(v[1], v[1], gsq[1]); gsq[2] = fmaf(v[2], v[2], gsq[2]); gsq[3] = fmaf(v[3], v[3], gsq[3]);
-          }
-        }
-        __syncthreads();               // every column pass is through: the tile memory is free
-        float* red = tile;             // [GNSL][BN] {sum, sum of squares}
-        if (gsl < GNSL) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) *(float2*)(red + ((size_t)(gsl * BN + gc4 * 4 + e) << 1)) = make_float2(gsum[e], gsq[e]);
-        }
-        __syncthreads();
-        if (tid < BN) {
-#pragma unroll
-          for (int sl = 0; sl < GNSL; ++sl) { const float2 v = *(const float2*)(red + ((size_t)(sl * BN + tid) << 1)); gcol_a += v.x; gcol_q += v.y; }
-        }
-      }
-    }
-  }
-  if (p.gn_cols && !p.geglu) {
-    // ---- GroupNorm statistics, producer side: column sums of this tile -> gn_cols; the last tile of the image folds the image's tiles (in tile order, fp64)
-    //      into gn_tot. Hand-off as for the K-split slabs: write-through stores, every wave drains, ONE lane draws the ticket; the folding workgroup takes
-    //      an agent-scope acquire (cdna_hip_programming.md Guideline 16).
-    if (tid < BN && bn0 + tid < hN) {
-      typedef unsigned u2v __attribute__((__vector_size__(2 * sizeof(unsigned))));
-      const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc((void*)p.gn_cols, 0, (int)min((size_t)tiles_m * hN * 8, (size_t)0x7ffffff0), 0x00020000);
-      const float2 v = make_float2(gcol_a, gcol_q);
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, v), gr, (int)(((size_t)tm * hN + bn0 + tid) * 8), 0, 16);      // sc1: write-through
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const int img = bm0 / p.gn_hw, tpi = p.gn_hw / BM;
-    if (tid == 0) *sk_flag = __hip_atomic_fetch_add(p.gn_tickets + img, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    if (*sk_flag == tpi * tiles_n - 1) {
-      if (tid == 0) {
-        __hip_atomic_store(p.gn_tickets + img, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      __syncthreads();
-      for (int col = tid; col < hN; col += NT) {
-        const float2* src = (const float2*)p.gn_cols + (size_t)img * tpi * hN + col;
-        double a = 0.0, q = 0.0;
-        for (int t0 = 0; t0 < tpi; t0 += 8) {
-          float2 v[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) v[u] = src[(size_t)min(t0 + u, tpi - 1) * hN];      // all loads of a round in flight (clamped, never branched around)
-#pragma unroll
-          for (int u = 0; u < 8; ++u)
-            if (t0 + u < tpi) { a += (double)v[u].x; q += (double)v[u].y; }
-        }
-        p.gn_tot[((size_t)img * hN + col) * 2] = a;
-        p.gn_tot[((size_t)img * hN + col) * 2 + 1] = q;
-      }
     }
   }
   pf_sink();
-  if (ctl.sig_cnt) tile_signal_panel(ctl, bm0, tid);      // chained launch: this tile's rows are written (write-through): count it into its row panel
-  if (ctl.dep_cnt) tile_release_panel(ctl, bm0, tid);
 #ifdef IA2P_CLOCK_STAMP
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the C stores of this wave have left
   __syncthreads();
@@ -1168,8 +1041,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
 template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int BK = 64, int PP = 0, int WGN = 2>
 __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_f16_kernel(const half_t* hA, const half_t* hW, const half_t* hzero, int hM, int hN, int hK, int hlda, int hldw, int hrpb, int hbstride,
                                                                          int hroff, int hsplitk, int hgroup_w, const GemmArgs p) {
-  const TileCtl ctl{(int)blockIdx.x, nullptr, 0, 1, nullptr, 0, nullptr, 1, nullptr, 0};
-  gemm_tile_body<BM, BN, NSTAGE, CONV, WGM, BK, PP, WGN, 0>(hA, hW, hzero, hM, hN, hK, hlda, hldw, hrpb, hbstride, hroff, hsplitk, hgroup_w, p, nullptr, ctl);
+  gemm_tile_body<BM, BN, NSTAGE, CONV, WGM, BK, PP, WGN, 0>(hA, hW, hzero, hM, hN, hK, hlda, hldw, hrpb, hbstride, hroff, hsplitk, hgroup_w, p, nullptr);
 }
 
 // grouped tile order: panel width (in tiles) such that the contiguous tile range an XCD works on is a compact block; 0 = plain order.
@@ -1182,7 +1054,7 @@ static inline int ia2p_tile_group_w(int tiles, int tiles_n, int smem, double a_o
   if (!group_mode) return 0;
   const int smem_per_cu = 160 * 1024 / smem;                                   // co-resident workgroups per CU by LDS
   const double resident = std::min<double>(tiles / 8.0, 32.0 * std::max(1, std::min(smem_per_cu, 2)));   // tiles an XCD holds at once
-  static const double gscale = getenv("IA2P_TILE_GROUP_SCALE") ? atof(getenv("IA2P_TILE_GROUP_SCALE")) : 1.0;
+  static const double gscale = ia2p_exp_env("IA2P_TILE_GROUP_SCALE") ? atof(ia2p_exp_env("IA2P_TILE_GROUP_SCALE")) : 1.0;
   const int w = (int)(gscale * std::sqrt(resident * a_over_w) + 0.5);
   return std::max(1, std::min(w, tiles_n));
 }
@@ -1221,7 +1093,6 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
   ia2p_gemm_prepare(b, smem, BM, BN, CONV);
   if (a.geglu && !b.vec8) return hipErrorInvalidValue;
   if (a.geglu && !b.phi_lut) return hipErrorOutOfMemory;
-  if (a.gn_cols && (!b.vec8 || a.geglu || !a.gn_tot || !a.gn_tickets || a.gn_hw < BM || a.gn_hw % BM || a.M % a.gn_hw)) return hipErrorInvalidValue;   // (callers ask ia2p_gn_epilogue_ok first)
   // b.sk_counters: as the caller (launch_any, gemm.hip) attached them -- null: the K-slices only write their slabs and a splitk_reduce_kernel launch finishes
   if (b.sk_counters && tiles > ia2p_sk_counter_capacity()) return hipErrorInvalidValue;
   const int extra = (!PP && a.pf && a.pf_bytes >= 4096) ? a.pf_blocks : 0;

@@ -100,8 +100,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* ax, half_t*
 
 template <int V>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* ax, half_t* ay, const half_t* agamma, const half_t* abeta, float* apartial, int aB, int aHW, int aC, int aG,
-                                                           int achunks, int arows_, int aarows, int aldx, int aldy, float aeps, int asilu, const half_t* ax2, int aldx2, int aCa,
-                                                           const double* atot1, const double* atot2) {
+                                                           int achunks, int arows_, int aarows, int aldx, int aldy, float aeps, int asilu, const half_t* ax2, int aldx2, int aCa) {
   // scalar arguments (the first 16 dwords are preloaded into SGPRs: build.py PRELOAD), re-assembled into the descriptor the body uses
   GNArgs p;
   p.x = ax; p.y = ay; p.gamma = agamma; p.beta = abeta; p.partial = apartial; p.B = aB; p.HW = aHW; p.C = aC; p.G = aG; p.chunks = achunks;
@@ -112,32 +111,6 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* ax, half_t*
   const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
   const int b = blockIdx.y, r0 = blockIdx.x * p.arows, r1 = min(r0 + p.arows, p.HW);
   const int Cg = p.C / p.G;
-  if (atot1) {
-    // statistics from the PRODUCER's epilogue (GemmArgs.gn_tot): per image and column {sum, sum of squares} in fp64, one table per source tensor
-    // (atot2: the skip half of an up-block input, channels [Ca, C)). 256 / G threads share a group's columns, combined through LDS in slice order.
-    double* fold = (double*)(stat + 2 * p.G);          // [nsl][G][2]
-    const int nsl = blockDim.x / p.G, g = threadIdx.x % p.G, sl = threadIdx.x / p.G;
-    const int c1 = atot2 ? p.Ca : p.C;                 // channels of the first source
-    if (sl < nsl) {
-      double a = 0.0, q = 0.0;
-      for (int c = g * Cg + sl; c < (g + 1) * Cg; c += nsl) {
-        const double* t = c < c1 ? atot1 + ((size_t)b * c1 + c) * 2 : atot2 + ((size_t)b * (p.C - c1) + (c - c1)) * 2;
-        a += t[0]; q += t[1];
-      }
-      fold[(sl * p.G + g) * 2] = a; fold[(sl * p.G + g) * 2 + 1] = q;
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < p.G) {
-      double a = 0.0, q = 0.0;
-      for (int t = 0; t < nsl; ++t) { a += fold[(t * p.G + g) * 2]; q += fold[(t * p.G + g) * 2 + 1]; }
-      const double n = (double)p.HW * Cg;
-      const double mean = a / n;
-      double var = q / n - mean * mean;
-      if (var < 0.0) var = 0.0;
-      stat[g * 2] = (float)mean;
-      stat[g * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
-    }
-  } else
   {   // fold the chunk partials of this batch: all threads, (group, chunk-slice) each, then across slices in fp64
     double* fold = (double*)(stat + 2 * p.G);          // [nsl][G][2]
     const int nsl = blockDim.x / p.G, g = threadIdx.x % p.G, sl = threadIdx.x / p.G;
@@ -216,17 +189,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* ax, half_t*
 
 // partial must hold B*chunks*G*2 floats. Returns the chunk count it used via *chunks_out when partial == null.
 int ia2p_gn_chunks(int B, int HW) {
-  static const int cap = getenv("IA2P_GN_STATS_WGS") ? atoi(getenv("IA2P_GN_STATS_WGS")) : 512;      // tuning hook (tools/gn_bench.py)
+  static const int cap = ia2p_exp_env("IA2P_GN_STATS_WGS") ? atoi(ia2p_exp_env("IA2P_GN_STATS_WGS")) : 512;      // tuning hook (tools/gn_bench.py)
   int chunks = 1;
   while (chunks < 64 && B * chunks < cap && (HW / (chunks * 2)) >= 8) chunks *= 2;
   return chunks;
 }
 
 hipError_t ia2p_launch_groupnorm(const half_t* x, int ldx, half_t* y, int ldy, const half_t* gamma, const half_t* beta,
-                                 float* partial, int B, int HW, int C, int G, float eps, int silu, hipStream_t s, const half_t* x2, int ldx2, int Ca,
-                                 const double* tot1, const double* tot2) {
-  // tot1 (and tot2 for a second source): the statistics come from the producers' epilogues -- no gn_stats_kernel launch, no second read of the tensor
-  if ((x2 != nullptr) != (tot2 != nullptr) && tot1) return hipErrorInvalidValue;
+                                 float* partial, int B, int HW, int C, int G, float eps, int silu, hipStream_t s, const half_t* x2, int ldx2, int Ca) {
   if (x2 && (Ca % 8 || Ca <= 0 || Ca >= C)) return hipErrorInvalidValue;
   GNArgs a;
   a.x2 = x2; a.ldx2 = ldx2; a.Ca = Ca;
@@ -241,7 +211,7 @@ hipError_t ia2p_launch_groupnorm(const half_t* x, int ldx, half_t* y, int ldy, c
   if (V > 2 || C % 8 || C % G) return hipErrorInvalidValue;
   const int TX = nvec / V, TY = 256 / TX;
   // apply pass: ~2k workgroups, each thread streaming >= 4 rows
-  static const int acap = getenv("IA2P_GN_APPLY_WGS") ? atoi(getenv("IA2P_GN_APPLY_WGS")) : 2048;    // tuning hook
+  constexpr int acap = 2048;
   int ablocks = 1;
   while (B * ablocks < acap && HW / (ablocks * 2) >= 4 * TY) ablocks *= 2;
   a.arows = (HW + ablocks - 1) / ablocks;
@@ -251,11 +221,11 @@ hipError_t ia2p_launch_groupnorm(const half_t* x, int ldx, half_t* y, int ldy, c
   if (sm1 > 65536) return hipErrorInvalidValue;
   const int wtf = ((ia2p_wt_mask() & 4) && (size_t)HW * ldy * 2 < (size_t)0x7ffffff0) ? 2 : 0;      // write-through y (per batch element: 32-bit offsets)
   if (V == 1) {
-    if (!tot1) hipLaunchKernelGGL(gn_stats_kernel<1>, grid, block, sm1, s, a.x, a.y, a.gamma, a.beta, a.partial, a.B, a.HW, a.C, a.G, a.chunks, a.rows, a.arows, a.ldx, a.ldy, a.eps, a.silu, a.x2, a.ldx2, a.Ca);
-    hipLaunchKernelGGL(gn_apply_kernel<1>, agrid, block, sm2, s, a.x, a.y, a.gamma, a.beta, a.partial, a.B, a.HW, a.C, a.G, a.chunks, a.rows, a.arows, a.ldx, a.ldy, a.eps, a.silu | wtf, a.x2, a.ldx2, a.Ca, tot1, tot2);
+    hipLaunchKernelGGL(gn_stats_kernel<1>, grid, block, sm1, s, a.x, a.y, a.gamma, a.beta, a.partial, a.B, a.HW, a.C, a.G, a.chunks, a.rows, a.arows, a.ldx, a.ldy, a.eps, a.silu, a.x2, a.ldx2, a.Ca);
+    hipLaunchKernelGGL(gn_apply_kernel<1>, agrid, block, sm2, s, a.x, a.y, a.gamma, a.beta, a.partial, a.B, a.HW, a.C, a.G, a.chunks, a.rows, a.arows, a.ldx, a.ldy, a.eps, a.silu | wtf, a.x2, a.ldx2, a.Ca);
   } else {
-    if (!tot1) hipLaunchKernelGGL(gn_stats_kernel<2>, grid, block, sm1, s, a.x, a.y, a.gamma, a.beta, a.partial, a.B, a.HW, a.C, a.G, a.chunks, a.rows, a.arows, a.ldx, a.ldy, a.eps, a.silu, a.x2, a.ldx2, a.Ca);
-    hipLaunchKernelGGL(gn_apply_kernel<2>, agrid, block, sm2, s, a.x, a.y, a.gamma, a.beta, a.partial, a.B, a.HW, a.C, a.G, a.chunks, a.rows, a.arows, a.ldx, a.ldy, a.eps, a.silu | wtf, a.x2, a.ldx2, a.Ca, tot1, tot2);
+    hipLaunchKernelGGL(gn_stats_kernel<2>, grid, block, sm1, s, a.x, a.y, a.gamma, a.beta, a.partial, a.B, a.HW, a.C, a.G, a.chunks, a.rows, a.arows, a.ldx, a.ldy, a.eps, a.silu, a.x2, a.ldx2, a.Ca);
+    hipLaunchKernelGGL(gn_apply_kernel<2>, agrid, block, sm2, s, a.x, a.y, a.gamma, a.beta, a.partial, a.B, a.HW, a.C, a.G, a.chunks, a.rows, a.arows, a.ldx, a.ldy, a.eps, a.silu | wtf, a.x2, a.ldx2, a.Ca);
   }
   return hipGetLastError();
 }

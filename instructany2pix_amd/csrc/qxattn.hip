@@ -17,8 +17,7 @@
 template <int MODE>      // attention core mode: 0 one key segment; 1 text + <= 64 image-token keys; 2 generic two segments
 __global__ __launch_bounds__(256, 2) void qproj_xattn_kernel(const half_t* hA, const half_t* hW, const half_t* hzero, int hM, int hN, int hK, int hlda, int hldw, int hrpb,
                                                              int hbstride, int hroff, int hsplitk, int hgroup_w, const GemmArgs p, const AttnArgs xa) {
-  const TileCtl ctl{(int)blockIdx.x, nullptr, 0, 1, nullptr, 0, nullptr, 1, nullptr, 0};
-  gemm_tile_body<128, 64, IA2P_QX_STAGES, false, 2, 64, 0, 2, MODE + 1>(hA, hW, hzero, hM, hN, hK, hlda, hldw, hrpb, hbstride, hroff, hsplitk, hgroup_w, p, &xa, ctl);
+  gemm_tile_body<128, 64, IA2P_QX_STAGES, false, 2, 64, 0, 2, MODE + 1>(hA, hW, hzero, hM, hN, hK, hlda, hldw, hrpb, hbstride, hroff, hsplitk, hgroup_w, p, &xa);
 }
 
 // Q = epilogue(A . W^T) is [B * Nq, heads * 64]; x.Q / x.ldq are ignored (Q stays on chip). Requires Nq % 128 == 0 (a tile must not straddle

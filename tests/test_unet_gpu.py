@@ -333,9 +333,12 @@ def test_fused_qproj_cross_attention_switch_agrees(tiny_models, monkeypatch):
     monkeypatch.setenv("IA2P_XATTN_FUSE", "0")
     plain = HipUNet2DConditionModel(cfg, DEV)
     monkeypatch.delenv("IA2P_XATTN_FUSE")
-    monkeypatch.setenv("IA2P_XATTN_MIN_TILES", "1")      # (by default only launches of >= 128 tiles are fused: the tiny model has fewer)
-    hip = HipUNet2DConditionModel(cfg, DEV)
-    monkeypatch.delenv("IA2P_XATTN_MIN_TILES")
+    from instructany2pix_amd import _ffi
+    _ffi.lib().ia2p_debug_set_xattn_min_tiles(1)           # (by default only launches of >= 128 tiles are fused: the tiny model has fewer)
+    try:
+        hip = HipUNet2DConditionModel(cfg, DEV)
+    finally:
+        _ffi.lib().ia2p_debug_set_xattn_min_tiles(-1)
     plain.load_state_dict(sd); hip.load_state_dict(sd)
     for L_, ip in ((81, True), (77, False)):
         for m in (hip, plain):
@@ -420,43 +423,3 @@ def test_load_unet_safetensors_gives_the_same_bits(tiny_models, tmp_path):
     assert torch.equal(fresh(x, 401, **kw)[0], moved)
 
 
-@pytest.mark.parametrize("B,h,w,L", [(2, 16, 16, 81), (8, 32, 32, 81), (1, 16, 24, 77)])
-def test_executor_switches_keep_parity(tiny_models, monkeypatch, B, h, w, L):
-    """The measured-and-left-off structures of round 3 stay correct: the feed-forward pair as ONE launch (IA2P_CHAIN=1: the bits of two launches, no wait
-    ever gives up) and GroupNorm statistics from the producers' epilogues (IA2P_GN_EPI=1 / 2: the statistics pass over the tensor replaced by
-    per-image column totals from the GEMM / conv epilogues -- a different fp32 summation order, so oracle tolerance, not bits); the in-step
-    context projection on a low-priority side stream (IA2P_KV_OVERLAP=1) against in line: same kernels, same bits, run twice (the second pass
-    reuses the workspace behind the join)."""
-    from instructany2pix_amd import _ffi
-    from instructany2pix_amd.unet import HipUNet2DConditionModel
-    cfg, sd, ipsd, hip, oracle = tiny_models
-    x, ctx, te, tid = _inputs(cfg, B, h, w, L, seed=7 * B + L)
-    args = (x.to(DEV), 501)
-    kw = dict(encoder_hidden_states=ctx.to(DEV), added_cond_kwargs=dict(text_embeds=te.to(DEV), time_ids=tid.to(DEV)))
-    _install_ip(hip, cfg, ipsd, 0.8)
-    base = hip(*args, **kw)[0].clone()
-    ref_net = oracle.build_unet(cfg, sd, ipsd, ip_scale=0.8)
-    with torch.no_grad():
-        ref = ref_net(x.float(), 501, ctx.float(), added_cond_kwargs=dict(text_embeds=te.float(), time_ids=tid.float()))[0]
-    for env, exact in ((dict(IA2P_CHAIN="1"), True), (dict(IA2P_KV_OVERLAP="1"), True), (dict(IA2P_GN_EPI="1"), False), (dict(IA2P_GN_EPI="2"), False), (dict(IA2P_CHAIN="1", IA2P_GN_EPI="1"), False)):
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)               # read when the context is created
-        m = HipUNet2DConditionModel(cfg, DEV)
-        for k in env:
-            monkeypatch.delenv(k)
-        m.load_state_dict(sd)
-        _install_ip(m, cfg, ipsd, 0.8)
-        out = m(*args, **kw)[0]
-        if "IA2P_KV_OVERLAP" in env:
-            hip.cache_context_kv = False    # the in-step context projection: in line by default, on the side stream in `m`
-            assert torch.equal(hip(*args, **kw)[0], base)
-            hip.cache_context_kv = True
-            m.cache_context_kv = False
-            out = m(*args, **kw)[0].clone()
-            assert torch.equal(m(*args, **kw)[0], out)
-        torch.cuda.synchronize()
-        assert _ffi.lib().ia2p_chain_errors(_ffi.current_stream()) == 0
-        if exact:
-            assert torch.equal(out, base), env
-        assert rel_l2(out, ref) < 5e-3, (env, rel_l2(out, ref))
-        assert rel_l2(out, base) < 3e-3, (env, rel_l2(out, base))
