@@ -223,6 +223,11 @@ ia2p_status ia2p_linear_small(void* stream, const void* X, const void* W, const 
                               int silu_in, int silu_out);
 
 void ia2p_debug_set_gemm_splitk(int splitk);  /* -1 auto (tests / tuning; engine path only) */
+/* K-split ticket counters (one buffer per device and stream) start a new epoch: each stream's buffer is re-zeroed, on that stream, in front of its next
+ * K-split launch. The library does this itself when a context is created and whenever it reports IA2P_ERR_HIP (a launch that died mid-flight may have left
+ * tickets behind); exported for tests and for hosts that catch a device error outside the library. */
+void ia2p_debug_invalidate_splitk_counters(void);
+int ia2p_debug_fill_splitk_counters(void* stream, int value);   /* tests: every ticket of the stream's buffer := value, on the stream (non-zero = what a dead launch leaves); 0 / -1 */
 void ia2p_debug_set_splitk_inkernel(long long bytes); /* slab-set size (splitk*M*N*4) up to which a K split combines inside the GEMM launch; < 0: IA2P_SPLITK_INKERNEL / default (tests, A/B runs) */
 void ia2p_debug_set_gemm_tile(int variant);   /* -1 auto; else index into IA2P_GEMM_TILES of csrc/common.h, 0..23 (tests / tuning) */
 /* fused to_q + cross-attention: contexts created AFTER this call fuse launches of at least `tiles` 128-query x head tiles (-1: the built-in 128). Tests only:

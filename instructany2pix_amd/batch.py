@@ -144,6 +144,14 @@ def denoise_batch(pipeline, requests: List[EditRequest], group: int = 4, shard: 
     for r in requests:
         if r.num_inference_steps is None or int(r.num_inference_steps) <= 0:
             raise ValueError(f"`num_inference_steps` has to be a positive integer but is {r.num_inference_steps}")
+        if float(r.cfg) <= 1.0:
+            # the reference (and pipeline.denoise) switch guidance OFF at guidance_scale <= 1 -- one conditional evaluation, eps = eps_c (sdxl_pipeline.py:842-844
+            # behind do_classifier_free_guidance) -- while a batched group always evaluates [uncond | cond] and blends: not the same numbers. Say so instead.
+            raise ValueError(f"denoise_batch blends eps_u + g (eps_c - eps_u) for every request; cfg={r.cfg} <= 1 means NO guidance in the reference: run that request "
+                             f"through pipeline.denoise / __call__ instead")
+    if not 1 <= int(group) <= 8:
+        raise ValueError(f"group={group}: a group is one launch sequence of 1..8 requests (B_eff = 2 * group <= 16 rows, the limit of the image-projection and "
+                         f"embedding kernels)")
     # polar-mixing noise comes from the global CPU RNG in REQUEST order (what N sequential reference calls would draw), on every rank alike
     noises = [r.noise if r.noise is not None else torch.randn(r.base_latents.shape, dtype=torch.float16) for r in requests]
     world = torch.distributed.get_world_size() if (shard and torch.distributed.is_available() and torch.distributed.is_initialized()) else 1

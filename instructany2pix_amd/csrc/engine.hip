@@ -93,6 +93,7 @@ ia2p_status fail(RunCtx* c, ia2p_status st, const char* fmt, ...) {
   va_end(ap);
   if (c) { c->err = buf; c->failed = true; }
   g_err = buf;
+  if (st == IA2P_ERR_HIP) ia2p_sk_counters_invalidate();      // a launch may have died mid-flight: K-split tickets are re-zeroed before their next use
   return st;
 }
 
@@ -860,6 +861,7 @@ ia2p_status ia2p_create(const ia2p_unet_config* cfg, ia2p_ctx** out) {
   if (st != IA2P_OK) { g_err = c->err; delete c; *out = nullptr; return st; }
   c->failed = false;
   c->groups = cfg->norm_num_groups;
+  ia2p_sk_counters_invalidate();      // a fresh context never trusts tickets an earlier (possibly failed) one left behind
   *out = c;
   return IA2P_OK;
 }

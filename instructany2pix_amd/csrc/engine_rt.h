@@ -117,6 +117,7 @@ enum { PK_GEMM0 = 0, PK_CONV0 = 24, PK_ATTN = 48, PK_GN, PK_LN, PK_EMBED, PK_CON
 const char* prof_name(int k);
 
 // state shared by the executors (conditional UNet, VAE): weights, workspace, prefetch plan, per-kernel timing
+void ia2p_sk_counters_invalidate();      // gemm.hip: new epoch of the K-split ticket buffers
 int ia2p_default_xattn_min_tiles();      // < 0: the built-in threshold (engine.hip; test hook ia2p_debug_set_xattn_min_tiles)
 struct RunCtx {
   std::string err;

@@ -15,6 +15,7 @@
 #include "gemm_kernel.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -138,28 +139,47 @@ extern "C" void ia2p_debug_set_gemm_splitk(int s) { g_force_splitk = s; }
 // Ticket counters of the in-launch K-split combine: one int per output tile, zero between launches (the last arriver of a tile resets its
 // counter). One buffer per (device, stream): launches on one stream are ordered, so two K-split launches can only share counters when they cannot
 // run at the same time -- contexts, executors and serving threads that work on different streams never see each other's tickets.
-// Layout of a pool buffer (ints): [0, SK) K-split tickets | spare
+// A launch that dies mid-flight would leave tickets behind: the counters carry an EPOCH. ia2p_sk_counters_invalidate() (called when a context is
+// created and whenever the library reports a HIP error) starts a new one, and the first K-split launch of a stream in a new epoch is preceded by a
+// hipMemsetAsync of that stream's buffer ON that stream -- per epoch, not per launch (78 K-split launches per step would each pay a memset node).
 static constexpr int POOL_INTS = 1 << 18, POOL_SK = POOL_INTS - 4096;
 int ia2p_sk_counter_capacity() { return POOL_SK; }
+static std::atomic<unsigned> g_sk_epoch{1};
+void ia2p_sk_counters_invalidate() { g_sk_epoch.fetch_add(1, std::memory_order_relaxed); }
+extern "C" void ia2p_debug_invalidate_splitk_counters(void) { ia2p_sk_counters_invalidate(); }
 static int* pool_buffer(hipStream_t s) {
+  struct Entry { int* p; unsigned epoch; };
   static std::mutex mu;
-  static std::map<std::pair<int, hipStream_t>, int*> pool;
+  static std::map<std::pair<int, hipStream_t>, Entry> pool;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  const unsigned epoch = g_sk_epoch.load(std::memory_order_relaxed);
+  const size_t bytes = (size_t)POOL_INTS * sizeof(int);
   std::lock_guard<std::mutex> lk(mu);
   auto it = pool.find({dev, s});
-  if (it != pool.end()) return it->second;
+  if (it != pool.end()) {
+    if (it->second.p && it->second.epoch != epoch) {      // first K-split launch of this stream in a new epoch: re-zero, ordered in front of it
+      if (hipMemsetAsync(it->second.p, 0, bytes, s) != hipSuccess) { (void)hipGetLastError(); return nullptr; }      // (this launch is finished by a reduce launch instead)
+      it->second.epoch = epoch;
+    }
+    return it->second.p;
+  }
   int* p = nullptr;
-  const size_t bytes = (size_t)POOL_INTS * sizeof(int);
   if (hipMalloc((void**)&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess) {      // (hipMemset: synchronous with respect to the host, done before the first launch)
     (void)hipGetLastError();
     if (p) (void)hipFree(p);
     p = nullptr;                      // remembered: this stream's K-splits are finished by reduce launches
   }
-  pool[{dev, s}] = p;
+  pool[{dev, s}] = Entry{p, epoch};
   return p;
 }
 int* ia2p_sk_counters(hipStream_t s, int tiles) { return tiles > POOL_SK ? nullptr : pool_buffer(s); }
+// tests: every ticket of the stream's buffer := value, ordered on the stream (value != 0 poisons them the way a launch that died mid-flight would); 0 ok, -1 no buffer
+extern "C" int ia2p_debug_fill_splitk_counters(void* stream, int value) {
+  int* p = pool_buffer((hipStream_t)stream);
+  if (!p) return -1;
+  return hipMemsetD32Async((hipDeviceptr_t)p, value, POOL_SK, (hipStream_t)stream) == hipSuccess ? 0 : -1;
+}
 // normal-CDF table of the GEGLU gate activation (gelu_lut_f, common.h): IA2P_PHI_LUT_N entries {Phi(x_i), Phi(x_i+1) - Phi(x_i)}, x_i = (i - 256) / 32,
 // computed in double precision (0.5 erfc(-x / sqrt 2)), one copy per device
 const float* ia2p_phi_lut() {

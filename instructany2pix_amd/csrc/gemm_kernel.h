@@ -14,6 +14,7 @@
 bool ia2p_splitk_inkernel(int M, int N, int splitk);
 int ia2p_sk_counter_capacity();
 int* ia2p_sk_counters(hipStream_t s, int tiles);
+void ia2p_sk_counters_invalidate();      // new epoch: every stream's ticket buffer is re-zeroed in front of its next K-split launch
 const float* ia2p_phi_lut();
 
 #define GLDS16(gptr, ldsptr)                                                                         \

@@ -334,3 +334,24 @@ def test_iter_safetensors_streams_and_validates_a_checkpoint(tmp_path):
     with pytest.raises(ValueError):
         next(iter_safetensors(str(tmp_path / "shape.safetensors"), specs))
     assert len(dict(iter_safetensors(str(tmp_path / "missing.safetensors")))) == len(sd) - 1           # without specs: whatever is there
+
+
+def test_denoise_batch_validates_guidance_and_group_before_touching_the_device():
+    """a batched group always blends eps_u + g (eps_c - eps_u); the reference switches guidance off at cfg <= 1 (one conditional evaluation) -- such a request is
+    refused with a message that says where it belongs; groups are 1..8 requests (B_eff <= 16 rows)"""
+    import types
+    import pytest
+    import torch
+    from instructany2pix_amd.batch import EditRequest, denoise_batch
+    z = torch.zeros
+    req = lambda cfg: EditRequest(base_latents=z(1, 4, 8, 8), latent_la=z(64), prompt_embeds=z(1, 77, 64), pooled_prompt_embeds=z(1, 64),
+                                  negative_prompt_embeds=z(1, 77, 64), negative_pooled_prompt_embeds=z(1, 64), cfg=cfg)
+    pipe = types.SimpleNamespace(ip_adapter_xl=object())
+    for bad in (1.0, 0.5, 0.0):
+        with pytest.raises(ValueError, match="NO guidance"):
+            denoise_batch(pipe, [req(7.5), req(bad)])
+    for g in (0, 9, 64):
+        with pytest.raises(ValueError, match="group="):
+            denoise_batch(pipe, [req(7.5)], group=g)
+    with pytest.raises(ValueError, match="at least one request"):
+        denoise_batch(pipe, [])

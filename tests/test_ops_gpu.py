@@ -350,6 +350,77 @@ def test_geglu_gate_table_range_and_special_values(L):
         assert torch.isfinite(out[:, 1:].float()).all()                       # only the output column fed by the poisoned weight row is affected
 
 
+def test_gemm_splitk_two_streams_run_concurrently(L):
+    """K-split launches of two streams overlap on the device (each stream has its own ticket buffer): 60 interleaved launches per stream of two different
+    problems -- one of them the FF-out shape of the step -- give, launch for launch, the bits of the same launches run alone."""
+    f = _ffi()
+    probs = [(2048, 1280, 5120, 3, 0), (1024, 640, 2560, 4, 12)]           # (M, N, K, split, tile)
+    data, alone = [], []
+    for i, (M, N, K, S, tile) in enumerate(probs):
+        A, W, b, R = rnd(M, K, seed=91 + i), rnd(N, K, seed=93 + i, scale=K ** -0.5), rnd(N, seed=95 + i), rnd(M, N, seed=97 + i)
+        part = torch.empty(S * M * N, dtype=torch.float32, device="cuda")
+        out = torch.empty(M, N, dtype=torch.half, device="cuda")
+        data.append((A, W, b, R, part, out))
+        L.ia2p_debug_set_gemm_tile(tile)
+        run(L, "ia2p_gemm_splitk", f.ptr(A), f.ptr(W), f.ptr(b), f.ptr(R), f.ptr(out), M, N, K, S, C.c_void_p(part.data_ptr()))
+        alone.append(out.clone())
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    bad = []
+    try:
+        for rep in range(60):
+            for i, (M, N, K, S, tile) in enumerate(probs):
+                A, W, b, R, part, out = data[i]
+                with torch.cuda.stream(streams[i]):
+                    if rep % 10 == 0:
+                        out.fill_(float("nan"))
+                    L.ia2p_debug_set_gemm_tile(tile)
+                    f.check(L.ia2p_gemm_splitk(C.c_void_p(streams[i].cuda_stream), f.ptr(A), f.ptr(W), f.ptr(b), f.ptr(R), f.ptr(out), M, N, K, S, C.c_void_p(part.data_ptr())))
+            if rep % 10 == 9:
+                torch.cuda.synchronize()
+                bad += [(rep, i) for i in range(2) if not torch.equal(data[i][5], alone[i])]
+    finally:
+        L.ia2p_debug_set_gemm_tile(-1)
+    torch.cuda.synchronize()
+    assert not bad, bad
+
+
+def test_gemm_splitk_recovers_from_poisoned_tickets(L):
+    """A launch that dies mid-flight leaves tickets behind: the next launch's "last arriver" of a tile is then an early one and combines slabs that are not written
+    yet. Poisoned here the same way (every ticket of the stream's buffer set to splitk - 1, through ia2p_debug_fill_splitk_counters): the launch after it is WRONG, which
+    is the failure the epoch guards against; ia2p_debug_invalidate_splitk_counters() -- what the library calls on IA2P_ERR_HIP and on context creation -- puts a
+    re-zeroing memset on the stream in front of the next K-split launch, and that launch and the one after it are right again."""
+    f = _ffi()
+    M, N, K, S = 2048, 1280, 5120, 8          # 160 tiles x 8 slices = 1280 workgroups: more than are resident at once, so the first slices finish before the last start
+    A, W, b, R = rnd(M, K, seed=71), rnd(N, K, seed=72, scale=K ** -0.5), rnd(N, seed=73), rnd(M, N, seed=74)
+    part = torch.empty(S * M * N, dtype=torch.float32, device="cuda")
+    ref = A.float() @ W.float().t() + b.float() + R.float()
+    st = torch.cuda.Stream()
+    sp = C.c_void_p(st.cuda_stream)
+    out = torch.empty(M, N, dtype=torch.half, device="cuda")
+
+    def launch():
+        out.fill_(float("nan"))
+        part.fill_(float("nan"))
+        torch.cuda.synchronize()
+        f.check(L.ia2p_gemm_splitk(sp, f.ptr(A), f.ptr(W), f.ptr(b), f.ptr(R), f.ptr(out), M, N, K, S, C.c_void_p(part.data_ptr())))
+        st.synchronize()
+        return out.clone()
+
+    L.ia2p_debug_set_gemm_tile(0)
+    try:
+        good = launch()
+        assert rel_l2(good, ref) < 1e-3
+        assert L.ia2p_debug_fill_splitk_counters(sp, S - 1) == 0      # the FIRST slice to arrive draws "last": it combines slabs nobody has written (NaN here)
+        bad = launch()
+        assert not torch.equal(bad, good)                             # the hazard is real
+        assert L.ia2p_debug_fill_splitk_counters(sp, S - 1) == 0      # (that launch left its own mess; poison again to a known state)
+        L.ia2p_debug_invalidate_splitk_counters()
+        assert torch.equal(launch(), good) and torch.equal(launch(), good)
+    finally:
+        L.ia2p_debug_set_gemm_tile(-1)
+
+
 def test_gemm_rejects_bad_shapes(L):
     f = _ffi()
     A, W, out = rnd(64, 96), rnd(64, 96), torch.empty(64, 64, dtype=torch.half, device="cuda")

@@ -423,3 +423,42 @@ def test_load_unet_safetensors_gives_the_same_bits(tiny_models, tmp_path):
     assert torch.equal(fresh(x, 401, **kw)[0], moved)
 
 
+
+
+def test_two_contexts_on_two_streams_with_k_splits(tiny_models):
+    """A base and a refiner context evaluate concurrently on two streams, every GEMM K-split in two (ia2p_debug_set_gemm_splitk: in-launch combine, ticket
+    counters per device and stream): each gives, evaluation after evaluation, the bits it gives alone."""
+    from instructany2pix_amd import _ffi
+    from instructany2pix_amd.attention_processor import AttnProcessor2_0
+    from instructany2pix_amd.config import tiny_refiner
+    from instructany2pix_amd.unet import HipUNet2DConditionModel
+    from instructany2pix_amd.weights import unet_param_specs, synthetic_state_dict
+    cfg, sd, ipsd, hip, _ = tiny_models
+    rcfg = tiny_refiner()
+    ref = HipUNet2DConditionModel(rcfg, DEV)
+    ref.load_state_dict(synthetic_state_dict(unet_param_specs(rcfg), seed=9))
+    hip.set_attn_processor(AttnProcessor2_0())
+    L = _ffi.lib()
+    models = [(hip, cfg, 6), (ref, rcfg, 5)]
+    ins = []
+    for m, c, ntid in models:
+        x, ctx, te, tid = _inputs(c, 4, 32, 32, 77, seed=31 + ntid)
+        ins.append((x.to(DEV), ctx.to(DEV), te.to(DEV), tid[:, :ntid].contiguous().to(DEV)))
+    L.ia2p_debug_set_gemm_splitk(2)
+    try:
+        alone = []
+        for (m, c, _), (x, ctx, te, tid) in zip(models, ins):
+            alone.append(m(x, 401, encoder_hidden_states=ctx, added_cond_kwargs=dict(text_embeds=te, time_ids=tid))[0].clone())
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        for rep in range(6):
+            outs = []
+            for ((m, c, _), (x, ctx, te, tid), st) in zip(models, ins, streams):
+                st.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(st):
+                    outs.append(m(x, 401, encoder_hidden_states=ctx, added_cond_kwargs=dict(text_embeds=te, time_ids=tid))[0])
+            torch.cuda.synchronize()
+            for i in range(2):
+                assert torch.equal(outs[i], alone[i]), (rep, i)
+    finally:
+        L.ia2p_debug_set_gemm_splitk(-1)
