@@ -203,24 +203,58 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   const int Hv = p.Hs << p.up, Wv = p.Ws << p.up;
   const int nk_all = hK / BK;
   const int kt0 = (int)((long)split * nk_all / nsplit), kt1 = (int)((long)(split + 1) * nk_all / nsplit);   // this workgroup's k-tiles
-  int tap = (kt0 * BK) / (CONV ? p.Cin : BK), ci0 = CONV ? (kt0 * BK) % p.Cin : 0;  // conv: position of the k-tile being staged
-  if (CONV && tap >= 9) {                                                             // (inside the appended 1x1 blocks)
-    ci0 = kt0 * BK - 9 * p.Cin; tap = 9;
-    if (ci0 >= p.Cin2) { ci0 -= p.Cin2; tap = 10; }
-  }
-  bool tap_fresh = true;
+  // conv: K is walked CHANNEL-BLOCK-major -- for each block of 64 input channels the nine taps, then the next block; after the 9 Cin columns of the 3x3 part the
+  // appended 1x1 blocks in storage order. The nine taps of a channel block re-read (almost) the same 64-channel pixel rows, so an XCD's distinct activation
+  // bytes between two uses of a line are tiles x (pixels + halo) x 128 B (1.6 MB for 32 tiles of 256 pixels) instead of tiles x pixels x Cin x 2 B (5 MB at 320
+  // channels: more than the 4 MiB L2, i.e. every tap re-fetched its rows through the fabric -- PMC traffic 3.65 x algorithmic on the 256 x 160 conv class, round 3).
+  // The WEIGHT layout is unchanged ([Co][tap][Ci] = column tap * Cin + ci): the walk just strides it (+Cin per tap, +64 - 8 Cin at a block change).
+  // Position of k-tile kt of the 3x3 part: tap = kt % 9, ci0 = (kt / 9) * 64. (Every tile variant walks K the same way: the bits still do not depend on the tile.)
   int cin_main = 0, cin_extra = 0;                         // (two named scalars: a select between two argument FIELDS became a 2-entry table in scratch)
   if (CONV) { cin_main = p.Cin; cin_extra = p.Cin2; asm volatile("" : "+s"(cin_main), "+s"(cin_extra)); }
+  const int nk_main = CONV ? 9 * (cin_main / BK) : 0;      // k-tiles of the 3x3 part
+  int tap = 0, ci0 = 0;
+  if (CONV) {
+#ifdef IA2P_CONV_TAP_MAJOR      // A/B builds: round 3's walk (all channels of a tap, then the next tap)
+    if (kt0 < nk_main) { tap = (kt0 * BK) / cin_main; ci0 = (kt0 * BK) % cin_main; }
+#else
+    if (kt0 < nk_main) { tap = kt0 % 9; ci0 = (kt0 / 9) * BK; }
+#endif
+    else {                                                 // (inside the appended 1x1 blocks)
+      ci0 = kt0 * BK - 9 * cin_main; tap = 9;
+      if (ci0 >= cin_extra) { ci0 -= cin_extra; tap = 10; }
+    }
+  }
+  bool tap_fresh = true;
+  // weight column (in elements) of the k-tile at (tap, ci0)
+  auto wcol = [&](int t, int c) { return t < 9 ? t * cin_main + c : t == 9 ? 9 * cin_main + c : 9 * cin_main + cin_extra + c; };
+  // the walk, one k-tile on: (tap, ci0) -> next
+  auto k_next = [&](int& t, int& c) {
+    if (t < 9) {
+#ifdef IA2P_CONV_TAP_MAJOR
+      c += BK;
+      if (c >= cin_main) { c = 0; ++t; }
+#else
+      if (++t == 9) { c += BK; if (c < cin_main) t = 0; else c = 0; }      // next channel block, or past the 3x3 part (tap = 9: appended block / end of K)
+#endif
+    } else {
+      c += BK;
+      if (t < 10 && c >= cin_extra) { c = 0; ++t; }                           // (the last block runs to the end of K)
+    }
+  };
+  // the weight side keeps its own copies of the position: one per weight half-tile (the 8-phase tile issues its weight halves at other points of the loop than
+  // its activation halves)
+  int wtap0 = tap, wci0 = ci0, wtap1 = tap, wci1 = ci0;
   if (kt0) {             // split-K: this workgroup starts at k-tile kt0
     if (!CONV) {
 #pragma unroll
       for (int i = 0; i < A_PW; ++i) a_ptr[i] += (size_t)kt0 * a_inc[i];
     }
+    const int w0 = CONV ? wcol(tap, ci0) : kt0 * BK;
 #pragma unroll
-    for (int i = 0; i < B_PW; ++i) w_ptr[i] += (size_t)kt0 * w_inc[i];
+    for (int i = 0; i < B_PW; ++i) w_ptr[i] += w_inc[i] ? (size_t)w0 : 0;
   }
 
-  // new filter tap (wave-uniform): re-derive the gathered pixel of each row once per Cin/64 k-steps
+  // new filter tap (wave-uniform; every k-tile of the 3x3 part): re-derive the gathered pixel of each row
   auto conv_tap_setup = [&]() {
     if (tap_fresh) {
       if (tap < 9) {
@@ -257,34 +291,43 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
     }
   };
   auto conv_tap_advance = [&]() {
-    ci0 += BK;
-    if (tap < 10 && ci0 >= (tap < 9 ? cin_main : cin_extra)) { ci0 = 0; ++tap; tap_fresh = true; }      // (the last block runs to the end of K)
+    const int t_old = tap;
+    k_next(tap, ci0);
+    if (t_old < 9 || tap != t_old) tap_fresh = true;      // (inside an appended block the running pointers just move on)
   };
   // LDS-DMA of this wave's activation pieces [i0, i1) / weight pieces [i0, i1) of the next k-tile into ring slot `buf`; running pointers: no per-step multiply
   auto issue_a = [&](int buf, auto i0_tag, auto i1_tag) {
 #pragma unroll
     for (int i = decltype(i0_tag)::value; i < decltype(i1_tag)::value; ++i) { GLDS16(a_ptr[i], smem + buf * STAGE + a_piece(i) * 1024); a_ptr[i] += a_inc[i]; }
   };
-  auto issue_b = [&](int buf, auto i0_tag, auto i1_tag) {
+  auto issue_b = [&](int buf, auto i0_tag, auto i1_tag, auto half_tag) {
+    long wstep = BK;                                      // elements to the next k-tile of the walk (wave-uniform)
+    if (CONV) {
+      int& wt = decltype(half_tag)::value ? wtap1 : wtap0;
+      int& wc = decltype(half_tag)::value ? wci1 : wci0;
+      const int c0 = wcol(wt, wc);
+      k_next(wt, wc);
+      wstep = wcol(wt, wc) - c0;
+    }
 #pragma unroll
     for (int i = decltype(i0_tag)::value; i < decltype(i1_tag)::value; ++i)
-      if (!B_UNEVEN || i < b_npw) { GLDS16(w_ptr[i], smem + buf * STAGE + BM * ROWB + b_piece(i) * 1024); w_ptr[i] += w_inc[i]; }      // (wave-uniform)
+      if (!B_UNEVEN || i < b_npw) { GLDS16(w_ptr[i], smem + buf * STAGE + BM * ROWB + b_piece(i) * 1024); w_ptr[i] += w_inc[i] ? wstep : 0; }      // (wave-uniform branch)
   };
   using I0 = std::integral_constant<int, 0>;
   auto stage = [&](int kt, int buf) {
     if (CONV) conv_tap_setup();
     issue_a(buf, I0{}, std::integral_constant<int, A_PW>{});
     if (CONV) conv_tap_advance();
-    issue_b(buf, I0{}, std::integral_constant<int, B_PW>{});
+    issue_b(buf, I0{}, std::integral_constant<int, B_PW>{}, I0{});
   };
   // 8-phase tile: one HALF of an operand tile per call, in the order B0, A0, B1, A1 of a k-tile (A0 opens the k-tile for the conv gather, A1 closes it)
   auto stage_part = [&](int buf, auto which_tag) {
     constexpr int WHICH = decltype(which_tag)::value;
     using AH = std::integral_constant<int, A_HP>;
     using BH = std::integral_constant<int, B_HP>;
-    if constexpr (WHICH == 0) issue_b(buf, I0{}, BH{});
+    if constexpr (WHICH == 0) issue_b(buf, I0{}, BH{}, I0{});
     else if constexpr (WHICH == 1) { if (CONV) conv_tap_setup(); issue_a(buf, I0{}, AH{}); }
-    else if constexpr (WHICH == 2) issue_b(buf, BH{}, std::integral_constant<int, B_PW>{});
+    else if constexpr (WHICH == 2) issue_b(buf, BH{}, std::integral_constant<int, B_PW>{}, std::integral_constant<int, 1>{});
     else { issue_a(buf, AH{}, std::integral_constant<int, A_PW>{}); if (CONV) conv_tap_advance(); }
   };
 
