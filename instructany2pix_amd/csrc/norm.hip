@@ -187,6 +187,126 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* ax, half_t*
   }
 }
 
+// ---- single-pass GroupNorm (round 4): ONE launch, the tensor read ONCE ------------------------------------------------------------------------------
+// A workgroup owns, for one image, a SPAN of `gs` whole groups = `NCH` 16-byte chunks per pixel (the smallest span that is both whole groups and whole
+// chunks: Cg = 40 or 80 channels -> one group = 5 / 10 chunks; Cg = 10 / 20 / 30 / 60 -> 4 / 2 / 4 / 2 groups = 5 / 5 / 15 / 15 chunks). Its slice of the image,
+// HW pixels x NCH chunks, stays IN REGISTERS between the statistics and the normalisation: wave w reads chunk column cc = w / WPC of pixels
+// (w % WPC) * 64 + lane, + P, + 2 P, ... (P = 64 WPC pixel lanes; IT of them per thread, compile time), so every lane of a wave has the same channels --
+// hence the same group membership, gamma and beta -- and the statistics are a fixed butterfly over the wave (a chunk spans at most two groups: two
+// {sum, sum of squares} pairs per lane), wave partials through LDS, folded per group in fp64 in wave order: deterministic, independent of the batch.
+// Replaces gn_stats_kernel + gn_apply_kernel (two launches, the tensor read twice) wherever HW x NCH fits the registers of one 15-wave workgroup: every
+// GroupNorm of the SDXL UNet at 512^2 except the 960-channel one at 64^2. Work: 2 x B x HW x C x 2 bytes (read once, write once).
+template <int NCH, int IT>
+__global__ __launch_bounds__(NCH == 10 ? 640 : 960) void gn_fused_kernel(const half_t* x, half_t* y, const half_t* gamma, const half_t* beta, int HW, int C, int Cg, int gs,
+                                                                                  int ldx, int ldy, float eps, int flags, const half_t* x2, int ldx2, int Ca) {
+  constexpr int WPC = NCH == 5 ? 3 : 1;            // waves per chunk column
+  constexpr int P = 64 * WPC, NW = NCH * WPC;      // pixel lanes, waves
+  __shared__ float wsum[NW][4];                    // per wave: {sum, sum of squares} of its first / second group
+  __shared__ float stat[16][2];                    // per group of the span: mean, rstd
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int cc = wave / WPC, pl = (wave % WPC) * 64 + lane;
+  const int b = blockIdx.y, span = blockIdx.x;
+  const int c0 = span * NCH * 8 + cc * 8;          // first channel of this thread's chunk
+  const int g0 = span * gs;                        // first group of the span
+  const int ga = c0 / Cg - g0;                     // (wave-uniform) group of the chunk's first element, span-local
+  const int esplit = min(8, (g0 + ga + 1) * Cg - c0);      // elements [0, esplit) belong to group ga, [esplit, 8) to ga + 1
+  const bool second = x2 && c0 >= Ca;
+  const half_t* src = second ? x2 + (size_t)b * HW * ldx2 + (c0 - Ca) : x + (size_t)b * HW * ldx + c0;
+  const int sld = second ? ldx2 : ldx;
+  h8 d[IT];
+#pragma unroll
+  for (int k = 0; k < IT; ++k) d[k] = *(const h8*)(src + (size_t)min(pl + k * P, HW - 1) * sld);      // all loads in flight (clamped, never branched around)
+  float sa = 0.f, qa = 0.f, sb = 0.f, qb = 0.f;
+#pragma unroll
+  for (int k = 0; k < IT; ++k)
+    if (pl + k * P < HW) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float f = (float)d[k][e];
+        if (e < esplit) { sa += f; qa = fmaf(f, f, qa); } else { sb += f; qb = fmaf(f, f, qb); }
+      }
+    }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { sa += __shfl_xor(sa, o, 64); qa += __shfl_xor(qa, o, 64); sb += __shfl_xor(sb, o, 64); qb += __shfl_xor(qb, o, 64); }
+  if (lane == 0) { wsum[wave][0] = sa; wsum[wave][1] = qa; wsum[wave][2] = sb; wsum[wave][3] = qb; }
+  __syncthreads();
+  if ((int)threadIdx.x < gs) {                     // group j of the span: its waves in wave order, fp64
+    const int j = threadIdx.x;
+    double a = 0.0, q = 0.0;
+    for (int w = 0; w < NW; ++w) {
+      const int wc0 = span * NCH * 8 + (w / WPC) * 8, wga = wc0 / Cg - g0;
+      const bool two = (g0 + wga + 1) * Cg - wc0 < 8;
+      if (wga == j) { a += (double)wsum[w][0]; q += (double)wsum[w][1]; }
+      if (two && wga + 1 == j) { a += (double)wsum[w][2]; q += (double)wsum[w][3]; }
+    }
+    const double n = (double)HW * Cg;
+    const double mean = a / n;
+    double var = q / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stat[j][0] = (float)mean;
+    stat[j][1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  const h8 gam = *(const h8*)(gamma + c0), bet = *(const h8*)(beta + c0);
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int g = e < esplit ? ga : ga + 1;
+    const float mean = stat[g][0], rstd = stat[g][1];
+    sc[e] = rstd * (float)gam[e];
+    sh[e] = (float)bet[e] - mean * sc[e];
+  }
+  const bool silu = (flags & 1) != 0, wt = (flags & 2) != 0;
+  half_t* obase = y + (size_t)b * HW * ldy;
+  const __amdgpu_buffer_rsrc_t y_rsrc = wt_rsrc((void*)obase, (size_t)HW * ldy * 2);
+#pragma unroll
+  for (int k = 0; k < IT; ++k) {
+    const int r = pl + k * P;
+    if (r < HW) {
+      h8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float f = (float)d[k][e] * sc[e] + sh[e];
+        if (silu) f = silu_f(f);
+        o[e] = (half_t)f;
+      }
+      const size_t off = (size_t)r * ldy + c0;
+      if (wt) store16_wt(y_rsrc, off * 2, o);
+      else *(h8*)(obase + off) = o;
+    }
+  }
+}
+
+// single-pass launch if the shape fits (returns false otherwise: the caller runs the two-pass kernels)
+static bool gn_fused_launch(const half_t* x, int ldx, half_t* y, int ldy, const half_t* gamma, const half_t* beta, int B, int HW, int C, int G, float eps, int flags,
+                            hipStream_t s, const half_t* x2, int ldx2, int Ca) {
+#ifdef IA2P_GN_TWOPASS      // A/B builds: the two-pass kernels everywhere
+  return false;
+#endif
+  if (C % G || C % 8 || ldx % 8 || ldy % 8 || (x2 && (ldx2 % 8 || Ca % 8))) return false;
+  const int Cg = C / G;
+  if (Cg < 8) return false;                        // (a chunk would span more than two groups)
+  int gs = 1;
+  while ((gs * Cg) % 8) ++gs;                      // smallest span of whole groups that is whole 16-byte chunks
+  const int nch = gs * Cg / 8;
+  if (G % gs || (nch != 5 && nch != 10 && nch != 15) || gs > 16) return false;
+  const int P = nch == 5 ? 192 : 64, it = (HW + P - 1) / P;
+  // one workgroup per CU takes its slice in at the rate of ONE CU (~25 GB/s from beyond L2): only launches that put a workgroup on (nearly) every CU pay --
+  // with 64 ... 128 workgroups (the 64^2 / 32^2 levels at 8 requests) the single pass measured +0.7 ms per step against the two-pass kernels' 2 000 workgroups
+  if ((long)(G / gs) * B < 200) return false;
+  const dim3 grid(G / gs, B), block(nch == 10 ? 640 : 960);
+#define IA2P_GNF(NCH_, IT_) hipLaunchKernelGGL((gn_fused_kernel<NCH_, IT_>), grid, block, 0, s, x, y, gamma, beta, HW, C, Cg, gs, ldx, ldy, eps, flags, x2, ldx2, Ca)
+  if (nch == 5) {
+    if (it <= 2) IA2P_GNF(5, 2); else if (it <= 6) IA2P_GNF(5, 6); else if (it <= 22) IA2P_GNF(5, 22); else return false;
+  } else if (nch == 10) {
+    if (it <= 4) IA2P_GNF(10, 4); else if (it <= 16) IA2P_GNF(10, 16); else return false;
+  } else {
+    if (it <= 4) IA2P_GNF(15, 4); else if (it <= 16) IA2P_GNF(15, 16); else return false;
+  }
+#undef IA2P_GNF
+  return true;
+}
+
 // partial must hold B*chunks*G*2 floats. Returns the chunk count it used via *chunks_out when partial == null.
 int ia2p_gn_chunks(int B, int HW) {
   static const int cap = ia2p_exp_env("IA2P_GN_STATS_WGS") ? atoi(ia2p_exp_env("IA2P_GN_STATS_WGS")) : 512;      // tuning hook (tools/gn_bench.py)
@@ -220,6 +340,7 @@ hipError_t ia2p_launch_groupnorm(const half_t* x, int ldx, half_t* y, int ldy, c
   const size_t sm1 = (size_t)2 * TY * C * sizeof(float), sm2 = (size_t)G * 2 * sizeof(float) + (size_t)(256 / G) * G * 2 * sizeof(double);
   if (sm1 > 65536) return hipErrorInvalidValue;
   const int wtf = ((ia2p_wt_mask() & 4) && (size_t)HW * ldy * 2 < (size_t)0x7ffffff0) ? 2 : 0;      // write-through y (per batch element: 32-bit offsets)
+  if (gn_fused_launch(x, ldx, y, ldy, gamma, beta, B, HW, C, G, eps, silu | wtf, s, x2, ldx2, Ca)) return hipGetLastError();      // one launch, one read of the tensor
   if (V == 1) {
     hipLaunchKernelGGL(gn_stats_kernel<1>, grid, block, sm1, s, a.x, a.y, a.gamma, a.beta, a.partial, a.B, a.HW, a.C, a.G, a.chunks, a.rows, a.arows, a.ldx, a.ldy, a.eps, a.silu, a.x2, a.ldx2, a.Ca);
     hipLaunchKernelGGL(gn_apply_kernel<1>, agrid, block, sm2, s, a.x, a.y, a.gamma, a.beta, a.partial, a.B, a.HW, a.C, a.G, a.chunks, a.rows, a.arows, a.ldx, a.ldy, a.eps, a.silu | wtf, a.x2, a.ldx2, a.Ca);
