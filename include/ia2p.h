@@ -214,6 +214,12 @@ ia2p_status ia2p_qproj_attention(void* stream, const void* X, const void* Wq, co
                                  int B, int heads, int Nq, int K, int nseg,
                                  const void* K0, const void* V0, int ld0, int nkeys0, float w0,
                                  const void* K1, const void* V1, int ld1, int nkeys1, float w1);
+/* Self-attention of AttnProcessor2_0 at 256 tokens per image (the 16 x 16 level) with its three projections, ONE launch (reference attention_processor.py:239 to_q,
+ * :246-247 to_k / to_v, :259 scaled_dot_product_attention): O[b, q, h*64:] = softmax(Q K^T / 8) V with [Q | K | V] = epilogue(X . Wqkv^T), the projected
+ * tensors never written -- bit-identical to ia2p_gemm_ex (N = 3 * heads * 64) followed by ia2p_attention. X [B*256, K]; Wqkv the stacked [3*heads*64, K]
+ * weight (rows: all of to_q, then to_k, then to_v; gamma-folded when ln != NULL, as ia2p_gemm_ex); bias [3*heads*64] or NULL (ignored with ln). */
+ia2p_status ia2p_qkv_self_attention(void* stream, const void* X, const void* Wqkv, const void* bias, const ia2p_ln_fold* ln, void* O, int ldo,
+                                    int B, int heads, int K);
 /* The `attn_map` side effect of IPAttnProcessor2_0 (reference attention_processor.py:390-391; stored on the processor, read only by the
  * attention-map hooks of diffusion/ip_adapter/utils.py:15-20):  out[b,h,q,t] = sum_d Q[b,q,h*64+d] * softmax_t(Kip[b,t,h*64+d]) -- the
  * softmax binds to ip_key^T, i.e. runs over the TOKEN axis, unscaled, before the matmul. Q rows stride ldq, Kip [B*ntok, ldk], out fp16

@@ -86,6 +86,7 @@ SIGNATURES = {
     "ia2p_conv_in": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I]),
     "ia2p_conv_out": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I]),
     "ia2p_attention": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _I, _I, _F, _P, _P, _I, _I, _F]),
+    "ia2p_qkv_self_attention": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I]),
     "ia2p_qproj_attention": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _F, _P, _P, _I, _I, _F]),
     "ia2p_linear_small": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I]),
     "ia2p_ip_attn_map": (_I, [_P, _P, _I, _P, _I, _P, _I, _I, _I, _I]),

@@ -92,6 +92,14 @@ static inline int ia2p_wt_mask() {
 // the folded-LayerNorm epilogue of one element, rstd * (acc - mean * colsum) + fbias, as TWO explicit FMAs: every site (GEMM epilogues, the K-split
 // reduce, the fused to_q tile) must round identically -- left to the compiler, the contraction of the plain expression differed between two instantiations
 __device__ __forceinline__ float ln_fold_f(float acc, float mean, float rstd, float colsum, float fbias) { return fmaf(rstd, fmaf(-mean, colsum, acc), fbias); }
+// mean and 1 / sqrt(var + eps) of a row from its {sum, sum of squares}: every rounding spelled out (two products, one FMA) -- left as the plain expression
+// `s2 * inv - mean * mean`, two instantiations of the GEMM template contracted it differently and their LayerNorm-folded outputs differed in the last bit
+__device__ __forceinline__ float2 ln_mean_rstd_f(float s1, float s2, int K, float eps) {
+  const float inv = 1.f / (float)K;
+  const float mean = __fmul_rn(s1, inv);
+  const float var = fmaxf(fmaf(s2, inv, -__fmul_rn(mean, mean)), 0.f);
+  return make_float2(mean, rsqrtf(__fadd_rn(var, eps)));
+}
 __device__ __forceinline__ float act_f(float x, int act) { return act == 1 ? gelu_erf_f(x) : act == 2 ? quick_gelu_f(x) : act == 3 ? gelu_tanh_f(x) : x; }
 
 // ---- launch descriptors shared by kernels and the host executor --------------------------------------

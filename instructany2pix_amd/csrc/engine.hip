@@ -56,7 +56,7 @@ extern "C" void ia2p_debug_set_xattn_min_tiles(int tiles) { g_xattn_min_tiles = 
 const char* prof_name(int k) {
   static char buf[PK_NCLASS][64];
   static const char* const other[] = {"attention_f16_kernel", "gn_stats_kernel+gn_apply_kernel", "layernorm_kernel",
-                                      "embed_kernel+linear_small_kernel", "conv_in_kernel", "conv_out_kernel", "concat_kernel", "splitk_reduce_kernel", "qproj_xattn_kernel"};
+                                      "embed_kernel+linear_small_kernel", "conv_in_kernel", "conv_out_kernel", "concat_kernel", "splitk_reduce_kernel", "qproj_xattn_kernel", "qkv_sattn_kernel"};
   if (k >= PK_ATTN) return other[k - PK_ATTN];
   const GemmTile t = IA2P_GEMM_TILES[(k % PK_CONV0) % IA2P_GEMM_NVARIANT];
   if (t.pp == 2) snprintf(buf[k], sizeof buf[k], "gemm_f16_kernel<%d, %d, %d, %s, 2, 64, 2, 4>", t.bm, t.bn, t.stages, k >= PK_CONV0 ? "true" : "false");
@@ -528,6 +528,20 @@ static T2 run_resnet(Fwd& f, const Resnet& r, T2 x, int H, int Wd, const T2* x2t
   return out;
 }
 
+// QKV projection (LayerNorm folded) + the self-attention that consumes it in ONE launch (qxattn.hip): Q, K, V never leave the CU. x: O / ldo / B / heads / Nq = 256
+static void op_qkv_sattn(RunCtx* c, const half_t* A, int lda, const half_t* W, const LnIn* ln, int M, int C, const AttnArgs& x) {
+  GemmArgs a;
+  memset(&a, 0, sizeof a);
+  a.pad = 1;
+  if (ln) { a.ln_stats = ln->stats; a.ln_slots = ln->slots; a.ln_cs = ln->cs; a.ln_bias = ln->lb; a.ln_eps = ln->eps; }
+  a.A = A; a.W = W; a.zero = zero_page(); a.M = M; a.N = 3 * C; a.K = C; a.ldw = C; a.lda = lda; a.ldc = 3 * C;
+  a.rows_per_batch = 1;
+  set_prefetch(c, a, W, (size_t)3 * C * C * sizeof(half_t));
+  ProfScope ps(c, PK_QKVATTN, 2.0 * M * 3.0 * C * C + 4.0 * x.B * x.heads * (double)x.Nq * x.Nq * 64, 2.0 * ((double)M * C + 3.0 * C * C + (double)M * C));
+  ps.pf = a.pf ? (double)a.pf_bytes : 0.0;
+  CHECK_LAUNCH(c, ia2p_launch_qkv_sattn(a, x, c->stream), "qkv projection + self-attention");
+}
+
 static void op_attn(RunCtx* c, const AttnArgs& a) {
   double keys = 0;
   for (int s = 0; s < a.nseg; ++s) keys += a.seg[s].nkeys;
@@ -582,14 +596,28 @@ static T2 run_transformer(Fwd& f, const Transformer& t, T2 x, int H, int Wd) {
   const int ldkv = c->kv_rows;
   for (const TBlock& b : t.blocks) {
     // self-attention (AttnProcessor2_0, reference attention_processor.py:205-279)
-    if (fold) {
+    // 256 tokens per image (the 16 x 16 level): the QKV tile of one image x one head holds everything that head's attention needs -- projection and attention
+    // as ONE launch when there are enough (image, head) pairs to fill the chip (same threshold and switch as the fused cross-attention)
+#ifdef IA2P_NO_SATTN_FUSE      // A/B builds: projection and self-attention as two launches everywhere
+    const bool fuse_sa = false;
+#else
+    const bool fuse_sa = fold && c->xattn_fuse && HW == 256 && C == t.heads * 64 && (long)f.B * t.heads >= c->xattn_min_tiles;
+#endif
+    if (fuse_sa) {
+      const LnIn ln{st, slots, F_(b.cs1), F_(b.lb1), eps};
+      AttnArgs a;
+      memset(&a, 0, sizeof a);
+      a.O = att.p; a.ldo = C; a.B = f.B; a.heads = t.heads; a.Nq = HW; a.nseg = 1; a.scale_log2e = sl2e;
+      a.seg[0].nkeys = HW; a.seg[0].weight = 1.f;
+      op_qkv_sattn(c, tk.p, C, W_(c, b.fqkv), &ln, M, C, a);
+    } else if (fold) {
       const LnIn ln{st, slots, F_(b.cs1), F_(b.lb1), eps};
       op_gemm(c, tk.p, C, W_(c, b.fqkv), nullptr, nullptr, 0, qkv.p, 3 * C, M, 3 * C, C, 0, 0, 0, 0, 0, &ln);
     } else {
       op_ln(c, tk.p, lnb.p, b.ln1g, b.ln1b, M, C);
       op_gemm(c, lnb.p, C, W_(c, b.wqkv), nullptr, nullptr, 0, qkv.p, 3 * C, M, 3 * C, C);
     }
-    {
+    if (!fuse_sa) {
       AttnArgs a;
       memset(&a, 0, sizeof a);
       a.Q = qkv.p; a.ldq = 3 * C; a.O = att.p; a.ldo = C; a.B = f.B; a.heads = t.heads; a.Nq = HW; a.nseg = 1; a.scale_log2e = sl2e;
@@ -1272,6 +1300,25 @@ ia2p_status ia2p_qproj_attention(void* stream, const void* X, const void* Wq, co
   if (!ia2p_qproj_xattn_ok(a, x)) return fail(nullptr, IA2P_ERR_SHAPE, "qproj_attention: shape not supported by the fused tile (bias must be 16-byte aligned)");
   hipError_t e = ia2p_launch_qproj_xattn(a, x, (hipStream_t)stream);
   RET_HIP(e, "qproj_attention");
+}
+ia2p_status ia2p_qkv_self_attention(void* stream, const void* X, const void* Wqkv, const void* bias, const ia2p_ln_fold* ln, void* O, int ldo, int B, int heads, int K) {
+  if (!X || !Wqkv || !O) return fail(nullptr, IA2P_ERR_INVALID, "qkv_self_attention: null argument");
+  if (ln && (!ln->stats || !ln->colsum || !ln->fbias || ln->slots < 1)) return fail(nullptr, IA2P_ERR_INVALID, "qkv_self_attention: incomplete ia2p_ln_fold");
+  if (B < 1 || heads < 1 || K < 64 || K % 64 || ldo % 8 || (((uintptr_t)O) & 15)) return fail(nullptr, IA2P_ERR_SHAPE, "qkv_self_attention: K=%d (multiple of 64), ldo=%d (multiple of 8), O 16-byte aligned", K, ldo);
+  GemmArgs a;
+  memset(&a, 0, sizeof a);
+  a.pad = 1;
+  a.A = (const half_t*)X; a.W = (const half_t*)Wqkv; a.zero = zero_page(); a.M = B * 256; a.N = 3 * heads * 64; a.K = K; a.ldw = K; a.lda = K; a.ldc = a.N;
+  a.bias = (const half_t*)bias; a.rows_per_batch = 1;
+  if (ln) { a.ln_stats = ln->stats; a.ln_slots = ln->slots; a.ln_cs = ln->colsum; a.ln_bias = ln->fbias; a.ln_eps = ln->eps; }
+  AttnArgs x;
+  memset(&x, 0, sizeof x);
+  x.O = (half_t*)O; x.ldo = ldo; x.B = B; x.heads = heads; x.Nq = 256; x.nseg = 1;
+  x.scale_log2e = 0.125f * 1.4426950408889634f;
+  x.seg[0].nkeys = 256; x.seg[0].weight = 1.f;
+  if (!ia2p_qkv_sattn_ok(a, x)) return fail(nullptr, IA2P_ERR_SHAPE, "qkv_self_attention: shape / alignment not supported by the fused tile");
+  hipError_t e = ia2p_launch_qkv_sattn(a, x, (hipStream_t)stream);
+  RET_HIP(e, "qkv_self_attention");
 }
 ia2p_status ia2p_ip_attn_map(void* stream, const void* Q, int ldq, const void* Kip, int ldk, void* out, int B, int heads, int Nq, int ntok) {
   if (!Q || !Kip || !out || B < 1 || heads < 1 || Nq < 1) return fail(nullptr, IA2P_ERR_INVALID, "ip_attn_map: bad argument");

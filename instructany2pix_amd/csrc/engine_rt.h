@@ -28,6 +28,8 @@ void ia2p_gemm_candidates(int M, int N, int K, bool conv, bool geglu, size_t max
 hipError_t ia2p_launch_attention(const AttnArgs& a, hipStream_t s);
 bool ia2p_qproj_xattn_ok(const GemmArgs& a, const AttnArgs& x);
 hipError_t ia2p_launch_qproj_xattn(const GemmArgs& a, const AttnArgs& x, hipStream_t s);   // qxattn.hip: to_q tile -> attention core, one launch
+bool ia2p_qkv_sattn_ok(const GemmArgs& a, const AttnArgs& x);
+hipError_t ia2p_launch_qkv_sattn(const GemmArgs& a, const AttnArgs& x, hipStream_t s);      // qxattn.hip: QKV tile of one image x one head -> self-attention, one launch
 int ia2p_gn_chunks(int B, int HW);
 hipError_t ia2p_launch_groupnorm(const half_t* x, int ldx, half_t* y, int ldy, const half_t* gamma, const half_t* beta,
                                  float* partial, int B, int HW, int C, int G, float eps, int silu, hipStream_t s, const half_t* x2 = nullptr, int ldx2 = 0, int Ca = 0);
@@ -113,7 +115,7 @@ struct ProfRec { hipEvent_t e0, e1; int k; double flops, bytes; int region; doub
 // profile regions of a UNet evaluation: what part of the network a launch belongs to (bench.py: conv-block roofline)
 enum { PR_OTHER = 0, PR_CONV_BLOCK = 1, PR_TRANSFORMER = 2, PR_NREGION };
 // profile classes = device kernel names as rocprofv3 prints them (template arguments included)
-enum { PK_GEMM0 = 0, PK_CONV0 = 24, PK_ATTN = 48, PK_GN, PK_LN, PK_EMBED, PK_CONV_IN, PK_CONV_OUT, PK_CONCAT, PK_REDUCE, PK_QXATTN, PK_NCLASS };
+enum { PK_GEMM0 = 0, PK_CONV0 = 24, PK_ATTN = 48, PK_GN, PK_LN, PK_EMBED, PK_CONV_IN, PK_CONV_OUT, PK_CONCAT, PK_REDUCE, PK_QXATTN, PK_QKVATTN, PK_NCLASS };
 const char* prof_name(int k);
 
 // state shared by the executors (conditional UNet, VAE): weights, workspace, prefetch plan, per-kernel timing

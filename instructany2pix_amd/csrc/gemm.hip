@@ -79,9 +79,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* hpartia
       for (int sl = lane; sl < p.ln_slots; sl += 64) { const float2 v = ((const float2*)p.ln_stats)[(size_t)sl * hM + m]; s1 += v.x; s2 += v.y; }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-      const float inv = 1.f / (float)p.K;
-      mu = s1 * inv;
-      rs = rsqrtf(fmaxf(s2 * inv - mu * mu, 0.f) + p.ln_eps);
+      const float2 mr = ln_mean_rstd_f(s1, s2, p.K, p.ln_eps);
+      mu = mr.x; rs = mr.y;
     }
     float st1 = 0.f, st2 = 0.f;
     for (int q = lane; q < nq; q += 64) {

@@ -65,7 +65,7 @@ struct EpiCfg {
   static constexpr int LUT_BYTES = BN % 32 == 0 ? ((IA2P_PHI_LUT_N * 8 + 15) & ~15) : 0;          // GEGLU-capable widths: the normal-CDF table of the gate activation
   static constexpr int extra_nolut(int cr) { return (2 * BM + 2 * BN + 4) * 4 + (POW2 ? 0 : cr * (BN / 8) * 8); }
   static constexpr int extra(int cr) { return extra_nolut(cr) + LUT_BYTES; }
-  static constexpr int LIMIT = PP == 2 ? 160 * 1024 : STAGE_BYTES > 80 * 1024 ? STAGE_BYTES : 80 * 1024;   // (the 8-phase tile owns its CU: the whole LDS)
+  static constexpr int LIMIT = (PP == 2 || (BM == 256 && BN == 192)) ? 160 * 1024 : STAGE_BYTES > 80 * 1024 ? STAGE_BYTES : 80 * 1024;   // (the 8-phase tile and the fused QKV + self-attention tile own their CU: the whole LDS)
   static constexpr int NCHUNK = (PP != 2 && BM * PITCH * 4 + extra(BM) <= LIMIT) ? 1 : 2;     // (8-phase tile: always one chunk per row half, the way its waves hold the rows)
   static_assert(WGM % NCHUNK == 0, "a chunk holds whole wave rows");
   static constexpr int CR = BM / NCHUNK;
@@ -88,6 +88,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   // hands them over in SGPRs, so the first tile loads go out without waiting for a cold read of the argument block (which costs every launch
   // ~1 us: tools/micro/launch_floor2.hip). The rest of GemmArgs (epilogue, conv geometry) arrives while those loads fly.   // >= 2 waves/SIMD: big tiles must fit 256 registers
   static_assert(PP != 1 || (WGM == 4 && NSTAGE == 3), "ping-pong schedule: 8 waves, 3-stage ring");
+  static_assert(PP != 3 || (WGM == 4 && NSTAGE == 2 && !CONV), "two-slot ping-pong schedule: 8 waves, 2 k-tile slots");
   static_assert(PP != 2 || (WGM == 2 && WGN == 4 && NSTAGE == 2 && BK == 64 && BM == 256 && (BN == 256 || BN == 128) && XA == 0), "8-phase schedule: 256-row tiles, 2 x 4 waves, two k-tile buffers");
   constexpr int NWAVE = WGM * WGN;
   constexpr int WM = BM / WGM, WN = BN / WGN;    // wave tile (waves arranged WGM x WGN; WGN = 1: narrow tiles, one wave per 128-byte column block)
@@ -194,7 +195,11 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
 #pragma unroll
   for (int i = 0; i < B_PW; ++i) {
     const int pi = min(b_piece(i), BNL / RPP - 1);
-    const int n = bn0 + pi * RPP + srow;
+    int n = bn0 + pi * RPP + srow;
+    if constexpr (XA == 4) {        // fused QKV + self-attention: the tile's 192 columns are rows h*64 .. h*64+63 of the Q, the K and the V block of the stacked [3C, C] weight
+      const int jl = pi * RPP + srow;
+      n = (jl >> 6) * (hN / 3) + tn * 64 + (jl & 63);
+    }
     const int gch = cpos ^ lds_swz<BK>(pi * RPP + srow);
     if (n < hN && pi * RPP + srow < BN) { w_ptr[i] = hW + (size_t)n * hldw + gch * 8; w_inc[i] = BK; }
     else         { w_ptr[i] = hzero; w_inc[i] = 0; }
@@ -459,6 +464,64 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
       }
       mm();
     }
+  } else if constexpr (PP == 3) {
+    // ---- ping-pong on TWO k-tile slots (the fused QKV + self-attention tile: 256 x 192 leaves LDS for two stages of 56 KiB, not three). Barriers b0, b1, ...;
+    //      group 0 (waves 0-3, rows 0-127) reads tile t in I_2t and multiplies it in I_2t+1; group 1 reads it in I_2t+1 and multiplies it in I_2t+2. EVERY wave
+    //      issues its DMA pieces of tile t+1 in I_2t -- group 0 behind its fragment reads, group 1 ahead of its MFMAs -- into the slot of tile t-1, whose last
+    //      reader (group 1, in I_2t-1) has retired its reads before b_2t; the pieces have two intervals to land and are waited for in front of b_2t+2.
+    static_assert(MR * NR <= 24, "two-slot ping-pong keeps the fragments of a whole k-tile in registers across a barrier");
+    const int grp = wave >> 2;
+    h8 af[KSUB][MR], wf[KSUB][NR];
+    auto rd = [&](int slot) {
+      const char* base = smem + slot * STAGE;
+#pragma unroll
+      for (int kk = 0; kk < KSUB; ++kk) {
+        const int coff = ((kk * 4 + fq) ^ fswz) << 4;
+#pragma unroll
+        for (int i = 0; i < MR; ++i) af[kk][i] = *(const h8*)(base + a_off + i * 16 * ROWB + coff);
+#pragma unroll
+        for (int j = 0; j < NR; ++j) wf[kk][j] = *(const h8*)(base + w_off + j * 16 * ROWB + coff);
+      }
+    };
+    auto mm = [&]() {
+#pragma unroll
+      for (int kk = 0; kk < KSUB; ++kk)
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+          for (int j = 0; j < NR; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
+    };
+    auto top = [&]() {           // b_2t: tile t has landed for every wave (nothing else is in flight); this wave's fragment reads of the interval before are retired
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mid = [&]() {           // b_2t+1
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    if (grp == 0) {
+      for (int t = 0; t < nk; ++t) {
+        top();
+        rd(t & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < nk) stage(t + 1, (t + 1) & 1);
+        mid();
+        mm();
+      }
+    } else {
+      for (int t = 0; t < nk; ++t) {
+        top();
+        if (t + 1 < nk) stage(t + 1, (t + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t > 0) mm();
+        mid();
+        rd(t & 1);
+      }
+      mm();
+    }
   } else if constexpr (PP == 2) {
     // ---- 8-phase schedule (cdna_hip_programming.md §5 "The 256^2 8-phase template"): a k-tile is multiplied in FOUR phases, one 64-row x (BN/8)-column
     //      quadrant of the wave tile x K = 64 each; every phase = { fragment reads of the quadrant's new operand half, LDS-DMA of ONE half-tile of a later
@@ -580,7 +643,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
     wait_ring<NSTAGE - 2, LPS>(ahead < NSTAGE - 2 ? ahead : NSTAGE - 2);
     // every wave has passed the barrier => tile kt has landed for all, and slot `nxt` (read in step kt-1) is free
     if (kt + NSTAGE - 1 < nk) stage(kt + NSTAGE - 1, nxt);
-    if constexpr (XA != 0) {
+    if constexpr (XA != 0 && XA != 4) {
       if (kt == 0) attn_kv_load(*xa, bm0 / xa->Nq, tn, tid, kvr);
     }
     const char* base = smem + cur * STAGE;
@@ -651,13 +714,17 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   __syncthreads();                    // every wave has finished reading the stage buffers
   if (p.ln_stats) {
     if (tid < BM) {
-      const float inv = 1.f / (float)hK;
-      const float mean = ln_s1 * inv;
-      const float var = fmaxf(ln_s2 * inv - mean * mean, 0.f);
-      ln_rows[tid] = mean;
-      ln_rows[BM + tid] = rsqrtf(var + p.ln_eps);
+      const float2 mr = ln_mean_rstd_f(ln_s1, ln_s2, hK, p.ln_eps);
+      ln_rows[tid] = mr.x;
+      ln_rows[BM + tid] = mr.y;
     }
-    if (tid < BN / 4 && bn0 + tid * 4 < hN) {
+    if constexpr (XA == 4) {
+      if (tid < BN / 4) {           // columns 4 tid .. of the tile = the same offsets inside the Q / K / V block of head tn
+        const int n = ((tid * 4) >> 6) * (hN / 3) + tn * 64 + ((tid * 4) & 63);
+        *(f4*)(ln_cs + tid * 4) = *(const f4*)(p.ln_cs + n);
+        *(f4*)(ln_lb + tid * 4) = *(const f4*)(p.ln_bias + n);
+      }
+    } else if (tid < BN / 4 && bn0 + tid * 4 < hN) {
       *(f4*)(ln_cs + tid * 4) = *(const f4*)(p.ln_cs + bn0 + tid * 4);
       *(f4*)(ln_lb + tid * 4) = *(const f4*)(p.ln_bias + bn0 + tid * 4);
     }
@@ -667,7 +734,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   // whose wait would otherwise (vmcnt retires in order) also wait for these HBM-cold lines -- and nothing consumes them before the kernel's
   // end, so they fly during the whole epilogue (round 2 XOR-ed them together right away: a 2-3 us stall of every workgroup ahead of its epilogue).
   unsigned pfacc = 0, pfv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (PP && p.pf) {
+  if ((PP == 1 || PP == 2) && p.pf) {
     const long nwg = (long)tiles_m * tiles_n * nsplit;
     const long per = ((p.pf_bytes + nwg - 1) / nwg + 255) & ~255L;
     const long lo = (long)blockIdx.x * per, hi = min(lo + per, p.pf_bytes & ~15L);
@@ -686,7 +753,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
       }
   }
   auto pf_sink = [&]() {              // keep the loads alive up to here
-    if (PP) asm volatile("" ::"v"(pfacc), "v"(pfv[0]), "v"(pfv[1]), "v"(pfv[2]), "v"(pfv[3]), "v"(pfv[4]), "v"(pfv[5]), "v"(pfv[6]), "v"(pfv[7]));
+    if (PP == 1 || PP == 2) asm volatile("" ::"v"(pfacc), "v"(pfv[0]), "v"(pfv[1]), "v"(pfv[2]), "v"(pfv[3]), "v"(pfv[4]), "v"(pfv[5]), "v"(pfv[6]), "v"(pfv[7]));
   };
   const float e_as = p.acc_scale == 0.f ? 1.f : p.acc_scale, e_bs = p.bias_scale == 0.f ? 1.f : p.bias_scale;
   const bool fast = p.vec8 != 0 && (hN & 7) == 0;     // 16-byte accesses everywhere (every shape of the executors); else 8-byte pieces
@@ -728,7 +795,56 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
       }
     }
   };
-  if constexpr (XA != 0) {
+  if constexpr (XA == 4) {
+    // ---- fused QKV projection + self-attention (reference attention_processor.py:239 `attn.to_q`, :246-247 `to_k` / `to_v`, :259 scaled_dot_product_attention of
+    //      AttnProcessor2_0; the LayerNorm in front of them folded into the projection): this tile is Q | K | V of ALL 256 tokens of one image x ONE head --
+    //      everything that head's attention needs. The accumulators get the projection epilogue (fp32, ONE rounding to fp16, exactly what the stand-alone GEMM
+    //      stores), go straight into the LDS images of the attention core (K and V images as stage_kv lays them out, Q as swizzled rows), and only O is written:
+    //      Q, K and V (15.7 MB per layer at batch 8) never travel to memory and back, one launch instead of two.
+    static_assert(XA != 4 || (BM == 256 && BN == 192 && WGM == 4 && WGN == 2 && !CONV && (PP == 0 || PP == 3)), "fused QKV + self-attention: 256 x 192 tiles, 8 waves");
+    char* sK = smem;
+    char* sV = smem + 32768;
+    char* sQ = smem + 65536;              // [256][128 B], 16-byte chunks XOR-swizzled by row & 7; later: the waves' O staging tiles (4 KiB each, a wave's own query rows)
+    __syncthreads();                      // row / column constants are in LDS (and every wave is through with the stage buffers: barrier above)
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+      const int r = wm0 + i * 16 + frow;
+      const float mu = p.ln_stats ? ln_rows[r] : 0.f, rs = p.ln_stats ? ln_rows[BM + r] : 1.f;
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        const int cl = wn0 + j * 16 + fq * 4;                     // tile column of acc[i][j][0]: 4 consecutive columns inside ONE of Q / K / V
+        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        if (p.ln_stats) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = ln_fold_f(v[e], mu, rs, ln_cs[cl + e], ln_lb[cl + e]);
+        } else if (p.bias) {
+          const h4 hb = *(const h4*)(p.bias + (cl >> 6) * (hN / 3) + tn * 64 + (cl & 63));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (float)hb[e];
+        }
+        h4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
+        const int which = cl >> 6, d = cl & 63, chunk = d >> 3, sub = (d & 7) * 2;
+        const int sw = which == 0 ? (r & 7) : which == 1 ? ((r >> 1) & 7) : (((r >> 1) & 1) << 2);
+        char* img = which == 0 ? sQ : which == 1 ? sK : sV;
+        *(h4*)(img + r * 128 + ((chunk ^ sw) << 4) + sub) = o;
+      }
+    }
+    __syncthreads();
+    const int r31 = lane & 31, hh = lane >> 5;
+    h8 qf[4];
+    {
+      const int r = wave * 32 + r31;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) qf[s] = *(const h8*)(sQ + r * 128 + (((2 * s + hh) ^ (r & 7)) << 4));
+    }
+    const AttnArgs& ap = *xa;
+    f16v otot[2];
+    attn_core<0, true>(ap, tm, tn, qf, sK, sV, tid, otot);       // this wave's 32 queries over the image's 256 keys (no workgroup barrier inside: resident images)
+    attn_store_o(otot, ap.O, (size_t)ap.B * ap.Nq * ap.ldo, tm, wave * 32, tn, ap.Nq, ap.ldo, sQ + wave * 4096, lane, (ap.xcd_map & 2) != 0);
+    return;
+  } else if constexpr (XA != 0) {
     // ---- fused to_q + cross-attention (reference attention_processor.py:344 `attn.to_q`, :371 / :387 the two SDPA calls, :397 `text + scale * ip`):
     //      this tile is Q of 128 queries x one head. It goes through the fp32 LDS tile once (projection epilogue applied there, rounded to fp16
     //      exactly as the stand-alone GEMM would store it), comes back as the Q^T fragments of the attention core, and only O is written.

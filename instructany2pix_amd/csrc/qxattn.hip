@@ -64,3 +64,51 @@ hipError_t ia2p_launch_qproj_xattn(const GemmArgs& a, const AttnArgs& x, hipStre
 #undef IA2P_QX_LAUNCH
   return hipGetLastError();
 }
+
+
+// ---- fused QKV projection + self-attention (round 4) -----------------------------------------------------------------------------------------------------
+// Reference: AttnProcessor2_0 (attention_processor.py:239 to_q, :246-247 to_k / to_v, :259 scaled_dot_product_attention), with the LayerNorm in front folded
+// into the projection. At the 16 x 16 level an image has 256 tokens: ONE 256 x 192 tile of the stacked projection = Q | K | V of all of an image's tokens for
+// ONE head = everything that head's attention needs. The tile body (gemm_kernel.h, XA = 4) turns its accumulators into the K / V images and Q fragments of the
+// attention core and writes only O: no QKV tensor (15.7 MB per layer at batch 8), no second launch. Same arithmetic in the same order as the stand-alone
+// pair: bit-identical to `ia2p_gemm_ex` + `ia2p_attention` (tests/test_ops_gpu.py).
+__global__ __launch_bounds__(512, 2) void qkv_sattn_kernel(const half_t* hA, const half_t* hW, const half_t* hzero, int hM, int hN, int hK, int hlda, int hldw, int hrpb,
+                                                           int hbstride, int hroff, int hsplitk, int hgroup_w, const GemmArgs p, const AttnArgs xa) {
+#ifndef IA2P_SATTN_PP
+#define IA2P_SATTN_PP 3      // k-loop schedule of the fused QKV + self-attention tile: 3 = two-slot ping-pong, 0 = plain loop (one barrier per k-step); A/B builds
+#endif
+  gemm_tile_body<256, 192, 2, false, 4, 64, IA2P_SATTN_PP, 2, 4>(hA, hW, hzero, hM, hN, hK, hlda, hldw, hrpb, hbstride, hroff, hsplitk, hgroup_w, p, &xa);
+}
+
+// A [B * 256, K] (un-normalised rows with a.ln_*, or plain), W the stacked [3 * heads * 64, K] projection; x: O / ldo / B / heads / Nq = 256.
+bool ia2p_qkv_sattn_ok(const GemmArgs& a, const AttnArgs& x) {
+  return x.Nq == 256 && x.B > 0 && a.M == x.B * 256 && a.N == 3 * x.heads * 64 && a.K >= 64 && a.K % 64 == 0 && a.splitk <= 1 && !a.geglu && !a.residual && !a.rowvec &&
+         !a.stats_out && !a.act && !a.rpb && x.nseg == 1 && x.ldo % 8 == 0 && ((((uintptr_t)x.O) & 15) == 0) && (!a.bias || ((((uintptr_t)a.bias) & 7) == 0)) &&
+         (!a.ln_stats || (((((uintptr_t)a.ln_cs) | ((uintptr_t)a.ln_bias)) & 15) == 0));
+}
+
+hipError_t ia2p_launch_qkv_sattn(const GemmArgs& a, const AttnArgs& x, hipStream_t s) {
+  if (!ia2p_qkv_sattn_ok(a, x)) return hipErrorInvalidValue;
+  constexpr int SMEM = EpiCfg<256, 192, 2, 4, 64, 2, 0>::SMEM;      // (the epilogue configuration does not depend on the k-loop schedule)
+  static_assert(SMEM >= 96 * 1024 + (2 * 256 + 2 * 192) * 4, "K / V / Q images + row and column constants");
+  static bool attr_set[64] = {false};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+    hipError_t e = hipFuncSetAttribute((const void*)qkv_sattn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
+  }
+  const int tiles_n = x.heads, tiles = x.B * tiles_n;
+  GemmArgs b = a;
+  b.vec8 = 1; b.splitk = 0; b.sk_counters = nullptr; b.partial = nullptr;
+  b.m_fastest = 0;
+  b.group_w = ia2p_tile_group_w(tiles, tiles_n, SMEM, 256, 192);
+  AttnArgs y = x;
+  y.seg[0].nkeys = 256; y.seg[0].weight = 1.f; y.nseg = 1;
+  y.xcd_map = ((ia2p_wt_mask() & 8) && (size_t)x.B * x.Nq * x.ldo * 2 < (size_t)0x7ffffff0) ? 2 : 0;      // bit 1: write-through O
+  const int extra = (a.pf && a.pf_bytes >= 4096) ? a.pf_blocks : 0;
+  hipLaunchKernelGGL(qkv_sattn_kernel, dim3(tiles + extra), dim3(512), SMEM, s, b.A, b.W, b.zero, b.M, b.N, b.K, b.lda, b.ldw, b.rpb, b.bstride, b.roff, b.splitk,
+                     b.group_w, b, y);
+  return hipGetLastError();
+}

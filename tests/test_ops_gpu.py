@@ -215,6 +215,30 @@ def test_layernorm_folded_into_gemm(L, M, C_, N, psplit, csplit, tile):
     assert rel_l2(out, ref) <= rel_l2(sep, ref) * 1.2 + 1e-4
 
 
+def test_layernorm_fold_bits_do_not_depend_on_the_tile(L):
+    """mean and rstd of the folded LayerNorm are derived inside every tile instantiation from the same {sum, sum of squares}: the roundings are spelled out
+    (common.h ln_mean_rstd_f), so -- like the plain GEMM -- the folded output is the same bits on every tile (round 3 left `s2/K - mean^2` to the compiler's
+    contraction and two instantiations differed in the last bit)."""
+    f, X, Wp, R, gamma, beta, W, b, Wf, cs, fb = _ln_fold_setup(L, 1024, 1280, 1920, seed=91)
+    M, C_, N = 1024, 1280, 1920
+    t = (X.float() * 3 + 0.5).half()
+    tf = t.float()
+    slots = C_ // 64
+    st = torch.stack([tf.view(M, slots, 64).sum(2), (tf * tf).view(M, slots, 64).sum(2)], dim=2).permute(1, 0, 2).contiguous()
+    ln = f.LnFoldC(st.data_ptr(), slots, cs.data_ptr(), fb.data_ptr(), 1e-5)
+    outs = []
+    try:
+        for tile in range(NTILES):
+            out = torch.empty(M, N, dtype=torch.half, device="cuda")
+            L.ia2p_debug_set_gemm_tile(tile)
+            run(L, "ia2p_gemm_ex", f.ptr(t), f.ptr(Wf), None, None, f.ptr(out), M, N, C_, 0, C.addressof(ln), None, None, 1, None)
+            outs.append(out)
+    finally:
+        L.ia2p_debug_set_gemm_tile(-1)
+    for i, o in enumerate(outs[1:]):
+        assert torch.equal(o, outs[0]), i + 1
+
+
 @pytest.mark.parametrize("M,C_", [(2048, 640), (130, 128)])
 def test_layernorm_folded_into_geglu(L, M, C_):
     f, X, Wp, R, gamma, beta, W, b, _, _, _ = _ln_fold_setup(L, M, C_, 8 * C_, seed=70)
@@ -618,6 +642,58 @@ def test_qproj_fused_with_cross_attention(L, B, heads, Nq, Lt, Li, scale, folded
         ref = ref + scale * _sdpa(sp(qref), sp(kvi[..., :C_]), sp(kvi[..., C_:]))
     ref = ref.transpose(1, 2).reshape(B, Nq, C_)
     assert rel_l2(one, ref) < 3e-3, rel_l2(one, ref)     # Q is rounded to fp16 between the projection and the scores, as in the reference
+
+
+@pytest.mark.parametrize("folded", [True, False])
+@pytest.mark.parametrize("B,heads,K", [(8, 20, 1280), (2, 4, 256), (1, 1, 64), (3, 10, 640)])
+def test_qkv_fused_with_self_attention(L, B, heads, K, folded):
+    """ia2p_qkv_self_attention = the stacked Q | K | V projection (optionally behind a folded LayerNorm) + the self-attention of AttnProcessor2_0 over the 256
+    tokens of an image in ONE launch (reference attention_processor.py:239, :246-247, :259): the same BITS as ia2p_gemm_ex (N = 3 C) followed by ia2p_attention
+    -- whatever tile the stand-alone GEMM runs on -- and within the attention tolerance of torch fp32."""
+    f = _ffi()
+    C_ = heads * 64
+    Nq, M = 256, B * 256
+    qkv = torch.empty(M, 3 * C_, dtype=torch.half, device="cuda")
+    two, one = torch.empty(B, Nq, C_, dtype=torch.half, device="cuda"), torch.full((B, Nq, C_), float("nan"), dtype=torch.half, device="cuda")
+    att = lambda out: run(L, "ia2p_attention", f.ptr(qkv), 3 * C_, f.ptr(out), C_, B, heads, Nq, 1,
+                          C.c_void_p(qkv.data_ptr() + 2 * C_), C.c_void_p(qkv.data_ptr() + 4 * C_), 3 * C_, Nq, 1.0, None, None, 0, 0, 0.0)
+    if folded:
+        g = torch.Generator().manual_seed(100 + heads)
+        t = (torch.randn(M, K, generator=g) * 1.5 + 0.3).half().cuda()
+        gamma, beta = (1.0 + 0.3 * torch.randn(K, generator=g)).half().cuda(), (0.2 * torch.randn(K, generator=g)).half().cuda()
+        W, b = (torch.randn(3 * C_, K, generator=g) * K ** -0.5).half().cuda(), None
+        Wf = torch.empty_like(W)
+        cs, fb = torch.empty(3 * C_, dtype=torch.float32, device="cuda"), torch.empty(3 * C_, dtype=torch.float32, device="cuda")
+        run(L, "ia2p_fold_layernorm", f.ptr(W), f.ptr(gamma), f.ptr(beta), None, f.ptr(Wf), f.ptr(cs), f.ptr(fb), 3 * C_, K)
+        tf = t.float()
+        slots = K // 64
+        st = torch.stack([tf.view(M, slots, 64).sum(2), (tf * tf).view(M, slots, 64).sum(2)], dim=2).permute(1, 0, 2).contiguous()
+        ln = f.LnFoldC(st.data_ptr(), slots, cs.data_ptr(), fb.data_ptr(), 1e-5)
+        for tile in (0, 12, 4):
+            L.ia2p_debug_set_gemm_tile(tile)
+            try:
+                run(L, "ia2p_gemm_ex", f.ptr(t), f.ptr(Wf), None, None, f.ptr(qkv), M, 3 * C_, K, 0, C.addressof(ln), None, None, 1, None)
+            finally:
+                L.ia2p_debug_set_gemm_tile(-1)
+            att(two)
+            one.fill_(float("nan"))
+            run(L, "ia2p_qkv_self_attention", f.ptr(t), f.ptr(Wf), None, C.addressof(ln), f.ptr(one), C_, B, heads, K)
+            assert torch.equal(one, two), (tile, float((one.float() - two.float()).abs().max()))
+        ref_qkv = F.layer_norm(tf, (K,), gamma.float(), beta.float(), 1e-5) @ W.float().t()
+    else:
+        X, W, b = rnd(M, K, seed=33), rnd(3 * C_, K, seed=34, scale=K ** -0.5), rnd(3 * C_, seed=35, scale=0.3)
+        run(L, "ia2p_gemm_ex", f.ptr(X), f.ptr(W), f.ptr(b), None, f.ptr(qkv), M, 3 * C_, K, 0, None, None, None, 1, None)
+        att(two)
+        run(L, "ia2p_qkv_self_attention", f.ptr(X), f.ptr(W), f.ptr(b), None, f.ptr(one), C_, B, heads, K)
+        assert torch.equal(one, two), float((one.float() - two.float()).abs().max())
+        ref_qkv = X.float() @ W.float().t() + b.float()
+    sp = lambda x: x.reshape(B, Nq, heads, 64).transpose(1, 2)
+    q, k, v = ref_qkv[:, :C_], ref_qkv[:, C_:2 * C_], ref_qkv[:, 2 * C_:]
+    ref = _sdpa(sp(q), sp(k), sp(v)).transpose(1, 2).reshape(B, Nq, C_)
+    assert rel_l2(one, ref) < 3e-3, rel_l2(one, ref)
+    # wrong shapes are refused, not mis-computed
+    assert L.ia2p_qkv_self_attention(f.current_stream(), f.ptr(one), f.ptr(W), None, None, f.ptr(one), C_, B, heads, 100) != 0      # K % 64
+    assert L.ia2p_qkv_self_attention(f.current_stream(), None, f.ptr(W), None, None, f.ptr(one), C_, B, heads, K) != 0
 
 
 def test_qproj_attention_rejects_bad_shapes(L):
