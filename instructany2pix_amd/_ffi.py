@@ -81,6 +81,7 @@ SIGNATURES = {
     "ia2p_debug_set_gemm_splitk": (None, [_I]),
     "ia2p_conv3x3": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I]),
     "ia2p_pack_conv3x3": (_I, [_P, _P, _P, _I, _I]),
+    "ia2p_pack_conv_out": (_I, [_P, _P, _P, _I, _I]),
     "ia2p_conv3x3_cat": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I]),
     "ia2p_pack_geglu": (_I, [_P, _P, _P, _I, _I]),
     "ia2p_conv_in": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I]),

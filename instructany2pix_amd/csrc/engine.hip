@@ -114,7 +114,7 @@ struct Planner {
   }
   size_t vec(const std::string& key, int n) { size_t o = take(n); reg(key, o, n); return o; }
   size_t mat(const std::string& key, int rows, int cols) { size_t o = take((size_t)rows * cols); reg(key, o, (size_t)rows * cols); return o; }
-  size_t conv3(const std::string& key, int co, int ci) { size_t o = take((size_t)co * ci * 9); reg(key, o, (size_t)co * ci * 9, PK_CONV, co, ci); return o; }
+  size_t conv3(const std::string& key, int co, int ci, PKind kind = PK_CONV) { size_t o = take((size_t)co * ci * 9); reg(key, o, (size_t)co * ci * 9, kind, co, ci); return o; }
 
   Resnet resnet(const std::string& p, int cin, int cout, int temb, size_t tw_all, size_t tb_all) {
     Resnet r;
@@ -275,7 +275,7 @@ static ia2p_status plan_pass(ia2p_ctx* c, size_t fold_base, size_t* raw_elems, s
   if (c->temb_total != tot) return fail(c, IA2P_ERR_STATE, "internal: time_emb_proj stacking mismatch %d != %d", c->temb_total, tot);
   if (P.kv_cursor != c->kv_rows) return fail(c, IA2P_ERR_STATE, "internal: context K/V stacking mismatch %d != %d", P.kv_cursor, c->kv_rows);
   c->ngo = P.vec("conv_norm_out.weight", ch[0]); c->nbo = P.vec("conv_norm_out.bias", ch[0]);
-  c->conv_out_w = P.conv3("conv_out.weight", g.out_channels, ch[0]); c->conv_out_b = P.vec("conv_out.bias", g.out_channels);
+  c->conv_out_w = P.conv3("conv_out.weight", g.out_channels, ch[0], PK_CONV_TAP); c->conv_out_b = P.vec("conv_out.bias", g.out_channels);
 
   // IP-Adapter keys: index = position in unet.attn_processors = down, up, mid (attn1 even, attn2 odd)
   int idx = 0;
@@ -844,7 +844,8 @@ ia2p_status rc_load_tensor(RunCtx* c, const char* key, const void* src, const in
   hipError_t e = hipSuccess;
   switch (p.kind) {
     case PK_COPY: e = hipMemcpyAsync(dst, src, n * sizeof(half_t), hipMemcpyDeviceToDevice, s); break;
-    case PK_CONV: e = ia2p_launch_pack_conv((const half_t*)src, dst, p.d0, p.d1, s); break;
+    case PK_CONV: e = ia2p_launch_pack_conv((const half_t*)src, dst, p.d0, p.d1, s, true); break;
+    case PK_CONV_TAP: e = ia2p_launch_pack_conv((const half_t*)src, dst, p.d0, p.d1, s, false); break;
     case PK_GEGLU_W: case PK_GEGLU_B: e = ia2p_launch_pack_geglu((const half_t*)src, dst, p.d0, p.d1, s); break;
     case PK_PAD_CONV_IN: e = ia2p_launch_pack_conv_in((const half_t*)src, dst, p.d0, p.d1, s); break;
   }
@@ -1242,8 +1243,14 @@ ia2p_status ia2p_conv3x3_cat(void* stream, const void* x, const void* x2, const 
 }
 ia2p_status ia2p_pack_conv3x3(void* stream, const void* src, void* dst, int Co, int Cin) {
   if (!src || !dst) return fail(nullptr, IA2P_ERR_INVALID, "pack_conv3x3: null argument");
-  hipError_t e = ia2p_launch_pack_conv((const half_t*)src, (half_t*)dst, Co, Cin, (hipStream_t)stream);
+  if (Cin % 64) return fail(nullptr, IA2P_ERR_SHAPE, "pack_conv3x3: Cin=%d must be a multiple of 64 (the layout of ia2p_conv3x3; ia2p_pack_conv_out packs for ia2p_conv_out)", Cin);
+  hipError_t e = ia2p_launch_pack_conv((const half_t*)src, (half_t*)dst, Co, Cin, (hipStream_t)stream, true);
   RET_HIP(e, "pack_conv3x3");
+}
+ia2p_status ia2p_pack_conv_out(void* stream, const void* src, void* dst, int Co, int C) {
+  if (!src || !dst) return fail(nullptr, IA2P_ERR_INVALID, "pack_conv_out: null argument");
+  hipError_t e = ia2p_launch_pack_conv((const half_t*)src, (half_t*)dst, Co, C, (hipStream_t)stream, false);
+  RET_HIP(e, "pack_conv_out");
 }
 // latent-boundary convolutions as operators (the executors call the launchers directly): conv_in reads NCHW and writes channels-last,
 // conv_out reads channels-last and writes NCHW; reference call sites: the diffusers UNet's conv_in / conv_out behind pnp_pipeline.py:253-260

@@ -163,7 +163,12 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   auto a_piece = [&](int i) { return PP == 2 ? (i / A_HP) * (BM / 2 / RPP) + wave * A_HP + i % A_HP : wave * A_PW + i; };
   const half_t* a_ptr[A_PW];
   int a_inc[A_PW];
-  int a_y[A_PW], a_x[A_PW], a_pix[A_PW], a_ch[A_PW];
+  // conv gather, per piece (= one tile row per lane): a_base = address of filter tap (0, 0)'s pixel for this lane's 16-byte chunk (may lie outside the image: only
+  // dereferenced under the mask); a_mask = bits 0-8: tap (ky, kx) falls inside the (virtual) image, bits 9 / 10: parity of the tap-0 row / column in the
+  // nearest-x2 upsampled view (source step of tap k = (k + parity) >> up). The k-loop changes tap EVERY k-tile (channel-block-major walk): deriving the tap's
+  // pointer from these is a bit test, a wave-uniform offset and a select -- not the long pixel arithmetic round 3 ran once per Cin / 64 k-tiles.
+  const half_t* a_base[A_PW];
+  int a_mask[A_PW];
 #pragma unroll
   for (int i = 0; i < A_PW; ++i) {
     const int pi = a_piece(i);
@@ -177,13 +182,19 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
         a_inc[i] = BK;
       } else { a_ptr[i] = hzero; a_inc[i] = 0; }
     } else {
-      a_ch[i] = gch * 8;
+      a_mask[i] = 0; a_base[i] = hzero;
       if (m < hM) {
         const int hw = p.Ho * p.Wo;
         const int b = m / hw, rem = m - b * hw;
         const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        a_y[i] = oy * p.stride - p.pad; a_x[i] = ox * p.stride - p.pad; a_pix[i] = b * p.Hs * p.Ws;
-      } else { a_y[i] = -(1 << 20); a_x[i] = 0; a_pix[i] = 0; }
+        const int y0 = oy * p.stride - p.pad, x0 = ox * p.stride - p.pad;      // tap (0, 0) in the (virtual, upsampled) image
+        const int Hv_ = p.Hs << p.up, Wv_ = p.Ws << p.up;
+        int mk = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) mk |= ((unsigned)(y0 + t / 3) < (unsigned)Hv_ && (unsigned)(x0 + t % 3) < (unsigned)Wv_) ? 1 << t : 0;
+        a_mask[i] = mk | ((y0 & 1) << 9) | ((x0 & 1) << 10);
+        a_base[i] = hA + ((long)b * p.Hs * p.Ws + (long)(y0 >> p.up) * p.Ws + (x0 >> p.up)) * hlda + gch * 8;      // (arithmetic shifts: row / column -1 stays -1)
+      }
     }
   }
   const half_t* w_ptr[B_PW];
@@ -205,14 +216,14 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
     else         { w_ptr[i] = hzero; w_inc[i] = 0; }
   }
 
-  const int Hv = p.Hs << p.up, Wv = p.Ws << p.up;
   const int nk_all = hK / BK;
   const int kt0 = (int)((long)split * nk_all / nsplit), kt1 = (int)((long)(split + 1) * nk_all / nsplit);   // this workgroup's k-tiles
   // conv: K is walked CHANNEL-BLOCK-major -- for each block of 64 input channels the nine taps, then the next block; after the 9 Cin columns of the 3x3 part the
   // appended 1x1 blocks in storage order. The nine taps of a channel block re-read (almost) the same 64-channel pixel rows, so an XCD's distinct activation
   // bytes between two uses of a line are tiles x (pixels + halo) x 128 B (1.6 MB for 32 tiles of 256 pixels) instead of tiles x pixels x Cin x 2 B (5 MB at 320
   // channels: more than the 4 MiB L2, i.e. every tap re-fetched its rows through the fabric -- PMC traffic 3.65 x algorithmic on the 256 x 160 conv class, round 3).
-  // The WEIGHT layout is unchanged ([Co][tap][Ci] = column tap * Cin + ci): the walk just strides it (+Cin per tap, +64 - 8 Cin at a block change).
+  // The weights are PACKED in walk order ([Co][Cin / 64][tap][64], misc.hip pack_conv_kernel): a weight row streams front to back, 128 bytes per k-tile (a walk
+  // that strode a tap-major row -- +Cin per tap -- ran the large-K convolutions 15 ... 45 % slower: the weights come from beyond L2, and they want whole rows).
   // Position of k-tile kt of the 3x3 part: tap = kt % 9, ci0 = (kt / 9) * 64. (Every tile variant walks K the same way: the bits still do not depend on the tile.)
   int cin_main = 0, cin_extra = 0;                         // (two named scalars: a select between two argument FIELDS became a 2-entry table in scratch)
   if (CONV) { cin_main = p.Cin; cin_extra = p.Cin2; asm volatile("" : "+s"(cin_main), "+s"(cin_extra)); }
@@ -230,8 +241,6 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
     }
   }
   bool tap_fresh = true;
-  // weight column (in elements) of the k-tile at (tap, ci0)
-  auto wcol = [&](int t, int c) { return t < 9 ? t * cin_main + c : t == 9 ? 9 * cin_main + c : 9 * cin_main + cin_extra + c; };
   // the walk, one k-tile on: (tap, ci0) -> next
   auto k_next = [&](int& t, int& c) {
     if (t < 9) {
@@ -246,17 +255,13 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
       if (t < 10 && c >= cin_extra) { c = 0; ++t; }                           // (the last block runs to the end of K)
     }
   };
-  // the weight side keeps its own copies of the position: one per weight half-tile (the 8-phase tile issues its weight halves at other points of the loop than
-  // its activation halves)
-  int wtap0 = tap, wci0 = ci0, wtap1 = tap, wci1 = ci0;
   if (kt0) {             // split-K: this workgroup starts at k-tile kt0
     if (!CONV) {
 #pragma unroll
       for (int i = 0; i < A_PW; ++i) a_ptr[i] += (size_t)kt0 * a_inc[i];
     }
-    const int w0 = CONV ? wcol(tap, ci0) : kt0 * BK;
 #pragma unroll
-    for (int i = 0; i < B_PW; ++i) w_ptr[i] += w_inc[i] ? (size_t)w0 : 0;
+    for (int i = 0; i < B_PW; ++i) w_ptr[i] += (size_t)kt0 * w_inc[i];
   }
 
   // new filter tap (wave-uniform; every k-tile of the 3x3 part): re-derive the gathered pixel of each row
@@ -264,12 +269,22 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
     if (tap_fresh) {
       if (tap < 9) {
         const int ky = tap / 3, kx = tap - ky * 3;
+        if (!p.up) {
+          const long toff = ((long)ky * p.Ws + kx) * hlda + ci0;      // wave-uniform: elements from tap (0, 0)'s pixel to this tap's, plus the channel block
 #pragma unroll
-        for (int i = 0; i < A_PW; ++i) {
-          const int iy = a_y[i] + ky, ix = a_x[i] + kx;
-          const bool ok = (unsigned)iy < (unsigned)Hv && (unsigned)ix < (unsigned)Wv;
-          a_ptr[i] = ok ? hA + (size_t)(a_pix[i] + (iy >> p.up) * p.Ws + (ix >> p.up)) * hlda + ci0 + a_ch[i] : hzero;
-          a_inc[i] = ok ? BK : 0;
+          for (int i = 0; i < A_PW; ++i) {
+            const bool ok = (a_mask[i] >> tap) & 1;
+            a_ptr[i] = ok ? a_base[i] + toff : hzero;
+            a_inc[i] = ok ? BK : 0;
+          }
+        } else {                  // nearest x2 upsample folded into the gather: the source step of a tap depends on the parity of the row / column
+#pragma unroll
+          for (int i = 0; i < A_PW; ++i) {
+            const bool ok = (a_mask[i] >> tap) & 1;
+            const int dy = (ky + ((a_mask[i] >> 9) & 1)) >> 1, dx = (kx + ((a_mask[i] >> 10) & 1)) >> 1;
+            a_ptr[i] = ok ? a_base[i] + ((long)dy * p.Ws + dx) * hlda + ci0 : hzero;
+            a_inc[i] = ok ? BK : 0;
+          }
         }
       } else {              // appended 1x1 block: the output pixel itself, from the second tensor (stride 1: pixel index = output row)
         // (two copies of the loop, not a select between p.A2 and p.A3: a select between FIELDS of the by-value argument struct is compiled
@@ -279,7 +294,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
           for (int i = 0; i < A_PW; ++i) {
             const int m = bm0 + a_piece(i) * RPP + srow;      // (re-derived: happens once or twice per launch)
             const bool ok = m < hM;
-            a_ptr[i] = ok ? p.A2 + (size_t)m * p.lda2 + ci0 + a_ch[i] : hzero;
+            a_ptr[i] = ok ? p.A2 + (size_t)m * p.lda2 + ci0 + (cpos ^ lds_swz<BK>(a_piece(i) * RPP + srow)) * 8 : hzero;
             a_inc[i] = ok ? BK : 0;
           }
         } else {
@@ -287,7 +302,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
           for (int i = 0; i < A_PW; ++i) {
             const int m = bm0 + a_piece(i) * RPP + srow;
             const bool ok = m < hM;
-            a_ptr[i] = ok ? p.A3 + (size_t)m * p.lda3 + ci0 + a_ch[i] : hzero;
+            a_ptr[i] = ok ? p.A3 + (size_t)m * p.lda3 + ci0 + (cpos ^ lds_swz<BK>(a_piece(i) * RPP + srow)) * 8 : hzero;
             a_inc[i] = ok ? BK : 0;
           }
         }
@@ -305,34 +320,26 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
 #pragma unroll
     for (int i = decltype(i0_tag)::value; i < decltype(i1_tag)::value; ++i) { GLDS16(a_ptr[i], smem + buf * STAGE + a_piece(i) * 1024); a_ptr[i] += a_inc[i]; }
   };
-  auto issue_b = [&](int buf, auto i0_tag, auto i1_tag, auto half_tag) {
-    long wstep = BK;                                      // elements to the next k-tile of the walk (wave-uniform)
-    if (CONV) {
-      int& wt = decltype(half_tag)::value ? wtap1 : wtap0;
-      int& wc = decltype(half_tag)::value ? wci1 : wci0;
-      const int c0 = wcol(wt, wc);
-      k_next(wt, wc);
-      wstep = wcol(wt, wc) - c0;
-    }
+  auto issue_b = [&](int buf, auto i0_tag, auto i1_tag) {
 #pragma unroll
     for (int i = decltype(i0_tag)::value; i < decltype(i1_tag)::value; ++i)
-      if (!B_UNEVEN || i < b_npw) { GLDS16(w_ptr[i], smem + buf * STAGE + BM * ROWB + b_piece(i) * 1024); w_ptr[i] += w_inc[i] ? wstep : 0; }      // (wave-uniform branch)
+      if (!B_UNEVEN || i < b_npw) { GLDS16(w_ptr[i], smem + buf * STAGE + BM * ROWB + b_piece(i) * 1024); w_ptr[i] += w_inc[i]; }      // (wave-uniform)
   };
   using I0 = std::integral_constant<int, 0>;
   auto stage = [&](int kt, int buf) {
     if (CONV) conv_tap_setup();
     issue_a(buf, I0{}, std::integral_constant<int, A_PW>{});
     if (CONV) conv_tap_advance();
-    issue_b(buf, I0{}, std::integral_constant<int, B_PW>{}, I0{});
+    issue_b(buf, I0{}, std::integral_constant<int, B_PW>{});
   };
   // 8-phase tile: one HALF of an operand tile per call, in the order B0, A0, B1, A1 of a k-tile (A0 opens the k-tile for the conv gather, A1 closes it)
   auto stage_part = [&](int buf, auto which_tag) {
     constexpr int WHICH = decltype(which_tag)::value;
     using AH = std::integral_constant<int, A_HP>;
     using BH = std::integral_constant<int, B_HP>;
-    if constexpr (WHICH == 0) issue_b(buf, I0{}, BH{}, I0{});
+    if constexpr (WHICH == 0) issue_b(buf, I0{}, BH{});
     else if constexpr (WHICH == 1) { if (CONV) conv_tap_setup(); issue_a(buf, I0{}, AH{}); }
-    else if constexpr (WHICH == 2) issue_b(buf, BH{}, std::integral_constant<int, B_PW>{}, std::integral_constant<int, 1>{});
+    else if constexpr (WHICH == 2) issue_b(buf, BH{}, std::integral_constant<int, B_PW>{});
     else { issue_a(buf, AH{}, std::integral_constant<int, A_PW>{}); if (CONV) conv_tap_advance(); }
   };
 

@@ -478,13 +478,17 @@ __global__ void touch_kernel(const uint4* p, size_t n16, unsigned* sink) {
 }
 
 // ---- one-time weight re-layouts -----------------------------------------------------------------------------------------
-// conv [Co][Ci][3][3] -> [Co][ky][kx][Ci] (implicit-GEMM K order)
-__global__ void pack_conv_kernel(const half_t* src, half_t* dst, int Co, int Ci) {
+// conv [Co][Ci][3][3] -> the implicit-GEMM K order of gemm_kernel.h: CHANNEL-BLOCK-major, [Co][Ci / 64][ky][kx][64] -- for each block of 64 input channels the
+// nine taps (blocked != 0; Ci % 64 == 0), so that the k-loop's walk (nine taps of a channel block, then the next block) streams a weight row front to back;
+// blocked == 0: [Co][ky][kx][Ci] (tap-major: conv_out_kernel's layout, any Ci)
+__global__ void pack_conv_kernel(const half_t* src, half_t* dst, int Co, int Ci, int blocked) {
   const long total = (long)Co * Ci * 9;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int ci = (int)(i % Ci);
-    const long t = i / Ci;
-    const int tap = (int)(t % 9), co = (int)(t / 9);
+    const int co = (int)(i / ((long)Ci * 9));
+    const int k = (int)(i - (long)co * Ci * 9);
+    int ci, tap;
+    if (blocked) { const int cb = k / 576, r = k - cb * 576; tap = r >> 6; ci = cb * 64 + (r & 63); }
+    else { tap = k / Ci; ci = k - tap * Ci; }
     dst[i] = src[((long)co * Ci + ci) * 9 + tap];
   }
 }
@@ -722,8 +726,12 @@ hipError_t ia2p_launch_touch(const void* p, size_t bytes, unsigned* sink, hipStr
   hipLaunchKernelGGL(touch_kernel, dim3((unsigned)std::min<size_t>(2048, (n16 + 255) / 256)), dim3(256), 0, s, (const uint4*)p, n16, sink);
   return hipGetLastError();
 }
-hipError_t ia2p_launch_pack_conv(const half_t* src, half_t* dst, int Co, int Ci, hipStream_t s) {
-  hipLaunchKernelGGL(pack_conv_kernel, dim3(grid_for((long)Co * Ci * 9, 256)), dim3(256), 0, s, src, dst, Co, Ci);
+hipError_t ia2p_launch_pack_conv(const half_t* src, half_t* dst, int Co, int Ci, hipStream_t s, bool blocked) {
+#ifdef IA2P_CONV_TAP_MAJOR      // A/B builds: round 3's tap-major K order everywhere
+  blocked = false;
+#endif
+  if (blocked && Ci % 64) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pack_conv_kernel, dim3(grid_for((long)Co * Ci * 9, 256)), dim3(256), 0, s, src, dst, Co, Ci, blocked ? 1 : 0);
   return hipGetLastError();
 }
 hipError_t ia2p_launch_pack_conv_in(const half_t* src, half_t* dst, int Co, int KT, hipStream_t s) {

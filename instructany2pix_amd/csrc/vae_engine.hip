@@ -33,7 +33,7 @@ struct VPlanner {
   size_t take(size_t e) { size_t o = cur; cur += (e + 127) & ~(size_t)127; return o; }
   size_t vec(const std::string& k, int n) { size_t o = take(n); c->params[k] = Param{o, (size_t)n, PK_COPY, 0, 0, false, false}; return o; }
   size_t mat(const std::string& k, int r, int cc) { size_t o = take((size_t)r * cc); c->params[k] = Param{o, (size_t)r * cc, PK_COPY, 0, 0, false, false}; return o; }
-  size_t conv3(const std::string& k, int co, int ci) { size_t o = take((size_t)co * ci * 9); c->params[k] = Param{o, (size_t)co * ci * 9, PK_CONV, co, ci, false, false}; return o; }
+  size_t conv3(const std::string& k, int co, int ci, PKind kind = PK_CONV) { size_t o = take((size_t)co * ci * 9); c->params[k] = Param{o, (size_t)co * ci * 9, kind, co, ci, false, false}; return o; }
   size_t conv_in(const std::string& k, int co, int kt) { size_t o = take((size_t)co * 64); c->params[k] = Param{o, (size_t)co * kt, PK_PAD_CONV_IN, co, kt, false, false}; return o; }
   VRes resnet(const std::string& p, int cin, int cout) {
     VRes r;
@@ -92,7 +92,7 @@ static ia2p_status vae_plan(ia2p_vae* c) {
   }
   c->emid = P.mid("encoder.mid_block", ch[n - 1]);
   c->e_ng = P.vec("encoder.conv_norm_out.weight", ch[n - 1]); c->e_nb = P.vec("encoder.conv_norm_out.bias", ch[n - 1]);
-  c->e_out_w = P.conv3("encoder.conv_out.weight", 2 * z, ch[n - 1]); c->e_out_b = P.vec("encoder.conv_out.bias", 2 * z);
+  c->e_out_w = P.conv3("encoder.conv_out.weight", 2 * z, ch[n - 1], PK_CONV_TAP); c->e_out_b = P.vec("encoder.conv_out.bias", 2 * z);
   c->q_w = P.mat("quant_conv.weight", 2 * z, 2 * z); c->q_b = P.vec("quant_conv.bias", 2 * z);
   c->pq_w = P.mat("post_quant_conv.weight", z, z); c->pq_b = P.vec("post_quant_conv.bias", z);
   c->d_in_w = P.conv_in("decoder.conv_in.weight", ch[n - 1], z * 9); c->d_in_b = P.vec("decoder.conv_in.bias", ch[n - 1]);
@@ -112,7 +112,7 @@ static ia2p_status vae_plan(ia2p_vae* c) {
     c->dec.push_back(st);
   }
   c->d_ng = P.vec("decoder.conv_norm_out.weight", ch[0]); c->d_nb = P.vec("decoder.conv_norm_out.bias", ch[0]);
-  c->d_out_w = P.conv3("decoder.conv_out.weight", g.out_channels, ch[0]); c->d_out_b = P.vec("decoder.conv_out.bias", g.out_channels);
+  c->d_out_w = P.conv3("decoder.conv_out.weight", g.out_channels, ch[0], PK_CONV_TAP); c->d_out_b = P.vec("decoder.conv_out.bias", g.out_channels);
   c->arena_elems = P.cur;
   return IA2P_OK;
 }

@@ -504,7 +504,7 @@ def test_conv_out_boundary(L, B, C_, H, W, Co):
     f = _ffi()
     x, w, b = rnd(B * H * W, C_, seed=44), rnd(Co, C_, 3, 3, seed=45, scale=(C_ * 9) ** -0.5), rnd(Co, seed=46, scale=0.2)
     wp = torch.empty(Co * 9 * C_, dtype=torch.half, device="cuda")
-    run(L, "ia2p_pack_conv3x3", f.ptr(w), f.ptr(wp), Co, C_)
+    run(L, "ia2p_pack_conv_out", f.ptr(w), f.ptr(wp), Co, C_)
     y = torch.full((B, Co, H, W), float("nan"), dtype=torch.half, device="cuda")
     run(L, "ia2p_conv_out", f.ptr(x), f.ptr(wp), f.ptr(b), f.ptr(y), B, C_, H, W, Co)
     ref = F.conv2d(x.float().reshape(B, H, W, C_).permute(0, 3, 1, 2), w.float(), b.float(), padding=1)

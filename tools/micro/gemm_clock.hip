@@ -15,10 +15,10 @@
 bool ia2p_splitk_inkernel(int, int, int) { return false; }
 int ia2p_sk_counter_capacity() { return 1 << 18; }
 int* ia2p_sk_counters(hipStream_t, int) { return nullptr; }
-bool ia2p_chain_words(hipStream_t, int**, int**, unsigned**) { return false; }
+void ia2p_sk_counters_invalidate() {}
 const float* ia2p_phi_lut() { static float* d = nullptr; if (!d) { hipMalloc(&d, 2 * IA2P_PHI_LUT_N * sizeof(float)); hipMemset(d, 0, 2 * IA2P_PHI_LUT_N * sizeof(float)); } return d; }   // (timing only)
 
-template <int BM, int BN, int ST, int WGM, int PP>
+template <int BM, int BN, int ST, int WGM, int PP, int WGN = 2>
 static void run(const char* name, int M, int N, int K, const half_t* A, const half_t* W, half_t* C, const half_t* zero, unsigned long long* stamps, int geglu = 0) {
   GemmArgs a;
   memset(&a, 0, sizeof a);
@@ -32,7 +32,7 @@ static void run(const char* name, int M, int N, int K, const half_t* A, const ha
   float ms = 0;
   while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 2.5) {
     hipEventRecord(e0);
-    for (int i = 0; i < 200; ++i) launch_cfg<BM, BN, ST, false, WGM, 64, PP>(a, 0);
+    for (int i = 0; i < 200; ++i) launch_cfg<BM, BN, ST, false, WGM, 64, PP, WGN>(a, 0);
     hipEventRecord(e1); hipEventSynchronize(e1);
     hipEventElapsedTime(&ms, e0, e1);
     launches += 200;
@@ -58,7 +58,8 @@ static void run(const char* name, int M, int N, int K, const half_t* A, const ha
 }
 
 int main() {
-  const int M = 2048, Nmax = 10240, Kmax = 5120;
+  const int M = 4096, Nmax = 10240, Kmax = 5120;      // (M = 4096: the 4096^3 probe shape; the step's shapes use the first 2048 rows)
+  const int M2 = 2048;
   std::mt19937 rng(1);
   std::normal_distribution<float> nd(0.f, 1.f);
   std::vector<half_t> hA((size_t)M * Kmax), hW((size_t)Nmax * Kmax);
@@ -68,16 +69,23 @@ int main() {
   hipMalloc(&A, hA.size() * 2); hipMalloc(&W, hW.size() * 2); hipMalloc(&C, (size_t)M * Nmax * 2); hipMalloc(&zero, 4096); hipMalloc(&stamps, 1 << 20);
   hipMemcpy(A, hA.data(), hA.size() * 2, hipMemcpyHostToDevice); hipMemcpy(W, hW.data(), hW.size() * 2, hipMemcpyHostToDevice);
   hipMemset(zero, 0, 4096); hipMemset(stamps, 0, 1 << 20);
-  run<128, 128, 2, 2, 0>("128x128x2 (QKV)", M, 3840, 1280, A, W, C, zero, stamps);
-  run<256, 128, 3, 4, 1>("256x128x3 pp (QKV)", M, 3840, 1280, A, W, C, zero, stamps);
-  run<128, 160, 2, 2, 0>("128x160x2 (FF-in*)", M, 10240, 1280, A, W, C, zero, stamps);
-  run<256, 128, 3, 4, 1>("256x128x3 pp K=5120", M, 3840, 5120, A, W, C, zero, stamps);
-  run<128, 128, 2, 2, 0>("128x128x2 K=5120", M, 3840, 5120, A, W, C, zero, stamps);
-  run<64, 64, 2, 2, 0>("64x64x2 (out-proj)", M, 1280, 1280, A, W, C, zero, stamps);
-  run<256, 160, 3, 4, 1>("256x160x3 pp (FF-in*)", M, 10240, 1280, A, W, C, zero, stamps);
-  run<256, 160, 3, 4, 1>("256x160x3 pp GEGLU", M, 10240, 1280, A, W, C, zero, stamps, 1);
-  run<128, 160, 2, 2, 0>("128x160x2 GEGLU", M, 10240, 1280, A, W, C, zero, stamps, 1);
-  run<256, 160, 3, 4, 1>("256x160x3 pp (QKV)", M, 3840, 1280, A, W, C, zero, stamps);
+  if (getenv("IA2P_CLOCK_8PHASE")) {      // round 4: the 8-phase 256 x 256 tile against the 256 x 128 ping-pong tile on the probe shape
+    run<256, 256, 2, 2, 2, 4>("256x256 8-phase 4096^3", 4096, 4096, 4096, A, W, C, zero, stamps);
+    run<256, 128, 3, 4, 1>("256x128x3 pp 4096^3", 4096, 4096, 4096, A, W, C, zero, stamps);
+    run<256, 256, 2, 2, 2, 4>("256x256 8-phase K=1280", 4096, 4096, 1280, A, W, C, zero, stamps);
+    run<256, 256, 2, 2, 2, 4>("256x256 8-phase QKV", 2048, 3840, 1280, A, W, C, zero, stamps);
+    return 0;
+  }
+  run<128, 128, 2, 2, 0>("128x128x2 (QKV)", M2, 3840, 1280, A, W, C, zero, stamps);
+  run<256, 128, 3, 4, 1>("256x128x3 pp (QKV)", M2, 3840, 1280, A, W, C, zero, stamps);
+  run<128, 160, 2, 2, 0>("128x160x2 (FF-in*)", M2, 10240, 1280, A, W, C, zero, stamps);
+  run<256, 128, 3, 4, 1>("256x128x3 pp K=5120", M2, 3840, 5120, A, W, C, zero, stamps);
+  run<128, 128, 2, 2, 0>("128x128x2 K=5120", M2, 3840, 5120, A, W, C, zero, stamps);
+  run<64, 64, 2, 2, 0>("64x64x2 (out-proj)", M2, 1280, 1280, A, W, C, zero, stamps);
+  run<256, 160, 3, 4, 1>("256x160x3 pp (FF-in*)", M2, 10240, 1280, A, W, C, zero, stamps);
+  run<256, 160, 3, 4, 1>("256x160x3 pp GEGLU", M2, 10240, 1280, A, W, C, zero, stamps, 1);
+  run<128, 160, 2, 2, 0>("128x160x2 GEGLU", M2, 10240, 1280, A, W, C, zero, stamps, 1);
+  run<256, 160, 3, 4, 1>("256x160x3 pp (QKV)", M2, 3840, 1280, A, W, C, zero, stamps);
   // batch-1 shapes (M = 256: 80-240 workgroups, at most one per CU): where does a latency-bound launch spend its time?
   run<64, 64, 3, 2, 0>("64x64x3 M=256 out-proj", 256, 1280, 1280, A, W, C, zero, stamps);
   run<64, 64, 4, 2, 0>("64x64x4 M=256 (swp)", 256, 1280, 1280, A, W, C, zero, stamps);
