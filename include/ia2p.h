@@ -182,7 +182,7 @@ ia2p_status ia2p_gemm_ex(void* stream, const void* A, const void* W, const void*
 /* same with K split over `splitk` workgroups per tile; partial holds splitk*M*N floats (deterministic slab reduce) */
 ia2p_status ia2p_gemm_splitk(void* stream, const void* A, const void* W, const void* bias, const void* residual, void* C,
                              int M, int N, int K, int splitk, float* partial);
-/* 3x3 conv, pad 1, over channels-last x[B,Hs,Ws,Cin] with W packed [Co][Cin/64][3][3][64] (ia2p_pack_conv3x3);
+/* 3x3 conv, pad 1, over channels-last x[B,Hs,Ws,Cin] with W packed by ia2p_pack_conv3x3 ([Co][3][3][Cin]);
  * stride 1|2; up=1 convolves the nearest-x2 upsampled x; rowvec [B,Co] (time embedding) and residual optional. */
 ia2p_status ia2p_conv3x3(void* stream, const void* x, const void* Wp, const void* bias, const void* rowvec, const void* residual,
                          void* y, int B, int Hs, int Ws, int Cin, int Co, int stride, int up);
@@ -191,7 +191,7 @@ ia2p_status ia2p_conv3x3(void* stream, const void* x, const void* Wp, const void
  * channel, the ia2p_pack_conv3x3 row of W2 followed by the row of Wsc; bias = b2 + bsc; x [B,Hs,Ws,Cin], x2 [B,Hs,Ws,Cin2] channels-last. */
 ia2p_status ia2p_conv3x3_cat(void* stream, const void* x, const void* x2, const void* Wcat, const void* bias, void* y,
                              int B, int Hs, int Ws, int Cin, int Cin2, int Co);
-ia2p_status ia2p_pack_conv3x3(void* stream, const void* w_oihw, void* w_packed, int Co, int Cin);   /* [Co][Cin][3][3] -> [Co][Cin/64][3][3][64]: the implicit-GEMM K order of ia2p_conv3x3 / _cat (nine taps per block of 64 input channels); Cin % 64 == 0 */
+ia2p_status ia2p_pack_conv3x3(void* stream, const void* w_oihw, void* w_packed, int Co, int Cin);   /* [Co][Cin][3][3] -> the implicit-GEMM K order ia2p_conv3x3 / _cat walk ([Co][3][3][Cin] in the shipped library); Cin % 64 == 0. Opaque to callers: pack with this, pass to those */
 ia2p_status ia2p_pack_conv_out(void* stream, const void* w_oihw, void* w_packed, int Co, int C);       /* [Co][C][3][3] -> [Co][3][3][C]: the layout ia2p_conv_out reads (any C % 32 == 0) */
 ia2p_status ia2p_pack_geglu(void* stream, const void* src, void* dst, int rows, int rowlen);
 /* The UNet's latent-boundary 3x3 convolutions (diffusers UNet2DConditionModel.conv_in / .conv_out behind pnp_pipeline.py:253-260; the VAE's too), pad 1:

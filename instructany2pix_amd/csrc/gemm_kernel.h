@@ -165,8 +165,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   int a_inc[A_PW];
   // conv gather, per piece (= one tile row per lane): a_base = address of filter tap (0, 0)'s pixel for this lane's 16-byte chunk (may lie outside the image: only
   // dereferenced under the mask); a_mask = bits 0-8: tap (ky, kx) falls inside the (virtual) image, bits 9 / 10: parity of the tap-0 row / column in the
-  // nearest-x2 upsampled view (source step of tap k = (k + parity) >> up). The k-loop changes tap EVERY k-tile (channel-block-major walk): deriving the tap's
-  // pointer from these is a bit test, a wave-uniform offset and a select -- not the long pixel arithmetic round 3 ran once per Cin / 64 k-tiles.
+  // nearest-x2 upsampled view (source step of tap k = (k + parity) >> up). A new tap's pointer is a bit test, a wave-uniform offset and a select.
   const half_t* a_base[A_PW];
   int a_mask[A_PW];
 #pragma unroll
@@ -218,22 +217,22 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
 
   const int nk_all = hK / BK;
   const int kt0 = (int)((long)split * nk_all / nsplit), kt1 = (int)((long)(split + 1) * nk_all / nsplit);   // this workgroup's k-tiles
-  // conv: K is walked CHANNEL-BLOCK-major -- for each block of 64 input channels the nine taps, then the next block; after the 9 Cin columns of the 3x3 part the
-  // appended 1x1 blocks in storage order. The nine taps of a channel block re-read (almost) the same 64-channel pixel rows, so an XCD's distinct activation
-  // bytes between two uses of a line are tiles x (pixels + halo) x 128 B (1.6 MB for 32 tiles of 256 pixels) instead of tiles x pixels x Cin x 2 B (5 MB at 320
-  // channels: more than the 4 MiB L2, i.e. every tap re-fetched its rows through the fabric -- PMC traffic 3.65 x algorithmic on the 256 x 160 conv class, round 3).
-  // The weights are PACKED in walk order ([Co][Cin / 64][tap][64], misc.hip pack_conv_kernel): a weight row streams front to back, 128 bytes per k-tile (a walk
-  // that strode a tap-major row -- +Cin per tap -- ran the large-K convolutions 15 ... 45 % slower: the weights come from beyond L2, and they want whole rows).
-  // Position of k-tile kt of the 3x3 part: tap = kt % 9, ci0 = (kt / 9) * 64. (Every tile variant walks K the same way: the bits still do not depend on the tile.)
+  // conv: K = (tap, channel) is walked TAP-major -- all Cin channels of a filter tap (64 per k-tile, running pointers: the gather of a row is derived once per
+  // tap), then the next tap; after the 9 Cin columns of the 3x3 part the appended 1x1 blocks. Weights are packed in that order ([Co][tap][Cin], misc.hip).
+  // The other walk -- channel-block-major: the nine taps of a block of 64 channels, then the next block, which keeps an XCD's activation working set between two
+  // uses of a line inside its L2 (the 256 x 160 conv class moves 3.65 x its algorithmic bytes through the fabric under the tap-major walk) -- was built in round
+  // 4 (-DIA2P_CONV_CHANNEL_MAJOR, weights packed [Co][Cin/64][tap][64]) and measured on one box against this one: 10 ... 20 % SLOWER on every large convolution
+  // (32768 x 640 x 5760: 247 vs 209 us; the step +0.4 ms), because the tap then changes every k-tile and its per-row pointer select (~8 vector instructions per
+  // staging piece and k-tile against 2 here) lands in the half-step where the partner wave group multiplies. These kernels are not bound by the fabric traffic.
   int cin_main = 0, cin_extra = 0;                         // (two named scalars: a select between two argument FIELDS became a 2-entry table in scratch)
   if (CONV) { cin_main = p.Cin; cin_extra = p.Cin2; asm volatile("" : "+s"(cin_main), "+s"(cin_extra)); }
   const int nk_main = CONV ? 9 * (cin_main / BK) : 0;      // k-tiles of the 3x3 part
   int tap = 0, ci0 = 0;
   if (CONV) {
-#ifdef IA2P_CONV_TAP_MAJOR      // A/B builds: round 3's walk (all channels of a tap, then the next tap)
-    if (kt0 < nk_main) { tap = (kt0 * BK) / cin_main; ci0 = (kt0 * BK) % cin_main; }
-#else
+#ifdef IA2P_CONV_CHANNEL_MAJOR      // A/B builds: the nine taps of a block of 64 channels, then the next block
     if (kt0 < nk_main) { tap = kt0 % 9; ci0 = (kt0 / 9) * BK; }
+#else
+    if (kt0 < nk_main) { tap = (kt0 * BK) / cin_main; ci0 = (kt0 * BK) % cin_main; }
 #endif
     else {                                                 // (inside the appended 1x1 blocks)
       ci0 = kt0 * BK - 9 * cin_main; tap = 9;
@@ -244,11 +243,11 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   // the walk, one k-tile on: (tap, ci0) -> next
   auto k_next = [&](int& t, int& c) {
     if (t < 9) {
-#ifdef IA2P_CONV_TAP_MAJOR
-      c += BK;
-      if (c >= cin_main) { c = 0; ++t; }
-#else
+#ifdef IA2P_CONV_CHANNEL_MAJOR
       if (++t == 9) { c += BK; if (c < cin_main) t = 0; else c = 0; }      // next channel block, or past the 3x3 part (tap = 9: appended block / end of K)
+#else
+      c += BK;
+      if (c >= cin_main) { c = 0; ++t; }                                    // next tap (tap = 9: appended block / end of K)
 #endif
     } else {
       c += BK;
@@ -264,7 +263,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
     for (int i = 0; i < B_PW; ++i) w_ptr[i] += (size_t)kt0 * w_inc[i];
   }
 
-  // new filter tap (wave-uniform; every k-tile of the 3x3 part): re-derive the gathered pixel of each row
+  // new filter tap (wave-uniform): re-derive the gathered pixel of each row (once per Cin / 64 k-tiles)
   auto conv_tap_setup = [&]() {
     if (tap_fresh) {
       if (tap < 9) {
@@ -313,7 +312,11 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   auto conv_tap_advance = [&]() {
     const int t_old = tap;
     k_next(tap, ci0);
-    if (t_old < 9 || tap != t_old) tap_fresh = true;      // (inside an appended block the running pointers just move on)
+#ifdef IA2P_CONV_CHANNEL_MAJOR
+    if (t_old < 9 || tap != t_old) tap_fresh = true;      // (the tap changes every k-tile; inside an appended block the running pointers just move on)
+#else
+    if (tap != t_old) tap_fresh = true;                   // (inside a tap / an appended block the running pointers just move on)
+#endif
   };
   // LDS-DMA of this wave's activation pieces [i0, i1) / weight pieces [i0, i1) of the next k-tile into ring slot `buf`; running pointers: no per-step multiply
   auto issue_a = [&](int buf, auto i0_tag, auto i1_tag) {
@@ -325,6 +328,10 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
     for (int i = decltype(i0_tag)::value; i < decltype(i1_tag)::value; ++i)
       if (!B_UNEVEN || i < b_npw) { GLDS16(w_ptr[i], smem + buf * STAGE + BM * ROWB + b_piece(i) * 1024); w_ptr[i] += w_inc[i]; }      // (wave-uniform)
   };
+  // The pointer arithmetic of the NEXT k-tile's gather (a few VALU instructions per piece, every k-tile) belongs beside the MFMAs of the current one, where its
+  // issue slots are free -- not in front of the DMA issue, between the barrier and the fragment reads: the loops below call this right ahead of their MFMA
+  // blocks (a no-op when the pointers are current; `stage` still derives them itself when nobody did).
+  auto conv_prepare = [&]() { if (CONV) conv_tap_setup(); };
   using I0 = std::integral_constant<int, 0>;
   auto stage = [&](int kt, int buf) {
     if (CONV) conv_tap_setup();
@@ -456,12 +463,14 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
         __builtin_amdgcn_sched_barrier(0);
         if (t + NSTAGE - 1 < nk) stage(t + NSTAGE - 1, slot_s);
         mid();
+        conv_prepare();
         mm();
         adv();
       }
     } else {
       for (int t = 0; t < nk; ++t) {
         top(t, std::integral_constant<int, LPS1>{});
+        conv_prepare();
         if (t > 0) mm();
         mid();
         rd(slot_r);
@@ -615,6 +624,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
       __builtin_amdgcn_sched_barrier(0);
       if (t + 2 < nk) stage_part(SL, S_B0{});
       bar1();
+      conv_prepare();
       mmq(H0{}, H1{}, wf1);
       bar2();
       // P3
@@ -666,6 +676,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
         for (int j = 0; j < NR; ++j) wf[kk][j] = *(const h8*)(base + w_off + j * 16 * ROWB + coff);
       }
       __builtin_amdgcn_sched_barrier(0);   // keep hipcc from sinking the reads back between the MFMAs
+      conv_prepare();
 #pragma unroll
       for (int kk = 0; kk < KSUB; ++kk)
 #pragma unroll
@@ -683,6 +694,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
         for (int i = 0; i < MR; ++i) af[i] = *(const h8*)(base + a_off + i * 16 * ROWB + coff);
 #pragma unroll
         for (int j = 0; j < NR; ++j) wf[j] = *(const h8*)(base + w_off + j * 16 * ROWB + coff);
+        if (kk == 0) conv_prepare();
 #pragma unroll
         for (int i = 0; i < MR; ++i)
 #pragma unroll

@@ -478,9 +478,8 @@ __global__ void touch_kernel(const uint4* p, size_t n16, unsigned* sink) {
 }
 
 // ---- one-time weight re-layouts -----------------------------------------------------------------------------------------
-// conv [Co][Ci][3][3] -> the implicit-GEMM K order of gemm_kernel.h: CHANNEL-BLOCK-major, [Co][Ci / 64][ky][kx][64] -- for each block of 64 input channels the
-// nine taps (blocked != 0; Ci % 64 == 0), so that the k-loop's walk (nine taps of a channel block, then the next block) streams a weight row front to back;
-// blocked == 0: [Co][ky][kx][Ci] (tap-major: conv_out_kernel's layout, any Ci)
+// conv [Co][Ci][3][3] -> the implicit-GEMM K order of gemm_kernel.h: [Co][ky][kx][Ci] (blocked == 0: tap-major, the walk the library ships; also
+// conv_out_kernel's layout, any Ci), or [Co][Ci / 64][ky][kx][64] (blocked != 0, Ci % 64 == 0: the channel-block-major walk of -DIA2P_CONV_CHANNEL_MAJOR builds)
 __global__ void pack_conv_kernel(const half_t* src, half_t* dst, int Co, int Ci, int blocked) {
   const long total = (long)Co * Ci * 9;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -727,7 +726,7 @@ hipError_t ia2p_launch_touch(const void* p, size_t bytes, unsigned* sink, hipStr
   return hipGetLastError();
 }
 hipError_t ia2p_launch_pack_conv(const half_t* src, half_t* dst, int Co, int Ci, hipStream_t s, bool blocked) {
-#ifdef IA2P_CONV_TAP_MAJOR      // A/B builds: round 3's tap-major K order everywhere
+#ifndef IA2P_CONV_CHANNEL_MAJOR      // the k-loop walks K tap-major (gemm_kernel.h): so are the weights; the blocked layout belongs to the A/B build of the other walk
   blocked = false;
 #endif
   if (blocked && Ci % 64) return hipErrorInvalidValue;
