@@ -293,7 +293,8 @@ static bool gn_fused_launch(const half_t* x, int ldx, half_t* y, int ldy, const 
   const int P = nch == 5 ? 192 : 64, it = (HW + P - 1) / P;
   // one workgroup per CU takes its slice in at the rate of ONE CU (~25 GB/s from beyond L2): only launches that put a workgroup on (nearly) every CU pay --
   // with 64 ... 128 workgroups (the 64^2 / 32^2 levels at 8 requests) the single pass measured +0.7 ms per step against the two-pass kernels' 2 000 workgroups
-  if ((long)(G / gs) * B < 200) return false;
+  // ... or whose slices are small enough that a workgroup's chain (load, reduce, normalise, store) is shorter than a second launch: the 16 x 16 level at any batch
+  if ((long)(G / gs) * B < 200 && (long)HW * nch * 16 > 48 * 1024) return false;
   const dim3 grid(G / gs, B), block(nch == 10 ? 640 : 960);
 #define IA2P_GNF(NCH_, IT_) hipLaunchKernelGGL((gn_fused_kernel<NCH_, IT_>), grid, block, 0, s, x, y, gamma, beta, HW, C, Cg, gs, ldx, ldy, eps, flags, x2, ldx2, Ca)
   if (nch == 5) {
