@@ -186,6 +186,10 @@ ia2p_status ia2p_gemm_splitk(void* stream, const void* A, const void* W, const v
  * stride 1|2; up=1 convolves the nearest-x2 upsampled x; rowvec [B,Co] (time embedding) and residual optional. */
 ia2p_status ia2p_conv3x3(void* stream, const void* x, const void* Wp, const void* bias, const void* rowvec, const void* residual,
                          void* y, int B, int Hs, int Ws, int Cin, int Co, int stride, int up);
+/* stride 1, no upsampling, with K split over `splitk` workgroups per tile (what the executor launches on the 16 x 16 feature maps); partial holds
+ * splitk * B*Hs*Ws * Co floats. Same reference call sites as ia2p_conv3x3 (diffusers ResnetBlock2D conv1 / conv2 behind pnp_pipeline.py:253-260). */
+ia2p_status ia2p_conv3x3_splitk(void* stream, const void* x, const void* Wp, const void* bias, const void* rowvec, const void* residual,
+                                void* y, int B, int Hs, int Ws, int Cin, int Co, int splitk, float* partial);
 /* The tail of a ResnetBlock2D with a channel change as ONE implicit GEMM (what the executor does; diffusers ResnetBlock2D `conv2(h) + conv_shortcut(x)`
  * behind pnp_pipeline.py:253-260):  y = conv3x3(x, W2) + conv1x1(x2, Wsc) + bias, K = 9 Cin + Cin2, stride 1. Wcat [Co][9 Cin + Cin2] holds, per output
  * channel, the ia2p_pack_conv3x3 row of W2 followed by the row of Wsc; bias = b2 + bsc; x [B,Hs,Ws,Cin], x2 [B,Hs,Ws,Cin2] channels-last. */

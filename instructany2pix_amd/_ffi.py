@@ -80,6 +80,7 @@ SIGNATURES = {
     "ia2p_gemm_ex": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
     "ia2p_debug_set_gemm_splitk": (None, [_I]),
     "ia2p_conv3x3": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I]),
+    "ia2p_conv3x3_splitk": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "ia2p_pack_conv3x3": (_I, [_P, _P, _P, _I, _I]),
     "ia2p_pack_conv_out": (_I, [_P, _P, _P, _I, _I]),
     "ia2p_conv3x3_cat": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I]),

@@ -59,7 +59,8 @@ const char* prof_name(int k) {
                                       "embed_kernel+linear_small_kernel", "conv_in_kernel", "conv_out_kernel", "concat_kernel", "splitk_reduce_kernel", "qproj_xattn_kernel", "qkv_sattn_kernel"};
   if (k >= PK_ATTN) return other[k - PK_ATTN];
   const GemmTile t = IA2P_GEMM_TILES[(k % PK_CONV0) % IA2P_GEMM_NVARIANT];
-  if (t.pp == 2) snprintf(buf[k], sizeof buf[k], "gemm_f16_kernel<%d, %d, %d, %s, 2, 64, 2, 4>", t.bm, t.bn, t.stages, k >= PK_CONV0 ? "true" : "false");
+  if (t.halo) snprintf(buf[k], sizeof buf[k], "conv_halo_f16_kernel<%d>", t.bn);
+  else if (t.pp == 2) snprintf(buf[k], sizeof buf[k], "gemm_f16_kernel<%d, %d, %d, %s, 2, 64, 2, 4>", t.bm, t.bn, t.stages, k >= PK_CONV0 ? "true" : "false");
   else if (t.pp) snprintf(buf[k], sizeof buf[k], "gemm_f16_kernel<%d, %d, %d, %s, 4, 64, 1, 2>", t.bm, t.bn, t.stages, k >= PK_CONV0 ? "true" : "false");
   else if (t.bn == 80) snprintf(buf[k], sizeof buf[k], "gemm_f16_kernel<%d, %d, %d, %s, 4, 64, 0, 1>", t.bm, t.bn, t.stages, k >= PK_CONV0 ? "true" : "false");
   else snprintf(buf[k], sizeof buf[k], "gemm_f16_kernel<%d, %d, %d, %s, 2, 64, 0, 2>", t.bm, t.bn, t.stages, k >= PK_CONV0 ? "true" : "false");
@@ -353,6 +354,8 @@ static void tune_site(RunCtx* c, const GemmArgs& a, bool conv) {
   // a candidate's score is its FASTEST round (launch-time noise only ever adds).
   std::vector<float> best_ms(cands.size(), 1e30f);
   std::vector<char> ok(cands.size(), 1);
+  for (size_t i = 0; i < cands.size(); ++i)
+    if (IA2P_GEMM_TILES[cands[i].variant].halo && !(conv && ia2p_conv_halo_ok(a) && cands[i].splitk <= a.Cin / 64)) ok[i] = 0;      // (this site is not one for the halo-staged kernel: its twin tile is in the list anyway)
   for (int r = -1; r < c->tune_reps; ++r)
     for (size_t i = 0; i < cands.size(); ++i) {
       if (!ok[i]) continue;
@@ -1226,6 +1229,22 @@ ia2p_status ia2p_conv3x3(void* stream, const void* x, const void* Wp, const void
   a.rowvec = (const half_t*)rowvec; a.rowvec_ld = Co; a.rows_per_batch = a.Ho * a.Wo; a.residual = (const half_t*)residual; a.ldr = Co;
   hipError_t e = ia2p_launch_gemm(a, true, (hipStream_t)stream, nullptr);
   RET_HIP(e, "conv3x3");
+}
+// the stride-1 form with K split over `splitk` workgroups per tile (what the executor launches for the 16 x 16 feature maps); partial: splitk * B*Hs*Ws * Co floats
+ia2p_status ia2p_conv3x3_splitk(void* stream, const void* x, const void* Wp, const void* bias, const void* rowvec, const void* residual, void* y,
+                                int B, int Hs, int Ws, int Cin, int Co, int splitk, float* partial) {
+  if (!x || !Wp || !y || !partial) return fail(nullptr, IA2P_ERR_INVALID, "conv3x3_splitk: null argument");
+  if (Cin % 64 || Co % 4 || splitk < 1 || splitk > 9 * Cin / 64) return fail(nullptr, IA2P_ERR_SHAPE, "conv3x3_splitk: Cin=%d (mult of 64) Co=%d (mult of 4) splitk=%d (1 .. 9 Cin / 64)", Cin, Co, splitk);
+  GemmArgs a;
+  memset(&a, 0, sizeof a);
+  a.pad = 1;
+  a.Ho = Hs; a.Wo = Ws;
+  a.A = (const half_t*)x; a.W = (const half_t*)Wp; a.C = (half_t*)y; a.zero = zero_page(); a.M = B * Hs * Ws; a.N = Co; a.K = 9 * Cin; a.ldw = a.K; a.lda = Cin; a.ldc = Co;
+  a.Hs = Hs; a.Ws = Ws; a.stride = 1; a.up = 0; a.Cin = Cin; a.bias = (const half_t*)bias;
+  a.rowvec = (const half_t*)rowvec; a.rowvec_ld = Co; a.rows_per_batch = Hs * Ws; a.residual = (const half_t*)residual; a.ldr = Co;
+  if (splitk > 1) { a.splitk = splitk; a.partial = partial; }
+  hipError_t e = ia2p_launch_gemm(a, true, (hipStream_t)stream, nullptr);
+  RET_HIP(e, "conv3x3_splitk");
 }
 // ResnetBlock2D tail as one implicit GEMM: y = conv3x3(x, W2) + conv1x1(x2, Wsc) + bias (+ rowvec), K = 9 Cin + Cin2; Wcat rows = [packed W2 row | Wsc row]
 ia2p_status ia2p_conv3x3_cat(void* stream, const void* x, const void* x2, const void* Wcat, const void* bias, void* y, int B, int Hs, int Ws, int Cin, int Cin2, int Co) {

@@ -34,10 +34,10 @@
 // more co-resident blocks hide the per-k-step load latency).
 static int g_force_variant = -1;   // test/tuning hook (ia2p_debug_set_gemm_tile)
 extern "C" void ia2p_debug_set_gemm_tile(int v) { g_force_variant = v; }
-// the tile table, for tools and tests: out = {bm, bn, ring stages, schedule (0 plain, 1 ping-pong, 2 eight-phase)}; returns 0, or -1 past the last variant
+// the tile table, for tools and tests: out = {bm, bn, ring stages, schedule (0 plain, 1 ping-pong, 2 eight-phase, 3 ping-pong over halo-staged patches: 3x3 convolutions only)}; returns 0, or -1 past the last variant
 extern "C" int ia2p_debug_gemm_tile_info(int v, int* out) {
   if (v < 0 || v >= IA2P_GEMM_NVARIANT || !out) return -1;
-  out[0] = IA2P_GEMM_TILES[v].bm; out[1] = IA2P_GEMM_TILES[v].bn; out[2] = IA2P_GEMM_TILES[v].stages; out[3] = IA2P_GEMM_TILES[v].pp;
+  out[0] = IA2P_GEMM_TILES[v].bm; out[1] = IA2P_GEMM_TILES[v].bn; out[2] = IA2P_GEMM_TILES[v].stages; out[3] = IA2P_GEMM_TILES[v].halo ? 3 : IA2P_GEMM_TILES[v].pp;
   return 0;
 }
 
@@ -227,7 +227,7 @@ static double plan_cost_us(int M, int N, int K, bool conv, const GemmTile& t, in
   const double per_cu = std::max(1.0, 0.6 * tiles / 256.0 + 0.4 * worst);
   const bool pingpong = t.pp != 0;      // 8 waves in two half-step-shifted groups: one workgroup behaves like two co-resident ones
   const double t_mfma = per_cu * (2.0 * t.bm * t.bn * 64) / (MFMA_EFF * (conc == 1 && !pingpong ? LONE_EFF : 1.0) * CU_FLOPS_PER_US);
-  const double t_fill = per_cu * ((t.bm + t.bn) * 128.0) / FILL_B_PER_US;
+  const double t_fill = per_cu * (((t.halo ? 36 : t.bm) + t.bn) * 128.0) / FILL_B_PER_US;      // (halo-staged convolution: an 18 x 18 pixel image per nine k-tiles)
   const double t_lat = batches * LAT_US / (t.stages - 1) * (pingpong ? 0.5 : 1.0);
   double total = BASE_US + nk * std::max({t_mfma, t_fill, t_lat}) + RAMP_US * batches;
   if (sk > 1) total += REDUCE_US + 2.0 * sk * (double)M * N * 4 / REDUCE_B_PER_US;
@@ -277,7 +277,7 @@ extern "C" int ia2p_plan_import(const char* text) {   // returns the number of e
   for (const char* p = text; *p;) {
     int M, N, K, cv, gg, v, sk, n = 0;
     if (sscanf(p, "%d,%d,%d,%d,%d,%d,%d;%n", &M, &N, &K, &cv, &gg, &v, &sk, &n) != 7 || n == 0) return -1;
-    if (M < 1 || N < 1 || K < 64 || v < 0 || v >= IA2P_GEMM_NVARIANT || sk < 1 || sk > K / 64 || (gg && (sk > 1 || IA2P_GEMM_TILES[v].bn % 32))) return -1;
+    if (M < 1 || N < 1 || K < 64 || v < 0 || v >= IA2P_GEMM_NVARIANT || sk < 1 || sk > K / 64 || (gg && (sk > 1 || IA2P_GEMM_TILES[v].bn % 32)) || (IA2P_GEMM_TILES[v].halo && !cv)) return -1;
     in.push_back({PlanKey{M, N, K, cv != 0, gg != 0}, GemmPlan{v, sk}});
     p += n;
   }
@@ -302,7 +302,7 @@ void ia2p_gemm_candidates(int M, int N, int K, bool conv, bool geglu, size_t max
   }();
   for (int v = 0; v < IA2P_GEMM_NVARIANT; ++v) {
     const GemmTile& t = IA2P_GEMM_TILES[v];
-    if ((geglu && t.bn % 32) || (excluded >> v & 1)) continue;
+    if ((geglu && t.bn % 32) || (excluded >> v & 1) || (t.halo && !conv)) continue;
     for (int sk : splits) {
       if (sk > 1 && (geglu || nk / sk < 4 || (size_t)sk * M * N * 4 > max_slab_bytes)) break;
       all.push_back({plan_cost_us(M, N, K, conv, t, sk), GemmPlan{v, sk}});
@@ -331,7 +331,7 @@ GemmPlan ia2p_gemm_plan(int M, int N, int K, bool conv, bool geglu) {
     double best = 1e30;
     for (int v = 0; v < IA2P_GEMM_NVARIANT; ++v) {
       const GemmTile& t = IA2P_GEMM_TILES[v];
-      if (geglu && t.bn % 32) continue;              // a (value, gate) block of 32 packed columns must not straddle tiles
+      if ((geglu && t.bn % 32) || t.halo) continue;              // a (value, gate) block of 32 packed columns must not straddle tiles; halo tiles: by measurement only
       for (int sk : splits) {
         if (sk > 1 && (geglu || nk / sk < 4)) break;
         const double c = plan_cost_us(M, N, K, conv, t, sk);
@@ -423,6 +423,14 @@ static hipError_t launch_any(const GemmArgs& a0, int v, hipStream_t s, bool with
     case 23:
       static_assert(IA2P_GEMM_TILES[23].bm == 256 && IA2P_GEMM_TILES[23].bn == 128 && IA2P_GEMM_TILES[23].stages == 2 && IA2P_GEMM_TILES[23].pp == 2, "tile table");
       e = launch_cfg<256, 128, 2, CONV, 2, 64, 2, 4>(a, s);
+      break;
+    case 24:      // halo-staged convolution; a launch it does not take (linear layer, stride 2, upsampled view, ragged patches, more K slices than blocks of 64 channels) runs the same tile shape with the gathered operand
+      static_assert(IA2P_GEMM_TILES[24].bm == 256 && IA2P_GEMM_TILES[24].bn == 160 && IA2P_GEMM_TILES[24].halo, "tile table");
+      e = (CONV && ia2p_conv_halo_ok(a) && a.splitk <= a.Cin / 64) ? launch_halo<160>(a, s) : launch_cfg<256, 160, 3, CONV, 4, 64, 1>(a, s);
+      break;
+    case 25:
+      static_assert(IA2P_GEMM_TILES[25].bm == 256 && IA2P_GEMM_TILES[25].bn == 128 && IA2P_GEMM_TILES[25].halo, "tile table");
+      e = (CONV && ia2p_conv_halo_ok(a) && a.splitk <= a.Cin / 64) ? launch_halo<128>(a, s) : launch_cfg<256, 128, 3, CONV, 4, 64, 1>(a, s);
       break;
 #undef IA2P_TILE_CASE
     // Measured and dropped in round 1 (tools/gemm_bench.py): 8-wave 256x128 (2- and 3-stage) and 256x320 at one

@@ -81,7 +81,14 @@ struct EpiCfg {
 // (profiles/r01g_gemm_loop_ablation.txt: the fill is the largest term of the 128x128 kernel).
 // XA != 0 (qxattn.hip; 128 x 64 tiles only): the tile is the to_q projection of 128 queries x ONE head and never leaves the CU -- the epilogue turns it
 // into the Q fragments of the attention core (attention_core.h, MODE = XA - 1) and writes the cross-attention output instead.
-template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int BK = 64, int PP = 0, int WGN = 2, int XA = 0>
+// HALO = 1 (conv_halo_f16_kernel; 3x3, stride 1, ping-pong schedule, 256-row tiles): the tile is a 16 x 16 pixel PATCH of one image, and the activation operand is
+// not staged k-tile by k-tile (nine taps = nine fetches of nearly the same pixels through the fabric) but once per block of 64 channels, as the patch plus its
+// one-pixel border: 18 x 18 pixels x 128 B, 144-B pixel pitch (8 data chunks + 1 pad chunk: fragment reads of 16 consecutive pixels hit 16 different 16-byte bank
+// groups), two such images (the next block's lands while this one is multiplied). A filter tap is then a CONSTANT byte offset on the fragment reads -- the k-loop has no
+// gather arithmetic at all -- and the L2 -> LDS traffic of a k-tile drops from (256 + BN) x 128 B to (36 + BN) x 128 B. K is walked block-major (nine taps of a block,
+// then the next block; appended 1x1 blocks: the centre tap of their own image) over the SAME packed weights: the weight tile of (block, tap) starts at column
+// tap * Cin + block * 64 of the [Co][tap][Cin] row.
+template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int BK = 64, int PP = 0, int WGN = 2, int XA = 0, int HALO = 0>
 __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* hW, const half_t* hzero, int hM, int hN, int hK, int hlda, int hldw, int hrpb, int hbstride,
                                                int hroff, int hsplitk, int hgroup_w, const GemmArgs& p, const AttnArgs* xa) {
   // The leading 16 dwords of the argument list are what the prologue needs; built with -amdgpu-kernarg-preload-count=16 the command processor
@@ -90,6 +97,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   static_assert(PP != 1 || (WGM == 4 && NSTAGE == 3), "ping-pong schedule: 8 waves, 3-stage ring");
   static_assert(PP != 3 || (WGM == 4 && NSTAGE == 2 && !CONV), "two-slot ping-pong schedule: 8 waves, 2 k-tile slots");
   static_assert(PP != 2 || (WGM == 2 && WGN == 4 && NSTAGE == 2 && BK == 64 && BM == 256 && (BN == 256 || BN == 128) && XA == 0), "8-phase schedule: 256-row tiles, 2 x 4 waves, two k-tile buffers");
+  static_assert(HALO == 0 || (CONV && PP == 1 && BM == 256 && BK == 64 && XA == 0 && WGN == 2), "halo-staged convolution: ping-pong schedule over a 16 x 16 patch");
   constexpr int NWAVE = WGM * WGN;
   constexpr int WM = BM / WGM, WN = BN / WGN;    // wave tile (waves arranged WGM x WGN; WGN = 1: narrow tiles, one wave per 128-byte column block)
   constexpr int MR = WM / 16, NR = WN / 16;
@@ -99,7 +107,11 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   constexpr bool B_UNEVEN = BS::UNEVEN;                              //  ping-pong tile, the second wave group takes one piece less per wave: BStage)
   constexpr int BNL = BS::BNL;                                       // weight rows held in LDS (>= BN)
   static_assert(BM % (RPP * NWAVE) == 0 && BN % 16 == 0 && WN % 16 == 0 && WM % 16 == 0, "tile / wave layout");
-  constexpr int STAGE = (BM + BNL) * ROWB;
+  constexpr int STAGE = ((HALO ? 0 : BM) + BNL) * ROWB;                // bytes of a ring slot (halo-staged convolution: the weight tile only)
+  constexpr int H_PITCH = 144, H_ROW = 18 * H_PITCH;                   // halo image: bytes per pixel (8 chunks + 1 pad), per row of 18 pixels
+  constexpr int H_SLOTS = ((18 * 18 * 9 + 63) / 64 + NWAVE - 1) / NWAVE, H_PIECES = H_SLOTS * NWAVE, H_BYTES = H_PIECES * 1024;      // 1-KiB DMA pieces of an image per wave (6), per image (48: the last two are padding, so that every wave issues the same count)
+  constexpr int H_BASE = NSTAGE * STAGE;                               // the two halo images sit behind the weight ring
+  static_assert(!HALO || H_BASE + 2 * H_BYTES <= EpiCfg<BM, BN, NSTAGE, WGM, BK, WGN, PP>::SMEM, "halo images + weight ring exceed the tile's LDS");
   constexpr int KSUB = BK / 32;                                       // 32-deep MFMA sub-steps per k-tile
   extern __shared__ __attribute__((aligned(1024))) char smem[];
 
@@ -153,6 +165,16 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   } else if (p.m_fastest) { tn = bid / tiles_m; tm = bid - tn * tiles_m; }
   else                    { tm = bid / tiles_n; tn = bid - tm * tiles_n; }
   const int bm0 = tm * BM, bn0 = tn * BN;
+  // tile row r -> output row (pixel index). Halo-staged convolution: the tile is the 16 x 16 patch (h_y0, h_x0) of image h_img, row r = pixel (r >> 4, r & 15) of it
+  int h_img = 0, h_y0 = 0, h_x0 = 0, h_m0 = 0;
+  if constexpr (HALO != 0) {
+    const int tpr = p.Wo >> 4, tpi = (p.Ho >> 4) * tpr;
+    h_img = tm / tpi;
+    const int rem = tm - h_img * tpi, ty = rem / tpr;
+    h_y0 = ty * 16; h_x0 = (rem - ty * tpr) * 16;
+    h_m0 = (h_img * p.Ho + h_y0) * p.Wo + h_x0;
+  }
+  auto row_m = [&](int r) { return HALO ? h_m0 + (r >> 4) * p.Wo + (r & 15) : bm0 + r; };
 
   // ---- staging addresses. Piece `pi` covers tile rows pi*8 .. pi*8+7; lane -> (row pi*8 + lane/8, LDS chunk lane%8),
   //      which must hold global chunk (lane%8) ^ swz(row), swz(row) = (row>>1)&7.
@@ -168,8 +190,24 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   // nearest-x2 upsampled view (source step of tap k = (k + parity) >> up). A new tap's pointer is a bit test, a wave-uniform offset and a select.
   const half_t* a_base[A_PW];
   int a_mask[A_PW];
+  // halo-staged convolution: DMA piece (slot * NWAVE + wave) of a halo image, lane -> 16-byte chunk j = piece * 64 + lane = (halo pixel j / 9, chunk j % 9);
+  // h_voff = byte offset of that chunk inside the source tensor (channel block 0), or an offset past any tensor: pad chunk / outside the image / past the image's
+  // last pixel -- the buffer load's range check then writes zeros (no zero page, no select)
+  constexpr int OOB = 0x7fffff00;
+  int h_voff[H_SLOTS];
+  if constexpr (HALO != 0) {
 #pragma unroll
-  for (int i = 0; i < A_PW; ++i) {
+    for (int sl = 0; sl < H_SLOTS; ++sl) {
+      const int j = (sl * NWAVE + wave) * 64 + lane;
+      const int hp = j / 9, c = j - hp * 9;
+      const int hy = hp / 18, hx = hp - hy * 18;
+      const int y = h_y0 - 1 + hy, x = h_x0 - 1 + hx;
+      const bool ok = c < 8 && hp < 18 * 18 && (unsigned)y < (unsigned)p.Ho && (unsigned)x < (unsigned)p.Wo;
+      h_voff[sl] = ok ? (((h_img * p.Ho + y) * p.Wo + x) * hlda + c * 8) * 2 : OOB;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < (HALO ? 0 : A_PW); ++i) {
     const int pi = a_piece(i);
     const int m = bm0 + pi * RPP + srow;
     const int gch = cpos ^ lds_swz<BK>(pi * RPP + srow);
@@ -198,6 +236,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   }
   const half_t* w_ptr[B_PW];
   int w_inc[B_PW];
+  int w_voff[B_PW];
   // this wave's weight pieces: [b_pi0, b_pi0 + b_npw)
   const int b_npw = B_UNEVEN && wave >= NWAVE / 2 ? B_PW - 1 : B_PW;
   const int b_pi0 = B_UNEVEN ? (wave < NWAVE / 2 ? wave * B_PW : (NWAVE / 2) * B_PW + (wave - NWAVE / 2) * (B_PW - 1)) : wave * B_PW;
@@ -213,6 +252,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
     const int gch = cpos ^ lds_swz<BK>(pi * RPP + srow);
     if (n < hN && pi * RPP + srow < BN) { w_ptr[i] = hW + (size_t)n * hldw + gch * 8; w_inc[i] = BK; }
     else         { w_ptr[i] = hzero; w_inc[i] = 0; }
+    if constexpr (HALO != 0) w_voff[i] = w_inc[i] ? (n * hldw + gch * 8) * 2 : OOB;      // (buffer loads: byte offset of the piece's chunk in the weight matrix, column 0)
   }
 
   const int nk_all = hK / BK;
@@ -259,8 +299,10 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
 #pragma unroll
       for (int i = 0; i < A_PW; ++i) a_ptr[i] += (size_t)kt0 * a_inc[i];
     }
+    if constexpr (HALO == 0) {
 #pragma unroll
-    for (int i = 0; i < B_PW; ++i) w_ptr[i] += (size_t)kt0 * w_inc[i];
+      for (int i = 0; i < B_PW; ++i) w_ptr[i] += (size_t)kt0 * w_inc[i];
+    }
   }
 
   // new filter tap (wave-uniform): re-derive the gathered pixel of each row (once per Cin / 64 k-tiles)
@@ -360,7 +402,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   const int wm0 = (wave / WGN) * (PP == 2 ? WM / 2 : WM), wn0 = (wave % WGN) * (PP == 2 ? WN / 2 : WN);
   const int frow = lane & 15, fq = lane >> 4;
   const int fswz = lds_swz<BK>(frow);
-  const int a_off = (wm0 + frow) * ROWB, w_off = BM * ROWB + (wn0 + frow) * ROWB;
+  const int a_off = (wm0 + frow) * ROWB, w_off = (HALO ? 0 : BM * ROWB) + (wn0 + frow) * ROWB;
 
   f4 acc[MR][NR];
   auto zero_acc = [&]() {
@@ -400,7 +442,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
     stage_part(0, std::integral_constant<int, 0>{}); stage_part(0, std::integral_constant<int, 1>{});
     stage_part(0, std::integral_constant<int, 2>{}); stage_part(0, std::integral_constant<int, 3>{});
     if (nk > 1) { stage_part(1, std::integral_constant<int, 0>{}); stage_part(1, std::integral_constant<int, 1>{}); stage_part(1, std::integral_constant<int, 2>{}); }
-  } else {
+  } else if constexpr (HALO == 0) {
 #pragma unroll
     for (int s = 0; s < NSTAGE - 1; ++s)
       if (s < nk) stage(s, s);
@@ -412,7 +454,208 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
 #ifdef IA2P_CLOCK_STAMP     // diagnostic build only (tools/micro/gemm_clock.hip): in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz around the k-loop
   const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  if constexpr (PP == 1) {
+  if constexpr (PP == 1 && HALO != 0) {
+    // ---- halo-staged convolution on the ping-pong schedule (barriers and groups as in the plain ping-pong loop below). Everything a k-tile does is known at compile
+    //      time: the nine taps of a block are nine straight-line bodies (tap offset of the fragment reads, ring slots t mod 3 = tap mod 3, the image piece this wave
+    //      fetches -- piece `tap` of the next block's image for taps 0..5 --, the counted vmcnt), operands come through BUFFER loads to LDS (descriptor + one 32-bit
+    //      VGPR offset per piece + a scalar offset for the channel block / weight column: no pointer arithmetic, rows and pixels outside the operand are range-
+    //      checked to zero by the load), and launches past the end of the K range still issue their loads against an EMPTY descriptor, so that every k-tile of
+    //      every wave has the same number of pieces in flight. What bounds a ping-pong k-tile is the issue of its DMA pieces in the read half-step
+    //      (100 ... 185 cycles each beside 18 ds_read_b128): 6.5 per wave in the gathered 256 x 160 tile, 3.5 here.
+    static_assert(MR * NR <= 20 && NSTAGE == 3, "ping-pong keeps the fragments of a whole k-tile in registers across a barrier; ring slot = tap mod 3");
+    const int grp = wave >> 2;
+    const half_t* src2 = p.A2;
+    const half_t* src3 = p.A3;
+    int ld2 = p.lda2, ld3 = p.lda3;
+    asm volatile("" : "+s"(src2), "+s"(src3), "+s"(ld2), "+s"(ld3));      // (named scalars: a select between FIELDS of the by-value argument struct goes through scratch)
+    const int nb_main = cin_main / BK, nk_main = 9 * nb_main, cin2 = cin_main * 2;
+    // this workgroup's k-tiles [k0, k1); inside the 3x3 part a K split starts and ends on whole blocks (the same rounding on both sides of a boundary)
+    int k0 = kt0, k1 = kt1;
+    if (k0 < nk_main) k0 -= k0 % 9;
+    if (k1 < nk_main) k1 -= k1 % 9;
+    const int nkt = k1 - k0;
+    const int blk0 = k0 < nk_main ? k0 / 9 : nb_main, blk1 = min(k1, nk_main) / 9 > blk0 ? min(k1, nk_main) / 9 : blk0;      // its blocks of the 3x3 part
+    const int n2 = nkt - 9 * (blk1 - blk0);                                                                               // its tiles of the appended 1x1 blocks
+    auto mk_rsrc = [](const void* q, size_t bytes) { return __builtin_amdgcn_make_buffer_rsrc((void*)q, 0, (int)min(bytes, (size_t)0x7ffffe00), 0x00020000); };
+    const __amdgpu_buffer_rsrc_t rs_w = mk_rsrc(hW, (size_t)hN * hldw * 2), rs_a = mk_rsrc(hA, (size_t)hM * hlda * 2), rs_none = mk_rsrc(hW, 0);
+#define BLDS16(rsrc, ldsptr, voff, soff) \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(ldsptr), 16, voff, soff, 0, 0)
+    auto issue_w = [&](__amdgpu_buffer_rsrc_t rs, int slot, int soff) {
+#pragma unroll
+      for (int i = 0; i < B_PW; ++i)
+        if (!B_UNEVEN || i < b_npw) BLDS16(rs, smem + slot * STAGE + b_piece(i) * 1024, w_voff[i], soff);
+    };
+    h8 af[KSUB][MR], wf[KSUB][NR];
+    auto mm = [&]() {
+#pragma unroll
+      for (int kk = 0; kk < KSUB; ++kk)
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+          for (int j = 0; j < NR; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][j], af[kk][i], acc[i][j], 0, 0, 0);
+    };
+    auto mid = [&]() {
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    constexpr int LPS0 = B_PW, LPS1 = B_UNEVEN ? B_PW - 1 : B_PW;       // weight pieces per k-tile of a wave of group 0 / group 1
+    const int a_rd0 = H_BASE + ((wm0 >> 4) * 18 + frow) * H_PITCH + fq * 16;      // this lane's pixel (tap (0, 0) of it) and 16-byte chunk inside a halo image
+    int a_rd = 0;                                                                  // + the image of the current block
+    int t = 0;                                                                     // k-tile of this workgroup at the top of the current block
+    // fragment reads of tap TAP of the current block, then -- behind them -- piece TAP of the next block's image and the weights of the tile two ahead
+    auto rd_tap = [&](auto tap_tag) {
+      constexpr int TAP = decltype(tap_tag)::value;
+      const char* hb = smem + a_rd + ((TAP / 3) * 18 + TAP % 3) * H_PITCH;
+      const char* bb = smem + (TAP % 3) * STAGE + w_off;
+#pragma unroll
+      for (int kk = 0; kk < KSUB; ++kk) {
+        const int coff = ((kk * 4 + fq) ^ fswz) << 4;
+#pragma unroll
+        for (int i = 0; i < MR; ++i) af[kk][i] = *(const h8*)(hb + i * H_ROW + kk * 64);
+#pragma unroll
+        for (int j = 0; j < NR; ++j) wf[kk][j] = *(const h8*)(bb + j * 16 * ROWB + coff);
+      }
+    };
+    auto issue_tap = [&](auto tap_tag, int blk) {
+      constexpr int TAP = decltype(tap_tag)::value;
+      if constexpr (TAP < H_SLOTS)
+        BLDS16(blk + 1 < blk1 ? rs_a : rs_none, smem + H_BASE + ((blk + 1) & 1) * H_BYTES + (TAP * NWAVE + wave) * 1024, h_voff[TAP], (blk + 1) * (2 * BK));
+      constexpr int S = TAP + 2;                                   // tap of the tile two ahead (9, 10: taps 0, 1 of the next block, or the first appended tiles)
+      int soff;
+      if constexpr (S <= 8) soff = blk * (2 * BK) + S * cin2;
+      else soff = blk + 1 < nb_main ? (blk + 1) * (2 * BK) + (S - 9) * cin2 : 9 * cin2 + (S - 9) * (2 * BK);
+      issue_w(t + S < nkt ? rs_w : rs_none, S % 3, soff);
+    };
+    auto top = [&](auto n_tag) {
+      __builtin_amdgcn_sched_barrier(0);
+      wait_vm_barrier<decltype(n_tag)::value>();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    if (blk1 > blk0) {
+      // prologue: the first block's image, the weights of its first two tiles
+#pragma unroll
+      for (int sl = 0; sl < H_SLOTS; ++sl) BLDS16(rs_a, smem + H_BASE + (blk0 & 1) * H_BYTES + (sl * NWAVE + wave) * 1024, h_voff[sl], blk0 * (2 * BK));
+      issue_w(rs_w, 0, blk0 * (2 * BK));
+      issue_w(rs_w, 1, blk0 * (2 * BK) + cin2);
+      if (grp == 0) {
+        auto body = [&](auto tap_tag, int blk) {
+          constexpr int TAP = decltype(tap_tag)::value;
+          top(std::integral_constant<int, LPS0 + (TAP >= 1 && TAP <= H_SLOTS ? 1 : 0)>{});      // in flight: what the interval before issued (weights; + an image piece after taps 0..5)
+          rd_tap(tap_tag);
+          __builtin_amdgcn_sched_barrier(0);
+          issue_tap(tap_tag, blk);
+          mid();
+          mm();
+        };
+        for (int blk = blk0; blk < blk1; ++blk) {
+          a_rd = a_rd0 + (blk & 1) * H_BYTES;
+          body(std::integral_constant<int, 0>{}, blk); body(std::integral_constant<int, 1>{}, blk); body(std::integral_constant<int, 2>{}, blk);
+          body(std::integral_constant<int, 3>{}, blk); body(std::integral_constant<int, 4>{}, blk); body(std::integral_constant<int, 5>{}, blk);
+          body(std::integral_constant<int, 6>{}, blk); body(std::integral_constant<int, 7>{}, blk); body(std::integral_constant<int, 8>{}, blk);
+          t += 9;
+        }
+      } else {
+        bool first = true;
+        auto body = [&](auto tap_tag, int blk) {
+          constexpr int TAP = decltype(tap_tag)::value;
+          top(std::integral_constant<int, LPS1 + (TAP >= 1 && TAP <= H_SLOTS ? 1 : 0)>{});
+          if (TAP != 0 || !first) mm();
+          mid();
+          rd_tap(tap_tag);
+          __builtin_amdgcn_sched_barrier(0);
+          issue_tap(tap_tag, blk);
+        };
+        for (int blk = blk0; blk < blk1; ++blk) {
+          a_rd = a_rd0 + (blk & 1) * H_BYTES;
+          body(std::integral_constant<int, 0>{}, blk); first = false;
+          body(std::integral_constant<int, 1>{}, blk); body(std::integral_constant<int, 2>{}, blk);
+          body(std::integral_constant<int, 3>{}, blk); body(std::integral_constant<int, 4>{}, blk); body(std::integral_constant<int, 5>{}, blk);
+          body(std::integral_constant<int, 6>{}, blk); body(std::integral_constant<int, 7>{}, blk); body(std::integral_constant<int, 8>{}, blk);
+          t += 9;
+        }
+        mm();
+      }
+    }
+    if (n2 > 0) {
+      // ---- the appended 1x1 blocks: one k-tile per block of 64 channels, nothing to share between tiles -- the plain ping-pong ring, its activation slots
+      //      (256 rows x 128 B, XOR-swizzled, rows = the patch's pixels) in the place of the two halo images. The pipeline is drained once in between.
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      int a2v[A_PW], a3v[A_PW];
+#pragma unroll
+      for (int i = 0; i < A_PW; ++i) {
+        const int r = a_piece(i) * RPP + srow, m = row_m(r), gch = cpos ^ lds_swz<BK>(r);
+        a2v[i] = (m * ld2 + gch * 8) * 2;
+        a3v[i] = (m * ld3 + gch * 8) * 2;
+      }
+      const __amdgpu_buffer_rsrc_t rs2 = mk_rsrc(src2, (size_t)hM * ld2 * 2), rs3 = mk_rsrc(src3, src3 ? (size_t)hM * ld3 * 2 : 0);
+      const int e0 = k0 > nk_main ? k0 - nk_main : 0;                      // first appended tile of this workgroup
+      const int staged = blk1 > blk0 ? 2 : 0;                              // tiles whose weights the 3x3 part has already put into the ring
+      auto stage2 = [&](int j, int slot, bool with_w) {                   // tile j of this part: weights (unless staged), then the activation rows
+        const int ch = (e0 + j) * BK;
+        if (with_w) issue_w(rs_w, slot, 9 * cin2 + (e0 + j) * (2 * BK));
+        char* dst = smem + H_BASE + slot * (BM * ROWB);
+        if (ch < cin_extra) {
+#pragma unroll
+          for (int i = 0; i < A_PW; ++i) BLDS16(rs2, dst + a_piece(i) * 1024, a2v[i], ch * 2);
+        } else {
+#pragma unroll
+          for (int i = 0; i < A_PW; ++i) BLDS16(rs3, dst + a_piece(i) * 1024, a3v[i], (ch - cin_extra) * 2);
+        }
+      };
+      auto rd2 = [&](int slot) {
+        const char* ab = smem + H_BASE + slot * (BM * ROWB) + a_off;
+        const char* bb = smem + slot * STAGE + w_off;
+#pragma unroll
+        for (int kk = 0; kk < KSUB; ++kk) {
+          const int coff = ((kk * 4 + fq) ^ fswz) << 4;
+#pragma unroll
+          for (int i = 0; i < MR; ++i) af[kk][i] = *(const h8*)(ab + i * 16 * ROWB + coff);
+#pragma unroll
+          for (int j = 0; j < NR; ++j) wf[kk][j] = *(const h8*)(bb + j * 16 * ROWB + coff);
+        }
+      };
+      stage2(0, 0, staged < 1);
+      if (n2 > 1) stage2(1, 1, staged < 2);
+      const int allow0 = n2 > 1 ? A_PW + (staged < 2 ? b_npw : 0) : 0;      // pieces of tile 1 that may still fly when tile 0 is read
+      int slot_r = 0, slot_s = NSTAGE - 1;
+      auto adv = [&]() { slot_r = slot_r + 1 == NSTAGE ? 0 : slot_r + 1; slot_s = slot_s + 1 == NSTAGE ? 0 : slot_s + 1; };
+      auto top2 = [&](int j, auto lps_tag) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (j == 0) wait_ring<A_PW + B_PW, 1>(allow0);
+        else if (j + 1 < n2) wait_vm_barrier<decltype(lps_tag)::value>();
+        else wait_vm_barrier<0>();
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      if (grp == 0) {
+        for (int j = 0; j < n2; ++j) {
+          top2(j, std::integral_constant<int, A_PW + LPS0>{});
+          rd2(slot_r);
+          __builtin_amdgcn_sched_barrier(0);
+          if (j + NSTAGE - 1 < n2) stage2(j + NSTAGE - 1, slot_s, true);
+          mid();
+          mm();
+          adv();
+        }
+      } else {
+        for (int j = 0; j < n2; ++j) {
+          top2(j, std::integral_constant<int, A_PW + LPS1>{});
+          if (j > 0) mm();
+          mid();
+          rd2(slot_r);
+          __builtin_amdgcn_sched_barrier(0);
+          if (j + NSTAGE - 1 < n2) stage2(j + NSTAGE - 1, slot_s, true);
+          adv();
+        }
+        mm();
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the loads against the empty descriptor write zeros into the ring: they have to be in before the epilogue takes the LDS)
+#undef BLDS16
+  } else if constexpr (PP == 1) {
     // Barrier sequence b0, b1, ...; interval I_n lies between b_n and b_n+1. Group 0 reads tile t in I_2t and multiplies it in I_2t+1; group 1
     // reads it in I_2t+1 and multiplies it in I_2t+2. Every wave waits for its DMA pieces of tile t before b_2t; the slot of tile t-1 is free
     // after b_2t (group 1 finished reading it in I_2t-1), so tile t+2 is issued into it in I_2t: two tiles stay in flight.
@@ -934,10 +1177,10 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
       if (ch) __syncthreads();
       acc_to_tile(ch);
       __syncthreads();
-      const int row0 = bm0 + ch * CR;
+      auto rowm = [&](int r) { return row_m(ch * CR + r); };      // tile row of this chunk -> output row
       for (int idx = tid; idx < CR * GPR; idx += NT) {
         const int r = idx / GPR, g = idx - r * GPR;
-        const int m = row0 + r, n = bn0 + g * 4;
+        const int m = rowm(r), n = bn0 + g * 4;
         if (m < hM && n < hN) {
           const f4 v = tl(r, g);
           typedef unsigned u4v __attribute__((__vector_size__(4 * sizeof(unsigned))));
@@ -962,7 +1205,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
 #pragma unroll(PP == 2 ? 2 : 1)
   for (int ch = 0; ch < EC::NCHUNK; ++ch) {
     if (ch || from_slabs) __syncthreads();          // the previous chunk has been read out
-    const int row0 = bm0 + ch * CR;
+    auto rowm = [&](int r) { return row_m(ch * CR + r); };      // tile row of this chunk -> output row
     acc_to_tile(ch);
     if (from_slabs) {
       // tile chunk = sum of the K-slice slabs in slab order (slab 0 first), whoever arrived last. This slice's own partial sums are still in its
@@ -986,7 +1229,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
             const int idx = min(tid + (i0 + u) * NT, CR * GPR - 1);
             const int r = idx / GPR, g = idx - r * GPR;
             off[u] = r * PITCH + ((g ^ (r & 7)) << 2);
-            const float* src = p.partial + (size_t)min(row0 + r, hM - 1) * hN + min(bn0 + g * 4, hN - 4);
+            const float* src = p.partial + (size_t)min(rowm(r), hM - 1) * hN + min(bn0 + g * 4, hN - 4);
 #pragma unroll
             for (int j = 0; j < NO; ++j) oth[j][u] = *(const f4*)(src + (size_t)(j < split ? j : j + 1) * slab_elems);     // (clamped addresses, never branched around)
           }
@@ -1013,7 +1256,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
         for (int idx = tid; idx < CR * GPR; idx += NT) {
           const int r = idx / GPR, g = idx - r * GPR;
           const int o = r * PITCH + ((g ^ (r & 7)) << 2);
-          const float* src = p.partial + (size_t)min(row0 + r, hM - 1) * hN + min(bn0 + g * 4, hN - 4);
+          const float* src = p.partial + (size_t)min(rowm(r), hM - 1) * hN + min(bn0 + g * 4, hN - 4);
           const f4 own = *(const f4*)(tile + o);
           f4 v = split == 0 ? own : *(const f4*)src;
           for (int sl = 1; sl < nsplit; ++sl) {
@@ -1047,7 +1290,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
           const int r = min(idx / GPR, CR - 1), g = idx - (idx / GPR) * GPR;
           const int ca = (g >> 1) * 8 + (g & 1) * 2;                   // first 16-B chunk of the 8 value columns; the gates sit 4 chunks further
           rr[u] = r; gg[u] = g;
-          live[u] = idx < TOTAL && row0 + r < hM && bn0 + ca * 4 < hN;
+          live[u] = idx < TOTAL && rowm(r) < hM && bn0 + ca * 4 < hN;
           a0[u] = tl(r, ca); a1[u] = tl(r, ca + 1); g0[u] = tl(r, ca + 4); g1[u] = tl(r, ca + 5);
           if (!p.ln_stats) {
             const int n = min(bn0 + ca * 4, hN - 24);      // values n .. n+7, gates n+16 .. n+23
@@ -1082,7 +1325,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
             o[e] = (half_t)(va[e] * gelu_lut_f(vg[e], phi));
 #endif
           }
-          if (live[u]) store_c8((size_t)(row0 + r) * p.ldc + (bn0 >> 1) + (g >> 1) * 16 + (g & 1) * 8, o);
+          if (live[u]) store_c8((size_t)(rowm(r)) * p.ldc + (bn0 >> 1) + (g >> 1) * 16 + (g & 1) * 8, o);
         }
       }
     } else {
@@ -1103,7 +1346,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
             const int idx = tid + (k * U + u) * NT;
             const int r = min(idx / GPR, CR - 1), g = idx - (idx / GPR) * GPR;
             rr[u] = r; gg[u] = g;
-            const int m = row0 + r, n = bn0 + g * 8;
+            const int m = rowm(r), n = bn0 + g * 8;
             live[u] = idx < TOTAL && m < hM && n < hN;
             const int mc = min(m, hM - 1), nc = min(n, hN - 8);
             x0[u] = tl(r, 2 * g); x1[u] = tl(r, 2 * g + 1);
@@ -1142,7 +1385,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
             h8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
-            if (live[u]) store_c8((size_t)(row0 + r) * p.ldc + bn0 + cl, o);
+            if (live[u]) store_c8((size_t)(rowm(r)) * p.ldc + bn0 + cl, o);
             st1[u] = st2[u] = 0.f;
             if (p.stats_out && live[u]) {
 #pragma unroll
@@ -1156,7 +1399,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
             const int idx = tid + (k * U + u) * NT;
             const int r = min(idx / GPR, CR - 1), g = idx - (idx / GPR) * GPR;
             rr[u] = r; gg[u] = g;
-            const int m = row0 + r;
+            const int m = rowm(r);
             live[u] = idx < TOTAL && m < hM && bn0 + g * 8 < hN;
             st1[u] = st2[u] = 0.f;
             if (!live[u]) continue;
@@ -1192,7 +1435,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
               float a = st1[u], b = st2[u];
 #pragma unroll
               for (int o = 1; o < GPR; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }      // fixed butterfly: deterministic
-              if (gg[u] == 0 && idx < TOTAL && row0 + rr[u] < hM) ((float2*)p.stats_out)[(size_t)tn * hM + row0 + rr[u]] = make_float2(a, b);
+              if (gg[u] == 0 && idx < TOTAL && rowm(rr[u]) < hM) ((float2*)p.stats_out)[(size_t)tn * hM + rowm(rr[u])] = make_float2(a, b);
             } else if (idx < TOTAL) part[idx] = make_float2(st1[u], st2[u]);
           }
         }
@@ -1200,10 +1443,10 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
       if constexpr (!POW2) {
         if (p.stats_out) {
           __syncthreads();
-          if (tid < CR && row0 + tid < hM) {
+          if (tid < CR && rowm(tid) < hM) {
             float s1 = 0.f, s2 = 0.f;
             for (int g = 0; g < GPR; ++g) { const float2 v = part[tid * GPR + g]; s1 += v.x; s2 += v.y; }      // group order: deterministic
-            ((float2*)p.stats_out)[(size_t)tn * hM + row0 + tid] = make_float2(s1, s2);
+            ((float2*)p.stats_out)[(size_t)tn * hM + rowm(tid)] = make_float2(s1, s2);
           }
         }
       }
@@ -1223,6 +1466,12 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_f16_kernel(const half_
   gemm_tile_body<BM, BN, NSTAGE, CONV, WGM, BK, PP, WGN, 0>(hA, hW, hzero, hM, hN, hK, hlda, hldw, hrpb, hbstride, hroff, hsplitk, hgroup_w, p, nullptr);
 }
 
+// the halo-staged 3x3 convolution (gemm_tile_body, HALO = 1): 256 x BN tiles of 16 x 16 pixel patches, ping-pong schedule
+template <int BN>
+__global__ __launch_bounds__(512, 2) void conv_halo_f16_kernel(const half_t* hA, const half_t* hW, const half_t* hzero, int hM, int hN, int hK, int hlda, int hldw, int hrpb, int hbstride,
+                                                                 int hroff, int hsplitk, int hgroup_w, const GemmArgs p) {
+  gemm_tile_body<256, BN, 3, true, 4, 64, 1, 2, 0, 1>(hA, hW, hzero, hM, hN, hK, hlda, hldw, hrpb, hbstride, hroff, hsplitk, hgroup_w, p, nullptr);
+}
 // grouped tile order: panel width (in tiles) such that the contiguous tile range an XCD works on is a compact block; 0 = plain order.
 // An XCD that holds r x c tiles fetches r activation row panels and c weight column panels: r a + c w bytes with r c fixed is least at c = sqrt(resident a / w).
 // a_over_w = bytes of one activation row panel over bytes of one weight column panel: BM / BN for a linear layer (both K deep), but a 3x3 convolution's
@@ -1276,6 +1525,27 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
   if (b.sk_counters && tiles > ia2p_sk_counter_capacity()) return hipErrorInvalidValue;
   const int extra = (!PP && a.pf && a.pf_bytes >= 4096) ? a.pf_blocks : 0;
   hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, NSTAGE, CONV, WGM, BK, PP, WGN>), dim3(tiles * (a.splitk > 1 ? a.splitk : 1) + extra), dim3(WGM * WGN * 64), smem, s,
+                     b.A, b.W, b.zero, b.M, b.N, b.K, b.lda, b.ldw, b.rpb, b.bstride, b.roff, b.splitk, b.group_w, b);
+  return hipGetLastError();
+}
+
+template <int BN>
+static hipError_t launch_halo(const GemmArgs& a, hipStream_t s) {
+  if (!ia2p_conv_halo_ok(a)) return hipErrorInvalidValue;
+  constexpr int smem = EpiCfg<256, BN, 3, 4, 64, 2, 1>::SMEM;
+  static bool attr_set[64] = {false};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_halo_f16_kernel<BN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
+  }
+  const int tiles = (a.M / 256) * ((a.N + BN - 1) / BN);
+  GemmArgs b = a;
+  ia2p_gemm_prepare(b, smem, 256, BN, true);
+  if (b.sk_counters && tiles > ia2p_sk_counter_capacity()) return hipErrorInvalidValue;
+  hipLaunchKernelGGL((conv_halo_f16_kernel<BN>), dim3(tiles * (a.splitk > 1 ? a.splitk : 1)), dim3(512), smem, s,
                      b.A, b.W, b.zero, b.M, b.N, b.K, b.lda, b.ldw, b.rpb, b.bstride, b.roff, b.splitk, b.group_w, b);
   return hipGetLastError();
 }

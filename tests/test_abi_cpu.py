@@ -81,7 +81,7 @@ def test_gemm_plan_is_a_pure_host_function_and_the_plan_table_round_trips(lib):
         tiles.append(tuple(t))
     from tests.test_ops_gpu import NTILES
     assert len(tiles) == NTILES and lib.ia2p_debug_gemm_tile_info(-1, t) == -1
-    assert tiles[0] == (128, 128, 2, 0) and tiles[18] == (256, 160, 3, 1) and tiles[22] == (256, 256, 2, 2)
+    assert tiles[0] == (128, 128, 2, 0) and tiles[18] == (256, 160, 3, 1) and tiles[22] == (256, 256, 2, 2) and tiles[24] == (256, 160, 3, 3)      # (schedule 3: halo-staged convolution)
     bn = [x[1] for x in tiles]
     for shape in [(2048, 1280, 1280), (8192, 640, 640), (64, 64, 64), (616, 166400, 2048), (37, 132, 128), (256, 1280, 5120), (4096, 4096, 4096)]:
         v, s = plan(*shape)
@@ -99,7 +99,7 @@ def test_gemm_plan_is_a_pure_host_function_and_the_plan_table_round_trips(lib):
     buf = C.create_string_buffer(n + 1)
     lib.ia2p_plan_export(buf, n + 1)
     assert sorted(buf.value.split(b";")) == sorted(text.split(b";"))
-    for bad in [b"garbage", b"2048,1280,1280,0,0,99,1;", b"2048,1280,1280,0,0,0,999;", b"2048,10240,1280,0,1,0,2;"]:
+    for bad in [b"garbage", b"2048,1280,1280,0,0,99,1;", b"2048,1280,1280,0,0,0,999;", b"2048,10240,1280,0,1,0,2;", b"2048,1280,1280,0,0,24,1;"]:      # (the last one: a halo-staged convolution tile for a linear layer)
         assert lib.ia2p_plan_import(bad) == -1
     lib.ia2p_plan_clear()
     assert lib.ia2p_plan_export(None, 0) == 0
