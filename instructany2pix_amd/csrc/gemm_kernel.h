@@ -17,6 +17,11 @@ int* ia2p_sk_counters(hipStream_t s, int tiles);
 void ia2p_sk_counters_invalidate();      // new epoch: every stream's ticket buffer is re-zeroed in front of its next K-split launch
 const float* ia2p_phi_lut();
 
+#ifndef IA2P_LIN_BUF
+#define IA2P_LIN_BUF 1      // linear layers stage their operands with BUFFER loads to LDS (descriptor + one 32-bit offset register per piece + a scalar k offset) instead of
+#endif                      // per-piece 64-bit running pointers; 0: the pointer form (A/B builds)
+#define BLDS16(rsrc, ldsptr, voff, soff) \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(ldsptr), 16, voff, soff, 0, 0)
 #define GLDS16(gptr, ldsptr)                                                                         \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),            \
                                    (__attribute__((address_space(3))) void*)(ldsptr), 16, 0, 0)
@@ -118,6 +123,12 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // linear layers: both operands through buffer loads -- a piece is (descriptor, this lane's byte offset of its row and chunk at k = 0, scalar byte offset of the
+  // k-tile); rows past M / N carry an offset past the descriptor's range and read zeros. Operands are addressed with 31 bits: the launcher refuses larger ones.
+  constexpr bool LINBUF = !CONV && IA2P_LIN_BUF != 0;
+  constexpr int OOB = 0x7fffff00;
+  const __amdgpu_buffer_rsrc_t lin_rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)hA, 0, 0x7ffffe00, 0x00020000);
+  const __amdgpu_buffer_rsrc_t lin_rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)hW, 0, 0x7ffffe00, 0x00020000);
 #ifdef IA2P_CLOCK_STAMP
   const unsigned long long stamp_entry = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -185,6 +196,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   auto a_piece = [&](int i) { return PP == 2 ? (i / A_HP) * (BM / 2 / RPP) + wave * A_HP + i % A_HP : wave * A_PW + i; };
   const half_t* a_ptr[A_PW];
   int a_inc[A_PW];
+  int a_voff[A_PW];
   // conv gather, per piece (= one tile row per lane): a_base = address of filter tap (0, 0)'s pixel for this lane's 16-byte chunk (may lie outside the image: only
   // dereferenced under the mask); a_mask = bits 0-8: tap (ky, kx) falls inside the (virtual) image, bits 9 / 10: parity of the tap-0 row / column in the
   // nearest-x2 upsampled view (source step of tap k = (k + parity) >> up). A new tap's pointer is a bit test, a wave-uniform offset and a select.
@@ -193,7 +205,6 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   // halo-staged convolution: DMA piece (slot * NWAVE + wave) of a halo image, lane -> 16-byte chunk j = piece * 64 + lane = (halo pixel j / 9, chunk j % 9);
   // h_voff = byte offset of that chunk inside the source tensor (channel block 0), or an offset past any tensor: pad chunk / outside the image / past the image's
   // last pixel -- the buffer load's range check then writes zeros (no zero page, no select)
-  constexpr int OOB = 0x7fffff00;
   int h_voff[H_SLOTS];
   if constexpr (HALO != 0) {
 #pragma unroll
@@ -217,7 +228,8 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
         if (hrpb) { const int b = m / hrpb; src = b * hbstride + (m - b * hrpb) + hroff; }
         a_ptr[i] = hA + (size_t)src * hlda + gch * 8;
         a_inc[i] = BK;
-      } else { a_ptr[i] = hzero; a_inc[i] = 0; }
+        a_voff[i] = (src * hlda + gch * 8) * 2;
+      } else { a_ptr[i] = hzero; a_inc[i] = 0; a_voff[i] = OOB; }
     } else {
       a_mask[i] = 0; a_base[i] = hzero;
       if (m < hM) {
@@ -252,7 +264,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
     const int gch = cpos ^ lds_swz<BK>(pi * RPP + srow);
     if (n < hN && pi * RPP + srow < BN) { w_ptr[i] = hW + (size_t)n * hldw + gch * 8; w_inc[i] = BK; }
     else         { w_ptr[i] = hzero; w_inc[i] = 0; }
-    if constexpr (HALO != 0) w_voff[i] = w_inc[i] ? (n * hldw + gch * 8) * 2 : OOB;      // (buffer loads: byte offset of the piece's chunk in the weight matrix, column 0)
+    if constexpr (HALO != 0 || LINBUF) w_voff[i] = w_inc[i] ? (n * hldw + gch * 8) * 2 : OOB;      // (buffer loads: byte offset of the piece's chunk in the weight matrix, column 0)
   }
 
   const int nk_all = hK / BK;
@@ -294,7 +306,8 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
       if (t < 10 && c >= cin_extra) { c = 0; ++t; }                           // (the last block runs to the end of K)
     }
   };
-  if (kt0) {             // split-K: this workgroup starts at k-tile kt0
+  int k_soff = kt0 * (2 * BK);      // buffer-load form: byte offset of the k-tile being staged
+  if (kt0 && !LINBUF) {             // split-K: this workgroup starts at k-tile kt0
     if (!CONV) {
 #pragma unroll
       for (int i = 0; i < A_PW; ++i) a_ptr[i] += (size_t)kt0 * a_inc[i];
@@ -363,12 +376,18 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   // LDS-DMA of this wave's activation pieces [i0, i1) / weight pieces [i0, i1) of the next k-tile into ring slot `buf`; running pointers: no per-step multiply
   auto issue_a = [&](int buf, auto i0_tag, auto i1_tag) {
 #pragma unroll
-    for (int i = decltype(i0_tag)::value; i < decltype(i1_tag)::value; ++i) { GLDS16(a_ptr[i], smem + buf * STAGE + a_piece(i) * 1024); a_ptr[i] += a_inc[i]; }
+    for (int i = decltype(i0_tag)::value; i < decltype(i1_tag)::value; ++i) {
+      if constexpr (LINBUF) BLDS16(lin_rs_a, smem + buf * STAGE + a_piece(i) * 1024, a_voff[i], k_soff);
+      else { GLDS16(a_ptr[i], smem + buf * STAGE + a_piece(i) * 1024); a_ptr[i] += a_inc[i]; }
+    }
   };
   auto issue_b = [&](int buf, auto i0_tag, auto i1_tag) {
 #pragma unroll
     for (int i = decltype(i0_tag)::value; i < decltype(i1_tag)::value; ++i)
-      if (!B_UNEVEN || i < b_npw) { GLDS16(w_ptr[i], smem + buf * STAGE + BM * ROWB + b_piece(i) * 1024); w_ptr[i] += w_inc[i]; }      // (wave-uniform)
+      if (!B_UNEVEN || i < b_npw) {      // (wave-uniform)
+        if constexpr (LINBUF) BLDS16(lin_rs_w, smem + buf * STAGE + BM * ROWB + b_piece(i) * 1024, w_voff[i], k_soff);
+        else { GLDS16(w_ptr[i], smem + buf * STAGE + BM * ROWB + b_piece(i) * 1024); w_ptr[i] += w_inc[i]; }
+      }
   };
   // The pointer arithmetic of the NEXT k-tile's gather (a few VALU instructions per piece, every k-tile) belongs beside the MFMAs of the current one, where its
   // issue slots are free -- not in front of the DMA issue, between the barrier and the fragment reads: the loops below call this right ahead of their MFMA
@@ -380,6 +399,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
     issue_a(buf, I0{}, std::integral_constant<int, A_PW>{});
     if (CONV) conv_tap_advance();
     issue_b(buf, I0{}, std::integral_constant<int, B_PW>{});
+    if constexpr (LINBUF) k_soff += 2 * BK;
   };
   // 8-phase tile: one HALF of an operand tile per call, in the order B0, A0, B1, A1 of a k-tile (A0 opens the k-tile for the conv gather, A1 closes it)
   auto stage_part = [&](int buf, auto which_tag) {
@@ -389,7 +409,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
     if constexpr (WHICH == 0) issue_b(buf, I0{}, BH{});
     else if constexpr (WHICH == 1) { if (CONV) conv_tap_setup(); issue_a(buf, I0{}, AH{}); }
     else if constexpr (WHICH == 2) issue_b(buf, BH{}, std::integral_constant<int, B_PW>{});
-    else { issue_a(buf, AH{}, std::integral_constant<int, A_PW>{}); if (CONV) conv_tap_advance(); }
+    else { issue_a(buf, AH{}, std::integral_constant<int, A_PW>{}); if (CONV) conv_tap_advance(); if constexpr (LINBUF) k_soff += 2 * BK; }
   };
 
   // ---- fragment read offsets (wave tile origin is a multiple of 16, so swz(row) = (lane>>1)&7)
@@ -478,8 +498,6 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
     const int n2 = nkt - 9 * (blk1 - blk0);                                                                               // its tiles of the appended 1x1 blocks
     auto mk_rsrc = [](const void* q, size_t bytes) { return __builtin_amdgcn_make_buffer_rsrc((void*)q, 0, (int)min(bytes, (size_t)0x7ffffe00), 0x00020000); };
     const __amdgpu_buffer_rsrc_t rs_w = mk_rsrc(hW, (size_t)hN * hldw * 2), rs_a = mk_rsrc(hA, (size_t)hM * hlda * 2), rs_none = mk_rsrc(hW, 0);
-#define BLDS16(rsrc, ldsptr, voff, soff) \
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(ldsptr), 16, voff, soff, 0, 0)
     auto issue_w = [&](__amdgpu_buffer_rsrc_t rs, int slot, int soff) {
 #pragma unroll
       for (int i = 0; i < B_PW; ++i)
@@ -654,7 +672,6 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the loads against the empty descriptor write zeros into the ring: they have to be in before the epilogue takes the LDS)
-#undef BLDS16
   } else if constexpr (PP == 1) {
     // Barrier sequence b0, b1, ...; interval I_n lies between b_n and b_n+1. Group 0 reads tile t in I_2t and multiplies it in I_2t+1; group 1
     // reads it in I_2t+1 and multiplies it in I_2t+2. Every wave waits for its DMA pieces of tile t before b_2t; the slot of tile t-1 is free
@@ -1521,6 +1538,10 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
   ia2p_gemm_prepare(b, smem, BM, BN, CONV);
   if (a.geglu && !b.vec8) return hipErrorInvalidValue;
   if (a.geglu && !b.phi_lut) return hipErrorOutOfMemory;
+  if (!CONV && IA2P_LIN_BUF) {      // buffer-load staging addresses an operand with a 31-bit byte offset
+    const size_t a_rows = a.rpb ? ((size_t)a.M / a.rpb + 1) * (size_t)std::max(a.bstride, 0) + a.roff + a.rpb : (size_t)a.M;
+    if (a_rows * a.lda * 2 >= (size_t)0x7ffffe00 || (size_t)a.N * a.ldw * 2 >= (size_t)0x7ffffe00) return hipErrorInvalidValue;
+  }
   // b.sk_counters: as the caller (launch_any, gemm.hip) attached them -- null: the K-slices only write their slabs and a splitk_reduce_kernel launch finishes
   if (b.sk_counters && tiles > ia2p_sk_counter_capacity()) return hipErrorInvalidValue;
   const int extra = (!PP && a.pf && a.pf_bytes >= 4096) ? a.pf_blocks : 0;
