@@ -76,7 +76,16 @@ struct EpiCfg {
   static constexpr int CR = BM / NCHUNK;
   static constexpr int TILE_BYTES = CR * PITCH * 4;
   static_assert(TILE_BYTES + extra(CR) <= LIMIT, "epilogue staging does not fit");
-  static constexpr int SMEM = STAGE_BYTES > TILE_BYTES + extra(CR) ? STAGE_BYTES : TILE_BYTES + extra(CR);
+  static constexpr int SMEM_F32 = STAGE_BYTES > TILE_BYTES + extra(CR) ? STAGE_BYTES : TILE_BYTES + extra(CR);
+  // register epilogue (launches without a K split, 16-byte-aligned outputs): the accumulators get bias / folded LayerNorm / activation in the MFMA layout, are
+  // rounded to fp16 and cross the LDS ONCE as a [BM][BN] fp16 tile (rows padded by 16 B: the 8-byte fragment writes of 16 rows land on 16 different bank groups)
+  static constexpr int P16 = BN * 2 + 16, T16_BYTES = BM * P16;
+  static constexpr int EXTRA16 = (2 * BM + 2 * BN + 4) * 4 + (POW2 ? 0 : BM * (BN / 8) * 8) + LUT_BYTES;
+#ifndef IA2P_REG_EPI_MIN
+#define IA2P_REG_EPI_MIN 0        // tiles of fewer elements keep the fp32 route (build-time knob for A/B builds)
+#endif
+  static constexpr bool REG_EPI = T16_BYTES + EXTRA16 <= LIMIT && BM * BN >= IA2P_REG_EPI_MIN;      // (else the fp32 chunked route only: 160 x 160)
+  static constexpr int SMEM = REG_EPI && T16_BYTES + EXTRA16 > SMEM_F32 ? T16_BYTES + EXTRA16 : SMEM_F32;
 };
 
 // PP = 1 ("ping-pong", 8 waves = WGM 4, 3-stage ring, ONE workgroup per CU): waves 0-3 own the upper half of the tile rows, waves 4-7 the
@@ -984,12 +993,17 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   constexpr int PITCH = EC::PITCH;
   constexpr int NT = NWAVE * 64, CR = EC::CR;                           // threads, tile rows per chunk
   float* tile = (float*)smem;
-  float* ln_rows = (float*)(smem + EC::TILE_BYTES);                     // [0, BM): mean, [BM, 2 BM): rstd
+  // two routes: the register epilogue (no K split, 16-byte accesses everywhere -- every shape of the executors; below) and the chunked fp32 route (K splits: the slabs are
+  // fp32; odd strides). Both compute  h = fp16(acc * as + bias * bs | folded LayerNorm, activation)  and  out = fp16(h + rowvec * bs + residual): the rounding of the
+  // reference's own fp16 modules (a Linear / Conv2d output is an fp16 tensor before the time-embedding row or the residual is added to it).
+  const bool reg_epi = XA == 0 && EC::REG_EPI && nsplit == 1 && p.vec8 != 0 && (hN & 7) == 0 && !p.act;      // (activations other than GEGLU: the CLIP / prior MLPs, on the fp32 route)
+  char* cbase = smem + (reg_epi ? EC::T16_BYTES : EC::TILE_BYTES);
+  float* ln_rows = (float*)cbase;                                       // [0, BM): mean, [BM, 2 BM): rstd
   float* ln_cs = ln_rows + 2 * BM;                                      // BN column sums and BN folded biases of this tile
   float* ln_lb = ln_cs + BN;
   int* sk_flag = (int*)(ln_lb + BN);                                    // K-split: the ticket this workgroup drew, broadcast to its waves
   float2* part = (float2*)(ln_lb + BN + 4);                             // row-statistics partials (tile widths whose 8-column groups per row are not a power of two)
-  const float2* phi = (const float2*)(smem + EC::TILE_BYTES + EC::extra_nolut(CR));      // GEGLU: normal-CDF table (gelu_lut_f), copied in below
+  const float2* phi = (const float2*)(cbase + (reg_epi ? EC::EXTRA16 - EC::LUT_BYTES : EC::extra_nolut(CR)));      // GEGLU: normal-CDF table (gelu_lut_f), copied in below
   __syncthreads();                    // every wave has finished reading the stage buffers
   if (p.ln_stats) {
     if (tid < BM) {
@@ -1181,6 +1195,164 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
 #endif
     return;
   }
+  if constexpr (XA == 0 && EC::REG_EPI) {
+  if (reg_epi) {
+    // ---- register epilogue. In the MFMA layout a lane holds 4 consecutive columns of MR x NR (row, column-quad) positions: the row constants of the folded
+    //      LayerNorm are MR values per lane, the column constants (or the bias) one 16-byte read per fragment column -- no index arithmetic, no per-group constant
+    //      reads. The fp16 tile then crosses the LDS once, half the bytes of the fp32 route and in ONE piece (no chunking, two barriers), and is read out
+    //      row-major, 16 bytes = 8 outputs per thread: plain launches copy it to C, the others add the time-embedding row / residual (fp32, one more rounding) or
+    //      multiply values by GELU(gates).
+    constexpr int P16 = EC::P16;
+    char* t16 = smem;
+    if (p.geglu && EC::LUT_BYTES) {
+      for (int i = tid; i < IA2P_PHI_LUT_N; i += NT) ((float2*)phi)[i] = ((const float2*)p.phi_lut)[i];
+    }
+    __syncthreads();                  // row / column constants are in LDS (and every wave is through with the stage buffers: barrier above)
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      const int cl = wn0 + frag_col(j) + fq * 4;                      // tile column of acc[.][j][0]
+      f4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};       // folded LayerNorm: column sums, folded biases; else: bias * bs, -
+      if (p.ln_stats) { c0 = *(const f4*)(ln_cs + cl); c1 = *(const f4*)(ln_lb + cl); }
+      else if (p.bias) {
+        const h4 hb = *(const h4*)(p.bias + min(bn0 + cl, hN - 4));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c0[e] = (float)hb[e];
+      }
+#pragma unroll
+      for (int i = 0; i < MR; ++i) {
+        const int r = wm0 + frag_row(i) + frow;
+        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        if (p.ln_stats) {
+          const float mu = ln_rows[r], rs = ln_rows[BM + r];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = ln_fold_f(v[e], mu, rs, c0[e], c1[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= e_as;
+          if (p.bias) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(c0[e], e_bs, v[e]);
+          }
+        }
+        h4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
+        *(h4*)(t16 + r * P16 + cl * 2) = o;
+      }
+    }
+    __syncthreads();
+    auto rowm = [&](int r) { return row_m(r); };
+    if (p.geglu) {                    // packed columns: 32-wide blocks [16 values | 16 gates]; out[m][n/2] = a * gelu(g)
+      constexpr int GPR = BN / 16, TOTAL = BM * GPR, U = 2, ITER = (TOTAL + NT * U - 1) / (NT * U);      // groups of 8 OUTPUT columns per row
+#pragma unroll 1
+      for (int k = 0; k < ITER; ++k) {
+        h8 ha[U], hg[U];
+        int rr[U], gg[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int idx = min(tid + (k * U + u) * NT, TOTAL - 1);
+          const int r = idx / GPR, g = idx - r * GPR;
+          rr[u] = r; gg[u] = g;
+          const char* q = t16 + r * P16 + ((g >> 1) * 32 + (g & 1) * 8) * 2;      // 8 values; their gates 16 columns on
+          ha[u] = *(const h8*)q; hg[u] = *(const h8*)(q + 32);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int r = rr[u], g = gg[u];
+          h8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+#ifdef IA2P_GEGLU_ERF
+            o[e] = (half_t)((float)ha[u][e] * gelu_erf_f((float)hg[u][e]));
+#else
+            o[e] = (half_t)((float)ha[u][e] * gelu_lut_f((float)hg[u][e], phi));
+#endif
+          }
+          const bool live = tid + (k * U + u) * NT < TOTAL && rowm(r) < hM && bn0 + (g >> 1) * 32 < hN;
+          if (live) store_c8((size_t)(rowm(r)) * p.ldc + (bn0 >> 1) + (g >> 1) * 16 + (g & 1) * 8, o);
+        }
+      }
+    } else {
+      constexpr int GPR = BN / 8, TOTAL = BM * GPR, U = 4, ITER = (TOTAL + NT * U - 1) / (NT * U);
+      constexpr bool POW2 = (GPR & (GPR - 1)) == 0;
+      static_assert(!POW2 || NT % GPR == 0, "row groups must not straddle waves");
+#pragma unroll 1
+      for (int k = 0; k < ITER; ++k) {
+        h8 hh[U], hv[U], hr[U];
+        int rr[U], gg[U];
+        bool live[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {     // all loads of U groups in flight before any arithmetic (clamped addresses, never branched around)
+          const int idx = tid + (k * U + u) * NT;
+          const int r = min(idx / GPR, BM - 1), g = idx - (idx / GPR) * GPR;
+          rr[u] = r; gg[u] = g;
+          const int m = rowm(r), n = bn0 + g * 8;
+          live[u] = idx < TOTAL && m < hM && n < hN;
+          const int mc = min(m, hM - 1), nc = min(n, hN - 8);
+          hh[u] = *(const h8*)(t16 + r * P16 + g * 16);
+          if (p.rowvec) hv[u] = *(const h8*)(p.rowvec + (size_t)(mc / p.rows_per_batch) * p.rowvec_ld + nc);
+          if (p.residual) hr[u] = *(const h8*)(p.residual + (size_t)mc * p.ldr + nc);
+        }
+        float st1[U], st2[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          h8 o = hh[u];
+          if (p.rowvec || p.residual) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (float)hh[u][e];
+            if (p.rowvec) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = fmaf((float)hv[u][e], e_bs, v[e]);
+            }
+            if (p.residual) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += (float)hr[u][e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (half_t)v[e];
+          }
+          if (live[u]) store_c8((size_t)(rowm(rr[u])) * p.ldc + bn0 + gg[u] * 8, o);
+          st1[u] = st2[u] = 0.f;
+          if (p.stats_out && live[u]) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float f = (float)o[e]; st1[u] += f; st2[u] += f * f; }
+          }
+        }
+        if (p.stats_out) {             // {sum, sum of squares} of the fp16 output row over this tile's columns: ONE partial per row and tile (slot = tile_n)
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int idx = tid + (k * U + u) * NT;
+            if constexpr (POW2) {
+              float a = st1[u], b = st2[u];
+#pragma unroll
+              for (int o = 1; o < GPR; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }      // fixed butterfly: deterministic
+              if (gg[u] == 0 && idx < TOTAL && rowm(rr[u]) < hM) ((float2*)p.stats_out)[(size_t)tn * hM + rowm(rr[u])] = make_float2(a, b);
+            } else if (idx < TOTAL) part[idx] = make_float2(st1[u], st2[u]);
+          }
+        }
+      }
+      if constexpr (!POW2) {
+        if (p.stats_out) {
+          __syncthreads();
+          if (tid < BM && rowm(tid) < hM) {
+            float s1 = 0.f, s2 = 0.f;
+            for (int g = 0; g < GPR; ++g) { const float2 v = part[tid * GPR + g]; s1 += v.x; s2 += v.y; }      // group order: deterministic
+            ((float2*)p.stats_out)[(size_t)tn * hM + rowm(tid)] = make_float2(s1, s2);
+          }
+        }
+      }
+    }
+    pf_sink();
+#ifdef IA2P_CLOCK_STAMP
+    if (tid == 0 && p.partial && nsplit == 1) ((unsigned long long*)p.partial)[8 * blockIdx.x + 6] = __builtin_amdgcn_s_memrealtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0 && p.partial && nsplit == 1) ((unsigned long long*)p.partial)[8 * blockIdx.x + 5] = __builtin_amdgcn_s_memrealtime();
+#endif
+    return;
+  }
+  }
   bool from_slabs = false;
   if (nsplit > 1) {
     // ---- K-split: this workgroup holds the partial sums of ONE K range. Every K-slice writes its raw fp32 slab (write-through `sc1` stores:
@@ -1221,6 +1393,9 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   }
 #pragma unroll(PP == 2 ? 2 : 1)
   for (int ch = 0; ch < EC::NCHUNK; ++ch) {
+#if defined(IA2P_CLOCK_STAMP) && defined(IA2P_STAMP_AT)
+    if (tid == 0 && p.partial && nsplit == 1 && IA2P_STAMP_AT == 2 && ch == 1) ((unsigned long long*)p.partial)[8 * blockIdx.x + 7] = __builtin_amdgcn_s_memrealtime();      // chunk 0's stores issued
+#endif
     if (ch || from_slabs) __syncthreads();          // the previous chunk has been read out
     auto rowm = [&](int r) { return row_m(ch * CR + r); };      // tile row of this chunk -> output row
     acc_to_tile(ch);
@@ -1289,6 +1464,9 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
       for (int i = tid; i < IA2P_PHI_LUT_N; i += NT) ((float2*)phi)[i] = ((const float2*)p.phi_lut)[i];
     }
     __syncthreads();
+#if defined(IA2P_CLOCK_STAMP) && defined(IA2P_STAMP_AT)      // (diagnostic build: where the epilogue's time goes; slot 7 of the stamp buffer)
+    if (tid == 0 && p.partial && nsplit == 1 && ((IA2P_STAMP_AT == 1 && ch == 0) || (IA2P_STAMP_AT == 3 && ch == 1))) ((unsigned long long*)p.partial)[8 * blockIdx.x + 7] = __builtin_amdgcn_s_memrealtime();
+#endif
     if (p.geglu) {                    // packed columns: 32-wide blocks [16 values | 16 gates]; out[m][n/2] = a * gelu(g)
       constexpr int GPR = BN / 16;    // groups of 8 OUTPUT columns per row
 #ifndef IA2P_GEGLU_U
@@ -1331,6 +1509,8 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
 #pragma unroll
             for (int e = 0; e < 8; ++e) { va[e] += (float)ba[u][e]; vg[e] += (float)bg[u][e]; }
           }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { va[e] = (float)(half_t)va[e]; vg[e] = (float)(half_t)vg[e]; }      // (the projection's output is an fp16 tensor: same rounding as the register epilogue)
           // (packed fp32 -- v_pk_fma_f32 on element pairs, the same operations -- was built and measured: +0.1 ms per step, same box, A/B builds;
           //  the compiler's own mix of scalar and packed instructions is the faster one. Round 3)
           h8 o;
@@ -1348,7 +1528,10 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
     } else {
       constexpr int GPR = BN / 8;     // groups of 8 columns per row
       constexpr bool POW2 = (GPR & (GPR - 1)) == 0;
-      constexpr int TOTAL = CR * GPR, U = EC::NCHUNK == 1 ? 4 : 1, ITER = (TOTAL + NT * U - 1) / (NT * U);   // (two chunks: the second chunk's accumulators are still live)
+      #ifndef IA2P_EPI_U2
+#define IA2P_EPI_U2 1         // groups in flight per thread in the two-chunk tiles (build-time knob for A/B builds)
+#endif
+      constexpr int TOTAL = CR * GPR, U = EC::NCHUNK == 1 ? 4 : IA2P_EPI_U2, ITER = (TOTAL + NT * U - 1) / (NT * U);   // (two chunks: the second chunk's accumulators are still live)
       static_assert(!POW2 || NT % GPR == 0, "row groups must not straddle waves");
 #pragma unroll 1
       for (int k = 0; k < ITER; ++k) {
@@ -1390,6 +1573,10 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
             if (p.act) {
 #pragma unroll
               for (int e = 0; e < 8; ++e) v[e] = act_f(v[e], p.act);
+            }
+            if (p.rowvec || p.residual) {      // (the layer's own output is an fp16 tensor before the time-embedding row / the residual is added: same rounding as the register epilogue)
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] = (float)(half_t)v[e];
             }
             if (p.rowvec) {
 #pragma unroll
@@ -1433,6 +1620,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
                 if (p.bias) { const h4 b = *(const h4*)(p.bias + n); v[0] = fmaf((float)b[0], e_bs, v[0]); v[1] = fmaf((float)b[1], e_bs, v[1]); v[2] = fmaf((float)b[2], e_bs, v[2]); v[3] = fmaf((float)b[3], e_bs, v[3]); }
               }
               if (p.act) { v[0] = act_f(v[0], p.act); v[1] = act_f(v[1], p.act); v[2] = act_f(v[2], p.act); v[3] = act_f(v[3], p.act); }
+              if (p.rowvec || p.residual) { v[0] = (float)(half_t)v[0]; v[1] = (float)(half_t)v[1]; v[2] = (float)(half_t)v[2]; v[3] = (float)(half_t)v[3]; }
               if (p.rowvec) { const h4 b = *(const h4*)(p.rowvec + (size_t)(m / p.rows_per_batch) * p.rowvec_ld + n); v[0] = fmaf((float)b[0], e_bs, v[0]); v[1] = fmaf((float)b[1], e_bs, v[1]); v[2] = fmaf((float)b[2], e_bs, v[2]); v[3] = fmaf((float)b[3], e_bs, v[3]); }
               if (p.residual) { const h4 b = *(const h4*)(p.residual + (size_t)m * p.ldr + n); v[0] += (float)b[0]; v[1] += (float)b[1]; v[2] += (float)b[2]; v[3] += (float)b[3]; }
               h4 o; o[0] = (half_t)v[0]; o[1] = (half_t)v[1]; o[2] = (half_t)v[2]; o[3] = (half_t)v[3];
@@ -1471,6 +1659,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   }
   pf_sink();
 #ifdef IA2P_CLOCK_STAMP
+  if (tid == 0 && p.partial && nsplit == 1) ((unsigned long long*)p.partial)[8 * blockIdx.x + 6] = __builtin_amdgcn_s_memrealtime();      // this wave has ISSUED its last C store
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the C stores of this wave have left
   __syncthreads();
   if (tid == 0 && p.partial && nsplit == 1) ((unsigned long long*)p.partial)[8 * blockIdx.x + 5] = __builtin_amdgcn_s_memrealtime();

@@ -39,19 +39,24 @@ static void run(const char* name, int M, int N, int K, const half_t* A, const ha
   }
   std::vector<unsigned long long> h(8 * tiles);
   hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost);
-  std::vector<double> ghz, cyc, pro, epi;
+  std::vector<double> ghz, cyc, pro, epi, epi_issue, epi_at;
   unsigned long long first_entry = ~0ull, last_exit = 0;
   for (int i = 0; i < tiles; ++i) if (h[8 * i + 1]) {
     ghz.push_back((double)h[8 * i] / (double)h[8 * i + 1] * 0.1); cyc.push_back((double)h[8 * i]);
     pro.push_back((double)(h[8 * i + 3] - h[8 * i + 2]) * 0.01); epi.push_back((double)(h[8 * i + 5] - h[8 * i + 4]) * 0.01);     // us (100 MHz counter)
+    epi_issue.push_back((double)(h[8 * i + 6] - h[8 * i + 4]) * 0.01);
+    if (h[8 * i + 7]) epi_at.push_back((double)(h[8 * i + 7] - h[8 * i + 4]) * 0.01);
     first_entry = std::min(first_entry, h[8 * i + 2]); last_exit = std::max(last_exit, h[8 * i + 5]);
   }
-  std::sort(ghz.begin(), ghz.end()); std::sort(cyc.begin(), cyc.end()); std::sort(pro.begin(), pro.end()); std::sort(epi.begin(), epi.end());
+  std::sort(ghz.begin(), ghz.end()); std::sort(cyc.begin(), cyc.end()); std::sort(pro.begin(), pro.end()); std::sort(epi.begin(), epi.end()); std::sort(epi_issue.begin(), epi_issue.end());
   const double us = ms * 1e3 / 200, tf = 2.0 * M * N * K / us / 1e6, g = ghz[ghz.size() / 2], c = cyc[cyc.size() / 2];
   const double loop_us = c / (g * 1e3);
   printf("%-22s %5d x %5d x %5d: %7.2f us/launch = %6.0f TFLOP/s; in-kernel clock %.2f GHz (min %.2f max %.2f over %zu workgroups); k-loop %6.0f cycles = %5.2f us"
          " = %5.1f cycles per k-step; MFMA peak AT THAT CLOCK %.0f TFLOP/s\n", name, M, N, K, us, tf, g, ghz.front(), ghz.back(), ghz.size(), c, loop_us,
          c / (K / 64), 256 * 4 * 1024.0 * g / 1e3);
+  std::sort(epi_at.begin(), epi_at.end());
+  if (!epi_at.empty()) printf("%-22s   k-loop end -> stamp point (IA2P_STAMP_AT: 1 chunk 0 in LDS, 2 chunk 0 read out and stored, 3 chunk 1 in LDS) %.2f us (median)\n", "", epi_at[epi_at.size() / 2]);
+  printf("%-22s   k-loop end -> last C store ISSUED by wave 0 %.2f us (median; max %.2f)\n", "", epi_issue[epi_issue.size() / 2], epi_issue.back());
   printf("%-22s   entry -> k-loop %.2f us (median; max %.2f), k-loop end -> stores left %.2f us (median; max %.2f), first entry -> last exit %.2f us, so %.2f us of the"
          " launch interval lie between kernels\n", "", pro[pro.size() / 2], pro.back(), epi[epi.size() / 2], epi.back(), (double)(last_exit - first_entry) * 0.01,
          us - (double)(last_exit - first_entry) * 0.01);
@@ -69,6 +74,15 @@ int main() {
   hipMalloc(&A, hA.size() * 2); hipMalloc(&W, hW.size() * 2); hipMalloc(&C, (size_t)M * Nmax * 2); hipMalloc(&zero, 4096); hipMalloc(&stamps, 1 << 20);
   hipMemcpy(A, hA.data(), hA.size() * 2, hipMemcpyHostToDevice); hipMemcpy(W, hW.data(), hW.size() * 2, hipMemcpyHostToDevice);
   hipMemset(zero, 0, 4096); hipMemset(stamps, 0, 1 << 20);
+  if (getenv("IA2P_CLOCK_EPI")) {         // round 4: where the fixed cost of a launch goes (epilogue arithmetic vs the drain of its stores)
+    run<256, 160, 3, 4, 1>("256x160x3 pp GEGLU", M2, 10240, 1280, A, W, C, zero, stamps, 1);
+    run<256, 160, 3, 4, 1>("256x160x3 pp GEGLU K=64", M2, 10240, 64, A, W, C, zero, stamps, 1);
+    run<256, 160, 3, 4, 1>("256x160x3 pp N=5120", M2, 5120, 1280, A, W, C, zero, stamps);
+    run<256, 256, 2, 2, 2, 4>("256x256 8-phase QKV", 2048, 3840, 1280, A, W, C, zero, stamps);
+    run<64, 64, 2, 2, 0>("64x64x2 (out-proj)", M2, 1280, 1280, A, W, C, zero, stamps);
+    run<128, 128, 2, 2, 0>("128x128x2 (QKV)", M2, 3840, 1280, A, W, C, zero, stamps);
+    return 0;
+  }
   if (getenv("IA2P_CLOCK_8PHASE")) {      // round 4: the 8-phase 256 x 256 tile against the 256 x 128 ping-pong tile on the probe shape
     run<256, 256, 2, 2, 2, 4>("256x256 8-phase 4096^3", 4096, 4096, 4096, A, W, C, zero, stamps);
     run<256, 128, 3, 4, 1>("256x128x3 pp 4096^3", 4096, 4096, 4096, A, W, C, zero, stamps);
