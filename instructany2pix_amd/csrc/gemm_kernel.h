@@ -1241,6 +1241,9 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
       }
     }
     __syncthreads();
+#ifdef IA2P_CLOCK_STAMP
+    if (tid == 0 && p.partial && nsplit == 1) ((unsigned long long*)p.partial)[8 * blockIdx.x + 7] = __builtin_amdgcn_s_memrealtime();      // the fp16 tile is in LDS
+#endif
     auto rowm = [&](int r) { return row_m(r); };
     if (p.geglu) {                    // packed columns: 32-wide blocks [16 values | 16 gates]; out[m][n/2] = a * gelu(g)
       constexpr int GPR = BN / 16, TOTAL = BM * GPR, U = 2, ITER = (TOTAL + NT * U - 1) / (NT * U);      // groups of 8 OUTPUT columns per row

@@ -55,7 +55,7 @@ static void run(const char* name, int M, int N, int K, const half_t* A, const ha
          " = %5.1f cycles per k-step; MFMA peak AT THAT CLOCK %.0f TFLOP/s\n", name, M, N, K, us, tf, g, ghz.front(), ghz.back(), ghz.size(), c, loop_us,
          c / (K / 64), 256 * 4 * 1024.0 * g / 1e3);
   std::sort(epi_at.begin(), epi_at.end());
-  if (!epi_at.empty()) printf("%-22s   k-loop end -> stamp point (IA2P_STAMP_AT: 1 chunk 0 in LDS, 2 chunk 0 read out and stored, 3 chunk 1 in LDS) %.2f us (median)\n", "", epi_at[epi_at.size() / 2]);
+  if (!epi_at.empty()) printf("%-22s   k-loop end -> the fp16 tile is in LDS (register epilogue; fp32 route with -DIA2P_STAMP_AT=1|2|3: chunk 0 in LDS | chunk 0 stored | chunk 1 in LDS) %.2f us (median)\n", "", epi_at[epi_at.size() / 2]);
   printf("%-22s   k-loop end -> last C store ISSUED by wave 0 %.2f us (median; max %.2f)\n", "", epi_issue[epi_issue.size() / 2], epi_issue.back());
   printf("%-22s   entry -> k-loop %.2f us (median; max %.2f), k-loop end -> stores left %.2f us (median; max %.2f), first entry -> last exit %.2f us, so %.2f us of the"
          " launch interval lie between kernels\n", "", pro[pro.size() / 2], pro.back(), epi[epi.size() / 2], epi.back(), (double)(last_exit - first_entry) * 0.01,
