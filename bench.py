@@ -372,7 +372,7 @@ class Workload:
 
 def roofline_block(table, regions, nprof, B_eff, hw, use_ip, ms_per_step, probe=None):
     tot_ms = sum(v["ms"] for k, v in table.items() if k != "ddim_step_kernel")
-    gemm = {k: v for k, v in table.items() if v["flops"] > 0 and (k.startswith("gemm_f16_kernel") or k.startswith("attention"))}
+    gemm = {k: v for k, v in table.items() if v["flops"] > 0 and (k.startswith("gemm_f16_kernel") or k.startswith("conv_halo_f16_kernel") or k.startswith("attention"))}
     dom = max(gemm, key=lambda k: gemm[k]["ms"])
     d = table[dom]
     ach = d["flops"] / (d["ms"] * 1e-3) / 1e12

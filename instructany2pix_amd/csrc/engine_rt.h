@@ -115,7 +115,7 @@ struct ProfRec { hipEvent_t e0, e1; int k; double flops, bytes; int region; doub
 // profile regions of a UNet evaluation: what part of the network a launch belongs to (bench.py: conv-block roofline)
 enum { PR_OTHER = 0, PR_CONV_BLOCK = 1, PR_TRANSFORMER = 2, PR_NREGION };
 // profile classes = device kernel names as rocprofv3 prints them (template arguments included)
-enum { PK_GEMM0 = 0, PK_CONV0 = 24, PK_ATTN = 48, PK_GN, PK_LN, PK_EMBED, PK_CONV_IN, PK_CONV_OUT, PK_CONCAT, PK_REDUCE, PK_QXATTN, PK_QKVATTN, PK_NCLASS };
+enum { PK_GEMM0 = 0, PK_CONV0 = IA2P_GEMM_NVARIANT, PK_ATTN = 2 * IA2P_GEMM_NVARIANT, PK_GN, PK_LN, PK_EMBED, PK_CONV_IN, PK_CONV_OUT, PK_CONCAT, PK_REDUCE, PK_QXATTN, PK_QKVATTN, PK_NCLASS };
 const char* prof_name(int k);
 
 // state shared by the executors (conditional UNet, VAE): weights, workspace, prefetch plan, per-kernel timing
