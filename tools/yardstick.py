@@ -67,7 +67,7 @@ def main():
         fl = 2.0 * M * N * K
         cands = []
         for v, (bm, bn, st, pp) in enumerate(TILES):
-            if only is not None and v not in only:
+            if (only is not None and v not in only) or pp == 3:      # (schedule 3: the halo-staged convolution tiles; a linear problem runs their gathered twins)
                 continue
             tiles = -(-M // bm) * -(-N // bn)
             if tiles > 16384 or (bm <= 64 and bn <= 64 and fl > 2e11):
