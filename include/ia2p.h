@@ -153,6 +153,8 @@ ia2p_status ia2p_mask_blend(void* stream, const void* x, const void* init, const
                             void* out, void* out2, int B, int C, int64_t HW);
 
 /* ---- per-operator entry points (unit tests, and hosts that keep their own module tree) ----------------------------- */
+/* Operand size: the contraction kernels address an operand (activations, weights) with a 31-bit byte offset -- a matrix of 2 GiB or more is refused with
+ * IA2P_ERR_HIP / invalid value (the largest operand of the reference's path, the stacked context K/V weights, is 0.68 GB). */
 ia2p_status ia2p_groupnorm_silu(void* stream, const void* x, void* y, const void* gamma, const void* beta, int B, int HW, int C,
                                 int groups, float eps, int silu, float* partial_ws /* >= B*64*groups*2 floats */);
 ia2p_status ia2p_layernorm(void* stream, const void* x, void* y, const void* gamma, const void* beta, int M, int C, float eps);

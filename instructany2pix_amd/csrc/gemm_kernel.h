@@ -1732,7 +1732,7 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
   if (a.geglu && !b.phi_lut) return hipErrorOutOfMemory;
   if (!CONV && IA2P_LIN_BUF) {      // buffer-load staging addresses an operand with a 31-bit byte offset
     const size_t a_rows = a.rpb ? ((size_t)a.M / a.rpb + 1) * (size_t)std::max(a.bstride, 0) + a.roff + a.rpb : (size_t)a.M;
-    if (a_rows * a.lda * 2 >= (size_t)0x7ffffe00 || (size_t)a.N * a.ldw * 2 >= (size_t)0x7ffffe00) return hipErrorInvalidValue;
+    if (!ia2p_fits_buffer(a_rows, a.lda) || !ia2p_fits_buffer(a.N, a.ldw)) return hipErrorInvalidValue;
   }
   // b.sk_counters: as the caller (launch_any, gemm.hip) attached them -- null: the K-slices only write their slabs and a splitk_reduce_kernel launch finishes
   if (b.sk_counters && tiles > ia2p_sk_counter_capacity()) return hipErrorInvalidValue;

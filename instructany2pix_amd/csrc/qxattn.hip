@@ -27,6 +27,7 @@ bool ia2p_qproj_xattn_ok(const GemmArgs& a, const AttnArgs& x) {
   return x.Nq > 0 && x.Nq % 128 == 0 && a.M == x.B * x.Nq && a.N == x.heads * 64 && a.K >= 64 && a.K % 64 == 0 && a.splitk <= 1 && !a.geglu && !a.residual && !a.rowvec &&
          !a.stats_out && !a.act && x.nseg >= 1 && x.nseg <= 2 && x.seg[0].nkeys > 0 && (x.nseg == 1 || x.seg[1].nkeys > 0) &&
          (!a.bias || ((((uintptr_t)a.bias) & 15) == 0 && a.N % 8 == 0)) && x.ldo % 8 == 0 && ((((uintptr_t)x.O) & 15) == 0) &&
+         ia2p_fits_buffer(a.rpb ? ((size_t)a.M / a.rpb + 1) * (size_t)(a.bstride > 0 ? a.bstride : 0) + a.roff + a.rpb : (size_t)a.M, a.lda) && ia2p_fits_buffer(a.N, a.ldw) &&
          attn_kv_resident(x);      // short contexts only: their K / V ride in registers through the projection loop
 }
 
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(512, 2) void qkv_sattn_kernel(const half_t* hA, con
 bool ia2p_qkv_sattn_ok(const GemmArgs& a, const AttnArgs& x) {
   return x.Nq == 256 && x.B > 0 && a.M == x.B * 256 && a.N == 3 * x.heads * 64 && a.K >= 64 && a.K % 64 == 0 && a.splitk <= 1 && !a.geglu && !a.residual && !a.rowvec &&
          !a.stats_out && !a.act && !a.rpb && x.nseg == 1 && x.ldo % 8 == 0 && ((((uintptr_t)x.O) & 15) == 0) && (!a.bias || ((((uintptr_t)a.bias) & 7) == 0)) &&
-         (!a.ln_stats || (((((uintptr_t)a.ln_cs) | ((uintptr_t)a.ln_bias)) & 15) == 0));
+         (!a.ln_stats || (((((uintptr_t)a.ln_cs) | ((uintptr_t)a.ln_bias)) & 15) == 0)) && ia2p_fits_buffer(a.M, a.lda) && ia2p_fits_buffer(a.N, a.ldw);
 }
 
 hipError_t ia2p_launch_qkv_sattn(const GemmArgs& a, const AttnArgs& x, hipStream_t s) {
