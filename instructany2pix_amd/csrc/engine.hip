@@ -847,8 +847,8 @@ ia2p_status rc_load_tensor(RunCtx* c, const char* key, const void* src, const in
   hipError_t e = hipSuccess;
   switch (p.kind) {
     case PK_COPY: e = hipMemcpyAsync(dst, src, n * sizeof(half_t), hipMemcpyDeviceToDevice, s); break;
-    case PK_CONV: e = ia2p_launch_pack_conv((const half_t*)src, dst, p.d0, p.d1, s, true); break;
-    case PK_CONV_TAP: e = ia2p_launch_pack_conv((const half_t*)src, dst, p.d0, p.d1, s, false); break;
+    case PK_CONV: e = ia2p_launch_pack_conv((const half_t*)src, dst, p.d0, p.d1, s); break;
+    case PK_CONV_TAP: e = ia2p_launch_pack_conv((const half_t*)src, dst, p.d0, p.d1, s); break;
     case PK_GEGLU_W: case PK_GEGLU_B: e = ia2p_launch_pack_geglu((const half_t*)src, dst, p.d0, p.d1, s); break;
     case PK_PAD_CONV_IN: e = ia2p_launch_pack_conv_in((const half_t*)src, dst, p.d0, p.d1, s); break;
   }
@@ -1263,12 +1263,12 @@ ia2p_status ia2p_conv3x3_cat(void* stream, const void* x, const void* x2, const 
 ia2p_status ia2p_pack_conv3x3(void* stream, const void* src, void* dst, int Co, int Cin) {
   if (!src || !dst) return fail(nullptr, IA2P_ERR_INVALID, "pack_conv3x3: null argument");
   if (Cin % 64) return fail(nullptr, IA2P_ERR_SHAPE, "pack_conv3x3: Cin=%d must be a multiple of 64 (the layout of ia2p_conv3x3; ia2p_pack_conv_out packs for ia2p_conv_out)", Cin);
-  hipError_t e = ia2p_launch_pack_conv((const half_t*)src, (half_t*)dst, Co, Cin, (hipStream_t)stream, true);
+  hipError_t e = ia2p_launch_pack_conv((const half_t*)src, (half_t*)dst, Co, Cin, (hipStream_t)stream);
   RET_HIP(e, "pack_conv3x3");
 }
 ia2p_status ia2p_pack_conv_out(void* stream, const void* src, void* dst, int Co, int C) {
   if (!src || !dst) return fail(nullptr, IA2P_ERR_INVALID, "pack_conv_out: null argument");
-  hipError_t e = ia2p_launch_pack_conv((const half_t*)src, (half_t*)dst, Co, C, (hipStream_t)stream, false);
+  hipError_t e = ia2p_launch_pack_conv((const half_t*)src, (half_t*)dst, Co, C, (hipStream_t)stream);
   RET_HIP(e, "pack_conv_out");
 }
 // latent-boundary convolutions as operators (the executors call the launchers directly): conv_in reads NCHW and writes channels-last,

@@ -58,7 +58,7 @@ hipError_t ia2p_launch_clip_pool(const int* ids, const half_t* x, const half_t* 
                                  float eps, hipStream_t s);
 hipError_t ia2p_launch_ip_attn_map(const half_t* Q, int ldq, const half_t* Kip, int ldk, half_t* out, int B, int heads, int Nq, int ntok, hipStream_t s);
 hipError_t ia2p_launch_touch(const void* p, size_t bytes, unsigned* sink, hipStream_t s);
-hipError_t ia2p_launch_pack_conv(const half_t* src, half_t* dst, int Co, int Ci, hipStream_t s, bool blocked = true);      // blocked: [Co][Ci/64][tap][64] (implicit-GEMM convs); else [Co][tap][Ci] (conv_out_kernel)
+hipError_t ia2p_launch_pack_conv(const half_t* src, half_t* dst, int Co, int Ci, hipStream_t s);      // [Co][Ci][3][3] -> [Co][tap][Ci]
 hipError_t ia2p_launch_pack_conv_in(const half_t* src, half_t* dst, int Co, int KT, hipStream_t s);
 hipError_t ia2p_launch_pack_geglu(const half_t* src, half_t* dst, int rows, int rowlen, hipStream_t s);
 hipError_t ia2p_launch_softmax_rows(half_t* x, long ld, int rows, int n, float scale, hipStream_t s);
@@ -67,7 +67,7 @@ hipError_t ia2p_launch_conv1x1_nchw(const half_t* x, const half_t* w, const half
 extern thread_local std::string g_err;   // error of a failed ia2p_*_create / ctx-less entry point
 const half_t* zero_page();
 
-enum PKind { PK_COPY = 0, PK_CONV = 1, PK_GEGLU_W = 2, PK_GEGLU_B = 3, PK_PAD_CONV_IN = 4, PK_CONV_TAP = 5 };   // PK_CONV: channel-block-major 3x3 weights (implicit GEMM); PK_CONV_TAP: tap-major (conv_out_kernel);   // PK_PAD_CONV_IN: d0 = Co, d1 = Cin*9; arena holds [Co][64]
+enum PKind { PK_COPY = 0, PK_CONV = 1, PK_GEGLU_W = 2, PK_GEGLU_B = 3, PK_PAD_CONV_IN = 4, PK_CONV_TAP = 5 };   // PK_CONV / PK_CONV_TAP: 3x3 weights [Co][tap][Ci] (one layout since round 4; two kinds kept for the callers that name their consumer: implicit GEMM / conv_out_kernel);   // PK_PAD_CONV_IN: d0 = Co, d1 = Cin*9; arena holds [Co][64]
 
 struct Param {
   size_t off;       // element offset in the arena

@@ -280,21 +280,15 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   const int kt0 = (int)((long)split * nk_all / nsplit), kt1 = (int)((long)(split + 1) * nk_all / nsplit);   // this workgroup's k-tiles
   // conv: K = (tap, channel) is walked TAP-major -- all Cin channels of a filter tap (64 per k-tile, running pointers: the gather of a row is derived once per
   // tap), then the next tap; after the 9 Cin columns of the 3x3 part the appended 1x1 blocks. Weights are packed in that order ([Co][tap][Cin], misc.hip).
-  // The other walk -- channel-block-major: the nine taps of a block of 64 channels, then the next block, which keeps an XCD's activation working set between two
-  // uses of a line inside its L2 (the 256 x 160 conv class moves 3.65 x its algorithmic bytes through the fabric under the tap-major walk) -- was built in round
-  // 4 (-DIA2P_CONV_CHANNEL_MAJOR, weights packed [Co][Cin/64][tap][64]) and measured on one box against this one: 10 ... 20 % SLOWER on every large convolution
-  // (32768 x 640 x 5760: 247 vs 209 us; the step +0.4 ms), because the tap then changes every k-tile and its per-row pointer select (~8 vector instructions per
-  // staging piece and k-tile against 2 here) lands in the half-step where the partner wave group multiplies. These kernels are not bound by the fabric traffic.
+  // (The gathered operand walked channel-block-major -- the nine taps of a block of 64 channels, then the next block -- halves the fabric traffic of the large convolutions
+  // and was 10 ... 20 % slower, docs/LOG.md r04u: the tap then changes every k-tile and its per-row pointer select sits in the read half-step. The block-major walk
+  // ships in the halo-staged kernel, HALO = 1, where a tap is a constant offset.)
   int cin_main = 0, cin_extra = 0;                         // (two named scalars: a select between two argument FIELDS became a 2-entry table in scratch)
   if (CONV) { cin_main = p.Cin; cin_extra = p.Cin2; asm volatile("" : "+s"(cin_main), "+s"(cin_extra)); }
   const int nk_main = CONV ? 9 * (cin_main / BK) : 0;      // k-tiles of the 3x3 part
   int tap = 0, ci0 = 0;
   if (CONV) {
-#ifdef IA2P_CONV_CHANNEL_MAJOR      // A/B builds: the nine taps of a block of 64 channels, then the next block
-    if (kt0 < nk_main) { tap = kt0 % 9; ci0 = (kt0 / 9) * BK; }
-#else
     if (kt0 < nk_main) { tap = (kt0 * BK) / cin_main; ci0 = (kt0 * BK) % cin_main; }
-#endif
     else {                                                 // (inside the appended 1x1 blocks)
       ci0 = kt0 * BK - 9 * cin_main; tap = 9;
       if (ci0 >= cin_extra) { ci0 -= cin_extra; tap = 10; }
@@ -304,12 +298,8 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   // the walk, one k-tile on: (tap, ci0) -> next
   auto k_next = [&](int& t, int& c) {
     if (t < 9) {
-#ifdef IA2P_CONV_CHANNEL_MAJOR
-      if (++t == 9) { c += BK; if (c < cin_main) t = 0; else c = 0; }      // next channel block, or past the 3x3 part (tap = 9: appended block / end of K)
-#else
       c += BK;
       if (c >= cin_main) { c = 0; ++t; }                                    // next tap (tap = 9: appended block / end of K)
-#endif
     } else {
       c += BK;
       if (t < 10 && c >= cin_extra) { c = 0; ++t; }                           // (the last block runs to the end of K)
@@ -376,11 +366,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   auto conv_tap_advance = [&]() {
     const int t_old = tap;
     k_next(tap, ci0);
-#ifdef IA2P_CONV_CHANNEL_MAJOR
-    if (t_old < 9 || tap != t_old) tap_fresh = true;      // (the tap changes every k-tile; inside an appended block the running pointers just move on)
-#else
     if (tap != t_old) tap_fresh = true;                   // (inside a tap / an appended block the running pointers just move on)
-#endif
   };
   // LDS-DMA of this wave's activation pieces [i0, i1) / weight pieces [i0, i1) of the next k-tile into ring slot `buf`; running pointers: no per-step multiply
   auto issue_a = [&](int buf, auto i0_tag, auto i1_tag) {

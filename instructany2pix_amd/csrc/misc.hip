@@ -478,16 +478,14 @@ __global__ void touch_kernel(const uint4* p, size_t n16, unsigned* sink) {
 }
 
 // ---- one-time weight re-layouts -----------------------------------------------------------------------------------------
-// conv [Co][Ci][3][3] -> the implicit-GEMM K order of gemm_kernel.h: [Co][ky][kx][Ci] (blocked == 0: tap-major, the walk the library ships; also
-// conv_out_kernel's layout, any Ci), or [Co][Ci / 64][ky][kx][64] (blocked != 0, Ci % 64 == 0: the channel-block-major walk of -DIA2P_CONV_CHANNEL_MAJOR builds)
-__global__ void pack_conv_kernel(const half_t* src, half_t* dst, int Co, int Ci, int blocked) {
+// conv [Co][Ci][3][3] -> [Co][ky][kx][Ci]: the K order of every 3x3 convolution kernel (the gathered tiles walk it tap-major, the halo-staged tiles block-major over the
+// same rows: weight tile (block, tap) starts at column tap * Ci + block * 64; conv_out_kernel reads the same layout, any Ci)
+__global__ void pack_conv_kernel(const half_t* src, half_t* dst, int Co, int Ci) {
   const long total = (long)Co * Ci * 9;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int co = (int)(i / ((long)Ci * 9));
     const int k = (int)(i - (long)co * Ci * 9);
-    int ci, tap;
-    if (blocked) { const int cb = k / 576, r = k - cb * 576; tap = r >> 6; ci = cb * 64 + (r & 63); }
-    else { tap = k / Ci; ci = k - tap * Ci; }
+    const int tap = k / Ci, ci = k - tap * Ci;
     dst[i] = src[((long)co * Ci + ci) * 9 + tap];
   }
 }
@@ -725,12 +723,8 @@ hipError_t ia2p_launch_touch(const void* p, size_t bytes, unsigned* sink, hipStr
   hipLaunchKernelGGL(touch_kernel, dim3((unsigned)std::min<size_t>(2048, (n16 + 255) / 256)), dim3(256), 0, s, (const uint4*)p, n16, sink);
   return hipGetLastError();
 }
-hipError_t ia2p_launch_pack_conv(const half_t* src, half_t* dst, int Co, int Ci, hipStream_t s, bool blocked) {
-#ifndef IA2P_CONV_CHANNEL_MAJOR      // the k-loop walks K tap-major (gemm_kernel.h): so are the weights; the blocked layout belongs to the A/B build of the other walk
-  blocked = false;
-#endif
-  if (blocked && Ci % 64) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(pack_conv_kernel, dim3(grid_for((long)Co * Ci * 9, 256)), dim3(256), 0, s, src, dst, Co, Ci, blocked ? 1 : 0);
+hipError_t ia2p_launch_pack_conv(const half_t* src, half_t* dst, int Co, int Ci, hipStream_t s) {
+  hipLaunchKernelGGL(pack_conv_kernel, dim3(grid_for((long)Co * Ci * 9, 256)), dim3(256), 0, s, src, dst, Co, Ci);
   return hipGetLastError();
 }
 hipError_t ia2p_launch_pack_conv_in(const half_t* src, half_t* dst, int Co, int KT, hipStream_t s) {
