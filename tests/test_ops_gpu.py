@@ -409,6 +409,34 @@ def test_gemm_splitk_two_streams_run_concurrently(L):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("tile", [-1, 0, 4, 12, 18, 22])
+def test_epilogue_rounds_where_the_reference_does(L, tile):
+    """The reference's fp16 modules round a Linear's output (bias included) to fp16 BEFORE the residual is added, and round the sum again. With an identity weight the
+    accumulators are exact, so the two rounding points are checked to the bit -- on the register epilogue (no K split), on the K-split route finished inside the launch and
+    on the one finished by the reduce launch; a single rounding of (x + b + r) differs from this in a few per cent of the elements at these magnitudes."""
+    f = _ffi()
+    M, N = 300, 256
+    A, b, R = rnd(M, N, seed=81), rnd(N, seed=82), rnd(M, N, seed=83)
+    eye = torch.eye(N, dtype=torch.half, device="cuda")
+    want = ((A.float() + b.float()).half().float() + R.float()).half()
+    once = (A.float() + b.float() + R.float()).half()
+    assert not torch.equal(want, once)                      # the test can tell the two apart
+    part = torch.empty(2 * M * N, dtype=torch.float32, device="cuda")
+    L.ia2p_debug_set_gemm_tile(tile)
+    try:
+        out = torch.empty(M, N, dtype=torch.half, device="cuda")
+        run(L, "ia2p_gemm", f.ptr(A), f.ptr(eye), f.ptr(b), f.ptr(R), f.ptr(out), M, N, N, 0)
+        assert torch.equal(out, want), "register epilogue"
+        for route, limit in (("in-launch", 1 << 40), ("reduce launch", 0)):
+            L.ia2p_debug_set_splitk_inkernel(limit)
+            out = torch.empty(M, N, dtype=torch.half, device="cuda")
+            run(L, "ia2p_gemm_splitk", f.ptr(A), f.ptr(eye), f.ptr(b), f.ptr(R), f.ptr(out), M, N, N, 2, C.c_void_p(part.data_ptr()))
+            assert torch.equal(out, want), route
+    finally:
+        L.ia2p_debug_set_splitk_inkernel(-1)
+        L.ia2p_debug_set_gemm_tile(-1)
+
+
 def test_gemm_splitk_recovers_from_poisoned_tickets(L):
     """A launch that dies mid-flight leaves tickets behind: the next launch's "last arriver" of a tile is then an early one and combines slabs that are not written
     yet. Poisoned here the same way (every ticket of the stream's buffer set to splitk - 1, through ia2p_debug_fill_splitk_counters): the launch after it is WRONG, which
