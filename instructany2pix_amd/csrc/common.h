@@ -166,10 +166,10 @@ struct GemmArgs {
 
 // buffer-load staging (linear layers, the halo-staged convolution) addresses an operand with a 31-bit byte offset: what a launch of `rows` x `ld` fp16 elements needs
 static inline bool ia2p_fits_buffer(size_t rows, size_t ld) { return rows * ld * 2 < (size_t)0x7ffffe00; }
-// what the halo-staged 3x3 convolution (conv_halo_f16_kernel, gemm_kernel.h) takes: stride 1, one pixel of zero padding, no upsampled view, whole 16 x 16 patches, whole blocks of 64 channels in every source
+// what the halo-staged 3x3 convolution (conv_halo_f16_kernel, gemm_kernel.h) takes: stride 1, one pixel of zero padding, the source itself or its nearest-x2 upsampled view, whole 16 x 16 patches, whole blocks of 64 channels in every source
 static inline bool ia2p_conv_halo_ok(const GemmArgs& a) {
   const int c2 = a.A2 ? a.Cin2 : 0, c3 = a.A3 ? a.Cin3 : 0;
-  return a.stride == 1 && !a.up && a.pad == 1 && a.Hs == a.Ho && a.Ws == a.Wo && a.Ho > 0 && a.Ho % 16 == 0 && a.Wo % 16 == 0 && a.Cin >= 64 && a.Cin % 64 == 0 && c2 % 64 == 0 &&
+  return a.stride == 1 && (a.up == 0 || (a.up == 1 && !a.A2)) && a.pad == 1 && (a.Hs << a.up) == a.Ho && (a.Ws << a.up) == a.Wo && a.Ho > 0 && a.Ho % 16 == 0 && a.Wo % 16 == 0 && a.Cin >= 64 && a.Cin % 64 == 0 && c2 % 64 == 0 &&
          c3 % 64 == 0 && a.Cin2 == c2 && (a.A3 == nullptr || a.A2 != nullptr) && a.K == 9 * a.Cin + c2 + c3 && a.M % (a.Ho * a.Wo) == 0 && !a.rpb && !a.geglu &&
          ia2p_fits_buffer(a.M, a.lda) && ia2p_fits_buffer(a.N, a.ldw) && (!a.A2 || ia2p_fits_buffer(a.M, a.lda2)) && (!a.A3 || ia2p_fits_buffer(a.M, a.lda3));
 }

@@ -425,7 +425,7 @@ static hipError_t launch_any(const GemmArgs& a0, int v, hipStream_t s, bool with
       static_assert(IA2P_GEMM_TILES[23].bm == 256 && IA2P_GEMM_TILES[23].bn == 128 && IA2P_GEMM_TILES[23].stages == 2 && IA2P_GEMM_TILES[23].pp == 2, "tile table");
       e = launch_cfg<256, 128, 2, CONV, 2, 64, 2, 4>(a, s);
       break;
-    case 24:      // halo-staged convolution; a launch it does not take (linear layer, stride 2, upsampled view, ragged patches, more K slices than blocks of 64 channels) runs the same tile shape with the gathered operand
+    case 24:      // halo-staged convolution; a launch it does not take (linear layer, stride 2, ragged patches, more K slices than blocks of 64 channels) runs the same tile shape with the gathered operand
       static_assert(IA2P_GEMM_TILES[24].bm == 256 && IA2P_GEMM_TILES[24].bn == 160 && IA2P_GEMM_TILES[24].halo, "tile table");
       e = (CONV && ia2p_conv_halo_ok(a) && a.splitk <= a.Cin / 64) ? launch_halo<160>(a, s) : launch_cfg<256, 160, 3, CONV, 4, 64, 1>(a, s);
       break;

@@ -223,7 +223,8 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
       const int hy = hp / 18, hx = hp - hy * 18;
       const int y = h_y0 - 1 + hy, x = h_x0 - 1 + hx;
       const bool ok = c < 8 && hp < 18 * 18 && (unsigned)y < (unsigned)p.Ho && (unsigned)x < (unsigned)p.Wo;
-      h_voff[sl] = ok ? (((h_img * p.Ho + y) * p.Wo + x) * hlda + c * 8) * 2 : OOB;
+      // (nearest-x2 upsampled view: the image in LDS IS the upsampled patch -- pixel (y, x) of it comes from source pixel (y / 2, x / 2), fetched up to four times out of L2)
+      h_voff[sl] = ok ? (((h_img * p.Hs + (y >> p.up)) * p.Ws + (x >> p.up)) * hlda + c * 8) * 2 : OOB;
     }
   }
 #pragma unroll
@@ -492,7 +493,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
     const int blk0 = k0 < nk_main ? k0 / 9 : nb_main, blk1 = min(k1, nk_main) / 9 > blk0 ? min(k1, nk_main) / 9 : blk0;      // its blocks of the 3x3 part
     const int n2 = nkt - 9 * (blk1 - blk0);                                                                               // its tiles of the appended 1x1 blocks
     auto mk_rsrc = [](const void* q, size_t bytes) { return __builtin_amdgcn_make_buffer_rsrc((void*)q, 0, (int)min(bytes, (size_t)0x7ffffe00), 0x00020000); };
-    const __amdgpu_buffer_rsrc_t rs_w = mk_rsrc(hW, (size_t)hN * hldw * 2), rs_a = mk_rsrc(hA, (size_t)hM * hlda * 2), rs_none = mk_rsrc(hW, 0);
+    const __amdgpu_buffer_rsrc_t rs_w = mk_rsrc(hW, (size_t)hN * hldw * 2), rs_a = mk_rsrc(hA, (size_t)(hM / (p.Ho * p.Wo)) * p.Hs * p.Ws * hlda * 2), rs_none = mk_rsrc(hW, 0);
     auto issue_w = [&](__amdgpu_buffer_rsrc_t rs, int slot, int soff) {
 #pragma unroll
       for (int i = 0; i < B_PW; ++i)

@@ -505,7 +505,7 @@ def test_conv3x3(L, B, H, W, Cin, Co, stride, up):
 
 
 @pytest.mark.parametrize("tile", list(range(NTILES)))
-@pytest.mark.parametrize("B,H,W,Cin,Co,stride,up", [(1, 32, 32, 320, 320, 1, 0), (2, 12, 20, 128, 192, 2, 0), (1, 10, 14, 64, 320, 1, 1)])
+@pytest.mark.parametrize("B,H,W,Cin,Co,stride,up", [(1, 32, 32, 320, 320, 1, 0), (2, 12, 20, 128, 192, 2, 0), (1, 10, 14, 64, 320, 1, 1), (2, 8, 16, 128, 160, 1, 1)])      # (the last one: an upsampled view in whole 16 x 16 patches -- the halo-staged tiles take it)
 def test_conv3x3_every_tile(L, tile, B, H, W, Cin, Co, stride, up):
     L.ia2p_debug_set_gemm_tile(tile)
     try:
