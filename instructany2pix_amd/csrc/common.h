@@ -177,7 +177,7 @@ static inline bool ia2p_conv_halo_ok(const GemmArgs& a) {
 struct GemmPlan { int variant; int splitk; };
 // tile variants of gemm_f16_kernel (id = index): {BM, BN, LDS ring stages}; 4 waves (2 x 2), BK = 64
 struct GemmTile { int bm, bn, stages, pp, halo; };      // pp = 1: 8-wave ping-pong schedule (one workgroup per CU); pp = 2: 8-wave 8-phase schedule; halo = 1: halo-staged 3x3 convolution only (conv_halo_f16_kernel)
-constexpr int IA2P_GEMM_NVARIANT = 26;
+constexpr int IA2P_GEMM_NVARIANT = 27;
 constexpr GemmTile IA2P_GEMM_TILES[IA2P_GEMM_NVARIANT] = {{128, 128, 2, 0, 0}, {128, 128, 3, 0, 0}, {128, 64, 2, 0, 0}, {128, 64, 3, 0, 0}, {64, 64, 2, 0, 0}, {64, 64, 3, 0, 0},
                                                           {64, 160, 2, 0, 0}, {64, 160, 3, 0, 0}, {128, 160, 2, 0, 0}, {128, 160, 3, 0, 0}, {160, 128, 2, 0, 0}, {160, 160, 2, 0, 0},
                                                           {256, 128, 3, 1, 0},                               // 12: the ping-pong tile
@@ -188,7 +188,8 @@ constexpr GemmTile IA2P_GEMM_TILES[IA2P_GEMM_NVARIANT] = {{128, 128, 2, 0, 0}, {
                                                           {32, 64, 3, 0, 0}, {32, 128, 3, 0, 0},                // 20..21: 32-row tiles (16-row wave tiles) for launches that leave CUs empty (batch 1: M = 256): a lone workgroup takes its
                                                                                                           // operands in at ~27 B/clk whatever its loop looks like (profiles/r03k_small_m_kloop.txt), so more, smaller workgroups win
                                                           {256, 256, 2, 2, 0}, {256, 128, 2, 2, 0},             // 22..23: 8-phase schedule (pp = 2): 2 x 4 waves of 128 x 64 (128 x 32), two k-tile buffers, one workgroup per CU, 128 flop per staged byte
-                                                          {256, 160, 3, 1, 1}, {256, 128, 3, 1, 1}};      // 24..25: halo-staged 3x3 convolution (16 x 16 pixel patches; an ineligible site runs variant 18 / 12 instead)
+                                                          {256, 160, 3, 1, 1}, {256, 128, 3, 1, 1},      // 24..25: halo-staged 3x3 convolution (16 x 16 pixel patches; an ineligible site runs variant 18 / 12 instead)
+                                                          {256, 80, 3, 1, 1}};                            // 26: the same, 80 wide (8 x 1 waves of 32 x 80; an ineligible site runs variant 16)
 GemmPlan ia2p_gemm_plan(int M, int N, int K, bool conv, bool geglu);
 bool ia2p_plan_lookup(int M, int N, int K, bool conv, bool geglu, GemmPlan* out);     // measured plan table (ia2p_autotune)
 void ia2p_plan_set(int M, int N, int K, bool conv, bool geglu, GemmPlan pl);

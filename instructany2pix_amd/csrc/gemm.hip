@@ -312,7 +312,7 @@ void ia2p_gemm_candidates(int M, int N, int K, bool conv, bool geglu, size_t max
   std::stable_sort(all.begin(), all.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
   out->clear();
   for (const auto& e : all)
-    if (e.first <= slack * all.front().first) out->push_back(e.second);
+    if (e.first <= slack * all.front().first || (IA2P_GEMM_TILES[e.second.variant].halo && e.second.splitk <= 4)) out->push_back(e.second);      // (the halo-staged tiles: always measured -- the model was calibrated on the gathered kernels)
 }
 
 // Tile variant and split-K factor for a problem: a measured plan if ia2p_autotune recorded one, else the cost model.
@@ -428,6 +428,10 @@ static hipError_t launch_any(const GemmArgs& a0, int v, hipStream_t s, bool with
     case 24:      // halo-staged convolution; a launch it does not take (linear layer, stride 2, ragged patches, more K slices than blocks of 64 channels) runs the same tile shape with the gathered operand
       static_assert(IA2P_GEMM_TILES[24].bm == 256 && IA2P_GEMM_TILES[24].bn == 160 && IA2P_GEMM_TILES[24].halo, "tile table");
       e = (CONV && ia2p_conv_halo_ok(a) && a.splitk <= a.Cin / 64) ? launch_halo<160>(a, s) : launch_cfg<256, 160, 3, CONV, 4, 64, 1>(a, s);
+      break;
+    case 26:
+      static_assert(IA2P_GEMM_TILES[26].bm == 256 && IA2P_GEMM_TILES[26].bn == 80 && IA2P_GEMM_TILES[26].halo, "tile table");
+      e = (CONV && ia2p_conv_halo_ok(a) && a.splitk <= a.Cin / 64) ? launch_halo<80>(a, s) : launch_cfg<128, 80, 2, CONV, 4, 64, 0, 1>(a, s);
       break;
     case 25:
       static_assert(IA2P_GEMM_TILES[25].bm == 256 && IA2P_GEMM_TILES[25].bn == 128 && IA2P_GEMM_TILES[25].halo, "tile table");

@@ -108,10 +108,10 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   // The leading 16 dwords of the argument list are what the prologue needs; built with -amdgpu-kernarg-preload-count=16 the command processor
   // hands them over in SGPRs, so the first tile loads go out without waiting for a cold read of the argument block (which costs every launch
   // ~1 us: tools/micro/launch_floor2.hip). The rest of GemmArgs (epilogue, conv geometry) arrives while those loads fly.   // >= 2 waves/SIMD: big tiles must fit 256 registers
-  static_assert(PP != 1 || (WGM == 4 && NSTAGE == 3), "ping-pong schedule: 8 waves, 3-stage ring");
+  static_assert(PP != 1 || (WGM * WGN == 8 && (WGM == 4 || WGM == 8) && NSTAGE == 3), "ping-pong schedule: 8 waves (two groups of 4 by tile rows), 3-stage ring");
   static_assert(PP != 3 || (WGM == 4 && NSTAGE == 2 && !CONV), "two-slot ping-pong schedule: 8 waves, 2 k-tile slots");
   static_assert(PP != 2 || (WGM == 2 && WGN == 4 && NSTAGE == 2 && BK == 64 && BM == 256 && (BN == 256 || BN == 128) && XA == 0), "8-phase schedule: 256-row tiles, 2 x 4 waves, two k-tile buffers");
-  static_assert(HALO == 0 || (CONV && PP == 1 && BM == 256 && BK == 64 && XA == 0 && WGN == 2), "halo-staged convolution: ping-pong schedule over a 16 x 16 patch");
+  static_assert(HALO == 0 || (CONV && PP == 1 && BM == 256 && BK == 64 && XA == 0), "halo-staged convolution: ping-pong schedule over a 16 x 16 patch");
   constexpr int NWAVE = WGM * WGN;
   constexpr int WM = BM / WGM, WN = BN / WGN;    // wave tile (waves arranged WGM x WGN; WGN = 1: narrow tiles, one wave per 128-byte column block)
   constexpr int MR = WM / 16, NR = WN / 16;
@@ -1663,10 +1663,13 @@ __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_f16_kernel(const half_
 }
 
 // the halo-staged 3x3 convolution (gemm_tile_body, HALO = 1): 256 x BN tiles of 16 x 16 pixel patches, ping-pong schedule
+// wave arrangement: 4 x 2 waves of 64 x (BN / 2); the 80-wide tile 8 x 1 waves of 32 x 80 (N = 640 / 1280 problems at M = 8192 / 2048 in 256 / 128 tiles of one per CU:
+// the 32^2 maps fill the chip without a K split, the 16^2 maps with two slices instead of three)
+template <int BN> struct HaloWaves { static constexpr int WGM = BN == 80 ? 8 : 4, WGN = BN == 80 ? 1 : 2; };
 template <int BN>
 __global__ __launch_bounds__(512, 2) void conv_halo_f16_kernel(const half_t* hA, const half_t* hW, const half_t* hzero, int hM, int hN, int hK, int hlda, int hldw, int hrpb, int hbstride,
                                                                  int hroff, int hsplitk, int hgroup_w, const GemmArgs p) {
-  gemm_tile_body<256, BN, 3, true, 4, 64, 1, 2, 0, 1>(hA, hW, hzero, hM, hN, hK, hlda, hldw, hrpb, hbstride, hroff, hsplitk, hgroup_w, p, nullptr);
+  gemm_tile_body<256, BN, 3, true, HaloWaves<BN>::WGM, 64, 1, HaloWaves<BN>::WGN, 0, 1>(hA, hW, hzero, hM, hN, hK, hlda, hldw, hrpb, hbstride, hroff, hsplitk, hgroup_w, p, nullptr);
 }
 // grouped tile order: panel width (in tiles) such that the contiguous tile range an XCD works on is a compact block; 0 = plain order.
 // An XCD that holds r x c tiles fetches r activation row panels and c weight column panels: r a + c w bytes with r c fixed is least at c = sqrt(resident a / w).
@@ -1732,7 +1735,7 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
 template <int BN>
 static hipError_t launch_halo(const GemmArgs& a, hipStream_t s) {
   if (!ia2p_conv_halo_ok(a)) return hipErrorInvalidValue;
-  constexpr int smem = EpiCfg<256, BN, 3, 4, 64, 2, 1>::SMEM;
+  constexpr int smem = EpiCfg<256, BN, 3, HaloWaves<BN>::WGM, 64, HaloWaves<BN>::WGN, 1>::SMEM;
   static bool attr_set[64] = {false};
   int dev = 0;
   (void)hipGetDevice(&dev);

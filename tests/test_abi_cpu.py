@@ -81,7 +81,7 @@ def test_gemm_plan_is_a_pure_host_function_and_the_plan_table_round_trips(lib):
         tiles.append(tuple(t))
     from tests.test_ops_gpu import NTILES
     assert len(tiles) == NTILES and lib.ia2p_debug_gemm_tile_info(-1, t) == -1
-    assert tiles[0] == (128, 128, 2, 0) and tiles[18] == (256, 160, 3, 1) and tiles[22] == (256, 256, 2, 2) and tiles[24] == (256, 160, 3, 3)      # (schedule 3: halo-staged convolution)
+    assert tiles[0] == (128, 128, 2, 0) and tiles[18] == (256, 160, 3, 1) and tiles[22] == (256, 256, 2, 2) and tiles[24] == (256, 160, 3, 3) and tiles[26] == (256, 80, 3, 3)      # (schedule 3: halo-staged convolution)
     bn = [x[1] for x in tiles]
     for shape in [(2048, 1280, 1280), (8192, 640, 640), (64, 64, 64), (616, 166400, 2048), (37, 132, 128), (256, 1280, 5120), (4096, 4096, 4096)]:
         v, s = plan(*shape)

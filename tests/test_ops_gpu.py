@@ -9,7 +9,7 @@ import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
-NTILES = 26      # entries of IA2P_GEMM_TILES (csrc/common.h); tests/test_abi_cpu.py checks it against the library's table
+NTILES = 27      # entries of IA2P_GEMM_TILES (csrc/common.h); tests/test_abi_cpu.py checks it against the library's table
 
 
 @pytest.fixture(scope="module")
@@ -547,7 +547,7 @@ def test_boundary_convs_reject_bad_shapes(L):
     assert L.ia2p_conv_out(f.current_stream(), f.ptr(x), f.ptr(x), f.ptr(x), f.ptr(x), 1, 64, 4, 4, 9) != 0              # Co > 8
 
 
-@pytest.mark.parametrize("tile", [-1, 0, 4, 6, 8, 12, 16, 20, 24, 25])      # 24 / 25: halo-staged patches (the ragged 9 x 7 map runs their gathered twins)
+@pytest.mark.parametrize("tile", [-1, 0, 4, 6, 8, 12, 16, 20, 24, 25, 26])      # 24 .. 26: halo-staged patches (the ragged 9 x 7 map runs their gathered twins)
 @pytest.mark.parametrize("B,H,W,Cin,Cin2,Co", [(2, 16, 16, 1280, 640, 1280), (1, 32, 32, 320, 960, 320), (2, 9, 7, 128, 64, 192), (1, 32, 48, 64, 128, 96)])
 def test_conv3x3_with_appended_shortcut(L, B, H, W, Cin, Cin2, Co, tile):
     """conv2(h) + conv_shortcut(x) of a ResnetBlock2D as ONE implicit GEMM (K = 9 Cin + Cin2), every tile family incl. K-split plans"""
@@ -571,8 +571,8 @@ def test_conv3x3_with_appended_shortcut(L, B, H, W, Cin, Cin2, Co, tile):
 
 @pytest.mark.parametrize("B,H,W,Cin,Co", [(8, 16, 16, 1280, 1280), (2, 32, 32, 640, 640), (1, 64, 64, 320, 320), (1, 16, 48, 64, 100), (3, 16, 16, 192, 256)])
 def test_conv3x3_halo_staged_patches(L, B, H, W, Cin, Co):
-    """conv_halo_f16_kernel (tile variants 24 / 25): the activation operand is staged once per block of 64 channels as a 16 x 16 pixel patch with its border and
-    the nine taps are read out of that image; K is walked block-major. Against the fp32 convolution; both tile widths give the same bits (same accumulation
+    """conv_halo_f16_kernel (tile variants 24 / 25 / 26 = 160 / 128 / 80 wide): the activation operand is staged once per block of 64 channels as a 16 x 16 pixel patch with its border and
+    the nine taps are read out of that image; K is walked block-major. Against the fp32 convolution; all three tile widths give the same bits (same accumulation
     order); a K split gives the same bits finished in the launch or by the reduce launch, and on a second run; splits are cut on whole blocks (more slices than
     blocks run the gathered twin tile); time-embedding row, bias and residual go through the patch-to-row map of the epilogue."""
     f = _ffi()
@@ -589,7 +589,7 @@ def test_conv3x3_halo_staged_patches(L, B, H, W, Cin, Co):
     try:
         for route, limit in (("in-launch", 1 << 40), ("reduce launch", 0)):
             L.ia2p_debug_set_splitk_inkernel(limit)
-            for tile in (24, 25):
+            for tile in (24, 25, 26):
                 L.ia2p_debug_set_gemm_tile(tile)
                 for sk in (1, 2, 3, 4):
                     if sk > 9 * Cin // 64:

@@ -11,7 +11,7 @@ bad = 0
 for it in range(60):
     B = random.choice([1, 2, 3, 5]); H = 16 * random.choice([1, 2, 3]); W = 16 * random.choice([1, 2, 4])
     Cin = 64 * random.choice([1, 2, 3, 5, 10]); Cin2 = 64 * random.choice([0, 0, 1, 3, 7]); Co = random.choice([64, 100, 128, 160, 192, 320, 328])
-    tile = random.choice([24, 25]); sk = random.choice([1, 1, 2, 3, 4]) if not Cin2 else 1
+    tile = random.choice([24, 25, 26]); sk = random.choice([1, 1, 2, 3, 4]) if not Cin2 else 1
     g = torch.Generator().manual_seed(it)
     x = torch.randn(B, H, W, Cin, generator=g).half().cuda()
     w = (torch.randn(Co, Cin, 3, 3, generator=g) * (9 * Cin) ** -0.5).half().cuda()
