@@ -372,7 +372,7 @@ class Workload:
 
 def roofline_block(table, regions, nprof, B_eff, hw, use_ip, ms_per_step, probe=None):
     tot_ms = sum(v["ms"] for k, v in table.items() if k != "ddim_step_kernel")
-    gemm = {k: v for k, v in table.items() if v["flops"] > 0 and (k.startswith("gemm_f16_kernel") or k.startswith("conv_halo_f16_kernel") or k.startswith("attention"))}
+    gemm = {k: v for k, v in table.items() if v["flops"] > 0 and (k.startswith("gemm_f16_kernel") or k.startswith("conv_halo_f16_kernel") or k.startswith("attention") or k.startswith("qkv_sattn") or k.startswith("qproj_xattn"))}
     dom = max(gemm, key=lambda k: gemm[k]["ms"])
     d = table[dom]
     ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
@@ -391,6 +391,10 @@ def roofline_block(table, regions, nprof, B_eff, hw, use_ip, ms_per_step, probe=
            "traffic_minus_prefetch_over_algorithmic": ((traffic - d.get("prefetch_bytes", 0.0) / d["launches"]) / (d["bytes"] / d["launches"])) if traffic else None,
            "launches_per_step": d["launches"] / nprof, "avg_launch_us": 1e3 * d["ms"] / d["launches"],
            "flops_per_launch": d["flops"] / d["launches"], "share_of_step": d["ms"] / tot_ms}
+    # the next MFMA kernel classes by time (which instantiation comes first depends on the plan table the tuner measured on this box: classes are kernel instantiations, and
+    # a tile shared by several layer shapes lumps them)
+    out["top_kernels"] = [{"kernel": k, "ms_per_step": v["ms"] / nprof, "launches_per_step": v["launches"] / nprof, "achieved": v["flops"] / (v["ms"] * 1e-3) / 1e12,
+                           "frac": v["flops"] / (v["ms"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS} for k, v in sorted(gemm.items(), key=lambda kv: -kv[1]["ms"])[:5]]
     launches = sum(v["launches"] for k, v in table.items() if k != "ddim_step_kernel") / nprof + 1
     out["launches_per_step_all_kernels"] = launches
     if probe:       # what the step spends on per-launch fixed cost: launches x measured dependent-launch floor (box_probe), as a share of the step
@@ -608,7 +612,7 @@ def main():
             if not args.no_roofline:
                 t2, rg2 = w2.profile(3)
                 rb = roofline_block(t2, rg2, 3, b2, hw2, L2 > 77, ms2, probe)
-                entry["roofline"] = {k: rb[k] for k in ("kernel", "achieved", "frac", "whole_step", "conv_blocks", "hbm_kernels", "launches_per_step_all_kernels", "fixed_share") if k in rb}
+                entry["roofline"] = {k: rb[k] for k in ("kernel", "achieved", "frac", "top_kernels", "whole_step", "conv_blocks", "hbm_kernels", "launches_per_step_all_kernels", "fixed_share") if k in rb}
                 if b2 == 1:
                     wbytes = 5.817e9 if inv_quirk else 5.135e9           # compulsory weight bytes of an evaluation with / without the IP-Adapter projections
                     entry["weight_streaming"] = {"bytes": wbytes, "bound_ms_at_6290": wbytes / HBM_COPY_GBS / 1e6, "frac_of_bound": wbytes / HBM_COPY_GBS / 1e6 / ms2}
