@@ -89,6 +89,10 @@ size_t ia2p_arena_raw_bytes(ia2p_ctx* ctx);
 ia2p_status ia2p_adopt_arena(ia2p_ctx* ctx, int with_ip_adapter);
 /* the same with the fold kernels ordered on `stream` -- the stream the broadcast that filled the head was enqueued on -- and synchronised there */
 ia2p_status ia2p_adopt_arena_on(ia2p_ctx* ctx, int with_ip_adapter, void* stream);
+/* GroupNorm + SiLU of the ResnetBlock2Ds (reference: diffusers ResnetBlock2D.norm1 / norm2 behind pnp_pipeline.py:253-260): 1 (default; IA2P_GN_FUSE) = applied inside the
+ * halo-staged 3x3 convolution that consumes it, statistics from the producers' epilogues; 0 = GroupNorm launches of their own (round 4's path); 2 = the fused path's
+ * unfused twin (the same statistics, ia2p_gn_apply_stats-style passes + plain convolutions: bit-identical to 1, for tests). Workspace sizes are valid for every mode. */
+ia2p_status ia2p_set_gn_fuse(ia2p_ctx* ctx, int mode);
 /* IP-Adapter plugin state: set_ip_adapter (ip_adapter.py:120-142) / set_scale (:211-214) / disable (:153-154). */
 ia2p_status ia2p_set_ip_adapter(ia2p_ctx* ctx, int enabled, int num_tokens, float scale);
 
@@ -153,8 +157,9 @@ ia2p_status ia2p_mask_blend(void* stream, const void* x, const void* init, const
                             void* out, void* out2, int B, int C, int64_t HW);
 
 /* ---- per-operator entry points (unit tests, and hosts that keep their own module tree) ----------------------------- */
-/* Operand size: the contraction kernels address an operand (activations, weights) with a 31-bit byte offset -- a matrix of 2 GiB or more is refused with
- * IA2P_ERR_HIP / invalid value (the largest operand of the reference's path, the stacked context K/V weights, is 0.68 GB). */
+/* Operand size: the linear-layer tiles (buffer-load staging), the halo-staged 3x3 convolution and the fused attention tiles address an operand (activations,
+ * weights) with a 31-bit byte offset and REFUSE a matrix of 2 GiB or more with IA2P_ERR_HIP / invalid value; the gathered 3x3 convolution kernels use 64-bit
+ * pointers and carry no such limit (a halo-ineligible site runs there). The largest operand of the reference's path, the stacked context K/V weights, is 0.68 GB. */
 ia2p_status ia2p_groupnorm_silu(void* stream, const void* x, void* y, const void* gamma, const void* beta, int B, int HW, int C,
                                 int groups, float eps, int silu, float* partial_ws /* >= B*64*groups*2 floats */);
 ia2p_status ia2p_layernorm(void* stream, const void* x, void* y, const void* gamma, const void* beta, int M, int C, float eps);
@@ -188,6 +193,28 @@ ia2p_status ia2p_gemm_splitk(void* stream, const void* A, const void* W, const v
  * stride 1|2; up=1 convolves the nearest-x2 upsampled x; rowvec [B,Co] (time embedding) and residual optional. */
 ia2p_status ia2p_conv3x3(void* stream, const void* x, const void* Wp, const void* bias, const void* rowvec, const void* residual,
                          void* y, int B, int Hs, int Ws, int Cin, int Co, int stride, int up);
+/* ---- GroupNorm + SiLU fused into the 3x3 convolution that consumes it (round 5). Reference: diffusers ResnetBlock2D `conv1(nonlinearity(norm1(x)))` /
+ * `conv2(dropout(nonlinearity(norm2(h))))` behind instructany2pix/ddim/pnp_pipeline.py:253-260 (in-tree twin: llm/model/vae/modules/blocks.py:122-142).
+ * The norm's statistics come from the PRODUCER of its input: per slot of `rows` consecutive rows (one M-tile; HW / rows slots per image) and per channel, fp64
+ * {sum, sum of squares}. A producer launch leaves them for its own output (ia2p_conv3x3_gn's gn_out, ia2p_gemm_gnstats); ia2p_gn_colstats computes the same numbers
+ * for any tensor. The consumer folds them per image (slot order, then channel order, fp64) and applies y = fp16(silu(fma(x, rstd*gamma, beta - mean*rstd*gamma))):
+ * inside the convolution's LDS images (ia2p_conv3x3_gn) or as a pass of its own (ia2p_gn_apply_stats) -- the two agree to the bit. */
+ia2p_status ia2p_gn_colstats(void* stream, const void* x, int M, int C, int rows, double* out /* [M / rows][C][2] */);
+ia2p_status ia2p_gn_apply_stats(void* stream, const void* x0, int C0, const double* st0, int rows0, const void* x1 /* or NULL */, int C1, const double* st1, int rows1,
+                                const void* gamma, const void* beta, void* y /* [B*HW, C0 + C1] */, int B, int HW, int groups, float eps, int silu);
+typedef struct {
+  const void* x0; int C0; const double* st0; int rows0;     /* operand [B*H*W, C0] and its producer's column sums; st0 == NULL: plain convolution of x0 (no norm) */
+  const void* x1; int C1; const double* st1; int rows1;     /* optional second source, channels [C0, C0 + C1): the up path's [hidden | skip] pair, never concatenated */
+  const void* gamma; const void* beta; int groups; float eps;   /* the GroupNorm's affine parameters over the C0 + C1 channels */
+  const void* Wp; const void* bias; const void* rowvec; const void* residual; void* y;   /* as ia2p_conv3x3 (Wp: ia2p_pack_conv3x3 over C0 + C1 [+ appended Ca columns]) */
+  int B, H, W, Co;
+  const void* xa; int Ca;                                   /* appended 1x1 block (conv2 + conv_shortcut as one implicit GEMM) or NULL / 0 */
+  int splitk; float* partial;                               /* K split (<= 1: none); partial: splitk * B*H*W * Co floats */
+  double* gn_out;                                           /* or NULL: column sums of y, [B*H*W / rows][Co][2] with rows = *gn_out_rows */
+} ia2p_conv_gn;
+ia2p_status ia2p_conv3x3_gn(void* stream, const ia2p_conv_gn* d, int* gn_out_rows);
+ia2p_status ia2p_gemm_gnstats(void* stream, const void* A, const void* W, const void* bias, const void* residual, void* C, int M, int N, int K, int splitk, float* partial,
+                              int HW, double* gn_out, int* rows);
 /* stride 1, no upsampling, with K split over `splitk` workgroups per tile (what the executor launches on the 16 x 16 feature maps); partial holds
  * splitk * B*Hs*Ws * Co floats. Same reference call sites as ia2p_conv3x3 (diffusers ResnetBlock2D conv1 / conv2 behind pnp_pipeline.py:253-260). */
 ia2p_status ia2p_conv3x3_splitk(void* stream, const void* x, const void* Wp, const void* bias, const void* rowvec, const void* residual,
@@ -242,11 +269,11 @@ void ia2p_debug_set_gemm_splitk(int splitk);  /* -1 auto (tests / tuning; engine
 void ia2p_debug_invalidate_splitk_counters(void);
 int ia2p_debug_fill_splitk_counters(void* stream, int value);   /* tests: every ticket of the stream's buffer := value, on the stream (non-zero = what a dead launch leaves); 0 / -1 */
 void ia2p_debug_set_splitk_inkernel(long long bytes); /* slab-set size (splitk*M*N*4) up to which a K split combines inside the GEMM launch; < 0: IA2P_SPLITK_INKERNEL / default (tests, A/B runs) */
-void ia2p_debug_set_gemm_tile(int variant);   /* -1 auto; else index into IA2P_GEMM_TILES of csrc/common.h, 0..23 (tests / tuning) */
+void ia2p_debug_set_gemm_tile(int variant);   /* -1 auto; else index into IA2P_GEMM_TILES of csrc/common.h, 0..26 (tests / tuning) */
 /* fused to_q + cross-attention: contexts created AFTER this call fuse launches of at least `tiles` 128-query x head tiles (-1: the built-in 128). Tests only:
  * lets a tiny model take the fused path. */
 void ia2p_debug_set_xattn_min_tiles(int tiles);
-/* the tile table (tests / tools): out[4] = {tile rows, tile columns, LDS ring stages, schedule: 0 plain, 1 ping-pong, 2 eight-phase}; 0, or -1 past the last variant */
+/* the tile table (tests / tools): out[4] = {tile rows, tile columns, LDS ring stages, schedule: 0 plain, 1 ping-pong, 2 eight-phase, 3 halo-staged 3x3 convolution (ping-pong over 16 x 16 pixel patches)}; 0, or -1 past the last variant */
 int ia2p_debug_gemm_tile_info(int variant, int* out);
 /* the tile variant and K-split the library picks for a problem (pure function of the shape; host-only, no GPU needed) */
 void ia2p_debug_gemm_plan(int M, int N, int K, int conv, int geglu, int* variant, int* splitk);
@@ -263,6 +290,14 @@ ia2p_status ia2p_profile_read(ia2p_ctx* ctx, int k, char* name, int name_len, in
 /* the same sums by REGION of the UNet evaluation: 0 = other (embeddings), 1 = conv blocks (conv_in / conv_out, the ResnetBlock2Ds with their
  * GroupNorm+SiLU and 1x1 shortcuts, resample convolutions, skip concatenation -- SURVEY.md §8d "conv blocks"), 2 = transformer blocks */
 ia2p_status ia2p_profile_read_region(ia2p_ctx* ctx, int region, int64_t* launches, double* ms, double* flops, double* bytes);
+/* the same sums by layer ROLE, i.e. by the executor's call site, whatever tile / fusion the plan table picked for the launch: 0 other, 1 FF-in (GEGLU projection),
+ * 2 FF-out, 3 QKV + self-attention, 4 attention out-projections (reference attention_processor.py:267,400), 5 to_q + cross-attention (:344,371,387,397),
+ * 6 3x3 convolutions (ResnetBlock2D convs incl. the fused shortcut, resample convs), 7 GroupNorm(+SiLU), 8 proj_in / proj_out, 9 context K/V projection (:358-359,379-380),
+ * 10 time / add embeddings, 11 conv_in / conv_out. bench.py keys `roofline` by role: the dominant kernel INSTANTIATION flips with the tuner's picks, the role does not. */
+int ia2p_profile_roles(void);
+ia2p_status ia2p_profile_read_role(ia2p_ctx* ctx, int role, char* name, int name_len, int64_t* launches, double* ms, double* flops, double* bytes);
+/* launches / milliseconds of role `role` that ran on kernel class k (ia2p_profile_read's index): which instantiations carried the role on this plan table */
+ia2p_status ia2p_profile_read_role_class(ia2p_ctx* ctx, int role, int k, int64_t* launches, double* ms);
 
 /* ---- VAE (diffusers AutoencoderKL): pipe.vae.encode / pipe.vae.decode ----------------------------
  * reference call sites: ddim/pnp_pipeline.py:190-204 (prepare_latents of the img2img base class), ddim/sdxl_pipeline.py:859-871.

@@ -43,6 +43,16 @@ class VAEConfigC(C.Structure):
 
 
 # every symbol include/ia2p.h declares: name -> (restype, argtypes)
+class ConvGnC(C.Structure):
+    """ia2p_conv_gn (include/ia2p.h): a 3x3 convolution with the GroupNorm + SiLU in front of it applied inside the kernel"""
+    _fields_ = [("x0", C.c_void_p), ("C0", C.c_int), ("st0", C.c_void_p), ("rows0", C.c_int),
+                ("x1", C.c_void_p), ("C1", C.c_int), ("st1", C.c_void_p), ("rows1", C.c_int),
+                ("gamma", C.c_void_p), ("beta", C.c_void_p), ("groups", C.c_int), ("eps", C.c_float),
+                ("Wp", C.c_void_p), ("bias", C.c_void_p), ("rowvec", C.c_void_p), ("residual", C.c_void_p), ("y", C.c_void_p),
+                ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("Co", C.c_int),
+                ("xa", C.c_void_p), ("Ca", C.c_int), ("splitk", C.c_int), ("partial", C.c_void_p), ("gn_out", C.c_void_p)]
+
+
 _P, _I, _F, _SZ, _I64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_int64
 SIGNATURES = {
     "ia2p_create": (_I, [C.POINTER(UNetConfigC), C.POINTER(_P)]),
@@ -124,6 +134,14 @@ SIGNATURES = {
     "ia2p_profile_classes": (_I, []),
     "ia2p_profile_read_region": (_I, [_P, _I, C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ia2p_profile_read_prefetch": (_I, [_P, _I, _P]),
+    "ia2p_set_gn_fuse": (_I, [_P, _I]),
+    "ia2p_gn_colstats": (_I, [_P, _P, _I, _I, _I, _P]),
+    "ia2p_gn_apply_stats": (_I, [_P, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _F, _I]),
+    "ia2p_conv3x3_gn": (_I, [_P, C.POINTER(ConvGnC), _P]),
+    "ia2p_gemm_gnstats": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P, _P]),
+    "ia2p_profile_roles": (_I, []),
+    "ia2p_profile_read_role_class": (_I, [_P, _I, _I, C.POINTER(_I64), C.POINTER(C.c_double)]),
+    "ia2p_profile_read_role": (_I, [_P, _I, C.c_char_p, _I, C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ia2p_profile_read": (_I, [_P, _I, C.c_char_p, _I, C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 

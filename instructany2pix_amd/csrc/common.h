@@ -4,6 +4,7 @@
 // convolution is an implicit GEMM whose K axis (tap, channel) is contiguous in channels.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdio>
 #include <cstdlib>
 #include <stdint.h>
 
@@ -77,7 +78,10 @@ static inline const char* ia2p_exp_env(const char* name) {
 #ifdef IA2P_EXPERIMENTS
   return getenv(name);
 #else
-  (void)name;
+  if (getenv(name)) {      // an A/B script is setting a knob this build does not read: say so (a few times), instead of silently comparing A with A
+    static thread_local int warned = 0;
+    if (warned < 8) { ++warned; fprintf(stderr, "[ia2p] %s is set but this build ignores it (experiment knob: rebuild with IA2P_EXTRA_FLAGS=-DIA2P_EXPERIMENTS)\n", name); }
+  }
   return nullptr;
 #endif
 }
@@ -162,11 +166,40 @@ struct GemmArgs {
   // producer side: row statistics of THIS launch's fp16 output, for the folded LayerNorm of the next contraction.
   // stats_out[(slot * M + m) * 2 + {0, 1}], slot = tile_n (or 0 for a K-split launch: the reduce kernel writes it)
   float* stats_out;
+  // ---- GroupNorm fused into a 3x3 convolution (round 5; reference: diffusers ResnetBlock2D `conv1(nonlinearity(norm1(x)))` / `conv2(dropout(nonlinearity(norm2(h))))` behind
+  //      instructany2pix/ddim/pnp_pipeline.py:253-260, in-tree twin llm/model/vae/modules/blocks.py:122-142).
+  // producer side: gn_out[(tile_m * N + n)] = {sum, sum of squares} (fp64) of THIS launch's fp16 output column n over the rows of M-tile tile_m (row tile m0 / BM of a
+  // linear tile, patch index of a halo-staged tile: both hold HW / BM slots per image when BM divides the image). Written by the register epilogue and by the last
+  // K slice of an in-launch K-split combine; nullptr: off.
+  double* gn_out;
+  // consumer side (halo-staged convolution only): the 3x3 operand is the RAW input of the GroupNorm, one tensor or two that are never concatenated (A: channels
+  // [0, gn.C0), A1b: channels [C0, Cin) -- the up path's [hidden | skip]); the kernel folds the producers' column sums into the 32 group statistics of its image and
+  // normalises + SiLUs every halo image in LDS before the taps read it (border pixels stay zero: the reference pads the ACTIVATED tensor).
+  const half_t* A1b; int lda1b;
+  struct GnIn {
+    const double* st0; int rows0;      // column sums of A's producer, rows per slot (HW % rows0 == 0)
+    const double* st1; int rows1;      // ... of A1b's producer (st1 == nullptr: one source)
+    int C0;                            // channels of the first source (== Cin when there is one)
+    const half_t* gamma; const half_t* beta;   // [Cin], concatenated channel order
+    int gs;                            // channels per group (Cin / groups)
+    int groups;
+    float eps; int silu;
+  } gn;                                // gn.st0 == nullptr: plain convolution
 };
 
 // buffer-load staging (linear layers, the halo-staged convolution) addresses an operand with a 31-bit byte offset: what a launch of `rows` x `ld` fp16 elements needs
 static inline bool ia2p_fits_buffer(size_t rows, size_t ld) { return rows * ld * 2 < (size_t)0x7ffffe00; }
 // what the halo-staged 3x3 convolution (conv_halo_f16_kernel, gemm_kernel.h) takes: stride 1, one pixel of zero padding, the source itself or its nearest-x2 upsampled view, whole 16 x 16 patches, whole blocks of 64 channels in every source
+// what the GroupNorm-fused form takes on top of ia2p_conv_halo_ok: no upsampled view, whole blocks of 64 channels in both sources, whole slots per image, at most
+// IA2P_GN_MAX_SLOTS slots per image and source (every workgroup folds them itself), at most 64 groups
+constexpr int IA2P_GN_MAX_SLOTS = 16;
+static inline bool ia2p_conv_gn_ok(const GemmArgs& a) {
+  if (!a.gn.st0) return true;
+  const int HW = a.Ho * a.Wo, C1 = a.Cin - a.gn.C0;
+  return a.up == 0 && a.gn.silu && a.gn.gamma && a.gn.beta && a.gn.groups > 0 && a.gn.groups <= 64 && a.gn.gs > 0 && a.gn.gs * a.gn.groups == a.Cin && a.gn.gs <= 96 && a.gn.C0 > 0 && a.gn.C0 % 64 == 0 && C1 >= 0 && C1 % 64 == 0 &&
+         a.gn.rows0 > 0 && HW % a.gn.rows0 == 0 && HW / a.gn.rows0 <= IA2P_GN_MAX_SLOTS && ((C1 == 0 && !a.gn.st1 && !a.A1b) || (C1 > 0 && a.gn.st1 && a.A1b && a.lda1b >= C1 && a.gn.rows1 > 0 && HW % a.gn.rows1 == 0 &&
+         HW / a.gn.rows1 <= IA2P_GN_MAX_SLOTS && ia2p_fits_buffer(a.M, a.lda1b))) && a.Cin <= 48 * 1024 / 16;      // (the per-channel sums of an image meet in one 48 KiB halo-image buffer)
+}
 static inline bool ia2p_conv_halo_ok(const GemmArgs& a) {
   const int c2 = a.A2 ? a.Cin2 : 0, c3 = a.A3 ? a.Cin3 : 0;
   return a.stride == 1 && (a.up == 0 || (a.up == 1 && !a.A2)) && a.pad == 1 && (a.Hs << a.up) == a.Ho && (a.Ws << a.up) == a.Wo && a.Ho > 0 && a.Ho % 16 == 0 && a.Wo % 16 == 0 && a.Cin >= 64 && a.Cin % 64 == 0 && c2 % 64 == 0 &&

@@ -67,6 +67,13 @@ const char* prof_name(int k) {
   return buf[k];
 }
 
+const char* role_name(int r) {
+  static const char* const names[ROLE_NROLE] = {"other", "ff_in (GEGLU projection, norm3 folded)", "ff_out", "qkv + self-attention (norm1 folded)", "attention out-projections (attn1 / attn2 to_out)",
+                                                "to_q + cross-attention (norm2 folded)", "conv3x3 (ResnetBlock2D convs incl. fused shortcut, resample convs)", "groupnorm (+SiLU)",
+                                                "proj_in / proj_out", "context K/V projection", "time / add embeddings", "conv_in / conv_out"};
+  return r >= 0 && r < ROLE_NROLE ? names[r] : "?";
+}
+
 struct ia2p_ctx : RunCtx {
   ia2p_unet_config cfg;
   int ip_enabled = 0, ip_tokens = 4;
@@ -94,8 +101,7 @@ ia2p_status fail(RunCtx* c, ia2p_status st, const char* fmt, ...) {
   va_end(ap);
   if (c) { c->err = buf; c->failed = true; }
   g_err = buf;
-  if (st == IA2P_ERR_HIP) ia2p_sk_counters_invalidate();      // a launch may have died mid-flight: K-split tickets are re-zeroed before their next use
-  return st;
+  return st;      // (K-split tickets: invalidated where a launch / sync error is seen -- CHECK_LAUNCH, RET_HIP -- not for argument refusals)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -393,7 +399,20 @@ static void tune_site(RunCtx* c, const GemmArgs& a, bool conv) {
 }
 
 // plan, K-split slabs, profiling class and launch of one GEMM / implicit-GEMM conv
-static void run_gemm(RunCtx* c, GemmArgs& a, bool conv, const char* what, double flops, double bytes, int* stat_slots = nullptr) {
+// rows per slot of the stand-alone statistics pass over an image of HW rows: the largest multiple of 16 that divides HW and is <= 1024 (0: none)
+static int gn_fallback_rows(int HW) {
+  for (int k = 1; k <= HW / 16; ++k)
+    if (HW % k == 0 && (HW / k) % 16 == 0 && HW / k <= 1024) return HW / k;
+  return 0;
+}
+// rows per slot of the column sums a launch's own epilogue leaves (0: it cannot): whole 16-row runs, whole tiles per image, 16-byte epilogue routes, at most
+// IA2P_GN_MAX_SLOTS slots per image; a K split only when it combines inside the launch
+static int gn_epilogue_rows(const GemmArgs& a, bool conv, int variant, int splitk, bool combined, int HW) {
+  const int bm = IA2P_GEMM_TILES[ia2p_gemm_variant_ran(a, conv, variant)].bm;
+  return (!a.geglu && !a.act && a.ldc % 8 == 0 && a.N % 8 == 0 && bm % 16 == 0 && HW % bm == 0 && a.M % HW == 0 && HW / bm <= IA2P_GN_MAX_SLOTS && (splitk <= 1 || combined)) ? bm : 0;
+}
+// gw != nullptr: the launch also leaves the GroupNorm statistics of its output (gn_fold.h) -- from its own epilogue when the tile allows, else from a gn_colstats_kernel pass
+static void run_gemm(RunCtx* c, GemmArgs& a, bool conv, const char* what, double flops, double bytes, int* stat_slots = nullptr, GnWant* gw = nullptr) {
   if (c->tuning && !c->dry && !c->failed) tune_site(c, a, conv);
   const GemmPlan pl = ia2p_gemm_plan(a.M, a.N, a.K, conv, a.geglu != 0);
   if (pl.variant < 0 || pl.variant >= IA2P_GEMM_NVARIANT) { fail(c, IA2P_ERR_INVALID, "%s: tile variant %d out of range", what, pl.variant); return; }
@@ -410,14 +429,36 @@ static void run_gemm(RunCtx* c, GemmArgs& a, bool conv, const char* what, double
   }
   struct Rel { RunCtx* c; T2 t; ~Rel() { wsfree(c, t); } } rel{c, slab};
   int combined = pl.splitk > 1 && ia2p_splitk_inkernel(a.M, a.N, pl.splitk);     // (dry pass: the policy's answer; the launcher reports what it really did)
+  int gn_rows_epi = 0, gn_rows_fb = 0;
+  if (gw) {
+    gw->out = GnStats{};
+    gn_rows_epi = gn_epilogue_rows(a, conv, pl.variant, pl.splitk, combined != 0, gw->HW);
+    gn_rows_fb = (a.N % 64 == 0 && a.ldc % 8 == 0 && a.M % gw->HW == 0) ? gn_fallback_rows(gw->HW) : 0;
+    const int slots = std::max(gn_rows_epi ? a.M / gn_rows_epi : 0, gn_rows_fb ? a.M / gn_rows_fb : 0);
+    if (slots > 0) {
+      gw->out.buf = wsalloc(c, (size_t)slots * a.N * 8);      // double2 per slot and column
+      if (gn_rows_epi) a.gn_out = (double*)gw->out.buf.p;
+    }
+  }
   {
     ProfScope ps(c, (conv ? PK_CONV0 : PK_GEMM0) + pl.variant, flops, bytes);
     ps.pf = a.pf ? (double)a.pf_bytes : 0.0;
-    CHECK_LAUNCH(c, ia2p_launch_gemm_variant(a, conv, pl.variant, c->stream, false, &combined), what);
+    int ran = pl.variant;
+    CHECK_LAUNCH(c, ia2p_launch_gemm_variant(a, conv, pl.variant, c->stream, false, &combined, &ran), what);
+    ps.set_class((conv ? PK_CONV0 : PK_GEMM0) + ran);      // (a halo-staged plan runs its gathered twin at a site it does not take: booked under the kernel that ran)
   }
   if (pl.splitk > 1 && !combined) {
     ProfScope ps(c, PK_REDUCE, 0, (double)pl.splitk * a.M * a.N * 4 + 2.0 * a.M * a.N);
     CHECK_LAUNCH(c, ia2p_launch_splitk_reduce(a, c->stream), what);
+  }
+  if (gw && gw->out.buf.off != (size_t)-1) {
+    if (gn_rows_epi && (pl.splitk <= 1 || combined)) gw->out.rows = gn_rows_epi;
+    else if (gn_rows_fb) {      // (the tile could not: the canonical statistics pass over the finished output)
+      RoleScope role(c, ROLE_GROUPNORM);
+      ProfScope ps(c, PK_GN, 4.0 * a.M * a.N, 2.0 * a.M * a.N);
+      CHECK_LAUNCH(c, ia2p_launch_gn_colstats(a.C, a.ldc, a.M, a.N, gn_rows_fb, (double*)gw->out.buf.p, c->stream), "groupnorm statistics");
+      gw->out.rows = gn_rows_fb;
+    } else { wsfree(c, gw->out.buf); gw->out = GnStats{}; }
   }
   // row-statistics slots of this launch's output: one per tile column, or ONE when a reduce launch wrote it
   if (stat_slots) *stat_slots = (pl.splitk > 1 && !combined) ? 1 : (a.N + IA2P_GEMM_TILES[pl.variant].bn - 1) / IA2P_GEMM_TILES[pl.variant].bn;
@@ -442,22 +483,23 @@ static GemmArgs gemm_args(RunCtx* c, const half_t* A, int lda, const half_t* W, 
 static double gemm_bytes(int M, int N, int K, int geglu, bool residual) { return 2.0 * ((double)M * K + (double)N * K + (double)M * (geglu ? N / 2 : N) + (residual ? (double)M * N : 0)); }
 void op_gemm(RunCtx* c, const half_t* A, int lda, const half_t* W, const half_t* bias, const half_t* residual, int ldr,
              half_t* C, int ldc, int M, int N, int K, int geglu, int rpb, int bstride, int roff, int ldw,
-             const LnIn* ln, float* stats_out, int* stat_slots, int act) {
+             const LnIn* ln, float* stats_out, int* stat_slots, int act, GnWant* gw) {
   GemmArgs a = gemm_args(c, A, lda, W, bias, residual, ldr, C, ldc, M, N, K, geglu, rpb, bstride, roff, ldw, ln, stats_out, act);
   set_prefetch(c, a, W, (size_t)N * K * sizeof(half_t));
-  run_gemm(c, a, false, "gemm", 2.0 * M * N * K, gemm_bytes(M, N, K, geglu, residual != nullptr), stat_slots);
+  run_gemm(c, a, false, "gemm", 2.0 * M * N * K, gemm_bytes(M, N, K, geglu, residual != nullptr), stat_slots, gw);
 }
 // GEGLU feed-forward: ff.net.0 (a: K = C, N = 8 C packed, GEGLU epilogue -> H [M, 4 C]) then ff.net.2 (b: reads H, + bias + residual): two launches.
 // (One launch with a per-row-panel hand-off between the two was built and measured in round 3: +0.45 ... +0.8 ms per step, docs/LOG.md; removed in round 4.)
 static void run_ffn(RunCtx* c, GemmArgs& a, GemmArgs& b, int* stat_slots_b) {
   set_prefetch(c, a, a.W, (size_t)a.N * a.K * sizeof(half_t));
   set_prefetch(c, b, b.W, (size_t)b.N * b.K * sizeof(half_t));
-  run_gemm(c, a, false, "ff.net.0", 2.0 * a.M * (double)a.N * a.K, gemm_bytes(a.M, a.N, a.K, 1, false));
+  { RoleScope role(c, ROLE_FF_IN); run_gemm(c, a, false, "ff.net.0", 2.0 * a.M * (double)a.N * a.K, gemm_bytes(a.M, a.N, a.K, 1, false)); }
+  RoleScope role(c, ROLE_FF_OUT);
   run_gemm(c, b, false, "ff.net.2", 2.0 * b.M * (double)b.N * b.K, gemm_bytes(b.M, b.N, b.K, 0, true), stat_slots_b);
 }
 void op_conv3(RunCtx* c, const half_t* X, int B, int Hs, int Ws, int Cin, const half_t* W, const half_t* bias, int Co,
               int stride, int up, const half_t* rowvec, int rowvec_ld, const half_t* residual, half_t* Y, int pad_lo, const half_t* X2, int Cin2,
-              const half_t* X3, int Cin3) {
+              const half_t* X3, int Cin3, const ConvGn* gn, GnWant* gw) {
   GemmArgs a;
   memset(&a, 0, sizeof a);
   // (appended blocks are described by their channel counts: in a dry pass the pointers are null, the shapes -- hence plans and slabs -- must not change)
@@ -467,6 +509,11 @@ void op_conv3(RunCtx* c, const half_t* X, int B, int Hs, int Ws, int Cin, const 
   const int Hv = Hs << up, Wv = Ws << up;
   a.Ho = (Hv + pad_lo + 1 - 3) / stride + 1; a.Wo = (Wv + pad_lo + 1 - 3) / stride + 1;
   a.A = X; a.W = W; a.C = Y; a.zero = zero_page(); a.M = B * a.Ho * a.Wo; a.N = Co; a.K = 9 * Cin + Cin2 + Cin3; a.ldw = a.K; a.lda = Cin; a.ldc = Co;
+  if (gn && gn->fused) {      // GroupNorm + SiLU applied inside the convolution: X [| X1b] is the RAW input of the norm (the caller asked ia2p_conv_gn_fusable)
+    a.lda = gn->C0; a.A1b = gn->X1b; a.lda1b = Cin - gn->C0;
+    a.gn.st0 = (const double*)gn->s0.buf.p; a.gn.rows0 = gn->s0.rows; a.gn.st1 = (const double*)gn->s1.buf.p; a.gn.rows1 = gn->s1.rows; a.gn.C0 = gn->C0;
+    a.gn.gamma = gn->gamma; a.gn.beta = gn->beta; a.gn.groups = gn->groups; a.gn.gs = Cin / gn->groups; a.gn.eps = gn->eps; a.gn.silu = 1;
+  }
   a.A2 = X2; a.lda2 = Cin2; a.Cin2 = Cin2;
   a.A3 = X3; a.lda3 = Cin3; a.Cin3 = Cin3;
   a.Hs = Hs; a.Ws = Ws; a.stride = stride; a.up = up; a.Cin = Cin;
@@ -474,9 +521,11 @@ void op_conv3(RunCtx* c, const half_t* X, int B, int Hs, int Ws, int Cin, const 
   a.m_fastest = 0;
   a.acc_scale = c->ep_acc_scale; a.bias_scale = c->ep_bias_scale; c->ep_acc_scale = c->ep_bias_scale = 1.f;
   set_prefetch(c, a, W, (size_t)Co * a.K * sizeof(half_t));
-  run_gemm(c, a, true, "conv3x3", 2.0 * a.M * (double)Co * a.K, 2.0 * ((double)B * Hs * Ws * Cin + (double)Co * a.K + (double)a.M * Co + (residual ? (double)a.M * Co : 0) + (double)a.M * (Cin2 + Cin3)));
+  RoleScope role(c, ROLE_CONV3X3);
+  run_gemm(c, a, true, "conv3x3", 2.0 * a.M * (double)Co * a.K, 2.0 * ((double)B * Hs * Ws * Cin + (double)Co * a.K + (double)a.M * Co + (residual ? (double)a.M * Co : 0) + (double)a.M * (Cin2 + Cin3)), nullptr, gw);
 }
 void op_gn(RunCtx* c, const half_t* x, half_t* y, size_t g, size_t b, int B, int HW, int C, float eps, int silu, float* partial, const half_t* x2, int Ca) {
+  RoleScope role(c, ROLE_GROUPNORM);
   ProfScope ps(c, PK_GN, 8.0 * B * HW * C, 4.0 * B * HW * C);
   if (x2) CHECK_LAUNCH(c, ia2p_launch_groupnorm(x, Ca, y, C, W_(c, g), W_(c, b), partial, B, HW, C, c->groups, eps, silu, c->stream, x2, C - Ca, Ca), "groupnorm");
   else CHECK_LAUNCH(c, ia2p_launch_groupnorm(x, C, y, C, W_(c, g), W_(c, b), partial, B, HW, C, c->groups, eps, silu, c->stream), "groupnorm");
@@ -494,40 +543,110 @@ struct Fwd {
   float* gn_partial;
   T2 kv_text, kv_ip;   // [B*Lt, kv_rows], [B*Li, kv_rows]
   const float* ip_scales = nullptr;   // device [B] or null: per-request IP-Adapter scale (else the context's one value)
+  // GroupNorm statistics of live activation tensors (keyed by workspace offset): left by the producer's epilogue, read by the GroupNorm-fused convolution that consumes
+  // the tensor -- possibly much later (the skips of the down path) --, released with the tensor
+  std::unordered_map<size_t, GnStats> gst;
+  bool gn_on = false;
 };
+static void gst_put(Fwd& f, T2 t, const GnStats& s) { if (s.ok() && t.off != (size_t)-1) f.gst[t.off] = s; else if (s.buf.off != (size_t)-1) wsfree(f.c, s.buf); }
+static GnStats gst_get(Fwd& f, T2 t) { auto it = f.gst.find(t.off); return it == f.gst.end() ? GnStats{} : it->second; }
+static void act_free(Fwd& f, T2 t) {      // release an activation tensor and its statistics
+  auto it = f.gst.find(t.off);
+  if (it != f.gst.end()) { wsfree(f.c, it->second.buf); f.gst.erase(it); }
+  wsfree(f.c, t);
+}
 
 struct RegionScope { RunCtx* c; int prev; RegionScope(RunCtx* c_, int r) : c(c_), prev(c_->region) { c->region = r; } ~RegionScope() { c->region = prev; } };
 
 // x2 != null: the block input is [x (cx channels) | x2 (cin - cx channels)], never concatenated (up path: hidden state | skip) -- GroupNorm reads the two
 // tensors, and the shortcut rides in conv2 as two appended K-blocks. Only with the fused shortcut (c->sc_fuse); the caller concatenates otherwise.
-static T2 run_resnet(Fwd& f, const Resnet& r, T2 x, int H, int Wd, const T2* x2t = nullptr, int cx = 0) {
+// may the GroupNorm in front of a stride-1 3x3 convolution of `cin` -> `cout` channels (+ cin2 + cin3 appended 1x1 channels) run inside that convolution? The shape part:
+// the plan table gives the site a halo-staged tile; the statistics part: every source has its producer's column sums, at most IA2P_GN_MAX_SLOTS slots per image
+static bool gn_conv_fusable(Fwd& f, int H, int Wd, int cin, int cout, int cin2, int cin3, const GnStats& s0, const GnStats* s1, int c0) {
+  if (!f.gn_on || !s0.ok() || (s1 && !s1->ok())) return false;
+  GemmArgs a;
+  memset(&a, 0, sizeof a);
+  a.pad = 1; a.Hs = a.Ho = H; a.Ws = a.Wo = Wd; a.stride = 1; a.Cin = cin; a.M = f.B * H * Wd; a.N = cout; a.K = 9 * cin + cin2 + cin3; a.lda = c0; a.ldw = a.K; a.ldc = cout;
+  a.Cin2 = cin2; a.Cin3 = cin3; a.lda2 = cin2; a.lda3 = cin3;
+  if (cin2) a.A2 = (const half_t*)16;      // (shape query: any non-null pointer)
+  if (cin3) a.A3 = (const half_t*)16;
+  const GemmPlan pl = ia2p_gemm_plan(a.M, a.N, a.K, true, false);
+  if (!ia2p_conv_gn_fusable(a, pl.variant, pl.splitk)) return false;
+  const int HW = H * Wd, groups = f.c->groups;
+  if (cin % groups || cin / groups > 96 || c0 % 64 || (cin - c0) % 64 || cin > 3072) return false;
+  return HW % s0.rows == 0 && HW / s0.rows <= IA2P_GN_MAX_SLOTS && (!s1 || (HW % s1->rows == 0 && HW / s1->rows <= IA2P_GN_MAX_SLOTS));
+}
+
+// out_stats: the block's output feeds another GroupNorm-fusable convolution (the next ResnetBlock2D, or -- as a skip -- one of the up path): its statistics are taken
+static T2 run_resnet(Fwd& f, const Resnet& r, T2 x, int H, int Wd, const T2* x2t = nullptr, int cx = 0, bool out_stats = false) {
   const half_t* x2 = x2t ? x2t->p : nullptr;
   const bool two = x2t != nullptr;
   ia2p_ctx* c = f.c;
   RegionScope rs(c, PR_CONV_BLOCK);
   const int HW = H * Wd, M = f.B * HW;
-  T2 n1 = wsalloc(c, (size_t)M * r.cin);
-  op_gn(c, x.p, n1.p, r.n1g, r.n1b, f.B, HW, r.cin, c->cfg.norm_eps, 1, f.gn_partial, x2, cx);
+  // norm1 + SiLU + conv1: inside the convolution when the site is a halo-staged one and the producers left their statistics (conv_halo_kernel.h, GN = 1)
+  const GnStats sx = gst_get(f, x), sx2 = two ? gst_get(f, *x2t) : GnStats{};
+  const bool fuse1 = gn_conv_fusable(f, H, Wd, r.cin, r.cout, 0, 0, sx, two ? &sx2 : nullptr, two ? cx : r.cin);
+  GnWant w1{HW};
+  const bool cat = r.shortcut && c->sc_fuse;      // conv2(h) + conv_shortcut(x) as ONE implicit GEMM (K = 9 cout + cin): no shortcut launch, no xs round trip
+  // (conv1's statistics are wanted when conv2 can take them: its plan is a halo-staged one)
+  GnStats probe; probe.rows = 256 <= HW && HW % 256 == 0 ? 256 : HW;
+  const bool want1 = f.gn_on && gn_conv_fusable(f, H, Wd, r.cout, r.cout, cat ? (two ? cx : r.cin) : 0, cat && two ? r.cin - cx : 0, probe, nullptr, r.cout);
   T2 hh = wsalloc(c, (size_t)M * r.cout);
-  op_conv3(c, n1.p, f.B, H, Wd, r.cin, W_(c, r.w1), W_(c, r.b1), r.cout, 1, 0, c->dry ? nullptr : f.temb_all.p + r.temb_off, c->temb_total, nullptr, hh.p);
-  wsfree(c, n1);
-  T2 n2 = wsalloc(c, (size_t)M * r.cout);
-  op_gn(c, hh.p, n2.p, r.n2g, r.n2b, f.B, HW, r.cout, c->cfg.norm_eps, 1, f.gn_partial);
-  wsfree(c, hh);
+  const bool twin = (c->gn_dry_mode >= 0 ? c->gn_dry_mode : c->gn_fuse) == 2;      // the fused path's unfused twin: the SAME statistics, normalised by a pass of its own, then the plain convolution
+  auto apply_stats = [&](const half_t* a0, int c0, const half_t* a1, const GnStats& s0, const GnStats& s1, size_t gam, size_t bet, int C, half_t* y) {
+    GemmArgs::GnIn g;
+    memset(&g, 0, sizeof g);
+    g.st0 = (const double*)s0.buf.p; g.rows0 = s0.rows; g.st1 = a1 ? (const double*)s1.buf.p : nullptr; g.rows1 = s1.rows; g.C0 = c0; g.gamma = W_(c, gam); g.beta = W_(c, bet);
+    g.groups = c->groups; g.gs = C / c->groups; g.eps = c->cfg.norm_eps; g.silu = 1;
+    RoleScope role(c, ROLE_GROUPNORM);
+    ProfScope ps(c, PK_GN, 8.0 * M * C, 4.0 * M * C);
+    CHECK_LAUNCH(c, ia2p_launch_gn_apply_stats(a0, c0, a1, C - c0, y, C, f.B, HW, C, g, c->stream), "groupnorm (apply from producer statistics)");
+  };
+  if (fuse1 && twin) {
+    T2 n1 = wsalloc(c, (size_t)M * r.cin);
+    apply_stats(x.p, two ? cx : r.cin, x2, sx, sx2, r.n1g, r.n1b, r.cin, n1.p);
+    op_conv3(c, n1.p, f.B, H, Wd, r.cin, W_(c, r.w1), W_(c, r.b1), r.cout, 1, 0, c->dry ? nullptr : f.temb_all.p + r.temb_off, c->temb_total, nullptr, hh.p, 1, nullptr, 0, nullptr, 0, nullptr, want1 ? &w1 : nullptr);
+    wsfree(c, n1);
+  } else if (fuse1) {
+    ConvGn g;
+    g.fused = true; g.X1b = x2; g.C0 = two ? cx : r.cin; g.s0 = sx; g.s1 = sx2; g.gamma = W_(c, r.n1g); g.beta = W_(c, r.n1b); g.eps = c->cfg.norm_eps; g.groups = c->groups;
+    op_conv3(c, x.p, f.B, H, Wd, r.cin, W_(c, r.w1), W_(c, r.b1), r.cout, 1, 0, c->dry ? nullptr : f.temb_all.p + r.temb_off, c->temb_total, nullptr, hh.p, 1, nullptr, 0, nullptr, 0, &g, want1 ? &w1 : nullptr);
+  } else {
+    T2 n1 = wsalloc(c, (size_t)M * r.cin);
+    op_gn(c, x.p, n1.p, r.n1g, r.n1b, f.B, HW, r.cin, c->cfg.norm_eps, 1, f.gn_partial, x2, cx);
+    op_conv3(c, n1.p, f.B, H, Wd, r.cin, W_(c, r.w1), W_(c, r.b1), r.cout, 1, 0, c->dry ? nullptr : f.temb_all.p + r.temb_off, c->temb_total, nullptr, hh.p, 1, nullptr, 0, nullptr, 0, nullptr, want1 ? &w1 : nullptr);
+    wsfree(c, n1);
+  }
+  const GnStats sh = w1.out;
+  const bool fuse2 = want1 && gn_conv_fusable(f, H, Wd, r.cout, r.cout, cat ? (two ? cx : r.cin) : 0, cat && two ? r.cin - cx : 0, sh, nullptr, r.cout);
+  ConvGn g2;
+  g2.fused = fuse2 && !twin; g2.C0 = r.cout; g2.s0 = sh; g2.gamma = W_(c, r.n2g); g2.beta = W_(c, r.n2b); g2.eps = c->cfg.norm_eps; g2.groups = c->groups;
+  T2 n2{(size_t)-1, nullptr};
+  if (!fuse2 || twin) {
+    n2 = wsalloc(c, (size_t)M * r.cout);
+    if (fuse2) apply_stats(hh.p, r.cout, nullptr, sh, GnStats{}, r.n2g, r.n2b, r.cout, n2.p);
+    else op_gn(c, hh.p, n2.p, r.n2g, r.n2b, f.B, HW, r.cout, c->cfg.norm_eps, 1, f.gn_partial);
+    wsfree(c, hh);
+  }
+  const half_t* in2 = g2.fused ? hh.p : n2.p;
+  GnWant w2{HW};
+  GnWant* gw2 = f.gn_on && out_stats ? &w2 : nullptr;
   T2 xs{(size_t)-1, nullptr};
   const half_t* resid = x.p;
-  const bool cat = r.shortcut && c->sc_fuse;      // conv2(h) + conv_shortcut(x) as ONE implicit GEMM (K = 9 cout + cin): no shortcut launch, no xs round trip
   if (r.shortcut && !cat) {
     xs = wsalloc(c, (size_t)M * r.cout);
-    op_gemm(c, x.p, r.cin, W_(c, r.wsc), W_(c, r.bsc), nullptr, 0, xs.p, r.cout, M, r.cout, r.cin);
+    { RoleScope role(c, ROLE_CONV3X3); op_gemm(c, x.p, r.cin, W_(c, r.wsc), W_(c, r.bsc), nullptr, 0, xs.p, r.cout, M, r.cout, r.cin); }
     resid = xs.p;
   }
   T2 out = wsalloc(c, (size_t)M * r.cout);
-  if (cat && two) op_conv3(c, n2.p, f.B, H, Wd, r.cout, W_(c, r.wcat), W_(c, r.bcat), r.cout, 1, 0, nullptr, 0, nullptr, out.p, 1, x.p, cx, x2, r.cin - cx);
-  else if (cat) op_conv3(c, n2.p, f.B, H, Wd, r.cout, W_(c, r.wcat), W_(c, r.bcat), r.cout, 1, 0, nullptr, 0, nullptr, out.p, 1, x.p, r.cin);
-  else op_conv3(c, n2.p, f.B, H, Wd, r.cout, W_(c, r.w2), W_(c, r.b2), r.cout, 1, 0, nullptr, 0, c->dry ? nullptr : resid, out.p);
-  wsfree(c, n2);
+  if (cat && two) op_conv3(c, in2, f.B, H, Wd, r.cout, W_(c, r.wcat), W_(c, r.bcat), r.cout, 1, 0, nullptr, 0, nullptr, out.p, 1, x.p, cx, x2, r.cin - cx, &g2, gw2);
+  else if (cat) op_conv3(c, in2, f.B, H, Wd, r.cout, W_(c, r.wcat), W_(c, r.bcat), r.cout, 1, 0, nullptr, 0, nullptr, out.p, 1, x.p, r.cin, nullptr, 0, &g2, gw2);
+  else op_conv3(c, in2, f.B, H, Wd, r.cout, W_(c, r.w2), W_(c, r.b2), r.cout, 1, 0, nullptr, 0, c->dry ? nullptr : resid, out.p, 1, nullptr, 0, nullptr, 0, &g2, gw2);
+  if (g2.fused) wsfree(c, hh); else wsfree(c, n2);
+  if (sh.buf.off != (size_t)-1) wsfree(c, sh.buf);
   if (r.shortcut && !cat) wsfree(c, xs);
+  if (gw2) gst_put(f, out, w2.out);
   return out;
 }
 
@@ -540,6 +659,7 @@ static void op_qkv_sattn(RunCtx* c, const half_t* A, int lda, const half_t* W, c
   a.A = A; a.W = W; a.zero = zero_page(); a.M = M; a.N = 3 * C; a.K = C; a.ldw = C; a.lda = lda; a.ldc = 3 * C;
   a.rows_per_batch = 1;
   set_prefetch(c, a, W, (size_t)3 * C * C * sizeof(half_t));
+  RoleScope role(c, ROLE_QKV_SATTN);
   ProfScope ps(c, PK_QKVATTN, 2.0 * M * 3.0 * C * C + 4.0 * x.B * x.heads * (double)x.Nq * x.Nq * 64, 2.0 * ((double)M * C + 3.0 * C * C + (double)M * C));
   ps.pf = a.pf ? (double)a.pf_bytes : 0.0;
   CHECK_LAUNCH(c, ia2p_launch_qkv_sattn(a, x, c->stream), "qkv projection + self-attention");
@@ -565,12 +685,13 @@ static void op_qxattn(RunCtx* c, const half_t* A, int lda, const half_t* W, cons
   set_prefetch(c, a, W, (size_t)N * K * sizeof(half_t));
   double keys = 0;
   for (int s = 0; s < x.nseg; ++s) keys += x.seg[s].nkeys;
+  RoleScope role(c, ROLE_Q_XATTN);
   ProfScope ps(c, PK_QXATTN, 2.0 * M * N * K + 4.0 * x.B * x.heads * (double)x.Nq * keys * 64,
                2.0 * ((double)M * K + (double)N * K + (double)M * N + 2.0 * x.B * keys * x.heads * 64));
   CHECK_LAUNCH(c, ia2p_launch_qproj_xattn(a, x, c->stream), "to_q + cross-attention");
 }
 
-static T2 run_transformer(Fwd& f, const Transformer& t, T2 x, int H, int Wd) {
+static T2 run_transformer(Fwd& f, const Transformer& t, T2 x, int H, int Wd, bool out_stats = false) {
   ia2p_ctx* c = f.c;
   RegionScope rs(c, PR_TRANSFORMER);
   const int HW = H * Wd, M = f.B * HW, C = t.c;
@@ -591,7 +712,7 @@ static T2 run_transformer(Fwd& f, const Transformer& t, T2 x, int H, int Wd) {
   auto F_ = [&](size_t off) { return (const float*)(c->arena + off); };
   const bool fold = c->ln_fold;
   if (!fold) st = nullptr;
-  op_gemm(c, n.p, C, W_(c, t.win), W_(c, t.bin), nullptr, 0, tk.p, C, M, C, C, 0, 0, 0, 0, 0, nullptr, st, &slots);
+  { RoleScope role(c, ROLE_PROJ_IO); op_gemm(c, n.p, C, W_(c, t.win), W_(c, t.bin), nullptr, 0, tk.p, C, M, C, C, 0, 0, 0, 0, 0, nullptr, st, &slots); }
   wsfree(c, n);
   T2 lnb = fold ? T2{(size_t)-1, nullptr} : wsalloc(c, (size_t)M * C);
   T2 qkv = wsalloc(c, (size_t)M * 3 * C), att = wsalloc(c, (size_t)M * C);
@@ -601,18 +722,27 @@ static T2 run_transformer(Fwd& f, const Transformer& t, T2 x, int H, int Wd) {
     // self-attention (AttnProcessor2_0, reference attention_processor.py:205-279)
     // 256 tokens per image (the 16 x 16 level): the QKV tile of one image x one head holds everything that head's attention needs -- projection and attention
     // as ONE launch when there are enough (image, head) pairs to fill the chip (same threshold and switch as the fused cross-attention)
+    {
+    RoleScope role_sa(c, ROLE_QKV_SATTN);
 #ifdef IA2P_NO_SATTN_FUSE      // A/B builds: projection and self-attention as two launches everywhere
-    const bool fuse_sa = false;
+    bool fuse_sa = false;
 #else
-    const bool fuse_sa = fold && c->xattn_fuse && HW == 256 && C == t.heads * 64 && (long)f.B * t.heads >= c->xattn_min_tiles;
+    bool fuse_sa = fold && c->sattn_fuse && HW == 256 && C == t.heads * 64 && (long)f.B * t.heads >= c->xattn_min_tiles;
 #endif
+    AttnArgs sa;
+    memset(&sa, 0, sizeof sa);
+    sa.O = att.p; sa.ldo = C; sa.B = f.B; sa.heads = t.heads; sa.Nq = HW; sa.nseg = 1; sa.scale_log2e = sl2e;
+    sa.seg[0].nkeys = HW; sa.seg[0].weight = 1.f;
+    if (fuse_sa) {      // a site the fused tile does not take (alignment of O / the folded constants, the 31-bit operand limit) runs projection + attention as two launches
+      GemmArgs g;       // (workspace and arena offsets are 256-byte aligned: the dry pass, with null pointers, decides the same way)
+      memset(&g, 0, sizeof g);
+      g.A = tk.p; g.W = W_(c, b.fqkv); g.M = M; g.N = 3 * C; g.K = C; g.lda = C; g.ldw = C; g.ldc = 3 * C;
+      g.ln_stats = st; g.ln_slots = slots; g.ln_cs = F_(b.cs1); g.ln_bias = F_(b.lb1);
+      fuse_sa = ia2p_qkv_sattn_ok(g, sa);
+    }
     if (fuse_sa) {
       const LnIn ln{st, slots, F_(b.cs1), F_(b.lb1), eps};
-      AttnArgs a;
-      memset(&a, 0, sizeof a);
-      a.O = att.p; a.ldo = C; a.B = f.B; a.heads = t.heads; a.Nq = HW; a.nseg = 1; a.scale_log2e = sl2e;
-      a.seg[0].nkeys = HW; a.seg[0].weight = 1.f;
-      op_qkv_sattn(c, tk.p, C, W_(c, b.fqkv), &ln, M, C, a);
+      op_qkv_sattn(c, tk.p, C, W_(c, b.fqkv), &ln, M, C, sa);
     } else if (fold) {
       const LnIn ln{st, slots, F_(b.cs1), F_(b.lb1), eps};
       op_gemm(c, tk.p, C, W_(c, b.fqkv), nullptr, nullptr, 0, qkv.p, 3 * C, M, 3 * C, C, 0, 0, 0, 0, 0, &ln);
@@ -628,9 +758,11 @@ static T2 run_transformer(Fwd& f, const Transformer& t, T2 x, int H, int Wd) {
       a.seg[0].nkeys = HW; a.seg[0].ld = 3 * C; a.seg[0].rows_per_batch = HW; a.seg[0].weight = 1.f;
       op_attn(c, a);
     }
-    op_gemm(c, att.p, C, W_(c, b.wo1), W_(c, b.bo1), tk.p, C, tk.p, C, M, C, C, 0, 0, 0, 0, 0, nullptr, st, &slots);
+    }
+    { RoleScope role(c, ROLE_ATTN_OUT); op_gemm(c, att.p, C, W_(c, b.wo1), W_(c, b.bo1), tk.p, C, tk.p, C, M, C, C, 0, 0, 0, 0, 0, nullptr, st, &slots); }
     // cross-attention (IPAttnProcessor2_0 :310-412 when the adapter is installed, else AttnProcessor2_0)
     {
+      RoleScope role(c, ROLE_Q_XATTN);
       AttnArgs a;
       memset(&a, 0, sizeof a);
       a.Q = qkv.p; a.ldq = C; a.O = att.p; a.ldo = C; a.B = f.B; a.heads = t.heads; a.Nq = HW; a.nseg = Li ? 2 : 1; a.scale_log2e = sl2e;
@@ -653,7 +785,7 @@ static T2 run_transformer(Fwd& f, const Transformer& t, T2 x, int H, int Wd) {
       }
       if (!fuse) op_attn(c, a);
     }
-    op_gemm(c, att.p, C, W_(c, b.wo2), W_(c, b.bo2), tk.p, C, tk.p, C, M, C, C, 0, 0, 0, 0, 0, nullptr, st, &slots);
+    { RoleScope role(c, ROLE_ATTN_OUT); op_gemm(c, att.p, C, W_(c, b.wo2), W_(c, b.bo2), tk.p, C, tk.p, C, M, C, C, 0, 0, 0, 0, 0, nullptr, st, &slots); }
     // GEGLU feed-forward
     if (!fold) op_ln(c, tk.p, lnb.p, b.ln3g, b.ln3b, M, C);
     {
@@ -667,8 +799,10 @@ static T2 run_transformer(Fwd& f, const Transformer& t, T2 x, int H, int Wd) {
   wsfree(c, stt); wsfree(c, lnb); wsfree(c, qkv); wsfree(c, att); wsfree(c, ff);
   (void)ctxd;
   T2 out = wsalloc(c, (size_t)M * C);
-  op_gemm(c, tk.p, C, W_(c, t.wout), W_(c, t.bout), x.p, C, out.p, C, M, C, C);
+  GnWant gw{HW};
+  { RoleScope role(c, ROLE_PROJ_IO); op_gemm(c, tk.p, C, W_(c, t.wout), W_(c, t.bout), x.p, C, out.p, C, M, C, C, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, 0, f.gn_on && out_stats ? &gw : nullptr); }
   wsfree(c, tk);
+  if (f.gn_on && out_stats) gst_put(f, out, gw.out);
   return out;
 }
 
@@ -676,6 +810,7 @@ static T2 run_transformer(Fwd& f, const Transformer& t, T2 x, int H, int Wd) {
 // attention_processor.py:358-359 (to_k/to_v) and :379-380 (to_k_ip/to_v_ip). kv_text: [B*Lt, kv_rows], kv_ip: [B*Li, kv_rows].
 static void project_context(ia2p_ctx* c, const half_t* context, int L, int B, half_t* kv_text, half_t* kv_ip) {
   RegionScope rs(c, PR_TRANSFORMER);
+  RoleScope role(c, ROLE_CTX_KV);
   const int ctxd = c->cfg.cross_attention_dim;
   const int Lt = c->ip_enabled ? L - c->ip_tokens : L, Li = c->ip_enabled ? c->ip_tokens : 0;
   op_gemm(c, context, ctxd, W_(c, c->kv_text_base), nullptr, nullptr, 0, kv_text, c->kv_rows, B * Lt, c->kv_rows, ctxd, 0, Lt, L, 0);
@@ -692,6 +827,8 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
   const int pooled = Ain - g.num_time_ids * Ad;
   Fwd f{c, B, h, w, L, context, T2{(size_t)-1, nullptr}, nullptr, T2{(size_t)-1, nullptr}, T2{(size_t)-1, nullptr}};
   f.ip_scales = ip_scales;
+  const int gn_mode = c->gn_dry_mode >= 0 ? c->gn_dry_mode : c->gn_fuse;
+  f.gn_on = gn_mode != 0 && !c->tuning;      // (the autotune pass measures the plain kernels: GroupNorm launches there)
 
   // GroupNorm partial sums (fp32) live at the front of the workspace
   T2 gnp = wsalloc(c, (size_t)B * 64 * g.norm_num_groups * 2 * 2);
@@ -701,6 +838,7 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
   T2 a1 = wsalloc(c, (size_t)B * T), emb = wsalloc(c, (size_t)B * T);
   f.temb_all = wsalloc(c, (size_t)B * c->temb_total);
   {
+    RoleScope role(c, ROLE_EMBED);
     ProfScope ps(c, PK_EMBED, 0, 0);
     CHECK_LAUNCH(c, ia2p_launch_embed(timestep, timesteps, text_embeds, time_ids, tsin.p, addin.p, B, Tp, pooled, Ad, g.num_time_ids, c->stream), "embed");
     // skinny linears hold <= 16 rows per launch: larger batches go in row chunks
@@ -745,23 +883,41 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
   std::vector<int> skip_c;
   T2 x = wsalloc(c, (size_t)B * H * Wd * g.block_out_channels[0]);
   {
+    RoleScope role(c, ROLE_CONV_IO);
     ProfScope ps(c, PK_CONV_IN, 2.0 * B * H * Wd * 9.0 * g.in_channels * g.block_out_channels[0],
                  2.0 * ((double)B * H * Wd * (g.in_channels + g.block_out_channels[0]) + 64.0 * g.block_out_channels[0]));
     CHECK_LAUNCH(c, ia2p_launch_conv_in(sample, W_(c, c->conv_in_w), W_(c, c->conv_in_b), x.p, B, g.in_channels, H, Wd, g.block_out_channels[0], c->stream), "conv_in");
+  }
+  // Every tensor below feeds a GroupNorm in front of a 3x3 convolution -- the next ResnetBlock2D's norm1, or (the skips) the norm1 of an up-path block much later --
+  // and carries its producer's column sums with it (f.gst); conv_in is a direct kernel: the canonical statistics pass runs over its output
+  if (f.gn_on) {
+    const int c0 = g.block_out_channels[0], rows = gn_fallback_rows(H * Wd);
+    if (rows && c0 % 64 == 0) {
+      GnStats s;
+      s.buf = wsalloc(c, (size_t)(B * H * Wd / rows) * c0 * 8);
+      s.rows = rows;
+      RoleScope role(c, ROLE_GROUPNORM);
+      ProfScope ps(c, PK_GN, 4.0 * B * H * Wd * c0, 2.0 * B * H * Wd * c0);
+      CHECK_LAUNCH(c, ia2p_launch_gn_colstats(x.p, c0, B * H * Wd, c0, rows, (double*)s.buf.p, c->stream), "groupnorm statistics (conv_in)");
+      gst_put(f, x, s);
+    }
   }
   skips.push_back(x); skip_c.push_back(g.block_out_channels[0]);
   for (int i = 0; i < n; ++i) {
     const Stage& st = c->down[i];
     for (size_t j = 0; j < st.res.size(); ++j) {
-      T2 r = run_resnet(f, st.res[j], x, H, Wd);
-      if (!st.att.empty()) { T2 t = run_transformer(f, st.att[j], r, H, Wd); wsfree(c, r); r = t; }
+      const bool att = !st.att.empty();
+      T2 r = run_resnet(f, st.res[j], x, H, Wd, nullptr, 0, !att);      // (with a transformer behind it the block's output only feeds that transformer's own GroupNorm)
+      if (att) { T2 t = run_transformer(f, st.att[j], r, H, Wd, true); act_free(f, r); r = t; }
       x = r;
       skips.push_back(x); skip_c.push_back(st.res[j].cout);
     }
     if (st.resample) {
       const int Ho = (H - 1) / 2 + 1, Wo = (Wd - 1) / 2 + 1;
       T2 d = wsalloc(c, (size_t)B * Ho * Wo * st.rc);
-      op_conv3(c, x.p, B, H, Wd, st.rc, W_(c, st.rw), W_(c, st.rb), st.rc, 2, 0, nullptr, 0, nullptr, d.p);
+      GnWant gw{Ho * Wo};
+      op_conv3(c, x.p, B, H, Wd, st.rc, W_(c, st.rw), W_(c, st.rb), st.rc, 2, 0, nullptr, 0, nullptr, d.p, 1, nullptr, 0, nullptr, 0, nullptr, f.gn_on ? &gw : nullptr);
+      if (f.gn_on) gst_put(f, d, gw.out);
       H = Ho; Wd = Wo; x = d;
       skips.push_back(x); skip_c.push_back(st.rc);
     }
@@ -769,8 +925,8 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
   // ---- mid
   {
     T2 r0 = run_resnet(f, c->mid_r0, x, H, Wd);          // x stays alive: it is the top skip
-    T2 t = run_transformer(f, c->mid_t, r0, H, Wd); wsfree(c, r0);
-    T2 r1 = run_resnet(f, c->mid_r1, t, H, Wd); wsfree(c, t);
+    T2 t = run_transformer(f, c->mid_t, r0, H, Wd, true); act_free(f, r0);
+    T2 r1 = run_resnet(f, c->mid_r1, t, H, Wd, nullptr, 0, true); act_free(f, t);
     x = r1;
   }
   // ---- up path
@@ -782,27 +938,31 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
       const int cx = st.res[j].cin - cs;
       const long M = (long)B * H * Wd;
       T2 r;
+      const bool att = !st.att.empty();
+      const bool last = i == n - 1 && j + 1 == st.res.size();      // (the last block's output feeds conv_norm_out: a GroupNorm launch of its own)
       if (c->sc_fuse && c->cat_free && st.res[j].shortcut && cx % 64 == 0 && cs % 64 == 0) {
         // torch.cat([hidden, skip]) never materialised: GroupNorm and the appended shortcut blocks of conv2 read the two tensors
-        r = run_resnet(f, st.res[j], x, H, Wd, &sk, cx);
-        wsfree(c, x); wsfree(c, sk);
+        r = run_resnet(f, st.res[j], x, H, Wd, &sk, cx, !att && !last);
+        act_free(f, x); act_free(f, sk);
       } else {
         T2 cat = wsalloc(c, (size_t)M * st.res[j].cin);
         {
           ProfScope ps(c, PK_CONCAT, 0, 4.0 * M * st.res[j].cin);
           CHECK_LAUNCH(c, ia2p_launch_concat(x.p, cx, cx, sk.p, cs, cs, cat.p, M, c->stream), "concat");
         }
-        wsfree(c, x); wsfree(c, sk);
-        r = run_resnet(f, st.res[j], cat, H, Wd);
+        act_free(f, x); act_free(f, sk);
+        r = run_resnet(f, st.res[j], cat, H, Wd, nullptr, 0, !att && !last);
         wsfree(c, cat);
       }
-      if (!st.att.empty()) { T2 t = run_transformer(f, st.att[j], r, H, Wd); wsfree(c, r); r = t; }
+      if (att) { T2 t = run_transformer(f, st.att[j], r, H, Wd, true); act_free(f, r); r = t; }
       x = r;
     }
     if (st.resample) {
       T2 u = wsalloc(c, (size_t)B * (2 * H) * (2 * Wd) * st.rc);
-      op_conv3(c, x.p, B, H, Wd, st.rc, W_(c, st.rw), W_(c, st.rb), st.rc, 1, 1, nullptr, 0, nullptr, u.p);
-      wsfree(c, x);
+      GnWant gw{4 * H * Wd};
+      op_conv3(c, x.p, B, H, Wd, st.rc, W_(c, st.rw), W_(c, st.rb), st.rc, 1, 1, nullptr, 0, nullptr, u.p, 1, nullptr, 0, nullptr, 0, nullptr, f.gn_on ? &gw : nullptr);
+      if (f.gn_on) gst_put(f, u, gw.out);
+      act_free(f, x);
       H *= 2; Wd *= 2; x = u;
     }
   }
@@ -811,11 +971,14 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
   const int c0 = g.block_out_channels[0];
   T2 no = wsalloc(c, (size_t)B * H * Wd * c0);
   op_gn(c, x.p, no.p, c->ngo, c->nbo, B, H * Wd, c0, g.norm_eps, 1, f.gn_partial);
-  wsfree(c, x);
+  act_free(f, x);
   {
+    RoleScope role(c, ROLE_CONV_IO);
     ProfScope ps(c, PK_CONV_OUT, 2.0 * B * H * Wd * 9.0 * c0 * g.out_channels, 2.0 * ((double)B * H * Wd * (c0 + g.out_channels) + 9.0 * c0 * g.out_channels));
     CHECK_LAUNCH(c, ia2p_launch_conv_out(no.p, c0, W_(c, c->conv_out_w), W_(c, c->conv_out_b), out, B, c0, H, Wd, g.out_channels, c->stream), "conv_out");
   }
+  for (auto& kv : f.gst) wsfree(c, kv.second.buf);      // (none left on a complete pass)
+  f.gst.clear();
   wsfree(c, no); wsfree(c, f.temb_all); wsfree(c, gnp); wsfree(c, f.kv_text); wsfree(c, f.kv_ip);
   return c->failed ? IA2P_ERR_HIP : IA2P_OK;
 }
@@ -952,6 +1115,12 @@ ia2p_status ia2p_adopt_arena_on(ia2p_ctx* c, int with_ip_adapter, void* stream) 
 }
 ia2p_status ia2p_adopt_arena(ia2p_ctx* c, int with_ip_adapter) { return ia2p_adopt_arena_on(c, with_ip_adapter, nullptr); }
 
+ia2p_status ia2p_set_gn_fuse(ia2p_ctx* c, int mode) {
+  if (!c || mode < 0 || mode > 2) return fail(c, IA2P_ERR_INVALID, "set_gn_fuse: mode %d (0 GroupNorm launches, 1 fused into the convolutions, 2 the fused path's unfused twin)", mode);
+  c->gn_fuse = mode;
+  c->wseq_key = -1;
+  return IA2P_OK;
+}
 ia2p_status ia2p_set_ip_adapter(ia2p_ctx* c, int enabled, int num_tokens, float scale) {
   if (!c) return IA2P_ERR_INVALID;
   if (enabled) {
@@ -974,12 +1143,20 @@ static ia2p_status check_fwd_shape(ia2p_ctx* c, int B, int h, int w, int L) {
 
 size_t ia2p_workspace_bytes(ia2p_ctx* c, int B, int h, int w, int L) {
   if (!c || check_fwd_shape(c, B, h, w, L) != IA2P_OK) return 0;
-  c->dry = true; c->failed = false;
-  c->ws.reset((size_t)1 << 46);
-  c->ws_base = nullptr;
-  (void)run_forward(c, nullptr, 0.f, nullptr, L, nullptr, nullptr, nullptr, B, h, w);
-  c->dry = false;
-  return c->failed ? 0 : c->ws.high + 256;
+  // three dry passes: the GroupNorms as launches of their own (also what the autotune pass runs), inside their convolutions (the product path), and the fused path's
+  // unfused twin -- a workspace sized here serves every ia2p_set_gn_fuse mode
+  size_t high = 0;
+  for (int pass = 0; pass < 3; ++pass) {
+    c->dry = true; c->failed = false;
+    c->gn_dry_mode = pass;
+    c->ws.reset((size_t)1 << 46);
+    c->ws_base = nullptr;
+    (void)run_forward(c, nullptr, 0.f, nullptr, L, nullptr, nullptr, nullptr, B, h, w);
+    c->dry = false; c->gn_dry_mode = -1;
+    if (c->failed) return 0;
+    high = std::max(high, c->ws.high);
+  }
+  return high + 256;
 }
 
 static ia2p_status unet_forward_impl(ia2p_ctx* c, void* stream, const void* sample, float timestep, const void* context, const void* kv, int L,
@@ -1233,7 +1410,7 @@ ia2p_status ia2p_conv3x3(void* stream, const void* x, const void* Wp, const void
 // the stride-1 form with K split over `splitk` workgroups per tile (what the executor launches for the 16 x 16 feature maps); partial: splitk * B*Hs*Ws * Co floats
 ia2p_status ia2p_conv3x3_splitk(void* stream, const void* x, const void* Wp, const void* bias, const void* rowvec, const void* residual, void* y,
                                 int B, int Hs, int Ws, int Cin, int Co, int splitk, float* partial) {
-  if (!x || !Wp || !y || !partial) return fail(nullptr, IA2P_ERR_INVALID, "conv3x3_splitk: null argument");
+  if (!x || !Wp || !y || (splitk > 1 && !partial)) return fail(nullptr, IA2P_ERR_INVALID, "conv3x3_splitk: null argument (partial is needed for splitk > 1 only)");
   if (Cin % 64 || Co % 4 || splitk < 1 || splitk > 9 * Cin / 64) return fail(nullptr, IA2P_ERR_SHAPE, "conv3x3_splitk: Cin=%d (mult of 64) Co=%d (mult of 4) splitk=%d (1 .. 9 Cin / 64)", Cin, Co, splitk);
   GemmArgs a;
   memset(&a, 0, sizeof a);
@@ -1245,6 +1422,89 @@ ia2p_status ia2p_conv3x3_splitk(void* stream, const void* x, const void* Wp, con
   if (splitk > 1) { a.splitk = splitk; a.partial = partial; }
   hipError_t e = ia2p_launch_gemm(a, true, (hipStream_t)stream, nullptr);
   RET_HIP(e, "conv3x3_splitk");
+}
+// ---- GroupNorm from producer-side column sums (round 5; csrc/gn_fold.h): the operators of the fused path, one by one -----------------------------------------------
+// canonical statistics of a tensor x [M, C]: out[(slot * C + c) * 2 + {0, 1}] = {sum, sum of squares} (fp64) over the `rows` rows of slot `slot` (what a GEMM / conv epilogue
+// leaves for its own output when asked: ia2p_gemm_gnstats, ia2p_conv3x3_gn)
+ia2p_status ia2p_gn_colstats(void* stream, const void* x, int M, int C, int rows, double* out) {
+  if (!x || !out) return fail(nullptr, IA2P_ERR_INVALID, "gn_colstats: null argument");
+  if (C % 64 || rows < 16 || rows % 16 || M < 1 || M % rows) return fail(nullptr, IA2P_ERR_SHAPE, "gn_colstats: C=%d (multiple of 64), rows=%d (multiple of 16 dividing M=%d)", C, rows, M);
+  hipError_t e = ia2p_launch_gn_colstats((const half_t*)x, C, M, C, rows, out, (hipStream_t)stream);
+  RET_HIP(e, "gn_colstats");
+}
+static ia2p_status gn_in_from_abi(const char* what, GemmArgs::GnIn* g, int C0, const double* st0, int rows0, int C1, const double* st1, int rows1, const void* gamma, const void* beta, int groups, float eps, int silu, int HW) {
+  const int C = C0 + C1;
+  if (!st0 || !gamma || !beta || (C1 > 0 && !st1)) return fail(nullptr, IA2P_ERR_INVALID, "%s: null argument", what);
+  if (groups < 1 || groups > 64 || C % groups || C0 < 8 || C0 % 8 || C1 < 0 || C1 % 8 || rows0 < 1 || HW % rows0 || (C1 > 0 && (rows1 < 1 || HW % rows1)))
+    return fail(nullptr, IA2P_ERR_SHAPE, "%s: C0=%d C1=%d groups=%d rows0=%d rows1=%d HW=%d", what, C0, C1, groups, rows0, rows1, HW);
+  memset(g, 0, sizeof *g);
+  g->st0 = st0; g->rows0 = rows0; g->st1 = C1 > 0 ? st1 : nullptr; g->rows1 = rows1; g->C0 = C0; g->gamma = (const half_t*)gamma; g->beta = (const half_t*)beta;
+  g->groups = groups; g->gs = C / groups; g->eps = eps; g->silu = silu;
+  return IA2P_OK;
+}
+// y = [silu](GroupNorm(groups)([x0 | x1])) with the statistics folded from the column sums of the sources' producers: the stand-alone twin of what ia2p_conv3x3_gn
+// does to its operand inside the convolution (same fold, same scale / shift, same element formula: the two agree to the bit)
+ia2p_status ia2p_gn_apply_stats(void* stream, const void* x0, int C0, const double* st0, int rows0, const void* x1, int C1, const double* st1, int rows1,
+                                const void* gamma, const void* beta, void* y, int B, int HW, int groups, float eps, int silu) {
+  if (!x0 || !y || (C1 > 0 && !x1)) return fail(nullptr, IA2P_ERR_INVALID, "gn_apply_stats: null argument");
+  GemmArgs::GnIn g;
+  const ia2p_status st = gn_in_from_abi("gn_apply_stats", &g, C0, st0, rows0, C1, st1, rows1, gamma, beta, groups, eps, silu, HW);
+  if (st != IA2P_OK) return st;
+  hipError_t e = ia2p_launch_gn_apply_stats((const half_t*)x0, C0, C1 > 0 ? (const half_t*)x1 : nullptr, C1, (half_t*)y, C0 + C1, B, HW, C0 + C1, g, (hipStream_t)stream);
+  RET_HIP(e, "gn_apply_stats");
+}
+// 3x3 convolution (stride 1) of silu(GroupNorm([x0 | x1])) with the norm applied INSIDE the convolution (d->st0 != NULL; conv_halo_kernel.h GN = 1), or of x0 itself
+// (d->st0 == NULL), + optional appended 1x1 block, time-embedding row, residual, K split; d->gn_out != NULL: also the column sums of y (*gn_out_rows: rows per slot,
+// 0 when this launch could not take them). Fused form: the site must have a halo-staged plan (IA2P_ERR_SHAPE otherwise; tests force one with ia2p_debug_set_gemm_tile).
+ia2p_status ia2p_conv3x3_gn(void* stream, const ia2p_conv_gn* d, int* gn_out_rows) {
+  if (gn_out_rows) *gn_out_rows = 0;
+  if (!d || !d->x0 || !d->Wp || !d->y || (d->splitk > 1 && !d->partial) || (d->Ca > 0 && !d->xa)) return fail(nullptr, IA2P_ERR_INVALID, "conv3x3_gn: null argument");
+  const int Cin = d->C0 + (d->st0 ? d->C1 : 0), HW = d->H * d->W;
+  if (Cin % 64 || d->C0 % 64 || d->Co % 8 || d->Ca % 64 || d->B < 1 || HW < 1 || d->splitk < 0 || d->splitk > (9 * Cin + d->Ca) / 64) return fail(nullptr, IA2P_ERR_SHAPE, "conv3x3_gn: C0=%d C1=%d Co=%d Ca=%d splitk=%d", d->C0, d->C1, d->Co, d->Ca, d->splitk);
+  GemmArgs a;
+  memset(&a, 0, sizeof a);
+  a.pad = 1; a.Ho = a.Hs = d->H; a.Wo = a.Ws = d->W; a.stride = 1;
+  a.A = (const half_t*)d->x0; a.W = (const half_t*)d->Wp; a.C = (half_t*)d->y; a.zero = zero_page(); a.M = d->B * HW; a.N = d->Co; a.K = 9 * Cin + d->Ca; a.ldw = a.K; a.lda = d->C0; a.ldc = d->Co;
+  a.Cin = Cin; a.bias = (const half_t*)d->bias; a.rowvec = (const half_t*)d->rowvec; a.rowvec_ld = d->Co; a.rows_per_batch = HW; a.residual = (const half_t*)d->residual; a.ldr = d->Co;
+  if (d->Ca > 0) { a.A2 = (const half_t*)d->xa; a.lda2 = d->Ca; a.Cin2 = d->Ca; }
+  if (d->splitk > 1) { a.splitk = d->splitk; a.partial = d->partial; }
+  const GemmPlan pl = ia2p_gemm_plan(a.M, a.N, a.K, true, false);
+  if (d->st0) {
+    const ia2p_status st = gn_in_from_abi("conv3x3_gn", &a.gn, d->C0, d->st0, d->rows0, d->C1, d->st1, d->rows1, d->gamma, d->beta, d->groups, d->eps, 1, HW);
+    if (st != IA2P_OK) return st;
+    a.A1b = d->C1 > 0 ? (const half_t*)d->x1 : nullptr; a.lda1b = d->C1;
+    if (d->C1 > 0 && !d->x1) return fail(nullptr, IA2P_ERR_INVALID, "conv3x3_gn: null second source");
+    if (!ia2p_conv_gn_fusable(a, pl.variant, a.splitk) || !ia2p_conv_gn_ok(a)) return fail(nullptr, IA2P_ERR_SHAPE, "conv3x3_gn: this site has no halo-staged plan (variant %d) or its statistics do not fit the fused kernel", pl.variant);
+  }
+  const bool combined = a.splitk > 1 && ia2p_splitk_inkernel(a.M, a.N, a.splitk);
+  int rows = 0;
+  if (d->gn_out) { rows = gn_epilogue_rows(a, true, pl.variant, a.splitk, combined, HW); if (rows) a.gn_out = d->gn_out; }
+  int comb = 0;
+  hipError_t e = ia2p_launch_gemm_variant(a, true, pl.variant, (hipStream_t)stream, true, &comb);
+  if (e == hipSuccess && gn_out_rows) *gn_out_rows = (rows && (a.splitk <= 1 || comb)) ? rows : 0;
+  RET_HIP(e, "conv3x3_gn");
+}
+// C = A . W^T + bias + residual as ia2p_gemm_splitk (splitk <= 1: no split), also leaving the GroupNorm column sums of C for images of HW rows (a Transformer2DModel's
+// proj_out in front of the next ResnetBlock2D); *rows: rows per slot, 0 when the tile the plan picked cannot take them (the caller runs ia2p_gn_colstats)
+ia2p_status ia2p_gemm_gnstats(void* stream, const void* A, const void* W, const void* bias, const void* residual, void* C, int M, int N, int K, int splitk, float* partial,
+                              int HW, double* gn_out, int* rows) {
+  if (rows) *rows = 0;
+  if (!A || !W || !C || !gn_out || !rows || (splitk > 1 && !partial)) return fail(nullptr, IA2P_ERR_INVALID, "gemm_gnstats: null argument");
+  if (K % 64 || N % 8 || HW < 16 || M % HW || splitk < 0 || splitk > K / 64) return fail(nullptr, IA2P_ERR_SHAPE, "gemm_gnstats: K=%d N=%d HW=%d splitk=%d", K, N, HW, splitk);
+  GemmArgs a;
+  memset(&a, 0, sizeof a);
+  a.pad = 1;
+  a.A = (const half_t*)A; a.W = (const half_t*)W; a.C = (half_t*)C; a.zero = zero_page(); a.M = M; a.N = N; a.K = K; a.ldw = a.K; a.lda = K; a.ldc = N;
+  a.bias = (const half_t*)bias; a.residual = (const half_t*)residual; a.ldr = N; a.rows_per_batch = 1; a.m_fastest = M <= N;
+  if (splitk > 1) { a.splitk = splitk; a.partial = partial; }
+  const GemmPlan pl = ia2p_gemm_plan(M, N, K, false, false);
+  const bool combined = splitk > 1 && ia2p_splitk_inkernel(M, N, splitk);
+  const int r = gn_epilogue_rows(a, false, pl.variant, a.splitk, combined, HW);
+  if (r) a.gn_out = gn_out;
+  int comb = 0;
+  hipError_t e = ia2p_launch_gemm_variant(a, false, pl.variant, (hipStream_t)stream, true, &comb);
+  if (e == hipSuccess) *rows = (r && (a.splitk <= 1 || comb)) ? r : 0;
+  RET_HIP(e, "gemm_gnstats");
 }
 // ResnetBlock2D tail as one implicit GEMM: y = conv3x3(x, W2) + conv1x1(x2, Wsc) + bias (+ rowvec), K = 9 Cin + Cin2; Wcat rows = [packed W2 row | Wsc row]
 ia2p_status ia2p_conv3x3_cat(void* stream, const void* x, const void* x2, const void* Wcat, const void* bias, void* y, int B, int Hs, int Ws, int Cin, int Cin2, int Co) {
@@ -1365,6 +1625,7 @@ ia2p_status ia2p_profile_enable(ia2p_ctx* c, int on) {
   c->recs.clear();
   for (int k = 0; k < PK_NCLASS; ++k) { c->p_ms[k] = c->p_fl[k] = c->p_by[k] = c->p_pf[k] = 0; c->p_n[k] = 0; }
   for (int k = 0; k < PR_NREGION; ++k) { c->r_ms[k] = c->r_fl[k] = c->r_by[k] = 0; c->r_n[k] = 0; }
+  for (int k = 0; k < ROLE_NROLE; ++k) { c->o_ms[k] = c->o_fl[k] = c->o_by[k] = 0; c->o_n[k] = 0; for (int q = 0; q < PK_NCLASS; ++q) { c->oc_ms[k][q] = 0; c->oc_n[k][q] = 0; } }
   c->prof = on != 0;
   return IA2P_OK;
 }
@@ -1377,6 +1638,9 @@ static void prof_fold(ia2p_ctx* c) {
     c->p_ms[r.k] += t; c->p_fl[r.k] += r.flops; c->p_by[r.k] += r.bytes; c->p_pf[r.k] += r.pf; c->p_n[r.k] += 1;
     const int g = r.region >= 0 && r.region < PR_NREGION ? r.region : PR_OTHER;
     c->r_ms[g] += t; c->r_fl[g] += r.flops; c->r_by[g] += r.bytes; c->r_n[g] += 1;
+    const int o = r.role >= 0 && r.role < ROLE_NROLE ? r.role : ROLE_OTHER;
+    c->o_ms[o] += t; c->o_fl[o] += r.flops; c->o_by[o] += r.bytes; c->o_n[o] += 1;
+    c->oc_ms[o][r.k] += t; c->oc_n[o][r.k] += 1;
     c->evpool.push_back(r.e0); c->evpool.push_back(r.e1);
   }
   c->recs.clear();
@@ -1388,6 +1652,26 @@ ia2p_status ia2p_profile_read_region(ia2p_ctx* c, int region, int64_t* launches,
   if (ms) *ms = c->r_ms[region];
   if (flops) *flops = c->r_fl[region];
   if (bytes) *bytes = c->r_by[region];
+  return IA2P_OK;
+}
+// per-ROLE sums (engine_rt.h ROLE_*): the layer a launch implements, whatever kernel instantiation the plan table picked for it
+int ia2p_profile_roles(void) { return ROLE_NROLE; }
+ia2p_status ia2p_profile_read_role(ia2p_ctx* c, int role, char* name, int name_len, int64_t* launches, double* ms, double* flops, double* bytes) {
+  if (!c || role < 0 || role >= ROLE_NROLE) return IA2P_ERR_INVALID;
+  prof_fold(c);
+  if (name && name_len > 0) { strncpy(name, role_name(role), name_len - 1); name[name_len - 1] = 0; }
+  if (launches) *launches = c->o_n[role];
+  if (ms) *ms = c->o_ms[role];
+  if (flops) *flops = c->o_fl[role];
+  if (bytes) *bytes = c->o_by[role];
+  return IA2P_OK;
+}
+// ... and the share of kernel class k in it (which instantiations carried the role on this plan table)
+ia2p_status ia2p_profile_read_role_class(ia2p_ctx* c, int role, int k, int64_t* launches, double* ms) {
+  if (!c || role < 0 || role >= ROLE_NROLE || k < 0 || k >= PK_NCLASS) return IA2P_ERR_INVALID;
+  prof_fold(c);
+  if (launches) *launches = c->oc_n[role][k];
+  if (ms) *ms = c->oc_ms[role][k];
   return IA2P_OK;
 }
 // bytes of next-contraction weights that the launches of class k streamed with their trailing prefetch workgroups (part of the class's HBM-side

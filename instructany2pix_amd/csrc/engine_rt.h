@@ -21,7 +21,12 @@
 // ---- kernel launchers (gemm.hip, attention.hip, norm.hip, misc.hip) ------------------------------------------
 hipError_t ia2p_launch_gemm(const GemmArgs& a, bool conv, hipStream_t s, int* picked, int* combined = nullptr);
 // *combined (optional): 1 when a K-split launch finishes inside the launch (ticket counters attached), 0 when its slabs wait for ia2p_launch_splitk_reduce
-hipError_t ia2p_launch_gemm_variant(const GemmArgs& a, bool conv, int variant, hipStream_t s, bool with_reduce = true, int* combined = nullptr);
+// *ran (optional): the variant whose kernel the launch really was (a halo-staged variant runs its gathered twin at a site it does not take)
+hipError_t ia2p_launch_gemm_variant(const GemmArgs& a, bool conv, int variant, hipStream_t s, bool with_reduce = true, int* combined = nullptr, int* ran = nullptr);
+int ia2p_gemm_variant_ran(const GemmArgs& a, bool conv, int v);
+bool ia2p_conv_gn_fusable(const GemmArgs& a, int v, int splitk);
+hipError_t ia2p_launch_gn_colstats(const half_t* x, int ldx, int M, int C, int rows, double* out, hipStream_t s);
+hipError_t ia2p_launch_gn_apply_stats(const half_t* x0, int ld0, const half_t* x1, int ld1, half_t* y, int ldy, int B, int HW, int C, const GemmArgs::GnIn& g, hipStream_t s);
 hipError_t ia2p_launch_splitk_reduce(const GemmArgs& a, hipStream_t s);
 bool ia2p_splitk_inkernel(int M, int N, int splitk);
 void ia2p_gemm_candidates(int M, int N, int K, bool conv, bool geglu, size_t max_slab_bytes, double slack, std::vector<GemmPlan>* out);
@@ -111,9 +116,14 @@ struct Arena {            // deterministic first-fit allocator over [0, cap)
   }
 };
 
-struct ProfRec { hipEvent_t e0, e1; int k; double flops, bytes; int region; double pf; };
+struct ProfRec { hipEvent_t e0, e1; int k; double flops, bytes; int region; double pf; int role; };
 // profile regions of a UNet evaluation: what part of the network a launch belongs to (bench.py: conv-block roofline)
 enum { PR_OTHER = 0, PR_CONV_BLOCK = 1, PR_TRANSFORMER = 2, PR_NREGION };
+// profile ROLES: which layer of the network a launch implements, whatever tile / fusion the plan table picked for it (bench.py keys its roofline by role: the dominant
+// kernel INSTANTIATION flips with the tuner's picks, the dominant role does not). Reference ops: attention_processor.py:239-267 / :344-400 (attention projections),
+// diffusers' BasicTransformerBlock.ff / ResnetBlock2D / Transformer2DModel.proj_in/out behind pnp_pipeline.py:253-260
+enum { ROLE_OTHER = 0, ROLE_FF_IN, ROLE_FF_OUT, ROLE_QKV_SATTN, ROLE_ATTN_OUT, ROLE_Q_XATTN, ROLE_CONV3X3, ROLE_GROUPNORM, ROLE_PROJ_IO, ROLE_CTX_KV, ROLE_EMBED, ROLE_CONV_IO, ROLE_NROLE };
+const char* role_name(int r);
 // profile classes = device kernel names as rocprofv3 prints them (template arguments included)
 enum { PK_GEMM0 = 0, PK_CONV0 = IA2P_GEMM_NVARIANT, PK_ATTN = 2 * IA2P_GEMM_NVARIANT, PK_GN, PK_LN, PK_EMBED, PK_CONV_IN, PK_CONV_OUT, PK_CONCAT, PK_REDUCE, PK_QXATTN, PK_QKVATTN, PK_NCLASS };
 const char* prof_name(int k);
@@ -146,6 +156,10 @@ struct RunCtx {
   bool cat_free = true;      // up path: torch.cat([hidden, skip]) never materialised (needs sc_fuse; IA2P_CAT_FREE=0: concat_kernel, for A/B runs)
   bool sc_fuse = true;       // ResnetBlock2D: conv2 + conv_shortcut as one implicit GEMM (IA2P_SC_FUSE=0: separate 1x1 launch + residual, for A/B runs)
   bool xattn_fuse = true;    // to_q + cross-attention as one launch where the shape allows (IA2P_XATTN_FUSE=0: two launches, for A/B runs)
+  int gn_dry_mode = -1;      // (ia2p_workspace_bytes: the dry passes walk every gn_fuse mode; -1: the context's own)
+  int gn_fuse = 1;           // 1: GroupNorm + SiLU of a ResnetBlock2D applied inside the halo-staged convolution that consumes it, statistics from the producers' epilogues;
+                             // 0 (IA2P_GN_FUSE=0): GroupNorm launches; 2: the fused path's UNFUSED TWIN -- the same statistics, gn_apply_stats_kernel + the plain convolution (tests: same bits as 1)
+  bool sattn_fuse = true;    // QKV projection + self-attention as one launch at 256 tokens per image (follows IA2P_XATTN_FUSE=0; IA2P_SATTN_FUSE in experiment builds)
   bool ln_fold = true;       // LayerNorms folded into their consumer GEMMs (IA2P_LN_FOLD=0: separate layernorm_kernel launches, for A/B runs)
   bool prof = false;
   // autotune pass (ia2p_autotune): every GEMM / conv site of an unmeasured shape times its candidate plans in place
@@ -158,6 +172,11 @@ struct RunCtx {
   double p_ms[PK_NCLASS], p_fl[PK_NCLASS], p_by[PK_NCLASS], p_pf[PK_NCLASS];     // p_pf: bytes of the NEXT contraction's weights the class's launches prefetched
   int64_t p_n[PK_NCLASS];
   int region = PR_OTHER;     // region the executor is in (tags the profile records)
+  int role = ROLE_OTHER;     // layer role the executor is issuing launches for (tags the profile records)
+  double o_ms[ROLE_NROLE], o_fl[ROLE_NROLE], o_by[ROLE_NROLE];
+  int64_t o_n[ROLE_NROLE];
+  double oc_ms[ROLE_NROLE][PK_NCLASS];      // ... split by kernel class (which instantiations carried the role on this plan table)
+  int64_t oc_n[ROLE_NROLE][PK_NCLASS];
   double r_ms[PR_NREGION], r_fl[PR_NREGION], r_by[PR_NREGION];
   int64_t r_n[PR_NREGION];
   float ep_acc_scale = 1.f, ep_bias_scale = 1.f;   // epilogue scales of the NEXT op_gemm / op_conv3 call (reset by it): range extension, vae_engine.hip
@@ -165,12 +184,15 @@ struct RunCtx {
   RunCtx() {
     if (const char* e = getenv("IA2P_PREFETCH")) prefetch = atoi(e) != 0;
     if (const char* e = getenv("IA2P_LN_FOLD")) ln_fold = atoi(e) != 0;
-    if (const char* e = getenv("IA2P_XATTN_FUSE")) xattn_fuse = atoi(e) != 0;
+    if (const char* e = getenv("IA2P_XATTN_FUSE")) xattn_fuse = sattn_fuse = atoi(e) != 0;
+    if (const char* e = getenv("IA2P_GN_FUSE")) gn_fuse = atoi(e);
+    if (const char* e = ia2p_exp_env("IA2P_SATTN_FUSE")) sattn_fuse = atoi(e) != 0;
     if (const char* e = ia2p_exp_env("IA2P_SC_FUSE")) sc_fuse = atoi(e) != 0;
     if (const char* e = ia2p_exp_env("IA2P_CAT_FREE")) cat_free = atoi(e) != 0;
     if (ia2p_default_xattn_min_tiles() >= 0) xattn_min_tiles = ia2p_default_xattn_min_tiles();      // (test hook: ia2p_debug_set_xattn_min_tiles)
     for (int k = 0; k < PK_NCLASS; ++k) { p_ms[k] = p_fl[k] = p_by[k] = p_pf[k] = 0; p_n[k] = 0; }
     for (int k = 0; k < PR_NREGION; ++k) { r_ms[k] = r_fl[k] = r_by[k] = 0; r_n[k] = 0; }
+    for (int k = 0; k < ROLE_NROLE; ++k) { o_ms[k] = o_fl[k] = o_by[k] = 0; o_n[k] = 0; for (int q = 0; q < PK_NCLASS; ++q) { oc_ms[k][q] = 0; oc_n[k][q] = 0; } }
   }
   ~RunCtx() {
     for (auto& r : recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
@@ -190,25 +212,35 @@ struct ProfScope {
   ProfScope(RunCtx* c_, int k_, double fl_, double by_) : c(c_), k(k_), fl(fl_), by(by_), on(c_ && c_->prof && !c_->dry) {
     if (on) { e0 = get_event(c); e1 = get_event(c); (void)hipEventRecord(e0, c->stream); }
   }
-  ~ProfScope() { if (on) { (void)hipEventRecord(e1, c->stream); c->recs.push_back(ProfRec{e0, e1, k, fl, by, c->region, pf}); } }
+  ~ProfScope() { if (on) { (void)hipEventRecord(e1, c->stream); c->recs.push_back(ProfRec{e0, e1, k, fl, by, c->region, pf, c->role}); } }
   void set_class(int kk) { k = kk; }
 };
+struct RoleScope { RunCtx* c; int prev; RoleScope(RunCtx* c_, int r) : c(c_), prev(c_->role) { c->role = r; } ~RoleScope() { c->role = prev; } };
+// (a launcher's own refusal of its arguments -- hipErrorInvalidValue, nothing was launched -- leaves the K-split tickets alone; any other error may come from a launch that
+//  died mid-flight and starts a new ticket epoch)
 #define CHECK_LAUNCH(c, expr, what)                                                             \
-  do { if (!(c)->dry && !(c)->failed) { hipError_t e_ = (expr); if (e_ != hipSuccess) fail((c), IA2P_ERR_HIP, "%s: %s", what, hipGetErrorString(e_)); } } while (0)
+  do { if (!(c)->dry && !(c)->failed) { hipError_t e_ = (expr); if (e_ != hipSuccess) { if (e_ != hipErrorInvalidValue) ia2p_sk_counters_invalidate(); fail((c), IA2P_ERR_HIP, "%s: %s", what, hipGetErrorString(e_)); } } } while (0)
 
 inline const half_t* W_(RunCtx* c, size_t off) { return c->arena + off; }
 
-#define RET_HIP(e, what) return (e) == hipSuccess ? IA2P_OK : fail(nullptr, IA2P_ERR_HIP, "%s: %s", what, hipGetErrorString(e))
+#define RET_HIP(e, what) do { if ((e) == hipSuccess) return IA2P_OK; if ((e) != hipErrorInvalidValue) ia2p_sk_counters_invalidate(); return fail(nullptr, IA2P_ERR_HIP, "%s: %s", what, hipGetErrorString(e)); } while (0)
 
+// GroupNorm statistics of an activation tensor, as its producer's epilogue (or gn_colstats_kernel) left them: [M / rows slots][C] {sum, sum of squares} fp64
+struct GnStats { T2 buf{(size_t)-1, nullptr}; int rows = 0; bool ok() const { return rows > 0; } };
+// what a producer launch is asked for: statistics of its output, an image being HW rows; filled in by run_gemm / op_gemm / op_conv3
+struct GnWant { int HW; GnStats out; };
+// GroupNorm fused into a 3x3 convolution (op_conv3): the operand is the raw tensor X (C0 channels) [| X1b (Cin - C0)] with the statistics of its producer(s)
+struct ConvGn { bool fused = false; const half_t* X1b = nullptr; int C0 = 0; GnStats s0, s1; const half_t* gamma = nullptr; const half_t* beta = nullptr; float eps = 1e-5f; int groups = 32; };
 // LayerNorm folded into a GEMM: where the consumer finds the row statistics and the folded constants
 struct LnIn { const float* stats; int slots; const float* cs; const float* lb; float eps; };
 
 // ---- operator wrappers: plan (tile / K-split / autotune), slabs, weight prefetch, profiling class, launch
 void op_gemm(RunCtx* c, const half_t* A, int lda, const half_t* W, const half_t* bias, const half_t* residual, int ldr,
              half_t* C, int ldc, int M, int N, int K, int geglu = 0, int rpb = 0, int bstride = 0, int roff = 0, int ldw = 0,
-             const LnIn* ln = nullptr, float* stats_out = nullptr, int* stat_slots = nullptr, int act = 0);
+             const LnIn* ln = nullptr, float* stats_out = nullptr, int* stat_slots = nullptr, int act = 0, GnWant* gw = nullptr);
 void op_conv3(RunCtx* c, const half_t* X, int B, int Hs, int Ws, int Cin, const half_t* W, const half_t* bias, int Co,
-              int stride, int up, const half_t* rowvec, int rowvec_ld, const half_t* residual, half_t* Y, int pad_lo = 1, const half_t* X2 = nullptr, int Cin2 = 0, const half_t* X3 = nullptr, int Cin3 = 0);
+              int stride, int up, const half_t* rowvec, int rowvec_ld, const half_t* residual, half_t* Y, int pad_lo = 1, const half_t* X2 = nullptr, int Cin2 = 0, const half_t* X3 = nullptr, int Cin3 = 0,
+              const ConvGn* gn = nullptr, GnWant* gw = nullptr);
 void op_gn(RunCtx* c, const half_t* x, half_t* y, size_t g, size_t b, int B, int HW, int C, float eps, int silu, float* partial, const half_t* x2 = nullptr, int Ca = 0);
 void op_ln(RunCtx* c, const half_t* x, half_t* y, size_t g, size_t b, int M, int C);
 

@@ -13,6 +13,7 @@
 // v_mfma_f32_16x16x32_f16 with W as the first operand so each lane ends up holding 4 consecutive output
 // columns of one row (8-byte epilogue stores/loads along N).
 #include "gemm_kernel.h"
+#include "conv_halo_kernel.h"
 
 #include <algorithm>
 #include <atomic>
@@ -364,7 +365,7 @@ hipError_t ia2p_launch_splitk_reduce(const GemmArgs& a0, hipStream_t s) {
 // no counters (policy, no buffer for this stream, too many tiles) -> the slices leave their slabs and splitk_reduce_kernel finishes, launched here
 // (with_reduce) or by the caller, who learns which way it went through *combined.
 template <bool CONV>
-static hipError_t launch_any(const GemmArgs& a0, int v, hipStream_t s, bool with_reduce, int* combined) {
+static hipError_t launch_any(const GemmArgs& a0, int v, hipStream_t s, bool with_reduce, int* combined, int* ran) {
   if (a0.splitk > 1 && !a0.partial) return hipErrorInvalidValue;
   hipError_t e;
   if (v < 0 || v >= IA2P_GEMM_NVARIANT) return hipErrorInvalidValue;
@@ -374,6 +375,11 @@ static hipError_t launch_any(const GemmArgs& a0, int v, hipStream_t s, bool with
   if (a.splitk > 1 && ia2p_splitk_inkernel(a.M, a.N, a.splitk))
     a.sk_counters = ia2p_sk_counters(s, ((a.M + IA2P_GEMM_TILES[v].bm - 1) / IA2P_GEMM_TILES[v].bm) * ((a.N + IA2P_GEMM_TILES[v].bn - 1) / IA2P_GEMM_TILES[v].bn));
   if (combined) *combined = a.sk_counters != nullptr;
+  // halo-staged variants run their gathered twin at a site they do not take (stride 2, ragged patches, more K slices than channel blocks): `ran` tells the caller which
+  // kernel the launch really was (its profile class must match the rocprofv3 trace)
+  const bool halo_site = CONV && ia2p_conv_halo_ok(a) && ia2p_conv_gn_ok(a) && a.splitk <= a.Cin / 64;
+  if (ran) *ran = ia2p_gemm_variant_ran(a, CONV, v);
+  if (a.gn.st0 && !(IA2P_GEMM_TILES[v].halo && halo_site)) return hipErrorInvalidValue;      // a GroupNorm-fused operand: the halo-staged kernel or nothing (callers ask ia2p_conv_gn_fusable first)
   switch (v) {
 #define IA2P_TILE_CASE(ID, BM_, BN_, ST_)                                                                                    \
   case ID:                                                                                                                   \
@@ -427,15 +433,15 @@ static hipError_t launch_any(const GemmArgs& a0, int v, hipStream_t s, bool with
       break;
     case 24:      // halo-staged convolution; a launch it does not take (linear layer, stride 2, ragged patches, more K slices than blocks of 64 channels) runs the same tile shape with the gathered operand
       static_assert(IA2P_GEMM_TILES[24].bm == 256 && IA2P_GEMM_TILES[24].bn == 160 && IA2P_GEMM_TILES[24].halo, "tile table");
-      e = (CONV && ia2p_conv_halo_ok(a) && a.splitk <= a.Cin / 64) ? launch_halo<160>(a, s) : launch_cfg<256, 160, 3, CONV, 4, 64, 1>(a, s);
+      e = halo_site ? launch_halo<160>(a, s) : launch_cfg<256, 160, 3, CONV, 4, 64, 1>(a, s);
       break;
     case 26:
       static_assert(IA2P_GEMM_TILES[26].bm == 256 && IA2P_GEMM_TILES[26].bn == 80 && IA2P_GEMM_TILES[26].halo, "tile table");
-      e = (CONV && ia2p_conv_halo_ok(a) && a.splitk <= a.Cin / 64) ? launch_halo<80>(a, s) : launch_cfg<128, 80, 2, CONV, 4, 64, 0, 1>(a, s);
+      e = halo_site ? launch_halo<80>(a, s) : launch_cfg<128, 80, 2, CONV, 4, 64, 0, 1>(a, s);
       break;
     case 25:
       static_assert(IA2P_GEMM_TILES[25].bm == 256 && IA2P_GEMM_TILES[25].bn == 128 && IA2P_GEMM_TILES[25].halo, "tile table");
-      e = (CONV && ia2p_conv_halo_ok(a) && a.splitk <= a.Cin / 64) ? launch_halo<128>(a, s) : launch_cfg<256, 128, 3, CONV, 4, 64, 1>(a, s);
+      e = halo_site ? launch_halo<128>(a, s) : launch_cfg<256, 128, 3, CONV, 4, 64, 1>(a, s);
       break;
 #undef IA2P_TILE_CASE
     // Measured and dropped in round 1 (tools/gemm_bench.py): 8-wave 256x128 (2- and 3-stage) and 256x320 at one
@@ -446,14 +452,24 @@ static hipError_t launch_any(const GemmArgs& a0, int v, hipStream_t s, bool with
   return ia2p_launch_splitk_reduce(a, s);
 }
 
+// the variant whose kernel a launch of plan variant v really is (a.splitk as the caller set it)
+int ia2p_gemm_variant_ran(const GemmArgs& a, bool conv, int v) {
+  if (v < 0 || v >= IA2P_GEMM_NVARIANT || !IA2P_GEMM_TILES[v].halo) return v;
+  const bool halo_site = conv && ia2p_conv_halo_ok(a) && ia2p_conv_gn_ok(a) && a.splitk <= a.Cin / 64;
+  return halo_site ? v : (v == 24 ? 18 : v == 25 ? 12 : 16);
+}
+// may this 3x3 site run GroupNorm-fused under plan (v, splitk)? (shape part of the answer: the statistics pointers may still be null -- dry pass)
+bool ia2p_conv_gn_fusable(const GemmArgs& a, int v, int splitk) {
+  return v >= 0 && v < IA2P_GEMM_NVARIANT && IA2P_GEMM_TILES[v].halo && ia2p_conv_halo_ok(a) && a.up == 0 && splitk <= a.Cin / 64;
+}
 // launch with an explicit tile variant (a.splitk / a.partial as the caller set them)
 // with_reduce = false: a K-split launch leaves its slabs for a separate ia2p_launch_splitk_reduce (the executor times the two apart)
-hipError_t ia2p_launch_gemm_variant(const GemmArgs& a, bool conv, int variant, hipStream_t s, bool with_reduce, int* combined) {
-  return conv ? launch_any<true>(a, variant, s, with_reduce, combined) : launch_any<false>(a, variant, s, with_reduce, combined);
+hipError_t ia2p_launch_gemm_variant(const GemmArgs& a, bool conv, int variant, hipStream_t s, bool with_reduce, int* combined, int* ran) {
+  return conv ? launch_any<true>(a, variant, s, with_reduce, combined, ran) : launch_any<false>(a, variant, s, with_reduce, combined, ran);
 }
 // *picked (optional) receives the variant id. a.splitk / a.partial must follow ia2p_gemm_plan (the caller owns the slabs).
 hipError_t ia2p_launch_gemm(const GemmArgs& a, bool conv, hipStream_t s, int* picked, int* combined) {
   const GemmPlan pl = ia2p_gemm_plan(a.M, a.N, a.K, conv, a.geglu != 0);
   if (picked) *picked = pl.variant;
-  return ia2p_launch_gemm_variant(a, conv, pl.variant, s, true, combined);
+  return ia2p_launch_gemm_variant(a, conv, pl.variant, s, true, combined, nullptr);
 }

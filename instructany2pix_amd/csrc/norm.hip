@@ -13,6 +13,7 @@
 //          derives per-channel scale/shift once, then streams its rows: y = silu(x*scale + shift).
 // Algorithmic traffic: read x twice (second read normally served by L2 / Infinity Cache), write y once.
 #include "common.h"
+#include "gn_fold.h"
 
 #include <cstdlib>
 
@@ -348,6 +349,134 @@ hipError_t ia2p_launch_groupnorm(const half_t* x, int ldx, half_t* y, int ldy, c
   } else {
     hipLaunchKernelGGL(gn_stats_kernel<2>, grid, block, sm1, s, a.x, a.y, a.gamma, a.beta, a.partial, a.B, a.HW, a.C, a.G, a.chunks, a.rows, a.arows, a.ldx, a.ldy, a.eps, a.silu, a.x2, a.ldx2, a.Ca);
     hipLaunchKernelGGL(gn_apply_kernel<2>, agrid, block, sm2, s, a.x, a.y, a.gamma, a.beta, a.partial, a.B, a.HW, a.C, a.G, a.chunks, a.rows, a.arows, a.ldx, a.ldy, a.eps, a.silu | wtf, a.x2, a.ldx2, a.Ca);
+  }
+  return hipGetLastError();
+}
+
+// ---- GroupNorm from producer-side column sums (round 5, gn_fold.h) -----------------------------------------------------------------------------------------
+// gn_colstats_kernel: the canonical statistics of a tensor whose producer did not emit them (conv_in's output; a launch finished by splitk_reduce_kernel; tiles of
+// fewer than 16 rows): out[(slot * C + c)] = {sum, sum of squares} (fp64) of channel c over the `rows` rows of slot `slot` -- fp32 over aligned runs of 16 rows in row
+// order, fp64 from there on: the very numbers a GEMM / conv epilogue writes for the same tensor (tests/test_ops_gpu.py compares them to the bit).
+// Block = (slot, span of 64 channels): thread (chunk tx < 8, slice ty < 32) takes the runs ty, ty + 32, ...; the slices meet in LDS.
+__global__ __launch_bounds__(256) void gn_colstats_kernel(const half_t* x, int ldx, int M, int C, int rows, double* out) {
+  __shared__ double2 red[32][64];
+  const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
+  const int slot = blockIdx.x, c0 = blockIdx.y * 64 + tx * 8;
+  const int r0 = slot * rows, nseg = rows / 16;
+  double ds[8], dq[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { ds[e] = 0.0; dq[e] = 0.0; }
+  for (int sg = ty; sg < nseg; sg += 32) {
+    h8 d[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) d[i] = *(const h8*)(x + (size_t)min(r0 + sg * 16 + i, M - 1) * ldx + c0);      // (clamped, never branched around)
+    float a[8], b[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a[e] = 0.f; b[e] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (r0 + sg * 16 + i < M) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gn_seg16_add((float)d[i][e], a[e], b[e]);
+      }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ds[e] += (double)a[e]; dq[e] += (double)b[e]; }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[ty][tx * 8 + e] = make_double2(ds[e], dq[e]);
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    double a = 0.0, q = 0.0;
+    const int nsl = nseg < 32 ? nseg : 32;
+    for (int t = 0; t < nsl; ++t) { const double2 v = red[t][threadIdx.x]; a += v.x; q += v.y; }
+    ((double2*)out)[(size_t)slot * C + blockIdx.y * 64 + threadIdx.x] = make_double2(a, q);
+  }
+}
+hipError_t ia2p_launch_gn_colstats(const half_t* x, int ldx, int M, int C, int rows, double* out, hipStream_t s) {
+  if (C % 64 || ldx % 8 || rows < 16 || rows % 16 || M < 1 || M % rows) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(gn_colstats_kernel, dim3(M / rows, C / 64), dim3(256), 0, s, x, ldx, M, C, rows, out);
+  return hipGetLastError();
+}
+
+// gn_apply_stats_kernel: y = [silu](GroupNorm(x)) with the statistics folded from producer-side column sums -- the stand-alone form of what the GroupNorm-fused
+// convolution does to its halo images (same fold, same scale / shift, same element formula: gn_fold.h), for consumers that are not halo-staged convolutions and as
+// the unfused twin the fused kernel is tested against (bit-identical). x: one tensor or two that are never concatenated ([x0: C0 channels | x1: C - C0]).
+// Block = (row block, image): every block folds the image's sums itself (C x slots loads out of L2), then streams its rows with a fixed thread -> channel map.
+template <int V>
+__global__ __launch_bounds__(256) void gn_apply_stats_kernel(const half_t* x0, int ld0, const half_t* x1, int ld1, half_t* y, int ldy, int HW, int C, int arows, int wt,
+                                                                 const GemmArgs::GnIn g) {
+  extern __shared__ __attribute__((aligned(16))) char gsm[];
+  double2* chs = (double2*)gsm;                        // [C]
+  float2* gstat = (float2*)(gsm + (size_t)C * 16);     // [groups]
+  const int b = blockIdx.y;
+  gn_channel_sums(g, C, HW, b, threadIdx.x, 256, chs);
+  __syncthreads();
+  gn_group_stats(g, HW, threadIdx.x, chs, gstat);
+  __syncthreads();
+  const int nvec = C >> 3, TX = nvec / V, TY = 256 / TX;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  if (ty >= TY) return;
+  float sc[V][8], sh[V][8];
+  const half_t* src[V]; int sld[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) {
+    const int c0 = (tx + v * TX) * 8;
+    const h8 ga = *(const h8*)(g.gamma + c0), be = *(const h8*)(g.beta + c0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float2 ab = gn_scale_shift(gstat[(c0 + e) / g.gs], (float)ga[e], (float)be[e]);
+      sc[v][e] = ab.x; sh[v][e] = ab.y;
+    }
+    const bool second = x1 && c0 >= g.C0;
+    src[v] = second ? x1 + (size_t)b * HW * ld1 + (c0 - g.C0) : x0 + (size_t)b * HW * ld0 + c0;
+    sld[v] = second ? ld1 : ld0;
+  }
+  const int r0 = blockIdx.x * arows, r1 = min(r0 + arows, HW);
+  half_t* obase = y + (size_t)b * HW * ldy;
+  const __amdgpu_buffer_rsrc_t y_rsrc = wt_rsrc((void*)obase, (size_t)HW * ldy * 2);
+  for (int r = r0 + ty; r < r1; r += 4 * TY) {         // 4 rows in flight per thread
+    h8 d[4][V];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int v = 0; v < V; ++v) d[u][v] = *(const h8*)(src[v] + (size_t)min(r + u * TY, r1 - 1) * sld[v]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (r + u * TY < r1) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          h8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (half_t)gn_apply_f((float)d[u][v][e], sc[v][e], sh[v][e], g.silu != 0);
+          if (wt) store16_wt(y_rsrc, ((size_t)(r + u * TY) * ldy + (tx + v * TX) * 8) * 2, o);
+          else *(h8*)(obase + (size_t)(r + u * TY) * ldy + (tx + v * TX) * 8) = o;
+        }
+      }
+  }
+}
+// g: st0 / rows0 (/ st1 / rows1 / C0), gamma, beta, gs, groups, eps, silu as in GemmArgs::GnIn; x1 == nullptr: one source of C channels
+hipError_t ia2p_launch_gn_apply_stats(const half_t* x0, int ld0, const half_t* x1, int ld1, half_t* y, int ldy, int B, int HW, int C, const GemmArgs::GnIn& g, hipStream_t s) {
+  const int C1 = C - g.C0;
+  if (!g.st0 || !g.gamma || !g.beta || C % 8 || g.groups < 1 || g.groups > 64 || g.gs * g.groups != C || g.C0 < 8 || g.C0 % 8 || C1 < 0 || (C1 > 0) != (x1 != nullptr) || (C1 > 0 && (!g.st1 || g.rows1 < 1 || HW % g.rows1)) ||
+      g.rows0 < 1 || HW % g.rows0 || ld0 % 8 || ldy % 8 || (x1 && ld1 % 8))
+    return hipErrorInvalidValue;
+  const int nvec = C / 8;
+  int V = 1;
+  while (nvec / V > 256 || nvec % V) ++V;
+  if (V > 2) return hipErrorInvalidValue;
+  const int TX = nvec / V, TY = 256 / TX;
+  int ablocks = 1;
+  while (B * ablocks < 2048 && HW / (ablocks * 2) >= 4 * TY) ablocks *= 2;
+  const int arows = (HW + ablocks - 1) / ablocks;
+  ablocks = (HW + arows - 1) / arows;
+  const size_t sm = (size_t)C * 16 + 64 * sizeof(float2);
+  const int wt = ((ia2p_wt_mask() & 4) && (size_t)HW * ldy * 2 < (size_t)0x7ffffff0) ? 1 : 0;
+  if (V == 1) {
+    if (sm > 48 * 1024 && hipFuncSetAttribute((const void*)gn_apply_stats_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) return hipGetLastError();
+    hipLaunchKernelGGL(gn_apply_stats_kernel<1>, dim3(ablocks, B), dim3(256), sm, s, x0, ld0, x1, ld1, y, ldy, HW, C, arows, wt, g);
+  } else {
+    if (sm > 48 * 1024 && hipFuncSetAttribute((const void*)gn_apply_stats_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm) != hipSuccess) return hipGetLastError();
+    hipLaunchKernelGGL(gn_apply_stats_kernel<2>, dim3(ablocks, B), dim3(256), sm, s, x0, ld0, x1, ld1, y, ldy, HW, C, arows, wt, g);
   }
   return hipGetLastError();
 }

@@ -241,6 +241,16 @@ class HipUNet2DConditionModel:
             _ffi.check(self._lib.ia2p_unet_forward(*args), self._ctx)
         return (out,) if not return_dict else SimpleNamespace(sample=out)
 
+    def set_gn_fuse(self, mode: int):
+        """GroupNorm + SiLU of the ResnetBlock2Ds: 1 (default) inside the halo-staged 3x3 convolutions that consume them (statistics from the producers' epilogues),
+        0 as GroupNorm launches of their own, 2 the fused path's unfused twin (same statistics, same bits as 1; tests). `ia2p_set_gn_fuse`."""
+        _ffi.check(self._lib.ia2p_set_gn_fuse(self._ctx, int(mode)), self._ctx)
+
+    def invalidate_context_kv(self):
+        """Forget the cached context K/V projections (a new request begins: the next evaluation projects its context again); the buffer is kept."""
+        if self._kv is not None:
+            self._kv = (None, -1, None, -1, self._kv[4], self._kv[5])
+
     def _context_kv(self, ctx_in, ctx, B, L, ws):
         """K/V projections of `ctx` (ia2p_project_context), cached while the same unmodified tensor object arrives with the same weights
         and IP-Adapter topology. The source tensor is kept alive so its address cannot be handed to another tensor."""
@@ -277,6 +287,26 @@ class HipUNet2DConditionModel:
             n, ms, fl, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
             _ffi.check(self._lib.ia2p_profile_read_region(self._ctx, r, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)), self._ctx)
             res[name] = dict(launches=n.value, ms=ms.value, flops=fl.value, bytes=by.value)
+        return res
+
+    def profile_read_roles(self):
+        """{layer role: dict(launches, ms, flops, bytes)} summed since profile(True): keyed by the executor's call site (FF-in, FF-out, QKV + self-attention,
+        out-projections, to_q + cross-attention, 3x3 convolutions, GroupNorm, ...), whatever kernel instantiation the plan table picked."""
+        res = {}
+        for r in range(self._lib.ia2p_profile_roles()):
+            name = C.create_string_buffer(128)
+            n, ms, fl, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
+            _ffi.check(self._lib.ia2p_profile_read_role(self._ctx, r, name, 128, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)), self._ctx)
+            if n.value:
+                kernels = {}
+                for k in range(self._lib.ia2p_profile_classes()):
+                    kn, kms = C.c_int64(), C.c_double()
+                    _ffi.check(self._lib.ia2p_profile_read_role_class(self._ctx, r, k, C.byref(kn), C.byref(kms)), self._ctx)
+                    if kn.value:
+                        kname = C.create_string_buffer(96)
+                        _ffi.check(self._lib.ia2p_profile_read(self._ctx, k, kname, 96, None, None, None, None), self._ctx)
+                        kernels[kname.value.decode()] = dict(launches=kn.value, ms=kms.value)
+                res[name.value.decode()] = dict(launches=n.value, ms=ms.value, flops=fl.value, bytes=by.value, kernels=kernels)
         return res
 
     def profile_read(self):

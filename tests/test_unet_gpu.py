@@ -462,3 +462,38 @@ def test_two_contexts_on_two_streams_with_k_splits(tiny_models):
                 assert torch.equal(outs[i], alone[i]), (rep, i)
     finally:
         L.ia2p_debug_set_gemm_splitk(-1)
+
+
+@pytest.mark.parametrize("tile", [24, 25, 26])
+def test_groupnorm_fused_into_the_convolutions_agrees_with_its_twin_and_the_oracle(tiny_models, tile):
+    """Round 5: norm1 / norm2 + SiLU of every ResnetBlock2D run INSIDE the halo-staged convolution that consumes them (statistics from the producers' epilogues,
+    conv_halo_kernel.h GN = 1) wherever the plan gives the site a halo-staged tile -- forced here for every site (the cost model alone never picks one). Mode 2 runs
+    the unfused twin on the same statistics (gn_apply_stats_kernel + the plain convolution): the same bits. Mode 0 is round 4's path (GroupNorm launches with their
+    own statistics): same function, other summation order. All three within the oracle tolerance; the fused mode launches fewer GroupNorm kernels."""
+    from instructany2pix_amd import _ffi
+    cfg, sd, ipsd, hip, oracle = tiny_models
+    _install_ip(hip, cfg, ipsd, 0.8)
+    x, ctx, te, tid = (t.to(DEV) for t in _inputs(cfg, 2, 32, 32, 81, seed=77))
+    kw = dict(encoder_hidden_states=ctx, added_cond_kwargs=dict(text_embeds=te, time_ids=tid))
+    outs, gn_launches = {}, {}
+    _ffi.lib().ia2p_debug_set_gemm_tile(tile)
+    try:
+        for mode in (0, 1, 2):
+            hip.set_gn_fuse(mode)
+            hip.profile(True)
+            outs[mode] = hip(x, 481, **kw)[0].clone()
+            torch.cuda.synchronize()
+            roles = hip.profile_read_roles()
+            hip.profile(False)
+            gn_launches[mode] = sum(v["launches"] for k, v in roles.items() if k.startswith("groupnorm"))
+    finally:
+        _ffi.lib().ia2p_debug_set_gemm_tile(-1)
+        hip.set_gn_fuse(1)
+    with torch.no_grad():
+        ref = oracle.build_unet(cfg, sd, ipsd, ip_scale=0.8)(x.float().cpu(), 481, ctx.float().cpu(), added_cond_kwargs=dict(text_embeds=te.float().cpu(), time_ids=tid.float().cpu()))[0]
+    for mode in (0, 1, 2):
+        assert torch.isfinite(outs[mode]).all()
+        assert rel_l2(outs[mode], ref) < 5e-3, (mode, rel_l2(outs[mode], ref))
+    assert torch.equal(outs[1], outs[2]), float((outs[1].float() - outs[2].float()).abs().max())
+    assert rel_l2(outs[1], outs[0]) < 3e-3
+    assert gn_launches[1] < gn_launches[0], gn_launches

@@ -1,5 +1,6 @@
 """GroupNorm(+SiLU) on the step's own shapes (cfg 3), back to back, us per call (stats + apply launches) and algorithmic GB/s.
-Tuning hooks: IA2P_GN_STATS_WGS / IA2P_GN_APPLY_WGS (workgroup targets of the two launches)."""
+Tuning hook: IA2P_GN_STATS_WGS (workgroup target of the statistics launch) -- an EXPERIMENT knob, read only by libraries built with
+IA2P_EXTRA_FLAGS=-DIA2P_EXPERIMENTS (the product build ignores it and says so on stderr); the apply launch's target became a constant in round 4."""
 import ctypes as C
 import os
 import sys
