@@ -269,6 +269,7 @@ void ia2p_debug_set_gemm_splitk(int splitk);  /* -1 auto (tests / tuning; engine
 void ia2p_debug_invalidate_splitk_counters(void);
 int ia2p_debug_fill_splitk_counters(void* stream, int value);   /* tests: every ticket of the stream's buffer := value, on the stream (non-zero = what a dead launch leaves); 0 / -1 */
 void ia2p_debug_set_splitk_inkernel(long long bytes); /* slab-set size (splitk*M*N*4) up to which a K split combines inside the GEMM launch; < 0: IA2P_SPLITK_INKERNEL / default (tests, A/B runs) */
+void ia2p_debug_set_gn_plan(int mode);         /* GroupNorm fused into its convolution: -1 as the measured plan of the site says (default), 1 wherever the site's tile is a halo-staged one, 0 nowhere (tests) */
 void ia2p_debug_set_gemm_tile(int variant);   /* -1 auto; else index into IA2P_GEMM_TILES of csrc/common.h, 0..26 (tests / tuning) */
 /* fused to_q + cross-attention: contexts created AFTER this call fuse launches of at least `tiles` 128-query x head tiles (-1: the built-in 128). Tests only:
  * lets a tiny model take the fused path. */

@@ -135,6 +135,7 @@ SIGNATURES = {
     "ia2p_profile_read_region": (_I, [_P, _I, C.POINTER(_I64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ia2p_profile_read_prefetch": (_I, [_P, _I, _P]),
     "ia2p_set_gn_fuse": (_I, [_P, _I]),
+    "ia2p_debug_set_gn_plan": (None, [_I]),
     "ia2p_gn_colstats": (_I, [_P, _P, _I, _I, _I, _P]),
     "ia2p_gn_apply_stats": (_I, [_P, _P, _I, _P, _I, _P, _I, _P, _I, _P, _P, _P, _I, _I, _I, _F, _I]),
     "ia2p_conv3x3_gn": (_I, [_P, C.POINTER(ConvGnC), _P]),

@@ -207,7 +207,7 @@ static inline bool ia2p_conv_halo_ok(const GemmArgs& a) {
          ia2p_fits_buffer(a.M, a.lda) && ia2p_fits_buffer(a.N, a.ldw) && (!a.A2 || ia2p_fits_buffer(a.M, a.lda2)) && (!a.A3 || ia2p_fits_buffer(a.M, a.lda3));
 }
 
-struct GemmPlan { int variant; int splitk; };
+struct GemmPlan { int variant; int splitk; int gn = 0; };      // gn = 1 (measured plans of 3x3 sites behind a GroupNorm only): the norm runs INSIDE the halo-staged convolution (conv_halo_kernel.h GN = 1)
 // tile variants of gemm_f16_kernel (id = index): {BM, BN, LDS ring stages}; 4 waves (2 x 2), BK = 64
 struct GemmTile { int bm, bn, stages, pp, halo; };      // pp = 1: 8-wave ping-pong schedule (one workgroup per CU); pp = 2: 8-wave 8-phase schedule; halo = 1: halo-staged 3x3 convolution only (conv_halo_f16_kernel)
 constexpr int IA2P_GEMM_NVARIANT = 27;

@@ -38,28 +38,14 @@ template <int BN, int GN> struct HaloSmem {
   static_assert(SMEM <= 160 * 1024, "halo-staged tile exceeds the CU's LDS");
 };
 
-// the normalisation of an image piece (~60 VALU slots, a third of them transcendental) goes BESIDE the NM MFMAs of a tap: one sched_group_barrier pipeline per tap --
-// the piece's LDS reads, a few MFMAs to cover their latency, then every MFMA followed by its share of the VALU work, the LDS write last. (Left to the scheduler the
-// whole piece sits in front of the first MFMA: the matrix pipe idles through ~500 cycles of VALU issue, six taps out of nine.)
-#ifndef IA2P_GN_VALU_SLOTS
-#define IA2P_GN_VALU_SLOTS 60      // VALU instructions of a piece the pipeline places (build-time knob for A/B builds)
-#endif
-template <int I, int N, int Q, int R> struct GnPipe {
-  static __device__ __forceinline__ void run() {
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-    if constexpr ((I < R ? Q + 1 : Q) > 0) __builtin_amdgcn_sched_group_barrier(0x002, I < R ? Q + 1 : Q, 0);
-    if constexpr (I + 1 < N) GnPipe<I + 1, N, Q, R>::run();
-  }
-};
-template <int NM> __device__ __forceinline__ void gn_pipeline() {
-#ifndef IA2P_GN_NO_PIPE
-  constexpr int LEAD = 4, NP = NM - LEAD;      // MFMAs ahead of the first VALU (the piece's LDS reads are in flight), MFMAs that carry VALU work
-  __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
-  __builtin_amdgcn_sched_group_barrier(0x008, LEAD, 0);
-  GnPipe<0, NP, IA2P_GN_VALU_SLOTS / NP, IA2P_GN_VALU_SLOTS % NP>::run();
-  __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-#endif
-}
+// The normalisation of an image piece (8 elements per lane: fma, exp, 1 / (1 + e), product -- gn_fold.h's four steps) goes BESIDE the MFMAs of a tap, one step per MFMA in
+// program order: GN_OPS[k] = {step, element} placed behind MFMA LEAD + k, software-pipelined over the elements (a step's operand was produced three MFMAs earlier). Left
+// to the scheduler the whole piece sits in front of the first MFMA (the matrix pipe idles through ~500 cycles of VALU issue, six taps out of nine); a
+// sched_group_barrier pipeline interleaves it but re-orders the MFMAs into back-to-back pairs on ONE accumulator (measured: +3 us per block of 64 channels).
+struct GnOp { int step, e; };
+constexpr int GN_NOPS = 32;
+constexpr GnOp GN_OPS[GN_NOPS] = {{0, 0}, {0, 1}, {0, 2}, {1, 0}, {0, 3}, {1, 1}, {2, 0}, {0, 4}, {1, 2}, {2, 1}, {3, 0}, {0, 5}, {1, 3}, {2, 2}, {3, 1}, {0, 6},
+                                  {1, 4}, {2, 3}, {3, 2}, {0, 7}, {1, 5}, {2, 4}, {3, 3}, {1, 6}, {2, 5}, {3, 4}, {1, 7}, {2, 6}, {3, 5}, {2, 7}, {3, 6}, {3, 7}};
 
 template <int BN, int GN>
 __device__ __forceinline__ void conv_halo_tile_body(const half_t* hA, const half_t* hW, int hM, int hN, int hK, int hlda, int hldw, int hsplitk, int hgroup_w, const GemmArgs& p) {
@@ -279,6 +265,76 @@ __device__ __forceinline__ void conv_halo_tile_body(const half_t* hA, const half
       *(h8*)q = o;                                                       // (chunks outside the image / pad chunks: 0 * 0 + 0 -> silu(0) = 0: they stay zero, the reference pads the activated tensor)
     }
   };
+  // piece SL of image buffer `buf` and its scale / shift entries, LDS -> registers: issued in the wave's READ half-step behind the fragment reads, where the barrier's
+  // own lgkmcnt(0) retires them -- read in the multiply half-step they would stall the in-order issue of the MFMAs behind them for a whole LDS round trip under load
+  h8 gn_v = {0, 0, 0, 0, 0, 0, 0, 0};
+  f4 gn_a0 = {0.f, 0.f, 0.f, 0.f}, gn_a1 = gn_a0, gn_b0 = gn_a0, gn_b1 = gn_a0;
+  auto gn_fetch = [&](auto sl_tag, int buf) {
+    if constexpr (GN != 0) {
+      constexpr int SL = decltype(sl_tag)::value;
+#if !(defined(IA2P_GN_ABL) && (IA2P_GN_ABL & 1))      // (ablation builds, tools/conv_gn_probe.py: timing only, wrong results)
+      gn_v = *(const h8*)(smem + gn_qoff + buf * H_BYTES + SL * NWAVE * 1024);
+      const char* tb = smem + gn_toff[SL];
+      gn_a0 = *(const f4*)tb; gn_a1 = *(const f4*)(tb + 128); gn_b0 = *(const f4*)(tb + 256); gn_b1 = *(const f4*)(tb + 384);
+#endif
+    }
+  };
+  // the MFMAs of a tap with the normalisation of the fetched piece (SL of image buffer `buf`) between them (same MFMA order as mm())
+  auto mm_gn = [&](auto sl_tag, int buf) {
+    if constexpr (GN != 0) {
+      constexpr int SL = decltype(sl_tag)::value;
+#ifndef IA2P_GN_LEAD
+#define IA2P_GN_LEAD 4        // MFMAs ahead of the first step; IA2P_GN_EVERY: a step behind every N-th MFMA (build-time knobs for A/B builds: tools/gn_ablation.sh)
+#endif
+#ifndef IA2P_GN_EVERY
+#define IA2P_GN_EVERY 1
+#endif
+      constexpr int NM = KSUB * MR * NR, LEAD = NM >= GN_NOPS + 4 ? (IA2P_GN_LEAD < NM ? IA2P_GN_LEAD : NM) : 2, STRIDE = NM - LEAD >= GN_NOPS ? 1 : 2;      // (tiles with fewer MFMAs than steps take two steps per MFMA)
+      char* q = smem + gn_qoff + buf * H_BYTES + SL * NWAVE * 1024;
+      const h8 v = gn_v;
+      const f4 a0 = gn_a0, a1 = gn_a1, b0 = gn_b0, b1 = gn_b1;
+      float gy[8], gt[8];
+      h8 o;
+      auto op = [&](int k) {
+        if (k < 0 || k >= GN_NOPS) return;
+#if defined(IA2P_GN_ABL) && (IA2P_GN_ABL & 2)
+        if (GN_OPS[k].step == 3) o[GN_OPS[k].e] = v[GN_OPS[k].e];
+        return;
+#endif
+        // (every step's result passes through an empty volatile asm: such statements keep their program order among themselves and the MFMA statements, which pins the
+        //  step between ITS two MFMAs -- the instruction selector's own list scheduler would otherwise sink all of them to their use, the LDS write behind the last MFMA)
+        const int st = GN_OPS[k].step, e = GN_OPS[k].e;
+        if (st == 0) { gy[e] = gn_step_y((float)v[e], e < 4 ? a0[e & 3] : a1[e & 3], e < 4 ? b0[e & 3] : b1[e & 3]); asm volatile("" : "+v"(gy[e])); }
+        else if (st == 1) { gt[e] = gn_step_e(gy[e]); asm volatile("" : "+v"(gt[e])); }
+        else if (st == 2) { gt[e] = gn_step_r(gt[e]); asm volatile("" : "+v"(gt[e])); }
+        else { float pr = gn_step_o(gy[e], gt[e]); asm volatile("" : "+v"(pr)); o[e] = (half_t)pr; }
+      };
+      int m = 0;
+#pragma unroll
+      for (int kk = 0; kk < KSUB; ++kk)
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+          for (int j = 0; j < NR; ++j) {
+            // (the MFMA as a volatile asm statement: statements of that kind keep their program order and nothing is scheduled across them, so the steps written between
+            //  two MFMAs ARE issued between them -- the instruction itself is the one mm() emits)
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(wf[kk][j]), "v"(af[kk][i]));
+            if (m >= LEAD && (m - LEAD) % IA2P_GN_EVERY == 0) {
+#pragma unroll
+              for (int u = 0; u < STRIDE; ++u) op((m - LEAD) / IA2P_GN_EVERY * STRIDE + u);
+            }
+            ++m;
+          }
+#pragma unroll
+      for (int k = (NM - LEAD + IA2P_GN_EVERY - 1) / IA2P_GN_EVERY * STRIDE; k < GN_NOPS; ++k) op(k);      // (whatever did not fit beside the MFMAs)
+#if defined(IA2P_GN_ABL) && (IA2P_GN_ABL & 4)
+      asm volatile("" :: "v"(o));
+      (void)q;
+#else
+      *(h8*)q = o;                                                       // (chunks outside the image / pad chunks: 0 * 0 + 0 -> silu(0) = 0: they stay zero, the reference pads the activated tensor)
+#endif
+    }
+  };
   if (blk1 > blk0) {
     // prologue: the first block's image, the weights of its first two tiles
     if (GN && blk0 >= nb0) {      // (a K slice that starts inside the second source)
@@ -316,12 +372,12 @@ __device__ __forceinline__ void conv_halo_tile_body(const half_t* hA, const half
         if constexpr (GN != 0 && TAP == 0) gn_build_tbl(blk + 1);      // table of the NEXT block (its gamma / beta were loaded at tap 8 of the block before: landed by this wait); written before mid() retires it
         if constexpr (GN != 0 && TAP == 8) gn_load_gb(blk + 2);        // (behind the counted wait, ahead of this interval's DMA pieces)
         rd_tap(tap_tag);
+        if constexpr (GN != 0 && TAP >= 2 && TAP <= 7) gn_fetch(std::integral_constant<int, (TAP >= 2 && TAP <= 7) ? TAP - 2 : 0>{}, (blk + 1) & 1);      // (this wave's own piece TAP - 2: landed by this tap's counted wait)
         __builtin_amdgcn_sched_barrier(0);
         issue_tap(tap_tag, blk);
         mid();
-        if constexpr (GN != 0 && TAP >= 2 && TAP <= 7) gn_norm_piece(std::integral_constant<int, (TAP >= 2 && TAP <= 7) ? TAP - 2 : 0>{}, (blk + 1) & 1);      // beside this tap's MFMAs
-        mm();
-        if constexpr (GN != 0 && TAP >= 2 && TAP <= 7) gn_pipeline<KSUB * MR * NR>();
+        if constexpr (GN != 0 && TAP >= 2 && TAP <= 7) mm_gn(std::integral_constant<int, (TAP >= 2 && TAP <= 7) ? TAP - 2 : 0>{}, (blk + 1) & 1);      // piece TAP - 2 of the next image, beside this tap's MFMAs
+        else mm();
       };
       for (int blk = blk0; blk < blk1; ++blk) {
         a_rd = a_rd0 + (blk & 1) * H_BYTES;
@@ -335,11 +391,11 @@ __device__ __forceinline__ void conv_halo_tile_body(const half_t* hA, const half
       auto body = [&](auto tap_tag, int blk) {
         constexpr int TAP = decltype(tap_tag)::value;
         top(std::integral_constant<int, LPS1 + (TAP >= 1 && TAP <= H_SLOTS ? 1 : 0)>{});
-        if constexpr (GN != 0 && TAP >= 2 && TAP <= 7) gn_norm_piece(std::integral_constant<int, (TAP >= 2 && TAP <= 7) ? TAP - 2 : 0>{}, (blk + 1) & 1);      // beside the MFMAs of the tap before
-        if (TAP != 0 || !first) mm();
-        if constexpr (GN != 0 && TAP >= 2 && TAP <= 7) gn_pipeline<KSUB * MR * NR>();
+        if constexpr (GN != 0 && TAP >= 3 && TAP <= 8) mm_gn(std::integral_constant<int, (TAP >= 3 && TAP <= 8) ? TAP - 3 : 0>{}, (blk + 1) & 1);      // the piece fetched in the read half-step before, beside the MFMAs of the tap before
+        else if (TAP != 0 || !first) mm();
         mid();
         rd_tap(tap_tag);
+        if constexpr (GN != 0 && TAP >= 2 && TAP <= 7) gn_fetch(std::integral_constant<int, (TAP >= 2 && TAP <= 7) ? TAP - 2 : 0>{}, (blk + 1) & 1);      // (own piece TAP - 2: issued in tap TAP - 2's read half-step, landed by this tap's counted wait)
         __builtin_amdgcn_sched_barrier(0);
         issue_tap(tap_tag, blk);
       };

@@ -351,6 +351,10 @@ static void set_prefetch(RunCtx* c, GemmArgs& a, const half_t* W, size_t bytes) 
 // the previous launch), not in L2. The prefetch workgroups of the site are part of every candidate launch. The fastest
 // goes into the plan table. Re-running a site is harmless: outputs are rewritten (in-place residuals only drift).
 static void tune_site(RunCtx* c, const GemmArgs& a, bool conv) {
+  // (what the caller left for THIS site -- taken and cleared before anything else: the pointer refers to the caller's frame)
+  const GemmArgs* fa = c->tune_fused;
+  const float gn_ms = (float)c->tune_gn_ms;
+  c->tune_fused = nullptr; c->tune_gn_ms = 0.0;
   if (ia2p_plan_lookup(a.M, a.N, a.K, conv, a.geglu != 0, nullptr)) return;
   std::vector<GemmPlan> cands;
   ia2p_gemm_candidates(a.M, a.N, a.K, conv, a.geglu != 0, c->tune_slab_bytes, ia2p_exp_env("IA2P_TUNE_SLACK") ? atof(ia2p_exp_env("IA2P_TUNE_SLACK")) : 1.7, &cands);
@@ -393,6 +397,46 @@ static void tune_site(RunCtx* c, const GemmArgs& a, bool conv) {
   GemmPlan best{-1, 1};
   for (size_t i = 0; i < cands.size() && best.variant < 0; ++i)
     if (ok[i] && best_ms[i] <= 1.02f * fastest) best = cands[i];
+  // A site behind a GroupNorm (the caller left c->tune_fused: the site's GroupNorm-FUSED form -- raw operand, producer statistics -- and c->tune_gn_ms: what the
+  // GroupNorm launch in front of it just took): the fused launch on every halo-staged tile / K split it may run on is timed the same way, and taken when it beats
+  // GroupNorm launch + best plain plan. The fused kernel normalises every halo image in LDS beside its MFMAs (+15 ... 25 % per launch): it pays where the norm's
+  // launch is expensive against the convolution (few input channels on the large maps), not everywhere.
+  if (fa && conv && best.variant >= 0 && gn_ms > 0.f) {
+    std::vector<GemmPlan> fc;
+    ia2p_conv_gn_candidates(*fa, c->tune_slab_bytes, &fc);
+    std::vector<float> fms(fc.size(), 1e30f);
+    hipEvent_t f0 = get_event(c), f1 = get_event(c);
+    for (int r = -1; r < c->tune_reps; ++r)
+      for (size_t i = 0; i < fc.size(); ++i) {
+        GemmArgs b = *fa;
+        b.splitk = fc[i].splitk > 1 ? fc[i].splitk : 0;
+        b.partial = fc[i].splitk > 1 ? (float*)c->tune_scratch : nullptr;
+        bool good = hipMemsetAsync(c->tune_scratch + c->tune_slab_bytes, r & 1, c->tune_flush_bytes, c->stream) == hipSuccess;
+        const size_t a_bytes = (size_t)(fa->M / std::max(1, fa->Ho * fa->Wo)) * fa->Hs * fa->Ws * fa->gn.C0 * sizeof(half_t);
+        good = good && ia2p_launch_touch(fa->A, std::min<size_t>(a_bytes, (size_t)64 << 20), (unsigned*)c->tune_scratch, c->stream) == hipSuccess;
+        if (fa->A1b) good = good && ia2p_launch_touch(fa->A1b, std::min<size_t>((size_t)fa->M * fa->lda1b * sizeof(half_t), (size_t)64 << 20), (unsigned*)c->tune_scratch, c->stream) == hipSuccess;
+        if (fa->residual) good = good && ia2p_launch_touch(fa->residual, std::min<size_t>((size_t)fa->M * fa->ldr * sizeof(half_t), (size_t)64 << 20), (unsigned*)c->tune_scratch, c->stream) == hipSuccess;
+        good = good && hipEventRecord(f0, c->stream) == hipSuccess;
+        good = good && ia2p_launch_gemm_variant(b, true, fc[i].variant, c->stream) == hipSuccess;
+        good = good && hipEventRecord(f1, c->stream) == hipSuccess && hipEventSynchronize(f1) == hipSuccess;
+        float ms = 0.f;
+        good = good && hipEventElapsedTime(&ms, f0, f1) == hipSuccess;
+        if (!good) { (void)hipGetLastError(); fms[i] = -1.f; continue; }
+        if (r >= 0 && fms[i] >= 0.f && ms < fms[i]) fms[i] = ms;
+      }
+    c->evpool.push_back(f0); c->evpool.push_back(f1);
+    float unfused = 1e30f;
+    for (size_t i = 0; i < cands.size(); ++i)
+      if (ok[i]) unfused = std::min(unfused, best_ms[i]);
+    unfused += gn_ms;
+    int bi = -1;
+    for (size_t i = 0; i < fc.size(); ++i) {
+      if (tune_log && fms[i] >= 0.f) fprintf(stderr, "[ia2p tune] %d %d %d conv=1 FUSED groupnorm variant=%d splitk=%d us=%.2f (groupnorm launch %.2f us + best plain plan = %.2f us)\n", fa->M, fa->N, fa->K, fc[i].variant, fc[i].splitk,
+                                             1e3 * fms[i], 1e3 * gn_ms, 1e3 * unfused);
+      if (fms[i] >= 0.f && fms[i] < 1e29f && (bi < 0 || fms[i] < fms[bi])) bi = (int)i;
+    }
+    if (bi >= 0 && fms[bi] < 0.97f * unfused) best = fc[bi];      // (3 % margin: the fused form also pays for the statistics in its producers' epilogues)
+  }
   if (best.variant < 0) { fail(c, IA2P_ERR_HIP, "autotune: no candidate plan ran for %d x %d x %d", a.M, a.N, a.K); return; }
   ia2p_plan_set(a.M, a.N, a.K, conv, a.geglu != 0, best);
   ++c->tune_sites;
@@ -414,6 +458,7 @@ static int gn_epilogue_rows(const GemmArgs& a, bool conv, int variant, int split
 // gw != nullptr: the launch also leaves the GroupNorm statistics of its output (gn_fold.h) -- from its own epilogue when the tile allows, else from a gn_colstats_kernel pass
 static void run_gemm(RunCtx* c, GemmArgs& a, bool conv, const char* what, double flops, double bytes, int* stat_slots = nullptr, GnWant* gw = nullptr) {
   if (c->tuning && !c->dry && !c->failed) tune_site(c, a, conv);
+  c->tune_fused = nullptr; c->tune_gn_ms = 0.0;
   const GemmPlan pl = ia2p_gemm_plan(a.M, a.N, a.K, conv, a.geglu != 0);
   if (pl.variant < 0 || pl.variant >= IA2P_GEMM_NVARIANT) { fail(c, IA2P_ERR_INVALID, "%s: tile variant %d out of range", what, pl.variant); return; }
   if (c->tuning && !c->dry && pl.splitk > 1 && (size_t)pl.splitk * a.M * a.N * sizeof(float) > c->tune_slab_bytes) {
@@ -429,15 +474,13 @@ static void run_gemm(RunCtx* c, GemmArgs& a, bool conv, const char* what, double
   }
   struct Rel { RunCtx* c; T2 t; ~Rel() { wsfree(c, t); } } rel{c, slab};
   int combined = pl.splitk > 1 && ia2p_splitk_inkernel(a.M, a.N, pl.splitk);     // (dry pass: the policy's answer; the launcher reports what it really did)
-  int gn_rows_epi = 0, gn_rows_fb = 0;
-  if (gw) {
+  int gn_rows_epi = 0;
+  if (gw) {      // (a launch whose tile cannot take the sums leaves none: the consumer that wants them runs the canonical pass itself, gn_ensure_stats)
     gw->out = GnStats{};
     gn_rows_epi = gn_epilogue_rows(a, conv, pl.variant, pl.splitk, combined != 0, gw->HW);
-    gn_rows_fb = (a.N % 64 == 0 && a.ldc % 8 == 0 && a.M % gw->HW == 0) ? gn_fallback_rows(gw->HW) : 0;
-    const int slots = std::max(gn_rows_epi ? a.M / gn_rows_epi : 0, gn_rows_fb ? a.M / gn_rows_fb : 0);
-    if (slots > 0) {
-      gw->out.buf = wsalloc(c, (size_t)slots * a.N * 8);      // double2 per slot and column
-      if (gn_rows_epi) a.gn_out = (double*)gw->out.buf.p;
+    if (gn_rows_epi) {
+      gw->out.buf = wsalloc(c, (size_t)(a.M / gn_rows_epi) * a.N * 8);      // double2 per slot and column
+      a.gn_out = (double*)gw->out.buf.p;
     }
   }
   {
@@ -453,12 +496,7 @@ static void run_gemm(RunCtx* c, GemmArgs& a, bool conv, const char* what, double
   }
   if (gw && gw->out.buf.off != (size_t)-1) {
     if (gn_rows_epi && (pl.splitk <= 1 || combined)) gw->out.rows = gn_rows_epi;
-    else if (gn_rows_fb) {      // (the tile could not: the canonical statistics pass over the finished output)
-      RoleScope role(c, ROLE_GROUPNORM);
-      ProfScope ps(c, PK_GN, 4.0 * a.M * a.N, 2.0 * a.M * a.N);
-      CHECK_LAUNCH(c, ia2p_launch_gn_colstats(a.C, a.ldc, a.M, a.N, gn_rows_fb, (double*)gw->out.buf.p, c->stream), "groupnorm statistics");
-      gw->out.rows = gn_rows_fb;
-    } else { wsfree(c, gw->out.buf); gw->out = GnStats{}; }
+    else { wsfree(c, gw->out.buf); gw->out = GnStats{}; }      // (the launcher finished the K split with a reduce launch after all)
   }
   // row-statistics slots of this launch's output: one per tile column, or ONE when a reduce launch wrote it
   if (stat_slots) *stat_slots = (pl.splitk > 1 && !combined) ? 1 : (a.N + IA2P_GEMM_TILES[pl.variant].bn - 1) / IA2P_GEMM_TILES[pl.variant].bn;
@@ -504,7 +542,7 @@ void op_conv3(RunCtx* c, const half_t* X, int B, int Hs, int Ws, int Cin, const 
   memset(&a, 0, sizeof a);
   // (appended blocks are described by their channel counts: in a dry pass the pointers are null, the shapes -- hence plans and slabs -- must not change)
   if ((Cin2 > 0 && (stride != 1 || up || pad_lo != 1 || Cin2 % 64)) || (Cin3 > 0 && (Cin2 <= 0 || Cin3 % 64)) || Cin2 < 0 || Cin3 < 0 ||
-      (!c->dry && ((Cin2 > 0) != (X2 != nullptr) || (Cin3 > 0) != (X3 != nullptr)))) { fail(c, IA2P_ERR_SHAPE, "conv3x3 with appended 1x1 blocks: stride 1, no upsampling, Cin2 / Cin3 % 64 == 0"); return; }
+      (!c->dry && ((Cin2 > 0) != (X2 != nullptr) || (Cin3 > 0) != (X3 != nullptr)))) { fail(c, IA2P_ERR_SHAPE, "conv3x3 with appended 1x1 blocks: stride 1, no upsampling, Cin2 / Cin3 %% 64 == 0 (stride %d up %d pad %d Cin %d Cin2 %d Cin3 %d, X2 %s, X3 %s)", stride, up, pad_lo, Cin, Cin2, Cin3, X2 ? "set" : "null", X3 ? "set" : "null"); return; }
   a.pad = pad_lo;           // zero rows/cols before the image; one row/col of zeros after it in every mode
   const int Hv = Hs << up, Wv = Ws << up;
   a.Ho = (Hv + pad_lo + 1 - 3) / stride + 1; a.Wo = (Wv + pad_lo + 1 - 3) / stride + 1;
@@ -521,6 +559,14 @@ void op_conv3(RunCtx* c, const half_t* X, int B, int Hs, int Ws, int Cin, const 
   a.m_fastest = 0;
   a.acc_scale = c->ep_acc_scale; a.bias_scale = c->ep_bias_scale; c->ep_acc_scale = c->ep_bias_scale = 1.f;
   set_prefetch(c, a, W, (size_t)Co * a.K * sizeof(half_t));
+  GemmArgs fa;      // autotune pass: the site's GroupNorm-fused form, for tune_site to time against GroupNorm launch + plain plan
+  if (gn && gn->tune && !gn->fused && c->tuning && !c->dry && gn->s0.ok() && gn->Xraw) {
+    fa = a;
+    fa.A = gn->Xraw; fa.lda = gn->C0; fa.A1b = gn->X1b; fa.lda1b = Cin - gn->C0;
+    fa.gn.st0 = (const double*)gn->s0.buf.p; fa.gn.rows0 = gn->s0.rows; fa.gn.st1 = gn->X1b ? (const double*)gn->s1.buf.p : nullptr; fa.gn.rows1 = gn->s1.rows; fa.gn.C0 = gn->C0;
+    fa.gn.gamma = gn->gamma; fa.gn.beta = gn->beta; fa.gn.groups = gn->groups; fa.gn.gs = Cin / gn->groups; fa.gn.eps = gn->eps; fa.gn.silu = 1;
+    if (ia2p_conv_gn_ok(fa)) c->tune_fused = &fa;
+  }
   RoleScope role(c, ROLE_CONV3X3);
   run_gemm(c, a, true, "conv3x3", 2.0 * a.M * (double)Co * a.K, 2.0 * ((double)B * Hs * Ws * Cin + (double)Co * a.K + (double)a.M * Co + (residual ? (double)a.M * Co : 0) + (double)a.M * (Cin2 + Cin3)), nullptr, gw);
 }
@@ -547,6 +593,7 @@ struct Fwd {
   // the tensor -- possibly much later (the skips of the down path) --, released with the tensor
   std::unordered_map<size_t, GnStats> gst;
   bool gn_on = false;
+  bool tune_like = false;      // the autotune pass (or the dry pass that sizes the workspace for it): GroupNorm launches, plus what tune_site needs to time the fused forms beside them
 };
 static void gst_put(Fwd& f, T2 t, const GnStats& s) { if (s.ok() && t.off != (size_t)-1) f.gst[t.off] = s; else if (s.buf.off != (size_t)-1) wsfree(f.c, s.buf); }
 static GnStats gst_get(Fwd& f, T2 t) { auto it = f.gst.find(t.off); return it == f.gst.end() ? GnStats{} : it->second; }
@@ -556,6 +603,20 @@ static void act_free(Fwd& f, T2 t) {      // release an activation tensor and it
   wsfree(f.c, t);
 }
 
+// autotune pass: times a GroupNorm launch in place and leaves the figure for the tune_site call of the convolution behind it
+struct TuneGnTimer {
+  RunCtx* c; hipEvent_t e0{}, e1{}; bool on;
+  explicit TuneGnTimer(RunCtx* c_) : c(c_), on(c_->tuning && !c_->dry && !c_->failed && c_->gn_fuse != 0) {
+    if (on) { e0 = get_event(c); e1 = get_event(c); (void)hipEventRecord(e0, c->stream); }
+  }
+  void stop() {
+    if (!on) return;
+    float ms = 0.f;
+    if (hipEventRecord(e1, c->stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) c->tune_gn_ms = ms;
+    c->evpool.push_back(e0); c->evpool.push_back(e1);
+    on = false;
+  }
+};
 struct RegionScope { RunCtx* c; int prev; RegionScope(RunCtx* c_, int r) : c(c_), prev(c_->region) { c->region = r; } ~RegionScope() { c->region = prev; } };
 
 // x2 != null: the block input is [x (cx channels) | x2 (cin - cx channels)], never concatenated (up path: hidden state | skip) -- GroupNorm reads the two
@@ -571,10 +632,32 @@ static bool gn_conv_fusable(Fwd& f, int H, int Wd, int cin, int cout, int cin2, 
   if (cin2) a.A2 = (const half_t*)16;      // (shape query: any non-null pointer)
   if (cin3) a.A3 = (const half_t*)16;
   const GemmPlan pl = ia2p_gemm_plan(a.M, a.N, a.K, true, false);
-  if (!ia2p_conv_gn_fusable(a, pl.variant, pl.splitk)) return false;
+  if (!pl.gn || !ia2p_conv_gn_fusable(a, pl.variant, pl.splitk)) return false;      // (the measured plan of the site says whether fusing pays there: tune_site)
   const int HW = H * Wd, groups = f.c->groups;
   if (cin % groups || cin / groups > 96 || c0 % 64 || (cin - c0) % 64 || cin > 3072) return false;
   return HW % s0.rows == 0 && HW / s0.rows <= IA2P_GN_MAX_SLOTS && (!s1 || (HW % s1->rows == 0 && HW / s1->rows <= IA2P_GN_MAX_SLOTS));
+}
+
+// statistics of tensor t ([B*HW, C]) for a consumer that is going to fuse: what its producer's epilogue left, or -- when the producer's tile could not (or left more than
+// IA2P_GN_MAX_SLOTS slots per image) -- the canonical pass over the tensor, run once and kept with it (conv_in's output feeds two such consumers)
+static GnStats gn_ensure_stats(Fwd& f, T2 t, int C, int HW) {
+  GnStats s = gst_get(f, t);
+  if (s.ok() && HW % s.rows == 0 && HW / s.rows <= IA2P_GN_MAX_SLOTS) return s;
+  RunCtx* c = f.c;
+  const int rows = gn_fallback_rows(HW);
+  if (!rows || C % 8) return GnStats{};
+  auto it = f.gst.find(t.off);
+  if (it != f.gst.end()) { wsfree(c, it->second.buf); f.gst.erase(it); }
+  s = GnStats{};
+  s.buf = wsalloc(c, (size_t)(f.B * HW / rows) * C * 8);
+  s.rows = rows;
+  {
+    RoleScope role(c, ROLE_GROUPNORM);
+    ProfScope ps(c, PK_GN, 4.0 * f.B * HW * C, 2.0 * f.B * HW * C);
+    CHECK_LAUNCH(c, ia2p_launch_gn_colstats(t.p, C, f.B * HW, C, rows, (double*)s.buf.p, c->stream), "groupnorm statistics");
+  }
+  f.gst[t.off] = s;
+  return s;
 }
 
 // out_stats: the block's output feeds another GroupNorm-fusable convolution (the next ResnetBlock2D, or -- as a skip -- one of the up path): its statistics are taken
@@ -585,13 +668,19 @@ static T2 run_resnet(Fwd& f, const Resnet& r, T2 x, int H, int Wd, const T2* x2t
   RegionScope rs(c, PR_CONV_BLOCK);
   const int HW = H * Wd, M = f.B * HW;
   // norm1 + SiLU + conv1: inside the convolution when the site is a halo-staged one and the producers left their statistics (conv_halo_kernel.h, GN = 1)
-  const GnStats sx = gst_get(f, x), sx2 = two ? gst_get(f, *x2t) : GnStats{};
-  const bool fuse1 = gn_conv_fusable(f, H, Wd, r.cin, r.cout, 0, 0, sx, two ? &sx2 : nullptr, two ? cx : r.cin);
+  // (first by shape alone -- does the plan give conv1 a halo-staged tile? -- then with the statistics, fetched or computed only when the site can use them)
+  GnStats probe; probe.rows = gn_fallback_rows(HW);
+  GnStats sx, sx2;
+  bool fuse1 = probe.ok() && gn_conv_fusable(f, H, Wd, r.cin, r.cout, 0, 0, probe, two ? &probe : nullptr, two ? cx : r.cin);
+  if (fuse1) {
+    sx = gn_ensure_stats(f, x, two ? cx : r.cin, HW);
+    if (two) sx2 = gn_ensure_stats(f, *x2t, r.cin - cx, HW);
+    fuse1 = gn_conv_fusable(f, H, Wd, r.cin, r.cout, 0, 0, sx, two ? &sx2 : nullptr, two ? cx : r.cin);
+  }
   GnWant w1{HW};
   const bool cat = r.shortcut && c->sc_fuse;      // conv2(h) + conv_shortcut(x) as ONE implicit GEMM (K = 9 cout + cin): no shortcut launch, no xs round trip
   // (conv1's statistics are wanted when conv2 can take them: its plan is a halo-staged one)
-  GnStats probe; probe.rows = 256 <= HW && HW % 256 == 0 ? 256 : HW;
-  const bool want1 = f.gn_on && gn_conv_fusable(f, H, Wd, r.cout, r.cout, cat ? (two ? cx : r.cin) : 0, cat && two ? r.cin - cx : 0, probe, nullptr, r.cout);
+  const bool want1 = f.gn_on && probe.ok() && gn_conv_fusable(f, H, Wd, r.cout, r.cout, cat ? (two ? cx : r.cin) : 0, cat && two ? r.cin - cx : 0, probe, nullptr, r.cout);
   T2 hh = wsalloc(c, (size_t)M * r.cout);
   const bool twin = (c->gn_dry_mode >= 0 ? c->gn_dry_mode : c->gn_fuse) == 2;      // the fused path's unfused twin: the SAME statistics, normalised by a pass of its own, then the plain convolution
   auto apply_stats = [&](const half_t* a0, int c0, const half_t* a1, const GnStats& s0, const GnStats& s1, size_t gam, size_t bet, int C, half_t* y) {
@@ -614,8 +703,19 @@ static T2 run_resnet(Fwd& f, const Resnet& r, T2 x, int H, int Wd, const T2* x2t
     op_conv3(c, x.p, f.B, H, Wd, r.cin, W_(c, r.w1), W_(c, r.b1), r.cout, 1, 0, c->dry ? nullptr : f.temb_all.p + r.temb_off, c->temb_total, nullptr, hh.p, 1, nullptr, 0, nullptr, 0, &g, want1 ? &w1 : nullptr);
   } else {
     T2 n1 = wsalloc(c, (size_t)M * r.cin);
+    // autotune pass: the site is measured both ways -- this GroupNorm launch + the best plain plan against the fused launch on the raw tensor(s) with their statistics
+    const bool tune = f.tune_like && probe.ok() && H % 16 == 0 && Wd % 16 == 0;
+    ConvGn tg1;
+    if (tune) {
+      tg1.tune = true; tg1.Xraw = x.p; tg1.X1b = x2; tg1.C0 = two ? cx : r.cin; tg1.gamma = W_(c, r.n1g); tg1.beta = W_(c, r.n1b); tg1.eps = c->cfg.norm_eps; tg1.groups = c->groups;
+      tg1.s0 = gn_ensure_stats(f, x, tg1.C0, HW);
+      if (two) tg1.s1 = gn_ensure_stats(f, *x2t, r.cin - cx, HW);
+    }
+    TuneGnTimer tg(c);
     op_gn(c, x.p, n1.p, r.n1g, r.n1b, f.B, HW, r.cin, c->cfg.norm_eps, 1, f.gn_partial, x2, cx);
-    op_conv3(c, n1.p, f.B, H, Wd, r.cin, W_(c, r.w1), W_(c, r.b1), r.cout, 1, 0, c->dry ? nullptr : f.temb_all.p + r.temb_off, c->temb_total, nullptr, hh.p, 1, nullptr, 0, nullptr, 0, nullptr, want1 ? &w1 : nullptr);
+    tg.stop();
+    op_conv3(c, n1.p, f.B, H, Wd, r.cin, W_(c, r.w1), W_(c, r.b1), r.cout, 1, 0, c->dry ? nullptr : f.temb_all.p + r.temb_off, c->temb_total, nullptr, hh.p, 1, nullptr, 0, nullptr, 0, tune ? &tg1 : nullptr,
+             want1 ? &w1 : nullptr);
     wsfree(c, n1);
   }
   const GnStats sh = w1.out;
@@ -623,11 +723,20 @@ static T2 run_resnet(Fwd& f, const Resnet& r, T2 x, int H, int Wd, const T2* x2t
   ConvGn g2;
   g2.fused = fuse2 && !twin; g2.C0 = r.cout; g2.s0 = sh; g2.gamma = W_(c, r.n2g); g2.beta = W_(c, r.n2b); g2.eps = c->cfg.norm_eps; g2.groups = c->groups;
   T2 n2{(size_t)-1, nullptr};
+  const bool tune2 = f.tune_like && probe.ok() && H % 16 == 0 && Wd % 16 == 0;      // (autotune pass: conv2 measured both ways, as conv1 above; hh stays alive for it)
+  if (tune2) {
+    g2.tune = true; g2.Xraw = hh.p;
+    g2.s0 = gn_ensure_stats(f, hh, r.cout, HW);
+  }
   if (!fuse2 || twin) {
     n2 = wsalloc(c, (size_t)M * r.cout);
     if (fuse2) apply_stats(hh.p, r.cout, nullptr, sh, GnStats{}, r.n2g, r.n2b, r.cout, n2.p);
-    else op_gn(c, hh.p, n2.p, r.n2g, r.n2b, f.B, HW, r.cout, c->cfg.norm_eps, 1, f.gn_partial);
-    wsfree(c, hh);
+    else {
+      TuneGnTimer tg(c);
+      op_gn(c, hh.p, n2.p, r.n2g, r.n2b, f.B, HW, r.cout, c->cfg.norm_eps, 1, f.gn_partial);
+      tg.stop();
+    }
+    if (!tune2) wsfree(c, hh);
   }
   const half_t* in2 = g2.fused ? hh.p : n2.p;
   GnWant w2{HW};
@@ -643,7 +752,7 @@ static T2 run_resnet(Fwd& f, const Resnet& r, T2 x, int H, int Wd, const T2* x2t
   if (cat && two) op_conv3(c, in2, f.B, H, Wd, r.cout, W_(c, r.wcat), W_(c, r.bcat), r.cout, 1, 0, nullptr, 0, nullptr, out.p, 1, x.p, cx, x2, r.cin - cx, &g2, gw2);
   else if (cat) op_conv3(c, in2, f.B, H, Wd, r.cout, W_(c, r.wcat), W_(c, r.bcat), r.cout, 1, 0, nullptr, 0, nullptr, out.p, 1, x.p, r.cin, nullptr, 0, &g2, gw2);
   else op_conv3(c, in2, f.B, H, Wd, r.cout, W_(c, r.w2), W_(c, r.b2), r.cout, 1, 0, nullptr, 0, c->dry ? nullptr : resid, out.p, 1, nullptr, 0, nullptr, 0, &g2, gw2);
-  if (g2.fused) wsfree(c, hh); else wsfree(c, n2);
+  if (g2.fused) wsfree(c, hh); else { wsfree(c, n2); if (tune2) act_free(f, hh); }
   if (sh.buf.off != (size_t)-1) wsfree(c, sh.buf);
   if (r.shortcut && !cat) wsfree(c, xs);
   if (gw2) gst_put(f, out, w2.out);
@@ -828,7 +937,8 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
   Fwd f{c, B, h, w, L, context, T2{(size_t)-1, nullptr}, nullptr, T2{(size_t)-1, nullptr}, T2{(size_t)-1, nullptr}};
   f.ip_scales = ip_scales;
   const int gn_mode = c->gn_dry_mode >= 0 ? c->gn_dry_mode : c->gn_fuse;
-  f.gn_on = gn_mode != 0 && !c->tuning;      // (the autotune pass measures the plain kernels: GroupNorm launches there)
+  f.tune_like = c->gn_fuse != 0 && (c->dry ? c->gn_dry_mode == 3 || (c->gn_dry_mode < 0 && c->tuning) : c->tuning);
+  f.gn_on = gn_mode != 0 && gn_mode != 3 && !c->tuning;      // (the autotune pass measures the plain kernels: GroupNorm launches there)
 
   // GroupNorm partial sums (fp32) live at the front of the workspace
   T2 gnp = wsalloc(c, (size_t)B * 64 * g.norm_num_groups * 2 * 2);
@@ -889,19 +999,7 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
     CHECK_LAUNCH(c, ia2p_launch_conv_in(sample, W_(c, c->conv_in_w), W_(c, c->conv_in_b), x.p, B, g.in_channels, H, Wd, g.block_out_channels[0], c->stream), "conv_in");
   }
   // Every tensor below feeds a GroupNorm in front of a 3x3 convolution -- the next ResnetBlock2D's norm1, or (the skips) the norm1 of an up-path block much later --
-  // and carries its producer's column sums with it (f.gst); conv_in is a direct kernel: the canonical statistics pass runs over its output
-  if (f.gn_on) {
-    const int c0 = g.block_out_channels[0], rows = gn_fallback_rows(H * Wd);
-    if (rows && c0 % 64 == 0) {
-      GnStats s;
-      s.buf = wsalloc(c, (size_t)(B * H * Wd / rows) * c0 * 8);
-      s.rows = rows;
-      RoleScope role(c, ROLE_GROUPNORM);
-      ProfScope ps(c, PK_GN, 4.0 * B * H * Wd * c0, 2.0 * B * H * Wd * c0);
-      CHECK_LAUNCH(c, ia2p_launch_gn_colstats(x.p, c0, B * H * Wd, c0, rows, (double*)s.buf.p, c->stream), "groupnorm statistics (conv_in)");
-      gst_put(f, x, s);
-    }
-  }
+  // and carries its producer's column sums with it (f.gst); conv_in is a direct kernel: the consumer that fuses runs the canonical statistics pass over its output
   skips.push_back(x); skip_c.push_back(g.block_out_channels[0]);
   for (int i = 0; i < n; ++i) {
     const Stage& st = c->down[i];
@@ -1143,10 +1241,10 @@ static ia2p_status check_fwd_shape(ia2p_ctx* c, int B, int h, int w, int L) {
 
 size_t ia2p_workspace_bytes(ia2p_ctx* c, int B, int h, int w, int L) {
   if (!c || check_fwd_shape(c, B, h, w, L) != IA2P_OK) return 0;
-  // three dry passes: the GroupNorms as launches of their own (also what the autotune pass runs), inside their convolutions (the product path), and the fused path's
-  // unfused twin -- a workspace sized here serves every ia2p_set_gn_fuse mode
+  // four dry passes: the GroupNorms as launches of their own, inside their convolutions (the product path), the fused path's unfused twin, and the autotune pass
+  // (GroupNorm launches + the statistics and live tensors its fused candidates need) -- a workspace sized here serves every ia2p_set_gn_fuse mode and ia2p_autotune
   size_t high = 0;
-  for (int pass = 0; pass < 3; ++pass) {
+  for (int pass = 0; pass < 4; ++pass) {
     c->dry = true; c->failed = false;
     c->gn_dry_mode = pass;
     c->ws.reset((size_t)1 << 46);
@@ -1428,7 +1526,7 @@ ia2p_status ia2p_conv3x3_splitk(void* stream, const void* x, const void* Wp, con
 // leaves for its own output when asked: ia2p_gemm_gnstats, ia2p_conv3x3_gn)
 ia2p_status ia2p_gn_colstats(void* stream, const void* x, int M, int C, int rows, double* out) {
   if (!x || !out) return fail(nullptr, IA2P_ERR_INVALID, "gn_colstats: null argument");
-  if (C % 64 || rows < 16 || rows % 16 || M < 1 || M % rows) return fail(nullptr, IA2P_ERR_SHAPE, "gn_colstats: C=%d (multiple of 64), rows=%d (multiple of 16 dividing M=%d)", C, rows, M);
+  if (C < 8 || C % 8 || rows < 16 || rows % 16 || M < 1 || M % rows) return fail(nullptr, IA2P_ERR_SHAPE, "gn_colstats: C=%d (multiple of 8), rows=%d (multiple of 16 dividing M=%d)", C, rows, M);
   hipError_t e = ia2p_launch_gn_colstats((const half_t*)x, C, M, C, rows, out, (hipStream_t)stream);
   RET_HIP(e, "gn_colstats");
 }

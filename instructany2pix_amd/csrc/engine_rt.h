@@ -25,6 +25,7 @@ hipError_t ia2p_launch_gemm(const GemmArgs& a, bool conv, hipStream_t s, int* pi
 hipError_t ia2p_launch_gemm_variant(const GemmArgs& a, bool conv, int variant, hipStream_t s, bool with_reduce = true, int* combined = nullptr, int* ran = nullptr);
 int ia2p_gemm_variant_ran(const GemmArgs& a, bool conv, int v);
 bool ia2p_conv_gn_fusable(const GemmArgs& a, int v, int splitk);
+void ia2p_conv_gn_candidates(const GemmArgs& a, size_t max_slab_bytes, std::vector<GemmPlan>* out);
 hipError_t ia2p_launch_gn_colstats(const half_t* x, int ldx, int M, int C, int rows, double* out, hipStream_t s);
 hipError_t ia2p_launch_gn_apply_stats(const half_t* x0, int ld0, const half_t* x1, int ld1, half_t* y, int ldy, int B, int HW, int C, const GemmArgs::GnIn& g, hipStream_t s);
 hipError_t ia2p_launch_splitk_reduce(const GemmArgs& a, hipStream_t s);
@@ -165,6 +166,8 @@ struct RunCtx {
   // autotune pass (ia2p_autotune): every GEMM / conv site of an unmeasured shape times its candidate plans in place
   bool tuning = false;
   int tune_reps = 5, tune_sites = 0;
+  double tune_gn_ms = 0.0;                       // autotune: time of the GroupNorm launch in front of the convolution being tuned next ...
+  const GemmArgs* tune_fused = nullptr;          // ... and that convolution's GroupNorm-FUSED form (raw operand + producer statistics): its candidates are timed against GroupNorm launch + plain plan
   char* tune_scratch = nullptr;                 // [slab region | flush region]
   size_t tune_slab_bytes = 0, tune_flush_bytes = 0;
   std::vector<ProfRec> recs;
@@ -230,7 +233,9 @@ struct GnStats { T2 buf{(size_t)-1, nullptr}; int rows = 0; bool ok() const { re
 // what a producer launch is asked for: statistics of its output, an image being HW rows; filled in by run_gemm / op_gemm / op_conv3
 struct GnWant { int HW; GnStats out; };
 // GroupNorm fused into a 3x3 convolution (op_conv3): the operand is the raw tensor X (C0 channels) [| X1b (Cin - C0)] with the statistics of its producer(s)
-struct ConvGn { bool fused = false; const half_t* X1b = nullptr; int C0 = 0; GnStats s0, s1; const half_t* gamma = nullptr; const half_t* beta = nullptr; float eps = 1e-5f; int groups = 32; };
+// (tune: autotune pass -- the launch itself is the plain one, on the normalised tensor; Xraw [| X1b] + statistics describe the site's FUSED form for tune_site to time beside it)
+struct ConvGn { bool fused = false; const half_t* X1b = nullptr; int C0 = 0; GnStats s0, s1; const half_t* gamma = nullptr; const half_t* beta = nullptr; float eps = 1e-5f; int groups = 32;
+                bool tune = false; const half_t* Xraw = nullptr; };
 // LayerNorm folded into a GEMM: where the consumer finds the row statistics and the folded constants
 struct LnIn { const float* stats; int slots; const float* cs; const float* lb; float eps; };
 

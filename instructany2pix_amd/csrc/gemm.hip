@@ -134,6 +134,8 @@ bool ia2p_splitk_inkernel(int M, int N, int splitk) {
   const size_t limit = g_sk_limit >= 0 ? (size_t)g_sk_limit : env_limit;
   return splitk > 1 && (size_t)splitk * M * N * sizeof(float) <= limit;
 }
+static int g_force_gn = -1;        // test hook (ia2p_debug_set_gn_plan): -1 the plan's own bit, 1 every eligible site fuses its GroupNorm, 0 none does
+extern "C" void ia2p_debug_set_gn_plan(int v) { g_force_gn = v; }
 static int g_force_splitk = -1;    // test/tuning hook
 extern "C" void ia2p_debug_set_gemm_splitk(int s) { g_force_splitk = s; }
 
@@ -265,8 +267,10 @@ extern "C" size_t ia2p_plan_export(char* buf, size_t len) {
   std::lock_guard<std::mutex> lk(g_plan_mu);
   std::string s;
   char tmp[96];
-  for (const auto& kv : tuned_plans()) {
-    snprintf(tmp, sizeof tmp, "%d,%d,%d,%d,%d,%d,%d;", std::get<0>(kv.first), std::get<1>(kv.first), std::get<2>(kv.first), std::get<3>(kv.first),
+  for (const auto& kv : tuned_plans()) {      // (an 8th field, "gn", only where it is set: tables without GroupNorm-fused sites keep round 4's seven-field form)
+    if (kv.second.gn) snprintf(tmp, sizeof tmp, "%d,%d,%d,%d,%d,%d,%d,%d;", std::get<0>(kv.first), std::get<1>(kv.first), std::get<2>(kv.first), std::get<3>(kv.first),
+                               std::get<4>(kv.first), kv.second.variant, kv.second.splitk, kv.second.gn);
+    else snprintf(tmp, sizeof tmp, "%d,%d,%d,%d,%d,%d,%d;", std::get<0>(kv.first), std::get<1>(kv.first), std::get<2>(kv.first), std::get<3>(kv.first),
              std::get<4>(kv.first), kv.second.variant, kv.second.splitk);
     s += tmp;
   }
@@ -277,10 +281,14 @@ extern "C" int ia2p_plan_import(const char* text) {   // returns the number of e
   if (!text) return -1;
   std::vector<std::pair<PlanKey, GemmPlan>> in;
   for (const char* p = text; *p;) {
-    int M, N, K, cv, gg, v, sk, n = 0;
-    if (sscanf(p, "%d,%d,%d,%d,%d,%d,%d;%n", &M, &N, &K, &cv, &gg, &v, &sk, &n) != 7 || n == 0) return -1;
-    if (M < 1 || N < 1 || K < 64 || v < 0 || v >= IA2P_GEMM_NVARIANT || sk < 1 || sk > K / 64 || (gg && (sk > 1 || IA2P_GEMM_TILES[v].bn % 32)) || (IA2P_GEMM_TILES[v].halo && !cv)) return -1;
-    in.push_back({PlanKey{M, N, K, cv != 0, gg != 0}, GemmPlan{v, sk}});
+    int M, N, K, cv, gg, v, sk, gn = 0, n = 0;
+    if (sscanf(p, "%d,%d,%d,%d,%d,%d,%d,%d;%n", &M, &N, &K, &cv, &gg, &v, &sk, &gn, &n) != 8 || n == 0) {      // seven fields: gn = 0
+      gn = 0; n = 0;
+      if (sscanf(p, "%d,%d,%d,%d,%d,%d,%d;%n", &M, &N, &K, &cv, &gg, &v, &sk, &n) != 7 || n == 0) return -1;
+    }
+    if (M < 1 || N < 1 || K < 64 || v < 0 || v >= IA2P_GEMM_NVARIANT || sk < 1 || sk > K / 64 || (gg && (sk > 1 || IA2P_GEMM_TILES[v].bn % 32)) || (IA2P_GEMM_TILES[v].halo && !cv) ||
+        gn < 0 || gn > 1 || (gn && !IA2P_GEMM_TILES[v].halo)) return -1;
+    in.push_back({PlanKey{M, N, K, cv != 0, gg != 0}, GemmPlan{v, sk, gn}});
     p += n;
   }
   std::lock_guard<std::mutex> lk(g_plan_mu);
@@ -322,6 +330,7 @@ GemmPlan ia2p_gemm_plan(int M, int N, int K, bool conv, bool geglu) {
   GemmPlan pl{-1, 1};
   if (g_force_variant < 0 && ia2p_plan_lookup(M, N, K, conv, geglu, &pl)) {
     if (g_force_splitk >= 1 && !geglu) pl.splitk = std::min(g_force_splitk, K / 64);
+    if (g_force_gn >= 0) pl.gn = g_force_gn && IA2P_GEMM_TILES[pl.variant].halo;
     return pl;
   }
   for (const ShapeRule& r : shape_rules())
@@ -344,6 +353,7 @@ GemmPlan ia2p_gemm_plan(int M, int N, int K, bool conv, bool geglu) {
   if (g_force_splitk >= 1 && !geglu) pl.splitk = g_force_splitk;
   if (pl.splitk > nk) pl.splitk = nk;
   if (pl.splitk < 1) pl.splitk = 1;
+  pl.gn = g_force_gn > 0 && conv && IA2P_GEMM_TILES[pl.variant].halo;      // (the cost model never fuses: by measurement only)
   return pl;
 }
 
@@ -461,6 +471,14 @@ int ia2p_gemm_variant_ran(const GemmArgs& a, bool conv, int v) {
 // may this 3x3 site run GroupNorm-fused under plan (v, splitk)? (shape part of the answer: the statistics pointers may still be null -- dry pass)
 bool ia2p_conv_gn_fusable(const GemmArgs& a, int v, int splitk) {
   return v >= 0 && v < IA2P_GEMM_NVARIANT && IA2P_GEMM_TILES[v].halo && ia2p_conv_halo_ok(a) && a.up == 0 && splitk <= a.Cin / 64;
+}
+// every (halo-staged tile, K split) a GroupNorm-fused launch of this site may run on, for the tuner
+void ia2p_conv_gn_candidates(const GemmArgs& a, size_t max_slab_bytes, std::vector<GemmPlan>* out) {
+  out->clear();
+  static const int splits[] = {1, 2, 3, 4};
+  for (int v = 0; v < IA2P_GEMM_NVARIANT; ++v)
+    for (int sk : splits)
+      if (ia2p_conv_gn_fusable(a, v, sk) && (sk == 1 || ((a.K / 64) / sk >= 4 && (size_t)sk * a.M * a.N * 4 <= max_slab_bytes))) out->push_back(GemmPlan{v, sk, 1});
 }
 // launch with an explicit tile variant (a.splitk / a.partial as the caller set them)
 // with_reduce = false: a K-split launch leaves its slabs for a separate ia2p_launch_splitk_reduce (the executor times the two apart)

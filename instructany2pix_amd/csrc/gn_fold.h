@@ -53,7 +53,14 @@ __device__ __forceinline__ float2 gn_scale_shift(float2 mean_rstd, float gamma, 
   const float a = __fmul_rn(mean_rstd.y, gamma);
   return make_float2(a, fmaf(-mean_rstd.x, a, beta));
 }
+// the normalisation of one element, y = fma(x, a, b), and its SiLU y / (1 + exp(-y)) as FOUR primitive steps -- so that a kernel may spread them between other work
+// (the fused convolution places them one by one between its MFMAs) and still produce the bits of gn_apply_f:
+//   y = gn_step_y(x, a, b);  e = gn_step_e(y) = 2^(y * -log2 e);  r = gn_step_r(e) = 1 / (1 + e);  out = gn_step_o(y, r) = y * r
+__device__ __forceinline__ float gn_step_y(float x, float a, float b) { return fmaf(x, a, b); }
+__device__ __forceinline__ float gn_step_e(float y) { return __builtin_amdgcn_exp2f(__fmul_rn(y, -1.4426950408889634f)); }
+__device__ __forceinline__ float gn_step_r(float e) { return __builtin_amdgcn_rcpf(__fadd_rn(1.0f, e)); }
+__device__ __forceinline__ float gn_step_o(float y, float r) { return __fmul_rn(y, r); }
 __device__ __forceinline__ float gn_apply_f(float x, float a, float b, bool silu) {
-  const float y = fmaf(x, a, b);
-  return silu ? silu_f(y) : y;
+  const float y = gn_step_y(x, a, b);
+  return silu ? gn_step_o(y, gn_step_r(gn_step_e(y))) : y;
 }

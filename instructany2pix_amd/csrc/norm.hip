@@ -361,7 +361,7 @@ hipError_t ia2p_launch_groupnorm(const half_t* x, int ldx, half_t* y, int ldy, c
 __global__ __launch_bounds__(256) void gn_colstats_kernel(const half_t* x, int ldx, int M, int C, int rows, double* out) {
   __shared__ double2 red[32][64];
   const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
-  const int slot = blockIdx.x, c0 = blockIdx.y * 64 + tx * 8;
+  const int slot = blockIdx.x, c0 = min(blockIdx.y * 64 + tx * 8, C - 8);      // (C % 8 == 0; the last span of a width that is not a multiple of 64 re-reads the final chunk: not written)
   const int r0 = slot * rows, nseg = rows / 16;
   double ds[8], dq[8];
 #pragma unroll
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void gn_colstats_kernel(const half_t* x, int l
 #pragma unroll
   for (int e = 0; e < 8; ++e) red[ty][tx * 8 + e] = make_double2(ds[e], dq[e]);
   __syncthreads();
-  if (threadIdx.x < 64) {
+  if (threadIdx.x < 64 && blockIdx.y * 64 + threadIdx.x < C) {
     double a = 0.0, q = 0.0;
     const int nsl = nseg < 32 ? nseg : 32;
     for (int t = 0; t < nsl; ++t) { const double2 v = red[t][threadIdx.x]; a += v.x; q += v.y; }
@@ -393,8 +393,8 @@ __global__ __launch_bounds__(256) void gn_colstats_kernel(const half_t* x, int l
   }
 }
 hipError_t ia2p_launch_gn_colstats(const half_t* x, int ldx, int M, int C, int rows, double* out, hipStream_t s) {
-  if (C % 64 || ldx % 8 || rows < 16 || rows % 16 || M < 1 || M % rows) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(gn_colstats_kernel, dim3(M / rows, C / 64), dim3(256), 0, s, x, ldx, M, C, rows, out);
+  if (C < 8 || C % 8 || ldx % 8 || rows < 16 || rows % 16 || M < 1 || M % rows) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(gn_colstats_kernel, dim3(M / rows, (C + 63) / 64), dim3(256), 0, s, x, ldx, M, C, rows, out);
   return hipGetLastError();
 }
 

@@ -265,11 +265,37 @@ def test_measured_plans_are_the_verified_configuration(full):
             # round 5: under measured plans the ResnetBlock2D GroupNorms run inside their halo-staged convolutions (at most the Transformer2DModel norms, conv_norm_out
             # and the statistics pass behind conv_in stay launches at 512 x 512) -- and the unfused twin on the same statistics gives the same bits
             gn = sum(v["launches"] for k, v in roles.items() if k.startswith("groupnorm"))
-            assert gn <= 20, (B, gn)
+            hip.set_gn_fuse(0)
+            hip.profile(True)
+            unfused = hip(lat, 981, encoder_hidden_states=ctx, added_cond_kwargs=added)[0].clone()
+            torch.cuda.synchronize()
+            gn0 = sum(v["launches"] for k, v in hip.profile_read_roles().items() if k.startswith("groupnorm"))
+            hip.profile(False)
             hip.set_gn_fuse(2)
             twin = hip(lat, 981, encoder_hidden_states=ctx, added_cond_kwargs=added)[0].clone()
             hip.set_gn_fuse(1)
             assert torch.equal(twin, out), float((twin.float() - out.float()).abs().max())
+            assert rel_l2(unfused, out) < 2e-3, rel_l2(unfused, out)      # round 4's path: same function, statistics summed in another order
+            # the tuner fuses a site only where the fused launch beat GroupNorm launch + plain plan on this box (the large maps with few input channels): never more
+            # GroupNorm-class launches than round 4's path, and at batch 8 fewer
+            assert gn <= gn0 and (B != 8 or gn < gn0), (B, gn, gn0)
+            # ... and with EVERY eligible site fused (not what the tuner would pick: slower) the evaluation still gives the twin's bits and stays within the oracle tolerance
+            from instructany2pix_amd import _ffi as _f
+            _f.lib().ia2p_debug_set_gn_plan(1)
+            try:
+                hip.profile(True)
+                allf = hip(lat, 981, encoder_hidden_states=ctx, added_cond_kwargs=added)[0].clone()
+                torch.cuda.synchronize()
+                gn_all = sum(v["launches"] for k, v in hip.profile_read_roles().items() if k.startswith("groupnorm"))
+                hip.profile(False)
+                hip.set_gn_fuse(2)
+                twin_all = hip(lat, 981, encoder_hidden_states=ctx, added_cond_kwargs=added)[0].clone()
+                hip.set_gn_fuse(1)
+            finally:
+                _f.lib().ia2p_debug_set_gn_plan(-1)
+            assert torch.equal(allf, twin_all) and rel_l2(allf, out) < 2e-3 and gn_all <= gn, (B, gn_all, gn)
+            if B == 8:
+                assert gn_all <= 16, gn_all      # the 11 Transformer2DModel norms, conv_norm_out, the statistics pass behind conv_in (+ sites whose plan is not a halo-staged tile)
             assert rel_l2(out, base) < 2e-3, rel_l2(out, base)          # same arithmetic up to the K-split summation order
             f = lambda t_: t_[sel].float().cpu()
             with torch.no_grad():

@@ -149,8 +149,13 @@ def test_epilogue_statistics_equal_colstats_of_the_stored_output(L, B, H, W, Cin
                     if rows == 0:
                         continue                  # (a tile that does not divide the image, e.g. 256 rows on a 16 x 48 map's 768 pixels is fine, 160 is not)
                     produced += 1
+                    # a slot of a halo-staged tile is a 16 x 16 PATCH, a slot of a linear tile 256 consecutive pixels: per image both cover the same aligned runs of
+                    # 16 pixels, and the per-image sums (what the consumer folds; exact in fp64) must agree to the bit
                     ref = colstats(L, y, rows)
-                    assert torch.equal(st, ref), (tile, sk, rows, float((st - ref).abs().max()))
+                    per_image = lambda t: t.reshape(B, H * W // rows, Co, 2).sum(1)
+                    assert torch.equal(per_image(st), per_image(ref)), (tile, sk, rows, float((per_image(st) - per_image(ref)).abs().max()))
+                    if tile not in (24, 25, 26):
+                        assert torch.equal(st, ref), (tile, sk, rows)
     finally:
         L.ia2p_debug_set_splitk_inkernel(-1)
         L.ia2p_debug_set_gemm_tile(-1)
@@ -262,7 +267,8 @@ def test_fused_groupnorm_conv_vs_fp32_and_its_unfused_pair(L, case):
                 pair, _, _ = conv_gn(L, x0=n, **kw)
                 assert torch.equal(fused, pair), (tile, sk, float((fused.float() - pair.float()).abs().max()))
                 if rows:
-                    assert torch.equal(st, colstats(L, fused, rows)), (tile, sk)
+                    per_image = lambda t: t.reshape(B, HW // rows, Co, 2).sum(1)
+                    assert torch.equal(per_image(st), per_image(colstats(L, fused, rows))), (tile, sk)
                 outs[(tile, sk)] = fused
     finally:
         L.ia2p_debug_set_gemm_tile(-1)

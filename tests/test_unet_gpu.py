@@ -464,7 +464,7 @@ def test_two_contexts_on_two_streams_with_k_splits(tiny_models):
         L.ia2p_debug_set_gemm_splitk(-1)
 
 
-@pytest.mark.parametrize("tile", [24, 25, 26])
+@pytest.mark.parametrize("tile", [24, 25])      # (the 80-wide tile cannot be forced on a whole network: GEGLU needs tile widths that are multiples of 32; tests/test_gn_fused_gpu.py covers it)
 def test_groupnorm_fused_into_the_convolutions_agrees_with_its_twin_and_the_oracle(tiny_models, tile):
     """Round 5: norm1 / norm2 + SiLU of every ResnetBlock2D run INSIDE the halo-staged convolution that consumes them (statistics from the producers' epilogues,
     conv_halo_kernel.h GN = 1) wherever the plan gives the site a halo-staged tile -- forced here for every site (the cost model alone never picks one). Mode 2 runs
@@ -477,6 +477,7 @@ def test_groupnorm_fused_into_the_convolutions_agrees_with_its_twin_and_the_orac
     kw = dict(encoder_hidden_states=ctx, added_cond_kwargs=dict(text_embeds=te, time_ids=tid))
     outs, gn_launches = {}, {}
     _ffi.lib().ia2p_debug_set_gemm_tile(tile)
+    _ffi.lib().ia2p_debug_set_gn_plan(1)          # (a measured plan says per site whether fusing pays; here: wherever the site is eligible)
     try:
         for mode in (0, 1, 2):
             hip.set_gn_fuse(mode)
@@ -488,6 +489,7 @@ def test_groupnorm_fused_into_the_convolutions_agrees_with_its_twin_and_the_orac
             gn_launches[mode] = sum(v["launches"] for k, v in roles.items() if k.startswith("groupnorm"))
     finally:
         _ffi.lib().ia2p_debug_set_gemm_tile(-1)
+        _ffi.lib().ia2p_debug_set_gn_plan(-1)
         hip.set_gn_fuse(1)
     with torch.no_grad():
         ref = oracle.build_unet(cfg, sd, ipsd, ip_scale=0.8)(x.float().cpu(), 481, ctx.float().cpu(), added_cond_kwargs=dict(text_embeds=te.float().cpu(), time_ids=tid.float().cpu()))[0]
