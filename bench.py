@@ -334,7 +334,7 @@ def stub_main(args):
     # that does not end by itself (a collective with a long timeout); the launcher has to notice the death and end the job
     if os.environ.get("IA2P_BENCH_STUB_DIE_RANK"):
         if rank == int(os.environ["IA2P_BENCH_STUB_DIE_RANK"]):
-            raise SystemExit(3)
+            os._exit(3)          # (dies on the spot, as a crashed rank does: no interpreter shutdown that would first tear down the process group's threads)
         time.sleep(float(os.environ.get("IA2P_BENCH_STUB_HANG_S", "600")))
     wl.run(args.warmup)
     D.barrier()

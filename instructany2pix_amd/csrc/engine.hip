@@ -740,7 +740,7 @@ static T2 run_resnet(Fwd& f, const Resnet& r, T2 x, int H, int Wd, const T2* x2t
   }
   const half_t* in2 = g2.fused ? hh.p : n2.p;
   GnWant w2{HW};
-  GnWant* gw2 = f.gn_on && out_stats ? &w2 : nullptr;
+  GnWant* gw2 = f.gn_on && out_stats && ia2p_plan_any_gn(M) ? &w2 : nullptr;      // (only when some 3x3 site of this resolution level fuses its GroupNorm under the measured plans)
   T2 xs{(size_t)-1, nullptr};
   const half_t* resid = x.p;
   if (r.shortcut && !cat) {
@@ -909,9 +909,10 @@ static T2 run_transformer(Fwd& f, const Transformer& t, T2 x, int H, int Wd, boo
   (void)ctxd;
   T2 out = wsalloc(c, (size_t)M * C);
   GnWant gw{HW};
-  { RoleScope role(c, ROLE_PROJ_IO); op_gemm(c, tk.p, C, W_(c, t.wout), W_(c, t.bout), x.p, C, out.p, C, M, C, C, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, 0, f.gn_on && out_stats ? &gw : nullptr); }
+  const bool want = f.gn_on && out_stats && ia2p_plan_any_gn(M);
+  { RoleScope role(c, ROLE_PROJ_IO); op_gemm(c, tk.p, C, W_(c, t.wout), W_(c, t.bout), x.p, C, out.p, C, M, C, C, 0, 0, 0, 0, 0, nullptr, nullptr, nullptr, 0, want ? &gw : nullptr); }
   wsfree(c, tk);
-  if (f.gn_on && out_stats) gst_put(f, out, gw.out);
+  if (want) gst_put(f, out, gw.out);
   return out;
 }
 
@@ -1014,8 +1015,9 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
       const int Ho = (H - 1) / 2 + 1, Wo = (Wd - 1) / 2 + 1;
       T2 d = wsalloc(c, (size_t)B * Ho * Wo * st.rc);
       GnWant gw{Ho * Wo};
-      op_conv3(c, x.p, B, H, Wd, st.rc, W_(c, st.rw), W_(c, st.rb), st.rc, 2, 0, nullptr, 0, nullptr, d.p, 1, nullptr, 0, nullptr, 0, nullptr, f.gn_on ? &gw : nullptr);
-      if (f.gn_on) gst_put(f, d, gw.out);
+      const bool want = f.gn_on && ia2p_plan_any_gn(B * Ho * Wo);
+      op_conv3(c, x.p, B, H, Wd, st.rc, W_(c, st.rw), W_(c, st.rb), st.rc, 2, 0, nullptr, 0, nullptr, d.p, 1, nullptr, 0, nullptr, 0, nullptr, want ? &gw : nullptr);
+      if (want) gst_put(f, d, gw.out);
       H = Ho; Wd = Wo; x = d;
       skips.push_back(x); skip_c.push_back(st.rc);
     }
@@ -1058,8 +1060,9 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
     if (st.resample) {
       T2 u = wsalloc(c, (size_t)B * (2 * H) * (2 * Wd) * st.rc);
       GnWant gw{4 * H * Wd};
-      op_conv3(c, x.p, B, H, Wd, st.rc, W_(c, st.rw), W_(c, st.rb), st.rc, 1, 1, nullptr, 0, nullptr, u.p, 1, nullptr, 0, nullptr, 0, nullptr, f.gn_on ? &gw : nullptr);
-      if (f.gn_on) gst_put(f, u, gw.out);
+      const bool want = f.gn_on && ia2p_plan_any_gn(4 * B * H * Wd);
+      op_conv3(c, x.p, B, H, Wd, st.rc, W_(c, st.rw), W_(c, st.rb), st.rc, 1, 1, nullptr, 0, nullptr, u.p, 1, nullptr, 0, nullptr, 0, nullptr, want ? &gw : nullptr);
+      if (want) gst_put(f, u, gw.out);
       act_free(f, x);
       H *= 2; Wd *= 2; x = u;
     }

@@ -25,6 +25,7 @@ hipError_t ia2p_launch_gemm(const GemmArgs& a, bool conv, hipStream_t s, int* pi
 hipError_t ia2p_launch_gemm_variant(const GemmArgs& a, bool conv, int variant, hipStream_t s, bool with_reduce = true, int* combined = nullptr, int* ran = nullptr);
 int ia2p_gemm_variant_ran(const GemmArgs& a, bool conv, int v);
 bool ia2p_conv_gn_fusable(const GemmArgs& a, int v, int splitk);
+bool ia2p_plan_any_gn(int M);
 void ia2p_conv_gn_candidates(const GemmArgs& a, size_t max_slab_bytes, std::vector<GemmPlan>* out);
 hipError_t ia2p_launch_gn_colstats(const half_t* x, int ldx, int M, int C, int rows, double* out, hipStream_t s);
 hipError_t ia2p_launch_gn_apply_stats(const half_t* x0, int ld0, const half_t* x1, int ld1, half_t* y, int ldy, int B, int HW, int C, const GemmArgs::GnIn& g, hipStream_t s);

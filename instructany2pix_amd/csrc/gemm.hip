@@ -257,6 +257,15 @@ void ia2p_plan_set(int M, int N, int K, bool conv, bool geglu, GemmPlan pl) {
   tuned_plans()[PlanKey{M, N, K, conv, geglu}] = pl;
   ++g_plan_gen;
 }
+// does any measured plan of a 3x3 site with M output rows (one resolution level of a forward) run GroupNorm-fused? Producers of that level's tensors take their
+// column sums only then (1 ... 2 us per launch that nobody would read otherwise)
+bool ia2p_plan_any_gn(int M) {
+  if (g_force_gn >= 0) return g_force_gn > 0;
+  std::lock_guard<std::mutex> lk(g_plan_mu);
+  for (const auto& kv : tuned_plans())
+    if (kv.second.gn && std::get<3>(kv.first) && std::get<0>(kv.first) == M) return true;
+  return false;
+}
 extern "C" void ia2p_plan_clear(void) {
   std::lock_guard<std::mutex> lk(g_plan_mu);
   tuned_plans().clear();

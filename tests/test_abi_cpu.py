@@ -105,6 +105,28 @@ def test_gemm_plan_is_a_pure_host_function_and_the_plan_table_round_trips(lib):
     assert lib.ia2p_plan_export(None, 0) == 0
 
 
+def test_plan_table_carries_the_groupnorm_fusion_bit(lib):
+    """Round 5: a measured plan of a 3x3 site may say "the GroupNorm in front of this convolution runs inside it" (8th field, gn = 1; halo-staged variants only).
+    Seven-field tables (round 4's form) still import; the workspace covers every GroupNorm mode (ia2p_set_gn_fuse 0 / 1 / 2 and the autotune pass)."""
+    lib.ia2p_plan_clear()
+    try:
+        assert lib.ia2p_plan_import(b"32768,320,2880,1,0,24,1,1;8192,640,5760,1,0,25,1;") == 2
+        n = lib.ia2p_plan_export(None, 0)
+        buf = C.create_string_buffer(n + 1)
+        lib.ia2p_plan_export(buf, n + 1)
+        text = buf.value.decode()
+        assert "32768,320,2880,1,0,24,1,1;" in text and "8192,640,5760,1,0,25,1;" in text, text
+        for bad in (b"32768,320,2880,1,0,18,1,1;", b"32768,320,2880,0,0,24,1,1;", b"32768,320,2880,1,0,24,1,2;"):      # gn on a gathered tile / a linear layer / out of range
+            assert lib.ia2p_plan_import(bad) == -1, bad
+        lib.ia2p_debug_set_gn_plan(1)          # test hook: every eligible site
+        v, sk = C.c_int(), C.c_int()
+        lib.ia2p_debug_gemm_plan(32768, 320, 2880, 1, 0, C.byref(v), C.byref(sk))
+        assert v.value == 24 and sk.value == 1
+    finally:
+        lib.ia2p_debug_set_gn_plan(-1)
+        lib.ia2p_plan_clear()
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "instructany2pix_amd")
     for dirpath, _, files in os.walk(pkg):

@@ -89,6 +89,40 @@ def test_bench_gpus2_launches_its_own_ranks_gloo_stub():
     assert len(pr) == 2 and pr[1] > pr[0] * 1.1                       # the straggler is visible ...
     assert abs(d["ms_per_step"] - max(pr)) < 0.2 * max(pr)            # ... and sets the step time
     assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"] + 1e-9      # whole-job steps/s = ranks x steps / max-over-ranks time
+    # round 5: before anything is timed the ranks verify their collectives for VALUES and the equality of their arenas (preflight), the straggler is called out
+    # (spread > 3 %), and every rank pinned itself to its own CPU core slice (two ranks on this box: disjoint halves of the usable cores)
+    assert "verified on 2 ranks" in c["preflight"] and "arena checksums equal" in c["preflight"], c["preflight"]
+    assert c["per_rank_spread"] > 0.1 and "slowest rank 1" in c["per_rank_spread_warning"], c
+    ncores = len(os.sched_getaffinity(0))
+    assert c["cores_per_rank"] == [float(max(1, ncores // 2))] * 2, (c["cores_per_rank"], ncores)
+
+
+def test_rank_core_slices_and_preflight_helpers():
+    """bench.py's N > 1 plumbing as pure functions: disjoint, equal core slices per rank (NUMA node of the rank's GPU first when it has a whole share left), the cpulist
+    parser of /sys/devices/system/node/nodeN/cpulist, the spread warning."""
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    sys.modules["bench_mod"] = b
+    spec.loader.exec_module(b)
+    assert b.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and b.parse_cpulist("") == []
+    sl = b.affinity_slices(8, list(range(64)))
+    assert [len(x) for x in sl] == [8] * 8 and sorted(c for x in sl for c in x) == list(range(64))
+    sl = b.affinity_slices(8, list(range(20)))            # 20 cores, 8 ranks: 2 each, 4 spare, all disjoint
+    assert [len(x) for x in sl] == [2] * 8 and len({c for x in sl for c in x}) == 16
+    sl = b.affinity_slices(4, [0, 1])                     # fewer cores than ranks: shared round-robin, never empty
+    assert sl == [[0], [1], [0], [1]]
+    numa = [list(range(32, 64))] * 4 + [list(range(0, 32))] * 4      # GPUs 0-3 on node 1, GPUs 4-7 on node 0
+    sl = b.affinity_slices(8, list(range(64)), numa)
+    assert all(set(sl[r]) <= set(numa[r]) for r in range(8)) and len({c for x in sl for c in x}) == 64
+    sl = b.affinity_slices(2, list(range(8)), [list(range(100, 104)), None])      # a node this job may not use: falls back to the pool
+    assert sorted(sl[0] + sl[1]) == list(range(8))
+    assert b.rank_spread([10.0, 10.1])[1] is None and b.rank_spread([10.0])[0] == 0.0
+    sp, warn = b.rank_spread([10.0, 10.0, 10.9])
+    assert abs(sp - 0.09) < 1e-9 and "slowest rank 2" in warn
+    assert b.preflight(None, 0, 1, "cpu") is None          # single rank: nothing to verify
 
 
 def test_bench_self_launch_fails_when_a_rank_fails():
