@@ -57,9 +57,10 @@ const char* prof_name(int k) {
   static char buf[PK_NCLASS][64];
   static const char* const other[] = {"attention_f16_kernel", "gn_stats_kernel+gn_apply_kernel", "layernorm_kernel",
                                       "embed_kernel+linear_small_kernel", "conv_in_kernel", "conv_out_kernel", "concat_kernel", "splitk_reduce_kernel", "qproj_xattn_kernel", "qkv_sattn_kernel"};
+  if (k >= PK_HALO_GN0) { snprintf(buf[k], sizeof buf[k], "conv_halo_f16_kernel<%d, 1>", IA2P_GEMM_TILES[24 + k - PK_HALO_GN0].bn); return buf[k]; }
   if (k >= PK_ATTN) return other[k - PK_ATTN];
   const GemmTile t = IA2P_GEMM_TILES[(k % PK_CONV0) % IA2P_GEMM_NVARIANT];
-  if (t.halo) snprintf(buf[k], sizeof buf[k], "conv_halo_f16_kernel<%d>", t.bn);
+  if (t.halo) snprintf(buf[k], sizeof buf[k], "conv_halo_f16_kernel<%d, 0>", t.bn);
   else if (t.pp == 2) snprintf(buf[k], sizeof buf[k], "gemm_f16_kernel<%d, %d, %d, %s, 2, 64, 2, 4>", t.bm, t.bn, t.stages, k >= PK_CONV0 ? "true" : "false");
   else if (t.pp) snprintf(buf[k], sizeof buf[k], "gemm_f16_kernel<%d, %d, %d, %s, 4, 64, 1, 2>", t.bm, t.bn, t.stages, k >= PK_CONV0 ? "true" : "false");
   else if (t.bn == 80) snprintf(buf[k], sizeof buf[k], "gemm_f16_kernel<%d, %d, %d, %s, 4, 64, 0, 1>", t.bm, t.bn, t.stages, k >= PK_CONV0 ? "true" : "false");
@@ -488,7 +489,7 @@ static void run_gemm(RunCtx* c, GemmArgs& a, bool conv, const char* what, double
     ps.pf = a.pf ? (double)a.pf_bytes : 0.0;
     int ran = pl.variant;
     CHECK_LAUNCH(c, ia2p_launch_gemm_variant(a, conv, pl.variant, c->stream, false, &combined, &ran), what);
-    ps.set_class((conv ? PK_CONV0 : PK_GEMM0) + ran);      // (a halo-staged plan runs its gathered twin at a site it does not take: booked under the kernel that ran)
+    ps.set_class(conv && a.gn.st0 && ran >= 24 && ran <= 26 ? PK_HALO_GN0 + ran - 24 : (conv ? PK_CONV0 : PK_GEMM0) + ran);      // (a halo-staged plan runs its gathered twin at a site it does not take: booked under the kernel that ran)
   }
   if (pl.splitk > 1 && !combined) {
     ProfScope ps(c, PK_REDUCE, 0, (double)pl.splitk * a.M * a.N * 4 + 2.0 * a.M * a.N);

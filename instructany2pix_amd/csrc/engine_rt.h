@@ -127,7 +127,7 @@ enum { PR_OTHER = 0, PR_CONV_BLOCK = 1, PR_TRANSFORMER = 2, PR_NREGION };
 enum { ROLE_OTHER = 0, ROLE_FF_IN, ROLE_FF_OUT, ROLE_QKV_SATTN, ROLE_ATTN_OUT, ROLE_Q_XATTN, ROLE_CONV3X3, ROLE_GROUPNORM, ROLE_PROJ_IO, ROLE_CTX_KV, ROLE_EMBED, ROLE_CONV_IO, ROLE_NROLE };
 const char* role_name(int r);
 // profile classes = device kernel names as rocprofv3 prints them (template arguments included)
-enum { PK_GEMM0 = 0, PK_CONV0 = IA2P_GEMM_NVARIANT, PK_ATTN = 2 * IA2P_GEMM_NVARIANT, PK_GN, PK_LN, PK_EMBED, PK_CONV_IN, PK_CONV_OUT, PK_CONCAT, PK_REDUCE, PK_QXATTN, PK_QKVATTN, PK_NCLASS };
+enum { PK_GEMM0 = 0, PK_CONV0 = IA2P_GEMM_NVARIANT, PK_ATTN = 2 * IA2P_GEMM_NVARIANT, PK_GN, PK_LN, PK_EMBED, PK_CONV_IN, PK_CONV_OUT, PK_CONCAT, PK_REDUCE, PK_QXATTN, PK_QKVATTN, PK_HALO_GN0 /* + 0 .. 2: the GroupNorm-fused halo-staged tiles 24 .. 26 */, PK_NCLASS = PK_HALO_GN0 + 3 };
 const char* prof_name(int k);
 
 // state shared by the executors (conditional UNet, VAE): weights, workspace, prefetch plan, per-kernel timing

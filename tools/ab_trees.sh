@@ -14,7 +14,7 @@ for sh in "${SH[@]}"; do
   for i in $(seq 1 $ROUNDS); do
     for t in $TREES; do
       label=${t%%=*}; dir=${t#*=}
-      (cd $dir && python3 bench.py --steps 30 --warmup 3 --repeats 3 --no-cpu-baseline --no-secondary --no-roofline $flags 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print('$name', '$label', 'round $i', 'ms/step', ['%.3f' % x for x in d['timing']['runs_ms_per_step']], 'probe', '%.0f' % d.get('box_probe', {}).get('gemm_4096_tflops', 0))")
+      (cd $dir && python3 bench.py --steps 30 --warmup 3 --repeats 3 --no-cpu-baseline --no-secondary --no-roofline $flags 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); c=d['config']; hoisted=c.get('ms_per_step_with_context_kv_hoisted'); every=c.get('ms_per_step_with_context_kv_every_step'); runs=d['timing']['runs_ms_per_step']; per_req=c.get('context_kv','').startswith('projected once'); print('$name', '$label', 'round $i', 'context K/V every step:', ('%.3f' % every) if every else ['%.3f' % x for x in runs], '| once per request:', ['%.3f' % x for x in runs] if per_req else (('%.3f' % hoisted) if hoisted else '-'), '| probe', '%.0f' % d.get('box_probe', {}).get('gemm_4096_tflops', 0))")
     done
   done
 done
