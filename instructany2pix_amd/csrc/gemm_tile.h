@@ -83,7 +83,8 @@ struct EpiCfg {
   static constexpr int P16 = BN * 2 + 16, T16_BYTES = BM * P16;
   static constexpr int EXTRA16 = (2 * BM + 2 * BN + 4) * 4 + (POW2 ? 0 : BM * (BN / 8) * 8) + LUT_BYTES;
 #ifndef IA2P_REG_EPI_MIN
-#define IA2P_REG_EPI_MIN 0        // tiles of fewer elements keep the fp32 route (build-time knob for A/B builds)
+#define IA2P_REG_EPI_MIN 4097     // tiles of fewer elements (64 x 64 and below: the M = 256 layers of a batch-1 step, the batch-8 out-projections) keep the fp32 route: same box -0.065 ms at batch 1,
+                                  // -0.04 ms at batch 8 against 0 (profiles/r05p_regepi.txt); the two routes give the same bits (build-time knob for A/B builds)
 #endif
   static constexpr bool REG_EPI = T16_BYTES + EXTRA16 <= LIMIT && BM * BN >= IA2P_REG_EPI_MIN;      // (else the fp32 chunked route only: 160 x 160)
   static constexpr int SMEM = REG_EPI && T16_BYTES + EXTRA16 > SMEM_F32 ? T16_BYTES + EXTRA16 : SMEM_F32;
