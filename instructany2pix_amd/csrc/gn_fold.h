@@ -25,12 +25,12 @@ __device__ __forceinline__ void gn_channel_sums(const GemmArgs::GnIn& g, int Cin
     const int cl = second ? c - g.C0 : c, ld = second ? C1 : g.C0, T = second ? T1 : T0;
     const double2* src = (const double2*)(second ? g.st1 : g.st0) + (size_t)img * T * ld + cl;
     double a = 0.0, q = 0.0;
-    for (int t0 = 0; t0 < T; t0 += 8) {
-      double2 v[8];
+    for (int t0 = 0; t0 < T; t0 += 16) {      // (up to IA2P_GN_MAX_SLOTS slots: ONE round trip per channel -- a workgroup of the fused convolution does this fold in its prologue, alone on its CU)
+      double2 v[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = src[(size_t)min(t0 + u, T - 1) * ld];      // all loads of a round in flight (clamped, never branched around)
+      for (int u = 0; u < 16; ++u) v[u] = src[(size_t)min(t0 + u, T - 1) * ld];      // all loads of a round in flight (clamped, never branched around)
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
+      for (int u = 0; u < 16; ++u)
         if (t0 + u < T) { a += v[u].x; q += v[u].y; }
     }
     chs[c] = make_double2(a, q);
