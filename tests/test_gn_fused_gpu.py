@@ -226,6 +226,8 @@ CASES = [  # B, H, W, C0, C1, Co, Ca (appended 1x1 block), producer slot rows (s
     (1, 64, 64, 320, 320, 320, 0, 256, 1024),        # up_blocks.2: two sources, 16 and 4 slots per image
     (3, 16, 16, 128, 64, 96, 64, 128, 256),
     (1, 16, 48, 64, 0, 160, 0, 256, 0),
+    (1, 96, 96, 320, 0, 320, 0, 1024, 0),            # BASELINE configs[4] (768 x 768): 9 216 pixels per image = 9 slots of 1 024 rows (the canonical pass: 36 tile slots would be too many)
+    (2, 48, 48, 640, 320, 640, 0, 256, 576),         # its 48 x 48 level: 9 slots of 256 rows and 4 slots of 576
 ]
 
 
