@@ -358,7 +358,7 @@ static void tune_site(RunCtx* c, const GemmArgs& a, bool conv) {
   c->tune_fused = nullptr; c->tune_gn_ms = 0.0;
   if (ia2p_plan_lookup(a.M, a.N, a.K, conv, a.geglu != 0, nullptr)) return;
   std::vector<GemmPlan> cands;
-  ia2p_gemm_candidates(a.M, a.N, a.K, conv, a.geglu != 0, c->tune_slab_bytes, ia2p_exp_env("IA2P_TUNE_SLACK") ? atof(ia2p_exp_env("IA2P_TUNE_SLACK")) : 1.7, &cands);
+  ia2p_gemm_candidates(a.M, a.N, a.K, conv, a.geglu != 0, c->tune_slab_bytes, ia2p_exp_env("IA2P_TUNE_SLACK") ? atof(ia2p_exp_env("IA2P_TUNE_SLACK")) : 2.5, &cands);      // (2.5 x the modelled best: -0.04 ms per step against 1.7 on the same box, profiles/r05t_slack_ab.txt; 4.0 measures 4 x the candidates for the same picks)
   static const bool tune_log = getenv("IA2P_TUNE_LOG") != nullptr;      // every candidate's time, for calibrating the cost model
   hipEvent_t e0 = get_event(c), e1 = get_event(c);
   // Rounds over all candidates (round -1 untimed), so that clock / cache drift during the measurement hits every candidate alike;
@@ -1053,7 +1053,7 @@ static ia2p_status run_forward(ia2p_ctx* c, const half_t* sample, float timestep
         }
         act_free(f, x); act_free(f, sk);
         r = run_resnet(f, st.res[j], cat, H, Wd, nullptr, 0, !att && !last);
-        wsfree(c, cat);
+        act_free(f, cat);      // (with whatever statistics a fusing consumer computed for it)
       }
       if (att) { T2 t = run_transformer(f, st.att[j], r, H, Wd, true); act_free(f, r); r = t; }
       x = r;
