@@ -228,6 +228,43 @@ def test_cfg5_768px_guided_first_step_all_four_requests(full):
             assert rel_l2(eps[r], eu[0]) < 5e-3 and rel_l2(eps[4 + r], ec[0]) < 5e-3, r       # the two UNet outputs themselves, before guidance amplifies their difference
 
 
+def test_cfg5_768px_fused_groupnorm_sites_equal_their_unfused_twin(full):
+    """BASELINE configs[4] shapes (96 x 96, 48 x 48 and 24 x 24 maps, B_eff = 8): every GroupNorm site the halo-staged convolution can take, FORCED fused (the
+    tuner would fuse fewer), gives the bits of the unfused twin on the same statistics, fewer GroupNorm launches than round 4's path, and that path's result up to
+    the summation order of the statistics. The 24 x 24 level is not a multiple of the 16 x 16 patch: its sites must stay unfused and still agree."""
+    from bench import make_inputs
+    from instructany2pix_amd import _ffi as _f
+    cfg, hip, ref, ip_procs, oracle = full
+    _set_ip(hip, ref, ip_procs, 1.0)
+    lat, ctx, pooled, tid = make_inputs(cfg, 8, 96, 81, DEV, cfg_id=5)
+    added = dict(text_embeds=pooled, time_ids=tid)
+
+    def run(mode):
+        hip.set_gn_fuse(mode)
+        hip.profile(True)
+        o = hip(lat, 981, encoder_hidden_states=ctx, added_cond_kwargs=added)[0].clone()
+        torch.cuda.synchronize()
+        n = sum(v["launches"] for k, v in hip.profile_read_roles().items() if k.startswith("groupnorm"))
+        hip.profile(False)
+        return o, n
+    from instructany2pix_amd.unet import clear_plans
+    try:
+        clear_plans()
+        hip.autotune(lat, 981, ctx, added)      # measured plans, as bench.py runs this configuration (halo-staged tiles enter a plan by measurement only, never from the cost model)
+        unfused, gn0 = run(0)
+        _f.lib().ia2p_debug_set_gn_plan(1)
+        fused, gn1 = run(1)
+        twin, _ = run(2)
+    finally:
+        _f.lib().ia2p_debug_set_gn_plan(-1)
+        hip.set_gn_fuse(1)
+        clear_plans()
+    assert torch.isfinite(fused).all()
+    assert torch.equal(fused, twin), float((fused.float() - twin.float()).abs().max())
+    assert gn1 < gn0, (gn1, gn0)
+    assert rel_l2(fused, unfused) < 2e-3, rel_l2(fused, unfused)
+
+
 def test_measured_plans_are_the_verified_configuration(full):
     """bench.py times the step under MEASURED kernel plans (ia2p_autotune: tile variant and K split per contraction shape), the tests above run under
     the cost model's plans. Tiles never change the bits, but a different K split sums fp32 partials in a different order -- so the configuration the
