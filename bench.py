@@ -758,7 +758,7 @@ def main():
             if not args.no_autotune and not args.plans:
                 tune(w2, name.split(":")[0])
             w2.run(3)
-            n2 = 30 if b2 == 1 else 10
+            n2 = 50      # one whole request per timed run: its context projection is inside, amortised over the 50 steps it serves
             r2 = [w2.timed(n2)[1] / n2 for _ in range(3)]
             ms2 = statistics.median(r2)
             entry = {"ms_per_step": ms2, "steps_per_s": 1e3 / ms2, "runs_ms_per_step": r2, "B_eff": b2, "latent": hw2, "context_tokens": L2, "guidance": g2}
