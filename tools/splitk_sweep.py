@@ -49,5 +49,5 @@ for (M, N, K, label) in SHAPES:
                 L.ia2p_gemm_splitk(s, _ffi.ptr(A), _ffi.ptr(W), None, _ffi.ptr(R), _ffi.ptr(out), M, N, K, sk, _ffi.ptr(part))
             ms = time_it(run)
             row.append(f"sk{sk}: {ms*1e3:6.1f}us {fl/ms/1e9:5.0f}TF")
-        print(f"  {NAMES[v]:10s} " + "  ".join(row))
+        print("  %-10s " % NAMES.get(v, "v%d" % v) + "  ".join(row))
 L.ia2p_debug_set_gemm_tile(-1)
