@@ -17,15 +17,17 @@ both sides -> `value` (max over ranks, wall clock). The same region is also brac
 launch stream, and `--repeats` (default 5) further K-step runs are timed the same way: `timing` carries every
 run and their median.
 
-Rank 0 prints ONE JSON line; besides the contract fields it carries
-  "roofline":     the kernel with the largest share of step time, timed live with HIP events on the launch
+Rank 0 prints ONE JSON line (< 8 KB, strict JSON, parsed back before it is printed: result_line); besides the
+contract fields it carries
+  "roofline":     the layer role with the largest share of step time, timed live with HIP events on the launch
                   stream (ia2p_profile_*): algorithmic FLOPs (2*M*N*K) per launch / average launch duration;
-                  plus `whole_step`, `conv_blocks` (MFMA and HBM fractions of the conv-block region on the
-                  algorithmic bytes of SURVEY.md §8d) and `hbm_kernels` (GroupNorm+SiLU, concat, K-split
-                  reduce, CFG + DDIM update against 8.0 TB/s spec and 6.29 TB/s measured-copy peak)
+                  plus `whole_step` and `conv_blocks` (MFMA and HBM fractions of the conv-block region on the
+                  algorithmic bytes of SURVEY.md §8d)
   "cpu_baseline": the CPU oracle (oracle/, torch fp32 on the host cores) timed on a bounded sample
-  "config.secondary": the other single-GPU BASELINE shapes (configs[1]: B=1, 77-token text-only; configs[4]:
-                  768x768 with guidance, B_eff = 8) measured in the same process, non-headline.
+  "config.secondary_ms_per_step": the other single-GPU BASELINE shapes (configs[1]: B=1, 77-token text-only;
+                  configs[4]: 768x768 with guidance, B_eff = 8; the reference's 1024x1024 defaults), non-headline.
+Everything else (per-role and per-kernel tables, HBM-bound kernels, the secondary shapes' own roofline blocks, the
+full box probe) goes to stderr and to `bench_detail.json` beside this script (write_detail).
 """
 import argparse
 import glob
@@ -41,6 +43,7 @@ sys.path.insert(0, ROOT)
 MFMA_PEAK_TFLOPS = 2500.0       # dense fp16/bf16, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0           # spec
 HBM_COPY_GBS = 6290.0           # measured float4 copy (same guide)
+DEFAULT_PLANS = os.path.join(ROOT, "instructany2pix_amd", "plans", "mi355x_bench.plans")      # the committed kernel plan table (one line "M,N,K,conv,geglu,variant,splitk[,gn];...", # comments)
 # algorithmic FLOPs per UNet evaluation and conv-block bytes / FLOPs (17 ResnetBlocks + 4 resample convs + conv_in/out;
 # input once, output once, weights once) at the BASELINE shapes, keyed by (B_eff, latent side, with IP-Adapter)
 STEP_TFLOP = {(1, 64, False): 1.591, (8, 64, True): 12.751, (8, 96, True): 29.195}
@@ -173,17 +176,105 @@ def affinity_slices(n_ranks, cores, numa_cores=None):
     return out
 
 
-def gpu_numa_cores(n_ranks):
-    """cores of the NUMA node of GPU r, for r < n_ranks, or None where sysfs does not say (no GPU / no NUMA / container without /sys/class/drm)"""
+def hip_device_bdfs(sysfs="/sys"):
+    """PCI addresses ("0000:c1:00.0") of the GPUs in HIP device order, from the KFD topology: HIP enumerates the KFD nodes that have SIMDs in node order (DRM card
+    numbering is NOT that order: a BMC / VGA card0, render-node gaps). ROCR_VISIBLE_DEVICES (applied first, by the runtime below HIP) and then HIP_VISIBLE_DEVICES
+    filter / permute the list when they are plain index lists; a UUID form makes the mapping unknowable from here -> None."""
+    nodes = []
+    for d in glob.glob(os.path.join(sysfs, "class/kfd/kfd/topology/nodes/[0-9]*")):
+        try:
+            props = dict(l.split()[:2] for l in open(os.path.join(d, "properties")).read().splitlines() if len(l.split()) >= 2)
+            if int(props.get("simd_count", "0")) <= 0:
+                continue                                   # a CPU node
+            loc, dom = int(props["location_id"]), int(props.get("domain", "0"))
+            nodes.append((int(os.path.basename(d)), f"{dom:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7:x}"))
+        except Exception:
+            continue
+    bdfs = [b for _, b in sorted(nodes)]
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is None or v.strip() == "":
+            continue
+        try:
+            idx = [int(x) for x in v.split(",") if x.strip() != ""]
+        except ValueError:
+            return None                                    # GPU-<uuid> form
+        bdfs = [bdfs[i] for i in idx if 0 <= i < len(bdfs)]
+    return bdfs
+
+
+def gpu_numa_cores(n_ranks, sysfs="/sys"):
+    """cores of the NUMA node of HIP device r, for r < n_ranks, or None where sysfs does not say (no GPU / no NUMA / a container without the KFD topology).
+    The device -> PCI address map comes from the KFD topology (hip_device_bdfs), the node from /sys/bus/pci/devices/<bdf>/numa_node."""
+    bdfs = hip_device_bdfs(sysfs)
     res = []
-    cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/numa_node"), key=lambda p: int("".join(ch for ch in p.split("/")[4] if ch.isdigit()) or 0))
     for r in range(n_ranks):
         try:
-            node = int(open(cards[r]).read())
-            res.append(parse_cpulist(open(f"/sys/devices/system/node/node{node}/cpulist").read()) if node >= 0 else None)
+            node = int(open(os.path.join(sysfs, "bus/pci/devices", bdfs[r], "numa_node")).read())
+            res.append(parse_cpulist(open(os.path.join(sysfs, f"devices/system/node/node{node}/cpulist")).read()) if node >= 0 else None)
         except Exception:
             res.append(None)
     return res
+
+
+LINE_LIMIT = 8192       # bytes of the ONE result line (the driver's record keeps a bounded stdout tail: round 5's 31.5 KB line could not be parsed)
+
+
+def _finite(x):
+    """NaN / +-Infinity are not JSON: a non-finite float becomes null, recursively"""
+    if isinstance(x, float):
+        return x if x == x and x not in (float("inf"), float("-inf")) else None
+    if isinstance(x, dict):
+        return {k: _finite(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_finite(v) for v in x]
+    return x
+
+
+def _round(x, nd=4):
+    """floats to `nd` significant-ish decimals (the line is read by people and a parser, not used for arithmetic)"""
+    if isinstance(x, float):
+        return float(f"{x:.{nd + 2}g}")
+    if isinstance(x, dict):
+        return {k: _round(v, nd) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_round(v, nd) for v in x]
+    return x
+
+
+def result_line(res):
+    """The one stdout line: strict JSON (no NaN / Infinity tokens), self-checked by parsing it back, under LINE_LIMIT bytes. Optional blocks are dropped in a fixed
+    order if a run ever produces more than that (they are all in the detail file)."""
+    res = _finite(res)
+    res = {k: (_round(v) if isinstance(v, (dict, list)) else v) for k, v in res.items()}      # (the contract scalars -- value, ms_per_step -- keep every digit)
+    drop = [("timing", "runs_ms_per_step"), ("config", "secondary_ms_per_step"), ("config", "per_rank_ms_per_step"), ("roofline", "traffic_source"), ("config", "box_probe"),
+            ("timing", None), ("roofline", "conv_blocks"), ("roofline", "whole_step")]
+    while True:
+        line = json.dumps(res, allow_nan=False, separators=(",", ":"))
+        if len(line.encode()) < LINE_LIMIT or not drop:
+            break
+        a, b = drop.pop(0)
+        if b is None:
+            res.pop(a, None)
+        elif isinstance(res.get(a), dict):
+            res[a].pop(b, None)
+    back = json.loads(line)
+    if len(line.encode()) >= LINE_LIMIT or "\n" in line or back.get("metric") != res.get("metric") or back.get("value") != res.get("value"):
+        raise RuntimeError(f"result line failed its self-check ({len(line)} bytes)")
+    return line
+
+
+def write_detail(detail, path=None):
+    """everything the line does not carry (per-role / per-kernel tables, the secondary shapes' blocks, the full box probe): stderr + a side file beside the script"""
+    path = path or os.path.join(ROOT, "bench_detail.json")
+    text = json.dumps(_finite(detail), indent=1)
+    try:
+        with open(path, "w") as f:
+            f.write(text + "\n")
+    except OSError as e:
+        log(f"[bench] could not write {path}: {e}")
+    log("[bench detail] " + json.dumps(_finite(detail)))
+    return path
 
 
 def pin_rank(local_rank, local_world):
@@ -347,13 +438,13 @@ def stub_main(args):
     if warn and rank == 0:
         log("[bench] WARNING: " + warn)
     if rank == 0:
-        print(json.dumps({"metric": "STUB (sleeping step, no GPU work): launcher / rendezvous / timing plumbing only", "value": world * args.steps / elapsed, "unit": "steps/s",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-                          "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "stub",
-                          "config": {"workload": "stub", "ranks": world, "dist_backend": torch.distributed.get_backend() if world > 1 else "none (single process)",
-                                     "weight_broadcast": {"bytes": int(buf.numel() * 4), "seconds": bcast_s}, "per_rank_ms_per_step": per_rank,
-                                     "per_rank_spread": spread, "per_rank_spread_warning": warn, "preflight": pf, "cores_per_rank": pins,
-                                     "self_launched": bool(os.environ.get("IA2P_BENCH_SELF_LAUNCHED"))}}), flush=True)
+        print(result_line({"metric": "STUB (sleeping step, no GPU work): launcher / rendezvous / timing plumbing only", "value": world * args.steps / elapsed, "unit": "steps/s",
+                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+                           "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "stub",
+                           "config": {"workload": "stub", "ranks": world, "dist_backend": torch.distributed.get_backend() if world > 1 else "none (single process)",
+                                      "weight_broadcast": {"bytes": int(buf.numel() * 4), "seconds": bcast_s}, "per_rank_ms_per_step": per_rank,
+                                      "per_rank_spread": spread, "per_rank_spread_warning": warn, "preflight": pf, "cores_per_rank": pins,
+                                      "self_launched": bool(os.environ.get("IA2P_BENCH_SELF_LAUNCHED"))}}), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
 
@@ -428,10 +519,10 @@ class Workload:
         self.x, self.y = self.lat.clone(), torch.empty_like(self.lat)
         self.i = 0
         # context K/V (reference attention_processor.py:358-359,379-380: `to_k/to_v(encoder_hidden_states)`, recomputed every step there although its input is
-        # constant over a request's steps): "per_request" = projected ONCE per request -- at the first step of every timed run and at every 50-step request
-        # boundary, INSIDE the timed region -- and read from that buffer by the other steps (what the product's pipelines do, bit-identical:
-        # tests/test_fullsize_gpu.py); "per_step" = the reference's own schedule.
-        self.context_kv = "per_request"
+        # constant over a request's steps): "per_step" = the reference's own schedule (what `value` is quoted on); "per_request" = projected ONCE per request --
+        # at the first step of every timed run and at every 50-step request boundary, INSIDE the timed region -- and read from that buffer by the other steps
+        # (what the product's pipelines do, bit-identical: tests/test_fullsize_gpu.py).
+        self.context_kv = "per_step"
 
     def step(self):
         from instructany2pix_amd.scheduler import fused_update
@@ -561,6 +652,32 @@ def roofline_block(table, regions, roles, nprof, B_eff, hw, use_ip, ms_per_step,
             hbm[name] = {"ms_per_step": v["ms"] / nprof, "launches_per_step": v["launches"] / nprof, "avg_launch_us": 1e3 * v["ms"] / v["launches"],
                          "algorithmic_gbs": gbs, "frac_of_8000": gbs / HBM_PEAK_GBS, "frac_of_6290": gbs / HBM_COPY_GBS}
     out["hbm_kernels"] = hbm
+    # MFMA-pipe busy fraction of the role's main instantiation (SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES): separate rocprofv3 --pmc passes,
+    # tools/pmc_mfma.py), static like `traffic`: from the latest profiles/r*_pmc_mfma.json, not measured in this run
+    pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_mfma.json")))
+    out["mfma_busy_frac"], out["mfma_busy_source"] = None, None
+    if pm and d.get("kernels"):
+        main_k = max(d["kernels"], key=lambda q: d["kernels"][q]["ms"])
+        k = json.load(open(pm[-1])).get("kernels", {}).get(main_k)
+        if k:
+            out["mfma_busy_frac"] = k.get("mfma_busy_frac")
+            out["mfma_busy_source"] = f"static: profiles/{os.path.basename(pm[-1])}, kernel {main_k}; NOT measured in this run"
+    return out
+
+
+def roofline_summary(rb):
+    """the part of roofline_block() that rides in the result line (scalars and two small blocks); the per-role / per-kernel tables go to the detail file"""
+    keep = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "algorithmic_bytes_per_launch", "prefetch_bytes_per_launch",
+            "traffic_over_algorithmic", "traffic_minus_prefetch_over_algorithmic", "avg_launch_us", "launches_per_step", "flops_per_launch", "share_of_step",
+            "launches_per_step_all_kernels", "mfma_busy_frac")
+    out = {k: rb[k] for k in keep if k in rb}
+    if out.get("traffic_source"):
+        out["traffic_source"] = out["traffic_source"].split(" (")[0] + "; NOT measured in this run"
+    main_k = max(rb["kernels_of_role"], key=lambda q: rb["kernels_of_role"][q]["ms_per_step"]) if rb.get("kernels_of_role") else None
+    out["main_kernel_of_role"] = main_k
+    ws, cb = rb["whole_step"], rb["conv_blocks"]
+    out["whole_step"] = {"algorithmic_tflop": ws["algorithmic_tflop"], "ms": ws["ms"], "tflops": ws["tflops"], "mfma_frac": ws["mfma_frac"]}
+    out["conv_blocks"] = {"ms": cb["ms"], "mfma_frac": cb["mfma_frac"], "hbm_gbs": cb["hbm_gbs"], "hbm_frac": cb["hbm_frac"]}
     return out
 
 
@@ -586,7 +703,9 @@ def main():
     ap.add_argument("--no-box-probe", action="store_true", help="skip the calibrated box-speed probe (4096^3 GEMM, 1 GiB copy, launch floor)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the non-headline BASELINE shapes (configs[1], configs[4])")
     ap.add_argument("--no-autotune", action="store_true", help="use the built-in cost model instead of measured kernel plans")
-    ap.add_argument("--plans", default=None, help="import this kernel plan table instead of measuring (profiler runs: keeps the tuning launches out of the trace)")
+    ap.add_argument("--tune", action="store_true", help="measure the kernel plans in place at start-up instead of importing the committed table")
+    ap.add_argument("--plans", default=None, help="import this kernel plan table (default: the committed instructany2pix_amd/plans/mi355x_bench.plans)")
+    ap.add_argument("--detail", default=None, help="where the detail JSON goes (default: bench_detail.json beside this script)")
     ap.add_argument("--save-plans", default=None, help="write the kernel plan table in use to this file")
     ap.add_argument("--kernel-table", default=None, help="write the per-kernel timing table (JSON) to this file")
     args = ap.parse_args()
@@ -628,7 +747,7 @@ def main():
         if args.unet == "base":      # the IP-Adapter tensors travel with the arena whatever the headline context is (secondary shapes use them)
             unet.load_ip_adapter_weights(iter_synthetic(ip_specs, seed, dev, torch.float16), scale=1.0, num_tokens=4)
     t_b = time.time()
-    D.broadcast_weights(unet, src=0, with_ip_adapter=args.unet == "base")
+    bcast_route = D.broadcast_weights(unet, src=0, with_ip_adapter=args.unet == "base")      # nccl backend: ia2p_bcast_arena (C ABI) on the process group's communicator
     torch.cuda.synchronize()
     bcast_s = time.time() - t_b
     pf_note = None
@@ -669,21 +788,24 @@ def main():
                 import_plans(table[0])
         return table[0]
 
-    plans = "cost model"
-    if args.plans:
-        text = open(args.plans).read().strip()
+    # Kernel plans ((tile, K-split, GroupNorm-fused) per GEMM / conv shape). Default: the COMMITTED table (instructany2pix_amd/plans/mi355x_bench.plans, measured once on
+    # an MI355X with `--tune --save-plans`): every box runs the same kernel instantiations and the same K-splits -- the same bits, and the per-kernel tables under
+    # profiles/ describe the kernels the driver times. `--tune` measures in place instead (the round-1..5 default); `--no-autotune` leaves every pick to the cost model.
+    plans, tuning = "cost model", False
+    if args.plans or (os.path.exists(DEFAULT_PLANS) and not args.tune and not args.no_autotune):
+        path = args.plans or DEFAULT_PLANS
+        text = "".join(l for l in open(path).read().splitlines() if not l.startswith("#")).strip()
         import_plans(text)
-        plans = f"imported from {os.path.basename(args.plans)} ({text.count(';')} shapes)"
+        import hashlib
+        plans = f"committed table {os.path.relpath(path, ROOT)} sha256:{hashlib.sha256(text.encode()).hexdigest()[:12]} ({text.count(';')} shapes; --tune measures in place)"
     elif not args.no_autotune:
+        tuning = True
         plans = f"measured in place at start-up ({tune(wl, 'headline').count(';')} shapes)"
-    if args.save_plans and rank == 0:
-        with open(args.save_plans, "w") as f:
-            f.write(export_plans() + "\n")
 
-    # The headline loop is the loop the product's pipelines run: the context K/V projection (step-invariant input) once per request, INSIDE the timed region --
-    # at the first timed step of every run and at every 50-step request boundary (Workload.timed / .step) -- and `ia2p_unet_forward_kv` for the other steps;
-    # bit-identical to projecting every step (tests/test_fullsize_gpu.py). The reference's own per-step schedule is reported beside it below.
-    wl.context_kv = "per_request"
+    # `value` is quoted on the REFERENCE's schedule: the context K/V projection (`to_k/to_v(encoder_hidden_states)`, attention_processor.py:358-359,379-380) runs in
+    # EVERY step, as rounds 1-4 measured it. The loop the product's pipelines run (projection once per request, the other steps read the buffer; bit-identical,
+    # tests/test_fullsize_gpu.py) is reported beside it as config.ms_per_step_context_kv_once_per_request.
+    wl.context_kv = "per_step"
     wl.run(args.warmup)
     D.barrier()
     wall, ev_ms = wl.timed(args.steps)
@@ -707,35 +829,36 @@ def main():
     res = {
         "metric": metric, "value": world * args.steps / elapsed, "unit": "steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic inputs" + (", checkpoint weights" if real else "") if real else "synthetic",
-        "config": {"workload": f"{'BASELINE configs[2]' if default_cfg else 'custom'}: {hw * 8}x{hw * 8} px, latent [{B},4,{hw},{hw}], 50-step DDIM schedule, "
-                               f"context {L} tokens ({'77 text + %d IP-Adapter image tokens' % (L - 77) if use_ip else 'text only'}), {'SDXL-base UNet (2.567 G params) + IP-Adapter' if args.unet == 'base' else 'SDXL-refiner UNet (2.260 G params)'}, "
-                               f"synthetic seeded weights", "global_batch": B * world, "parallelism": f"dp{world}", "kernel_plans": plans,
-                   "image_steps_per_s": world * (B // 2 if args.guidance else B) * args.steps / elapsed,
-                   "context_kv": "projected once per request, timed (first step of every timed run and every 50-step request boundary; the other steps read the buffer)",
-                   "ranks": world, "dist_backend": backend or "none (single process)", "per_rank_ms_per_step": per_rank_ms,
-                   "self_launched": bool(os.environ.get("IA2P_BENCH_SELF_LAUNCHED")), "preflight": pf_note, "cpu_cores_pinned": pinned,
-                   "per_rank_spread": spread, "per_rank_spread_warning": spread_warn,
-                   "weight_broadcast": {"bytes": int(unet.arena_raw.numel()), "seconds": bcast_s, "note": "head of the arena only; LayerNorm-folded tail derived per rank"} if world > 1 else None},
-        "timing": {"method": "rank 0: HIP events on the launch stream around each K-step run; run 0 is the region `value` is quoted on (wall clock, max over ranks)",
-                   "runs_ms_per_step": runs, "median_ms_per_step": statistics.median(runs), "steps_per_s_median": 1e3 / statistics.median(runs)},
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic inputs, checkpoint weights" if real else "synthetic",
+        "config": {"workload": f"{'BASELINE configs[2]' if default_cfg else 'custom'}: {hw * 8}x{hw * 8}, latent [{B},4,{hw},{hw}], 50-step DDIM, ctx {L} "
+                               f"({'77 text + %d IP tokens' % (L - 77) if use_ip else 'text only'}), {'SDXL-base UNet + IP-Adapter' if args.unet == 'base' else 'SDXL-refiner UNet'}",
+                   "global_batch": B * world, "parallelism": f"dp{world}", "kernel_plans": plans,
+                   "context_kv": "projected in every step (reference schedule, as rounds 1-4)",
+                   "ranks": world, "dist_backend": backend or "none (single process)", "per_rank_ms_per_step": per_rank_ms, "per_rank_spread": spread,
+                   "weight_broadcast_s": bcast_s if world > 1 else None, "weight_broadcast_route": bcast_route, "detail_file": "bench_detail.json"},
+        "timing": {"runs_ms_per_step": runs, "median_ms_per_step": statistics.median(runs)},
     }
+    # what the line does not carry goes to stderr and to bench_detail.json beside this script
+    detail = {"metric": metric, "timing_method": "rank 0: HIP events on the launch stream around each K-step run; run 0 is the region `value` is quoted on (wall clock, max over ranks)",
+              "image_steps_per_s": world * (B // 2 if args.guidance else B) * args.steps / elapsed, "self_launched": bool(os.environ.get("IA2P_BENCH_SELF_LAUNCHED")),
+              "preflight": pf_note, "cpu_cores_pinned": pinned, "per_rank_spread_warning": spread_warn,
+              "weight_broadcast": {"bytes": int(unet.arena_raw.numel()), "seconds": bcast_s, "note": "head of the arena only; LayerNorm-folded tail derived per rank"} if world > 1 else None}
 
     if probe:
-        res["box_probe"] = probe
-        # the three figures that tell a fast box from a slow one, inside `config` (the driver's record keeps `config`; it drops unknown top-level keys)
-        res["config"]["box_probe"] = {k: probe[k] for k in ("gemm_4096_tflops", "copy_1gib_gbs", "launch_floor_us")}
-    if rank == 0:      # side note, not `value`: the reference's own schedule -- the context projected in EVERY step (attention_processor.py:358-359,379-380)
-        wl.context_kv = "per_step"
-        wl.run(1)
-        nk = min(20, args.steps)
-        _, ms = wl.timed(nk)
-        res["config"]["ms_per_step_with_context_kv_every_step"] = ms / nk
+        detail["box_probe"] = probe
+        res["config"]["box_probe"] = {k: probe[k] for k in ("gemm_4096_tflops", "copy_1gib_gbs", "launch_floor_us")}      # tells a fast box from a slow one
+    if rank == 0:      # side note, not `value`: the loop the product's pipelines run -- one whole 50-step request per timed run, its context projected once, inside
         wl.context_kv = "per_request"
+        wl.run(1)
+        _, ms = wl.timed(50)
+        res["config"]["ms_per_step_context_kv_once_per_request"] = ms / 50
+        wl.context_kv = "per_step"
     if rank == 0 and not args.no_roofline:
         nprof = 3
         table, regions, roles = wl.profile(nprof)
-        res["roofline"] = roofline_block(table, regions, roles, nprof, B, hw, use_ip, statistics.median(runs), probe)
+        rb = roofline_block(table, regions, roles, nprof, B, hw, use_ip, statistics.median(runs), probe)
+        detail["roofline"] = rb
+        res["roofline"] = roofline_summary(rb)
         log_table(table, nprof)
         if args.kernel_table:
             os.makedirs(os.path.dirname(os.path.abspath(args.kernel_table)), exist_ok=True)
@@ -755,32 +878,43 @@ def main():
             else:
                 unet.set_attn_processor(AttnProcessor2_0())
             w2 = Workload(unet, cfg, b2, hw2, L2, g2, dev, cfg_id=cid)
-            if not args.no_autotune and not args.plans:
+            w2.context_kv = "per_request"      # (secondary shapes: the product's loop, one whole 50-step request per timed run)
+            if tuning:
                 tune(w2, name.split(":")[0])
             w2.run(3)
             n2 = 50      # one whole request per timed run: its context projection is inside, amortised over the 50 steps it serves
             r2 = [w2.timed(n2)[1] / n2 for _ in range(3)]
             ms2 = statistics.median(r2)
-            entry = {"ms_per_step": ms2, "steps_per_s": 1e3 / ms2, "runs_ms_per_step": r2, "B_eff": b2, "latent": hw2, "context_tokens": L2, "guidance": g2}
+            entry = {"ms_per_step": ms2, "steps_per_s": 1e3 / ms2, "runs_ms_per_step": r2, "B_eff": b2, "latent": hw2, "context_tokens": L2, "guidance": g2, "context_kv": "once per request"}
             if not args.no_roofline:
                 t2, rg2, ro2 = w2.profile(3)
-                rb = roofline_block(t2, rg2, ro2, 3, b2, hw2, L2 > 77, ms2, probe)
-                entry["roofline"] = {k: rb[k] for k in ("kernel", "achieved", "frac", "roles", "top_kernels", "whole_step", "conv_blocks", "hbm_kernels", "launches_per_step_all_kernels", "fixed_share") if k in rb}
+                rb2 = roofline_block(t2, rg2, ro2, 3, b2, hw2, L2 > 77, ms2, probe)
+                entry["roofline"] = {k: rb2[k] for k in ("kernel", "achieved", "frac", "roles", "top_kernels", "whole_step", "conv_blocks", "hbm_kernels", "launches_per_step_all_kernels", "fixed_share") if k in rb2}
                 if b2 == 1:
                     wbytes = 5.817e9 if inv_quirk else 5.135e9           # compulsory weight bytes of an evaluation with / without the IP-Adapter projections
                     entry["weight_streaming"] = {"bytes": wbytes, "bound_ms_at_6290": wbytes / HBM_COPY_GBS / 1e6, "frac_of_bound": wbytes / HBM_COPY_GBS / 1e6 / ms2}
             sec[name] = entry
             log(f"[secondary] {name}: {ms2:.2f} ms/step")
-        res["config"]["secondary"] = sec
+        detail["secondary"] = sec
+        res["config"]["secondary_ms_per_step"] = {("cfg2_b1_512" if "configs[1]" in k else "cfg5_768_cfg_b8" if "configs[4]" in k else "ref1024_inv_b1" if "inversion" in k else "ref1024_cfg_b2"): v["ms_per_step"]
+                                                  for k, v in sec.items()}
         unet.load_ip_adapter_weights([], scale=1.0, num_tokens=4)
+    if args.save_plans and rank == 0:      # (after the secondary shapes: a --tune run leaves ONE table that covers every workload of this file)
+        with open(args.save_plans, "w") as f:
+            f.write(export_plans() + "\n")
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         inputs_cpu = [t.cpu() for t in (wl.lat, wl.ctx, wl.added["text_embeds"], wl.added["time_ids"])]
         t_step, cores, what = cpu_baseline(cfg, unet_specs, ip_specs, seed, dev, inputs_cpu, L, B)
-        res["cpu_baseline"] = {"value": 1.0 / t_step, "unit": "steps/s", "cores": cores, "kind": "port", "sample": what}
+        detail["cpu_baseline_sample"] = what
+        res["cpu_baseline"] = {"value": 1.0 / t_step, "unit": "steps/s", "cores": cores, "kind": "port",
+                               "sample": f"oracle (torch fp32, {cores} threads): 1 warm-up + 1 timed step of 1 request, then ONE real batch-{B} UNet+DDIM step ({t_step:.1f} s)"
+                                         if "EXTRAPOLATED" not in what else f"oracle (torch fp32, {cores} threads): steps of 1 and 2 requests, batch-{B} step EXTRAPOLATED ({t_step:.1f} s)"}
 
     if rank == 0:
-        print(json.dumps(res), flush=True)
+        detail["line"] = res
+        write_detail(detail, args.detail)
+        print(result_line(res), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
 

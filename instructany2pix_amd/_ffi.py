@@ -1,4 +1,4 @@
-"""ctypes binding of libia2p_hip.so (C ABI declared in include/ia2p.h).
+"""ctypes binding of libia2p_hip.so (C ABI declared in include/ia2p.h; test hooks and the profile interface in include/ia2p_debug.h).
 
 The product path has no CPU fallback: if the library is missing this module raises at import of the
 symbols, and every compute entry point needs device pointers on an MI355X.
@@ -42,7 +42,6 @@ class VAEConfigC(C.Structure):
                 ("norm_eps", C.c_float), ("stream_scale", C.c_float)]
 
 
-# every symbol include/ia2p.h declares: name -> (restype, argtypes)
 class ConvGnC(C.Structure):
     """ia2p_conv_gn (include/ia2p.h): a 3x3 convolution with the GroupNorm + SiLU in front of it applied inside the kernel"""
     _fields_ = [("x0", C.c_void_p), ("C0", C.c_int), ("st0", C.c_void_p), ("rows0", C.c_int),
@@ -54,6 +53,7 @@ class ConvGnC(C.Structure):
 
 
 _P, _I, _F, _SZ, _I64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_int64
+# every symbol include/ia2p.h and include/ia2p_debug.h declare: name -> (restype, argtypes)
 SIGNATURES = {
     "ia2p_create": (_I, [C.POINTER(UNetConfigC), C.POINTER(_P)]),
     "ia2p_destroy": (None, [_P]),
@@ -66,6 +66,8 @@ SIGNATURES = {
     "ia2p_adopt_arena": (_I, [_P, _I]),
     "ia2p_adopt_arena_on": (_I, [_P, _I, _P]),
     "ia2p_arena_raw_bytes": (_SZ, [_P]),
+    "ia2p_bcast_arena": (_I, [_P, _P, _I, _I, _P]),
+    "ia2p_rccl_available": (_I, []),
     "ia2p_set_ip_adapter": (_I, [_P, _I, _I, _F]),
     "ia2p_workspace_bytes": (_SZ, [_P, _I, _I, _I, _I]),
     "ia2p_unet_forward": (_I, [_P, _P, _P, _F, _P, _I, _P, _P, _P, _I, _I, _I, _P, _SZ]),

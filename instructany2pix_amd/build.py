@@ -10,7 +10,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-INCLUDE = os.path.join(os.path.dirname(HERE), "include", "ia2p.h")
+INCLUDES = [os.path.join(os.path.dirname(HERE), "include", f) for f in ("ia2p.h", "ia2p_debug.h")]
 OUT = os.path.join(HERE, "libia2p_hip.so")
 SOURCES = ["gemm.hip", "qxattn.hip", "attention.hip", "norm.hip", "misc.hip", "engine.hip", "vae_engine.hip", "clip_engine.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -23,7 +23,7 @@ FILE_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"] + PRELOAD, "
 
 def _stamp():
     h = hashlib.sha256()
-    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))] + [INCLUDE]
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))] + INCLUDES
     for p in files:
         h.update(os.path.basename(p).encode())
         h.update(open(p, "rb").read())

@@ -62,7 +62,7 @@ static ia2p_status clip_fold(ia2p_clip* c, hipStream_t stream = nullptr, bool sy
     if (e == hipSuccess) e = ia2p_launch_fold_ln(Hp(l.w1), Hp(l.ln2g), Hp(l.ln2b), Hp(l.b1), Hp(l.f1), Fp(l.cs2), Fp(l.lb2), I, H, stream);
   }
   if (e == hipSuccess && sync) e = hipStreamSynchronize(stream);
-  if (e != hipSuccess) return fail(c, IA2P_ERR_HIP, "clip LayerNorm folding: %s", hipGetErrorString(e));
+  if (e != hipSuccess) return fail_hip(c, e, "clip LayerNorm folding");
   c->fold_dirty = false;
   return IA2P_OK;
 }
@@ -82,7 +82,7 @@ static ia2p_status clip_run(ia2p_clip* c, const int* ids, const half_t* embeds, 
     const CLayer& l = c->layers[i];
     if (i == L - 1 && hid2 && !c->dry && !c->failed) {     // hidden_states[-2]: what the last layer reads
       hipError_t e = hipMemcpyAsync(hid2, x.p, (size_t)M * H * sizeof(half_t), hipMemcpyDeviceToDevice, c->stream);
-      if (e != hipSuccess) fail(c, IA2P_ERR_HIP, "clip: %s", hipGetErrorString(e));
+      if (e != hipSuccess) fail_hip(c, e, "clip");
     }
     {
       const LnIn ln{st, slots, Fp(l.cs1), Fp(l.lb1), g.layer_norm_eps};
@@ -98,7 +98,7 @@ static ia2p_status clip_run(ia2p_clip* c, const int* ids, const half_t* embeds, 
   }
   if (!need_last && hid2 && !c->dry && !c->failed) {
     hipError_t e = hipMemcpyAsync(hid2, x.p, (size_t)M * H * sizeof(half_t), hipMemcpyDeviceToDevice, c->stream);
-    if (e != hipSuccess) fail(c, IA2P_ERR_HIP, "clip: %s", hipGetErrorString(e));
+    if (e != hipSuccess) fail_hip(c, e, "clip");
   }
   if (last) CHECK_LAUNCH(c, ia2p_launch_layernorm(x.p, H, last, H, W_(c, c->lnfg), W_(c, c->lnfb), M, H, g.layer_norm_eps, c->stream), "clip final_layer_norm");
   if (pooled) {

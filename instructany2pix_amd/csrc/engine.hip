@@ -10,6 +10,9 @@
 // deterministic first-fit allocator (sized by a dry run of the same code path).
 #include "engine_rt.h"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // types and prototypes only: the symbols are bound at run time (ia2p_bcast_arena), the library is not linked
+
 thread_local std::string g_err;
 
 const half_t* zero_page() {
@@ -102,7 +105,11 @@ ia2p_status fail(RunCtx* c, ia2p_status st, const char* fmt, ...) {
   va_end(ap);
   if (c) { c->err = buf; c->failed = true; }
   g_err = buf;
-  return st;      // (K-split tickets: invalidated where a launch / sync error is seen -- CHECK_LAUNCH, RET_HIP -- not for argument refusals)
+  return st;      // (K-split tickets: invalidated where a launch / sync error is seen -- CHECK_LAUNCH, RET_HIP, fail_hip -- not for argument refusals)
+}
+ia2p_status fail_hip(RunCtx* c, hipError_t e, const char* what) {
+  if (e != hipErrorInvalidValue) ia2p_sk_counters_invalidate();
+  return fail(c, IA2P_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1117,7 +1124,7 @@ ia2p_status rc_load_tensor(RunCtx* c, const char* key, const void* src, const in
     case PK_GEGLU_W: case PK_GEGLU_B: e = ia2p_launch_pack_geglu((const half_t*)src, dst, p.d0, p.d1, s); break;
     case PK_PAD_CONV_IN: e = ia2p_launch_pack_conv_in((const half_t*)src, dst, p.d0, p.d1, s); break;
   }
-  if (e != hipSuccess) return fail(c, IA2P_ERR_HIP, "load '%s': %s", key, hipGetErrorString(e));
+  if (e != hipSuccess) return fail_hip(c, e, (std::string("load '") + key + "'").c_str());
   p.loaded = true;
   c->fold_dirty = true;     // data derived from the parameters at finalize (LayerNorm folds) is stale until the owner re-derives it
   return IA2P_OK;
@@ -1198,7 +1205,7 @@ static ia2p_status fold_all(ia2p_ctx* c, hipStream_t stream, bool sync) {
     if (r->shortcut && e == hipSuccess)
       e = ia2p_launch_cat_rows(H(r->w2), 9 * r->cout, H(r->wsc), r->cin, H(r->b2), H(r->bsc), H(r->wcat), H(r->bcat), r->cout, stream);
   if (e == hipSuccess && sync) e = hipStreamSynchronize(stream);
-  if (e != hipSuccess) return fail(c, IA2P_ERR_HIP, "weight folding: %s", hipGetErrorString(e));
+  if (e != hipSuccess) return fail_hip(c, e, "weight folding");
   c->fold_dirty = false;
   return IA2P_OK;
 }
@@ -1216,6 +1223,62 @@ ia2p_status ia2p_adopt_arena_on(ia2p_ctx* c, int with_ip_adapter, void* stream) 
   return st == IA2P_OK ? fold_all(c, (hipStream_t)stream, true) : st;
 }
 ia2p_status ia2p_adopt_arena(ia2p_ctx* c, int with_ip_adapter) { return ia2p_adopt_arena_on(c, with_ip_adapter, nullptr); }
+
+// ---- the one collective of the batch-data-parallel path, through the C ABI: RCCL broadcast of the arena head + local adoption -------------------------
+// RCCL is bound late (dlopen / dlsym): the library has no link-time dependency on it, and a host that already carries an RCCL instance (PyTorch bundles its
+// own librccl.so with SONAME librccl.so.1) must be served by THAT instance -- the communicator handed in was created by it. RTLD_NOLOAD first: whatever is
+// already in the process; only a host without any RCCL gets the system one loaded for it.
+namespace {
+struct Rccl {
+  ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok = false;
+};
+const Rccl& rccl() {
+  static const Rccl r = [] {
+    Rccl x;
+    void* h = nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so"})
+      if (!h) h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+      if (!h) h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    if (!h) return x;
+    x.Broadcast = (decltype(x.Broadcast))dlsym(h, "ncclBroadcast");
+    x.CommUserRank = (decltype(x.CommUserRank))dlsym(h, "ncclCommUserRank");
+    x.CommCount = (decltype(x.CommCount))dlsym(h, "ncclCommCount");
+    x.GetErrorString = (decltype(x.GetErrorString))dlsym(h, "ncclGetErrorString");
+    x.ok = x.Broadcast && x.CommUserRank && x.CommCount && x.GetErrorString;
+    return x;
+  }();
+  return r;
+}
+}  // namespace
+int ia2p_rccl_available(void) { return rccl().ok ? 1 : 0; }
+ia2p_status ia2p_bcast_arena(ia2p_ctx* c, void* rccl_comm, int root, int with_ip_adapter, void* stream) {
+  if (!c || !rccl_comm) return fail(c, IA2P_ERR_INVALID, "bcast_arena: null argument");
+  if (!c->arena) return fail(c, IA2P_ERR_STATE, "bcast_arena before bind_arena");
+  const Rccl& r = rccl();
+  if (!r.ok) return fail(c, IA2P_ERR_STATE, "bcast_arena: no RCCL in this process and none could be loaded (librccl.so.1)");
+  ncclComm_t comm = (ncclComm_t)rccl_comm;
+  int rank = -1, n = 0;
+  ncclResult_t e = r.CommUserRank(comm, &rank);
+  if (e == ncclSuccess) e = r.CommCount(comm, &n);
+  if (e != ncclSuccess) return fail(c, IA2P_ERR_INVALID, "bcast_arena: not a usable communicator (%s)", r.GetErrorString(e));
+  if (root < 0 || root >= n) return fail(c, IA2P_ERR_INVALID, "bcast_arena: root %d outside a communicator of %d ranks", root, n);
+  // a few large messages (ring broadcast over point-to-point xGMI is per-link bound: message COUNT is what to keep small), each below 2^31 bytes
+  char* p = (char*)c->arena;
+  const size_t total = c->arena_raw_elems * sizeof(half_t), piece = (size_t)1 << 30;
+  for (size_t lo = 0; lo < total && e == ncclSuccess; lo += piece)
+    e = r.Broadcast(p + lo, p + lo, std::min(piece, total - lo), ncclInt8, root, comm, (hipStream_t)stream);
+  if (e != ncclSuccess) { ia2p_sk_counters_invalidate(); return fail(c, IA2P_ERR_HIP, "bcast_arena: ncclBroadcast: %s", r.GetErrorString(e)); }
+  if (rank == root) {                  // the root keeps its own tail; its stream is synchronised like the receivers' (the call returns with the head sent)
+    const hipError_t he = hipStreamSynchronize((hipStream_t)stream);
+    return he == hipSuccess ? IA2P_OK : fail_hip(c, he, "bcast_arena");
+  }
+  return ia2p_adopt_arena_on(c, with_ip_adapter, stream);      // fold kernels ordered behind the broadcast on the same stream, which is synchronised before returning
+}
 
 ia2p_status ia2p_set_gn_fuse(ia2p_ctx* c, int mode) {
   if (!c || mode < 0 || mode > 2) return fail(c, IA2P_ERR_INVALID, "set_gn_fuse: mode %d (0 GroupNorm launches, 1 fused into the convolutions, 2 the fused path's unfused twin)", mode);
@@ -1384,7 +1447,7 @@ ia2p_status ia2p_autotune(ia2p_ctx* c, void* stream, const void* sample, float t
 ia2p_status ia2p_ddim_step(void* stream, const void* x, const void* eu, const void* ec, float g, float c_x, float c_e, void* out, void* out2, int64_t n) {
   if (!x || !eu || !out || n < 0) return fail(nullptr, IA2P_ERR_INVALID, "ddim_step: null argument");
   hipError_t e = ia2p_launch_ddim_step((const half_t*)x, (const half_t*)eu, (const half_t*)ec, g, c_x, c_e, (half_t*)out, (half_t*)out2, (long)n, (hipStream_t)stream);
-  return e == hipSuccess ? IA2P_OK : fail(nullptr, IA2P_ERR_HIP, "ddim_step: %s", hipGetErrorString(e));
+  return e == hipSuccess ? IA2P_OK : fail_hip(nullptr, e, "ddim_step");
 }
 
 // The same update with per-request coefficients: coef (device, float [B][3]) = {guidance g, c_x, c_e} of batch element b, `per` elements each --
@@ -1392,7 +1455,7 @@ ia2p_status ia2p_ddim_step(void* stream, const void* x, const void* eu, const vo
 ia2p_status ia2p_ddim_step_v(void* stream, const void* x, const void* eu, const void* ec, const float* coef, void* out, void* out2, int B, int64_t per) {
   if (!x || !eu || !out || !coef || B < 0 || per < 1) return fail(nullptr, IA2P_ERR_INVALID, "ddim_step_v: bad argument");
   hipError_t e = ia2p_launch_ddim_step((const half_t*)x, (const half_t*)eu, (const half_t*)ec, 0.f, 0.f, 0.f, (half_t*)out, (half_t*)out2, (long)B * per, (hipStream_t)stream, coef, (long)per);
-  return e == hipSuccess ? IA2P_OK : fail(nullptr, IA2P_ERR_HIP, "ddim_step_v: %s", hipGetErrorString(e));
+  return e == hipSuccess ? IA2P_OK : fail_hip(nullptr, e, "ddim_step_v");
 }
 
 ia2p_status ia2p_mask_blend(void* stream, const void* x, const void* init, const void* noise, const void* mask, float c0, float c1,
@@ -1400,14 +1463,14 @@ ia2p_status ia2p_mask_blend(void* stream, const void* x, const void* init, const
   if (!x || !init || !noise || !mask || !out || B < 0 || C < 1 || HW < 1) return fail(nullptr, IA2P_ERR_INVALID, "mask_blend: bad argument");
   hipError_t e = ia2p_launch_mask_blend((const half_t*)x, (const half_t*)init, (const half_t*)noise, (const half_t*)mask, c0, c1, (half_t*)out, (half_t*)out2,
                                         B, C, (long)HW, (hipStream_t)stream);
-  return e == hipSuccess ? IA2P_OK : fail(nullptr, IA2P_ERR_HIP, "mask_blend: %s", hipGetErrorString(e));
+  return e == hipSuccess ? IA2P_OK : fail_hip(nullptr, e, "mask_blend");
 }
 
 ia2p_status ia2p_prior_step(void* stream, const float* sample, const void* out_cond, const void* out_uncond, const float* noise, float g, float sqrt_a,
                             float sqrt_b, float k0, float k1, float sigma, float* out, int64_t n) {
   if (!sample || !out_uncond || !out || n < 0 || !(sqrt_a > 0.f) || !(sqrt_b > 0.f)) return fail(nullptr, IA2P_ERR_INVALID, "prior_step: bad argument");
   hipError_t e = ia2p_launch_prior_step(sample, (const half_t*)out_cond, (const half_t*)out_uncond, noise, g, sqrt_a, sqrt_b, k0, k1, sigma, out, (long)n, (hipStream_t)stream);
-  return e == hipSuccess ? IA2P_OK : fail(nullptr, IA2P_ERR_HIP, "prior_step: %s", hipGetErrorString(e));
+  return e == hipSuccess ? IA2P_OK : fail_hip(nullptr, e, "prior_step");
 }
 
 // ---- per-operator entry points ---------------------------------------------------------------------------------------

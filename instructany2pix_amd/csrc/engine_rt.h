@@ -15,7 +15,7 @@
 #include <unordered_map>
 #include <vector>
 
-#include "../../include/ia2p.h"
+#include "../../include/ia2p_debug.h"      // (the product ABI, ia2p.h, + the test hooks / profile interface this library also exports)
 #include "common.h"
 
 // ---- kernel launchers (gemm.hip, attention.hip, norm.hip, misc.hip) ------------------------------------------
@@ -205,6 +205,9 @@ struct RunCtx {
 };
 
 ia2p_status fail(RunCtx* c, ia2p_status st, const char* fmt, ...);
+// a HIP runtime error seen OUTSIDE CHECK_LAUNCH / RET_HIP (copies, synchronisations, the sampler-update launchers): unless it is a launcher's own refusal of its
+// arguments (hipErrorInvalidValue: nothing was launched) a launch may have died mid-flight and left K-split tickets behind -> new ticket epoch, then fail()
+ia2p_status fail_hip(RunCtx* c, hipError_t e, const char* what);
 
 struct T2 { size_t off; half_t* p; };   // workspace tensor
 T2 wsalloc(RunCtx* c, size_t elems);

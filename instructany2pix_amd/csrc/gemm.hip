@@ -33,8 +33,13 @@
 // (96 KiB LDS at 128x128) and loses 20-30 %, so 2 stages is the default; tile = largest that still gives every
 // CU >= 1.5-2 workgroups (the kernels run at ~13 TB/s of L2->LDS traffic, i.e. they are L2-bandwidth bound and
 // more co-resident blocks hide the per-k-step load latency).
+// generation of everything the executor's plan (and so its workspace allocation pattern) depends on: the measured-plan table AND the test hooks that override it.
+// Hosts key their workspace on it (ia2p_plan_generation; HipUNet2DConditionModel.workspace_for) and re-query ia2p_workspace_bytes when it moves.
+static std::mutex g_plan_mu;
+static unsigned long long g_plan_gen = 0;
+static void plan_gen_bump() { std::lock_guard<std::mutex> lk(g_plan_mu); ++g_plan_gen; }
 static int g_force_variant = -1;   // test/tuning hook (ia2p_debug_set_gemm_tile)
-extern "C" void ia2p_debug_set_gemm_tile(int v) { g_force_variant = v; }
+extern "C" void ia2p_debug_set_gemm_tile(int v) { if (v != g_force_variant) plan_gen_bump(); g_force_variant = v; }
 // the tile table, for tools and tests: out = {bm, bn, ring stages, schedule (0 plain, 1 ping-pong, 2 eight-phase, 3 ping-pong over halo-staged patches: 3x3 convolutions only)}; returns 0, or -1 past the last variant
 extern "C" int ia2p_debug_gemm_tile_info(int v, int* out) {
   if (v < 0 || v >= IA2P_GEMM_NVARIANT || !out) return -1;
@@ -135,9 +140,9 @@ bool ia2p_splitk_inkernel(int M, int N, int splitk) {
   return splitk > 1 && (size_t)splitk * M * N * sizeof(float) <= limit;
 }
 static int g_force_gn = -1;        // test hook (ia2p_debug_set_gn_plan): -1 the plan's own bit, 1 every eligible site fuses its GroupNorm, 0 none does
-extern "C" void ia2p_debug_set_gn_plan(int v) { g_force_gn = v; }
+extern "C" void ia2p_debug_set_gn_plan(int v) { if (v != g_force_gn) plan_gen_bump(); g_force_gn = v; }      // (changes every site's fuse decision: the workspace pattern moves with it)
 static int g_force_splitk = -1;    // test/tuning hook
-extern "C" void ia2p_debug_set_gemm_splitk(int s) { g_force_splitk = s; }
+extern "C" void ia2p_debug_set_gemm_splitk(int s) { if (s != g_force_splitk) plan_gen_bump(); g_force_splitk = s; }
 
 // Ticket counters of the in-launch K-split combine: one int per output tile, zero between launches (the last arriver of a tile resets its
 // counter). One buffer per (device, stream): launches on one stream are ordered, so two K-split launches can only share counters when they cannot
@@ -240,8 +245,6 @@ static double plan_cost_us(int M, int N, int K, bool conv, const GemmTile& t, in
 
 // ---- measured plans (ia2p_autotune): shape -> (variant, splitk), process-wide; consulted before the cost model
 using PlanKey = std::tuple<int, int, int, int, int>;
-static std::mutex g_plan_mu;
-static unsigned long long g_plan_gen = 0;      // bumped by every change of the table (hosts re-size their workspace when it moves)
 extern "C" unsigned long long ia2p_plan_generation(void) { std::lock_guard<std::mutex> lk(g_plan_mu); return g_plan_gen; }
 static std::map<PlanKey, GemmPlan>& tuned_plans() { static std::map<PlanKey, GemmPlan> m; return m; }
 

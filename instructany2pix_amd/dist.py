@@ -72,12 +72,45 @@ def broadcast_flat(buf: torch.Tensor, src: int = 0, chunk_bytes: int = 1 << 30) 
     return buf
 
 
-def broadcast_weights(unet, src: int = 0, with_ip_adapter: bool = True):
+def rccl_comm_ptr(device) -> int:
+    """The raw ncclComm_t of the default process group's RCCL communicator on `device` (0 when there is none: another backend, a torch build without the
+    accessor). The communicator is created by the first collective: a one-element broadcast makes sure it exists."""
+    if not dist.is_initialized() or dist.get_backend() != "nccl":
+        return 0
+    try:
+        t = torch.zeros(1, device=device)
+        dist.broadcast(t, src=0)
+        torch.cuda.synchronize(device)
+        pg = dist.distributed_c10d._get_default_group()._get_backend(torch.device(device))
+        return int(pg._comm_ptr())
+    except Exception:
+        return 0
+
+
+def broadcast_weights(unet, src: int = 0, with_ip_adapter: bool = True) -> str:
     """Rank `src` holds loaded weights; everyone else receives the HEAD of the arena (the parameters as loaded: 5.8 GB for SDXL-base +
-    IP-Adapter, six messages) and derives the LayerNorm-folded tail locally (`ia2p_adopt_arena`), which keeps 2.5 GB off xGMI."""
+    IP-Adapter, six messages) and derives the LayerNorm-folded tail locally (`ia2p_adopt_arena`), which keeps 2.5 GB off xGMI.
+    Under the "nccl" backend (= RCCL) the whole step is ONE C-ABI call, `ia2p_bcast_arena` (include/ia2p.h), on the process group's own communicator -- what a
+    host without torch.distributed would call with its ncclComm_t; IA2P_BCAST=torch (or a torch build that does not hand out the communicator) keeps the
+    torch.distributed broadcast, as the gloo path always does. Returns which route ran ("abi" / "torch" / "none")."""
+    if not _active():
+        return "none"
+    if dist.get_backend() == "nccl" and os.environ.get("IA2P_BCAST", "abi") != "torch":
+        from . import _ffi
+        comm = rccl_comm_ptr(unet.device) if _ffi.lib().ia2p_rccl_available() else 0
+        ok = torch.tensor([1.0 if comm else 0.0], device=unet.device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)               # every rank or none: a collective must not be entered by some ranks only
+        if float(ok.item()) > 0:
+            torch.cuda.synchronize(unet.device)                 # nothing of torch's is in flight on this communicator
+            import ctypes as C
+            _ffi.check(_ffi.lib().ia2p_bcast_arena(unet._ctx, C.c_void_p(comm), int(src), int(with_ip_adapter), _ffi.current_stream()), unet._ctx)
+            if dist.get_rank() != src:
+                unet._weights_gen += 1
+            return "abi"
     broadcast_flat(unet.arena_raw, src)
-    if dist.is_initialized() and dist.get_rank() != src:
+    if dist.get_rank() != src:
         unet.adopt_arena(with_ip_adapter)
+    return "torch"
 
 
 def barrier():

@@ -23,7 +23,8 @@ unet = HipUNet2DConditionModel(cfg, dev)
 if rank == 0:
     unet.load_state_dict(synthetic_state_dict(unet_param_specs(cfg), seed=7))
     unet.load_ip_adapter_weights(synthetic_state_dict(ip_adapter_specs(cfg, 64)["ip_adapter"], seed=7), scale=0.9, num_tokens=4)
-D.broadcast_weights(unet, src=0, with_ip_adapter=True)            # RCCL broadcast of unet.arena_raw + local fold on ranks != 0
+route = D.broadcast_weights(unet, src=0, with_ip_adapter=True)    # RCCL broadcast of unet.arena_raw + local fold on ranks != 0: ONE C-ABI call per rank (ia2p_bcast_arena)
+assert route == "abi", route
 if rank != 0:
     unet.load_ip_adapter_weights([], scale=0.9, num_tokens=4)
 torch.cuda.synchronize()

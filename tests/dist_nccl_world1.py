@@ -23,9 +23,25 @@ unet = HipUNet2DConditionModel(sdxl_base(), dev)
 unet.arena.view(torch.int16)[::4097] = 12345                      # (recognisable bytes in the head)
 before = int(unet.arena_raw.view(torch.int16)[::4097].to(torch.int64).sum())
 t0 = time.time()
-D.broadcast_weights(unet, src=0, with_ip_adapter=True)            # six 1 GiB broadcasts through RCCL
+route = D.broadcast_weights(unet, src=0, with_ip_adapter=True)    # six 1 GiB broadcasts through RCCL, issued by ONE C-ABI call: ia2p_bcast_arena on torch's communicator
 torch.cuda.synchronize()
 dt = time.time() - t0
+assert route == "abi", route                                      # round 6: the broadcast is part of the C ABI (include/ia2p.h), RCCL bound at run time from torch's instance
+assert int(unet.arena_raw.view(torch.int16)[::4097].to(torch.int64).sum()) == before
+# the entry point's own argument checks (no communicator, a root outside the communicator), and the torch.distributed route kept behind IA2P_BCAST=torch
+import ctypes as C
+from instructany2pix_amd import _ffi
+L = _ffi.lib()
+assert L.ia2p_rccl_available() == 1
+comm = D.rccl_comm_ptr(dev)
+assert comm != 0
+assert L.ia2p_bcast_arena(unet._ctx, None, 0, 1, _ffi.current_stream()) == 1                       # IA2P_ERR_INVALID
+assert L.ia2p_bcast_arena(unet._ctx, C.c_void_p(comm), 3, 1, _ffi.current_stream()) == 1 and b"root 3" in L.ia2p_last_error(unet._ctx)
+assert L.ia2p_bcast_arena(unet._ctx, C.c_void_p(comm), 0, 1, _ffi.current_stream()) == 0          # straight through ctypes, as a host without torch.distributed would
+os.environ["IA2P_BCAST"] = "torch"
+assert D.broadcast_weights(unet, src=0, with_ip_adapter=True) == "torch"
+del os.environ["IA2P_BCAST"]
+torch.cuda.synchronize()
 assert int(unet.arena_raw.view(torch.int16)[::4097].to(torch.int64).sum()) == before
 x = torch.randn(8, 4, 64, 64, device=dev).half()
 assert torch.equal(D.gather_batches(x), x)

@@ -95,6 +95,86 @@ def test_bench_gpus2_launches_its_own_ranks_gloo_stub():
     assert c["per_rank_spread"] > 0.1 and "slowest rank 1" in c["per_rank_spread_warning"], c
     ncores = len(os.sched_getaffinity(0))
     assert c["cores_per_rank"] == [float(max(1, ncores // 2))] * 2, (c["cores_per_rank"], ncores)
+    # round 6: the one line is what a bounded-tail reader can take -- under 8 KB, strict JSON (no NaN / Infinity tokens), one line
+    assert len(lines[0].encode()) < 8192 and "NaN" not in lines[0] and "Infinity" not in lines[0]
+
+
+def _bench_module():
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    sys.modules["bench_mod"] = b
+    spec.loader.exec_module(b)
+    return b
+
+
+def test_result_line_is_bounded_strict_json():
+    """bench.result_line: the ONE stdout line stays under 8 KB whatever a run produced (round 5's line was 31.5 KB and the driver's record could not parse it),
+    carries `roofline` and `cpu_baseline`, holds no NaN / Infinity tokens, and optional blocks are shed in a fixed order before the contract fields would be."""
+    import json
+    b = _bench_module()
+    res = {"metric": "denoise-steps/sec (512x512, 50-step DDIM, batch 8)", "value": 51.123456789, "unit": "steps/s", "n_gpus": 1, "steps": 20, "warmup": 5,
+           "ms_per_step": 19.5601234, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+           "config": {"workload": "BASELINE configs[2]: 512x512, latent [8,4,64,64], 50-step DDIM, ctx 81 (77 text + 4 IP tokens), SDXL-base UNet + IP-Adapter",
+                      "global_batch": 8, "parallelism": "dp1", "kernel_plans": "committed table instructany2pix_amd/plans/mi355x_bench.plans sha256:0123456789ab (118 shapes)",
+                      "context_kv": "projected in every step (reference schedule, as rounds 1-4)", "ranks": 1, "dist_backend": "none (single process)",
+                      "per_rank_ms_per_step": [19.56], "per_rank_spread": 0.0, "box_probe": {"gemm_4096_tflops": 921.0, "copy_1gib_gbs": 5200.0, "launch_floor_us": 7.3},
+                      "secondary_ms_per_step": {"cfg2_b1_512": 8.4, "cfg5_768_cfg_b8": 36.6, "ref1024_inv_b1": 14.4, "ref1024_cfg_b2": 20.9}},
+           "roofline": {"bound": "mfma", "kernel": "ff_in (GEGLU projection)", "achieved": 841.0, "peak": 2500.0, "unit": "TFLOP/s", "frac": 0.3364, "traffic": 160167060.8,
+                        "traffic_source": "static: profiles/r05z_pmc_traffic.json; NOT measured in this run", "algorithmic_bytes_per_launch": 52428800.0,
+                        "avg_launch_us": float("nan"), "whole_step": {"algorithmic_tflop": 12.751, "ms": 19.56, "tflops": 652.0, "mfma_frac": 0.26},
+                        "conv_blocks": {"ms": 3.61, "mfma_frac": 0.36, "hbm_gbs": 394.0, "hbm_frac": float("inf")}},
+           "cpu_baseline": {"value": 0.0772, "unit": "steps/s", "cores": 16, "kind": "port", "sample": "oracle (torch fp32, 16 threads): 1 warm-up + 1 timed step of 1 request, then ONE real batch-8 step"},
+           "timing": {"runs_ms_per_step": [19.56, 19.55, 19.57, 19.56, 19.58], "median_ms_per_step": 19.56}}
+    line = b.result_line(res)
+    d = json.loads(line)
+    assert len(line.encode()) < 4096 and "\n" not in line and "NaN" not in line and "Infinity" not in line
+    assert d["roofline"]["avg_launch_us"] is None and d["roofline"]["conv_blocks"]["hbm_frac"] is None       # non-finite -> null
+    assert d["roofline"]["frac"] == 0.3364 and d["cpu_baseline"]["cores"] == 16 and abs(d["value"] - 51.123456789) < 1e-3
+    # a run that produces far too much sheds the optional blocks, never the contract fields
+    fat = json.loads(json.dumps(b._finite(res)))
+    fat["timing"]["runs_ms_per_step"] = [19.5 + 1e-3 * i for i in range(2000)]
+    fat["config"]["per_rank_ms_per_step"] = [19.5] * 1500
+    line = b.result_line(fat)
+    d = json.loads(line)
+    assert len(line.encode()) < b.LINE_LIMIT and "runs_ms_per_step" not in d.get("timing", {}) and "per_rank_ms_per_step" not in d["config"]
+    assert d["value"] == fat["value"] and d["roofline"]["frac"] == 0.3364 and d["cpu_baseline"]["value"] == 0.0772
+    fat["metric"] = "x" * 10000              # nothing left to shed: refuse to print rather than emit a line a reader cannot take
+    with pytest.raises(RuntimeError):
+        b.result_line(fat)
+
+
+def test_gpu_numa_cores_follow_the_kfd_topology_not_the_drm_card_order(tmp_path, monkeypatch):
+    """DRM card order is not HIP order (a BMC / VGA card0, *_VISIBLE_DEVICES). bench.gpu_numa_cores maps HIP device r through the KFD topology
+    (GPU nodes in node order -> PCI address) to /sys/bus/pci/devices/<bdf>/numa_node; a fake sysfs: 2 CPU nodes + 4 GPU nodes, GPUs 0-1 on NUMA 1, GPUs 2-3 on NUMA 0."""
+    b = _bench_module()
+    sysfs = tmp_path / "sys"
+    bdf = []
+    for i, (simd, bus, numa) in enumerate([(0, 0, 0), (0, 0, 1), (1024, 0xc1, 1), (1024, 0xd1, 1), (1024, 0x21, 0), (1024, 0x31, 0)]):
+        nd = sysfs / "class/kfd/kfd/topology/nodes" / str(i)
+        nd.mkdir(parents=True)
+        (nd / "properties").write_text(f"cpu_cores_count {0 if simd else 32}\nsimd_count {simd}\nlocation_id {bus << 8}\ndomain 0\n")
+        if simd:
+            a = f"0000:{bus:02x}:00.0"
+            bdf.append(a)
+            (sysfs / "bus/pci/devices" / a).mkdir(parents=True)
+            (sysfs / "bus/pci/devices" / a / "numa_node").write_text(f"{numa}\n")
+    for n, cl in ((0, "0-31"), (1, "32-63")):
+        (sysfs / f"devices/system/node/node{n}").mkdir(parents=True)
+        (sysfs / f"devices/system/node/node{n}/cpulist").write_text(cl + "\n")
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES", raising=False)
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES", raising=False)
+    assert b.hip_device_bdfs(str(sysfs)) == bdf
+    cores = b.gpu_numa_cores(4, str(sysfs))
+    assert cores[0] == cores[1] == list(range(32, 64)) and cores[2] == cores[3] == list(range(0, 32))
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "3,0")                     # device 0 is physical GPU 3 now
+    cores = b.gpu_numa_cores(2, str(sysfs))
+    assert cores == [list(range(0, 32)), list(range(32, 64))]
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "GPU-deadbeef")             # a UUID list: unknowable from here -> no NUMA preference, never a wrong one
+    assert b.gpu_numa_cores(2, str(sysfs)) == [None, None]
+    assert b.gpu_numa_cores(2, str(tmp_path / "nothing")) == [None, None]
 
 
 def test_rank_core_slices_and_preflight_helpers():

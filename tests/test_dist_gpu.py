@@ -48,6 +48,9 @@ def test_bench_gpus2_real_step_two_ranks_on_one_gpu():
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["config"]["ranks"] == 2 and d["config"]["dist_backend"] == "gloo" and d["config"]["self_launched"] is True
+    assert d["n_gpus"] == 2 and d["config"]["ranks"] == 2 and d["config"]["dist_backend"] == "gloo"
     assert d["config"]["global_batch"] == 16 and len(d["config"]["per_rank_ms_per_step"]) == 2
-    assert d["config"]["weight_broadcast"]["bytes"] > 5e9 and d["value"] > 0 and d["ms_per_step"] > 0
+    assert d["config"]["weight_broadcast_s"] > 0 and d["config"]["weight_broadcast_route"] == "torch" and d["value"] > 0 and d["ms_per_step"] > 0      # (gloo here; RCCL: "abi")
+    assert len(lines[0].encode()) < 8192                                # the line a bounded-tail reader can take (bench.result_line)
+    det = json.load(open(os.path.join(ROOT, "bench_detail.json")))     # ... and everything else beside the script
+    assert det["self_launched"] is True and det["weight_broadcast"]["bytes"] > 5e9 and det["line"]["n_gpus"] == 2
