@@ -209,8 +209,11 @@ static inline bool ia2p_conv_halo_ok(const GemmArgs& a) {
 
 struct GemmPlan { int variant; int splitk; int gn = 0; };      // gn = 1 (measured plans of 3x3 sites behind a GroupNorm only): the norm runs INSIDE the halo-staged convolution (conv_halo_kernel.h GN = 1)
 // tile variants of gemm_f16_kernel (id = index): {BM, BN, LDS ring stages}; 4 waves (2 x 2), BK = 64
-struct GemmTile { int bm, bn, stages, pp, halo; };      // pp = 1: 8-wave ping-pong schedule (one workgroup per CU); pp = 2: 8-wave 8-phase schedule; halo = 1: halo-staged 3x3 convolution only (conv_halo_f16_kernel)
-constexpr int IA2P_GEMM_NVARIANT = 27;
+static inline bool ia2p_tile_geglu_only(int pp) { return pp == 4; }
+// what the 256 x 320 GEGLU tile (variant 27, gemm_geglu_kernel.h) takes: GEGLU launches of linear layers in whole tiles
+static inline bool ia2p_geglu320_shape_ok(int M, int N, int K, bool conv, bool geglu) { return geglu && !conv && M > 0 && M % 256 == 0 && N > 0 && N % 320 == 0 && K >= 64 && K % 64 == 0; }
+struct GemmTile { int bm, bn, stages, pp, halo; };      // pp = 1: 8-wave ping-pong schedule (one workgroup per CU); pp = 2: 8-wave 8-phase schedule; pp = 4: ping-pong on 32-deep sub-steps, GEGLU launches of linear layers only (gemm_geglu_kernel.h); halo = 1: halo-staged 3x3 convolution only (conv_halo_f16_kernel)
+constexpr int IA2P_GEMM_NVARIANT = 28;
 constexpr GemmTile IA2P_GEMM_TILES[IA2P_GEMM_NVARIANT] = {{128, 128, 2, 0, 0}, {128, 128, 3, 0, 0}, {128, 64, 2, 0, 0}, {128, 64, 3, 0, 0}, {64, 64, 2, 0, 0}, {64, 64, 3, 0, 0},
                                                           {64, 160, 2, 0, 0}, {64, 160, 3, 0, 0}, {128, 160, 2, 0, 0}, {128, 160, 3, 0, 0}, {160, 128, 2, 0, 0}, {160, 160, 2, 0, 0},
                                                           {256, 128, 3, 1, 0},                               // 12: the ping-pong tile
@@ -222,7 +225,8 @@ constexpr GemmTile IA2P_GEMM_TILES[IA2P_GEMM_NVARIANT] = {{128, 128, 2, 0, 0}, {
                                                                                                           // operands in at ~27 B/clk whatever its loop looks like (profiles/r03k_small_m_kloop.txt), so more, smaller workgroups win
                                                           {256, 256, 2, 2, 0}, {256, 128, 2, 2, 0},             // 22..23: 8-phase schedule (pp = 2): 2 x 4 waves of 128 x 64 (128 x 32), two k-tile buffers, one workgroup per CU, 128 flop per staged byte
                                                           {256, 160, 3, 1, 1}, {256, 128, 3, 1, 1},      // 24..25: halo-staged 3x3 convolution (16 x 16 pixel patches; an ineligible site runs variant 18 / 12 instead)
-                                                          {256, 80, 3, 1, 1}};                            // 26: the same, 80 wide (8 x 1 waves of 32 x 80; an ineligible site runs variant 16)
+                                                          {256, 80, 3, 1, 1},                             // 26: the same, 80 wide (8 x 1 waves of 32 x 80; an ineligible site runs variant 16)
+                                                          {256, 320, 2, 4, 0}};                           // 27 (round 6): the GEGLU projection in ONE round of 256 tiles (2048 x 10240): 4 x 2 waves of 64 x 160, two k-tile slots, ping-pong on 32-deep sub-steps; GEGLU launches only
 GemmPlan ia2p_gemm_plan(int M, int N, int K, bool conv, bool geglu);
 bool ia2p_plan_lookup(int M, int N, int K, bool conv, bool geglu, GemmPlan* out);     // measured plan table (ia2p_autotune)
 void ia2p_plan_set(int M, int N, int K, bool conv, bool geglu, GemmPlan pl);

@@ -14,6 +14,7 @@
 // columns of one row (8-byte epilogue stores/loads along N).
 #include "gemm_kernel.h"
 #include "conv_halo_kernel.h"
+#include "gemm_geglu_kernel.h"
 
 #include <algorithm>
 #include <atomic>
@@ -40,7 +41,7 @@ static unsigned long long g_plan_gen = 0;
 static void plan_gen_bump() { std::lock_guard<std::mutex> lk(g_plan_mu); ++g_plan_gen; }
 static int g_force_variant = -1;   // test/tuning hook (ia2p_debug_set_gemm_tile)
 extern "C" void ia2p_debug_set_gemm_tile(int v) { if (v != g_force_variant) plan_gen_bump(); g_force_variant = v; }
-// the tile table, for tools and tests: out = {bm, bn, ring stages, schedule (0 plain, 1 ping-pong, 2 eight-phase, 3 ping-pong over halo-staged patches: 3x3 convolutions only)}; returns 0, or -1 past the last variant
+// the tile table, for tools and tests: out = {bm, bn, ring stages, schedule (0 plain, 1 ping-pong, 2 eight-phase, 3 ping-pong over halo-staged patches: 3x3 convolutions only, 4 ping-pong on 32-deep sub-steps: GEGLU launches only)}; returns 0, or -1 past the last variant
 extern "C" int ia2p_debug_gemm_tile_info(int v, int* out) {
   if (v < 0 || v >= IA2P_GEMM_NVARIANT || !out) return -1;
   out[0] = IA2P_GEMM_TILES[v].bm; out[1] = IA2P_GEMM_TILES[v].bn; out[2] = IA2P_GEMM_TILES[v].stages; out[3] = IA2P_GEMM_TILES[v].halo ? 3 : IA2P_GEMM_TILES[v].pp;
@@ -298,7 +299,7 @@ extern "C" int ia2p_plan_import(const char* text) {   // returns the number of e
       gn = 0; n = 0;
       if (sscanf(p, "%d,%d,%d,%d,%d,%d,%d;%n", &M, &N, &K, &cv, &gg, &v, &sk, &n) != 7 || n == 0) return -1;
     }
-    if (M < 1 || N < 1 || K < 64 || v < 0 || v >= IA2P_GEMM_NVARIANT || sk < 1 || sk > K / 64 || (gg && (sk > 1 || IA2P_GEMM_TILES[v].bn % 32)) || (IA2P_GEMM_TILES[v].halo && !cv) ||
+    if (M < 1 || N < 1 || K < 64 || v < 0 || v >= IA2P_GEMM_NVARIANT || sk < 1 || sk > K / 64 || (gg && (sk > 1 || IA2P_GEMM_TILES[v].bn % 32)) || (IA2P_GEMM_TILES[v].halo && !cv) || (ia2p_tile_geglu_only(IA2P_GEMM_TILES[v].pp) && !ia2p_geglu320_shape_ok(M, N, K, cv != 0, gg != 0)) ||
         gn < 0 || gn > 1 || (gn && !IA2P_GEMM_TILES[v].halo)) return -1;
     in.push_back({PlanKey{M, N, K, cv != 0, gg != 0}, GemmPlan{v, sk, gn}});
     p += n;
@@ -324,7 +325,7 @@ void ia2p_gemm_candidates(int M, int N, int K, bool conv, bool geglu, size_t max
   }();
   for (int v = 0; v < IA2P_GEMM_NVARIANT; ++v) {
     const GemmTile& t = IA2P_GEMM_TILES[v];
-    if ((geglu && t.bn % 32) || (excluded >> v & 1) || (t.halo && !conv)) continue;
+    if ((geglu && t.bn % 32) || (excluded >> v & 1) || (t.halo && !conv) || (ia2p_tile_geglu_only(t.pp) && !ia2p_geglu320_shape_ok(M, N, K, conv, geglu))) continue;
     for (int sk : splits) {
       if (sk > 1 && (geglu || nk / sk < 4 || (size_t)sk * M * N * 4 > max_slab_bytes)) break;
       all.push_back({plan_cost_us(M, N, K, conv, t, sk), GemmPlan{v, sk}});
@@ -333,28 +334,31 @@ void ia2p_gemm_candidates(int M, int N, int K, bool conv, bool geglu, size_t max
   std::stable_sort(all.begin(), all.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
   out->clear();
   for (const auto& e : all)
-    if (e.first <= slack * all.front().first || (IA2P_GEMM_TILES[e.second.variant].halo && e.second.splitk <= 4)) out->push_back(e.second);      // (the halo-staged tiles: always measured -- the model was calibrated on the gathered kernels)
+    if (e.first <= slack * all.front().first || (IA2P_GEMM_TILES[e.second.variant].halo && e.second.splitk <= 4) || ia2p_tile_geglu_only(IA2P_GEMM_TILES[e.second.variant].pp))
+      out->push_back(e.second);      // (the halo-staged tiles and the GEGLU tile: always measured -- the model was calibrated on the gathered kernels)
 }
 
 // Tile variant and split-K factor for a problem: a measured plan if ia2p_autotune recorded one, else the cost model.
 // Pure function of the shape and the plan table (the executor sizes its workspace with it).
 GemmPlan ia2p_gemm_plan(int M, int N, int K, bool conv, bool geglu) {
   GemmPlan pl{-1, 1};
-  if (g_force_variant < 0 && ia2p_plan_lookup(M, N, K, conv, geglu, &pl)) {
+  // (a forced variant that only takes GEGLU launches of linear layers in whole tiles leaves every other launch to the table / the model: tests force one variant for a whole network)
+  const int force_variant = (g_force_variant >= 0 && g_force_variant < IA2P_GEMM_NVARIANT && ia2p_tile_geglu_only(IA2P_GEMM_TILES[g_force_variant].pp) && !ia2p_geglu320_shape_ok(M, N, K, conv, geglu)) ? -1 : g_force_variant;
+  if (force_variant < 0 && ia2p_plan_lookup(M, N, K, conv, geglu, &pl)) {
     if (g_force_splitk >= 1 && !geglu) pl.splitk = std::min(g_force_splitk, K / 64);
     if (g_force_gn >= 0) pl.gn = g_force_gn && IA2P_GEMM_TILES[pl.variant].halo;
     return pl;
   }
   for (const ShapeRule& r : shape_rules())
     if (r.M == M && r.N == N && r.K == K) pl.variant = r.v;
-  if (g_force_variant >= 0) pl.variant = g_force_variant;
+  if (force_variant >= 0) pl.variant = force_variant;
   const int nk = K / 64;
   if (pl.variant < 0) {
     static const int splits[] = {1, 2, 3, 4, 6, 8};
     double best = 1e30;
     for (int v = 0; v < IA2P_GEMM_NVARIANT; ++v) {
       const GemmTile& t = IA2P_GEMM_TILES[v];
-      if ((geglu && t.bn % 32) || t.halo) continue;              // a (value, gate) block of 32 packed columns must not straddle tiles; halo tiles: by measurement only
+      if ((geglu && t.bn % 32) || t.halo || ia2p_tile_geglu_only(t.pp)) continue;              // a (value, gate) block of 32 packed columns must not straddle tiles; halo tiles and the GEGLU tile: by measurement only
       for (int sk : splits) {
         if (sk > 1 && (geglu || nk / sk < 4)) break;
         const double c = plan_cost_us(M, N, K, conv, t, sk);
@@ -453,6 +457,10 @@ static hipError_t launch_any(const GemmArgs& a0, int v, hipStream_t s, bool with
       static_assert(IA2P_GEMM_TILES[23].bm == 256 && IA2P_GEMM_TILES[23].bn == 128 && IA2P_GEMM_TILES[23].stages == 2 && IA2P_GEMM_TILES[23].pp == 2, "tile table");
       e = launch_cfg<256, 128, 2, CONV, 2, 64, 2, 4>(a, s);
       break;
+    case 27:      // GEGLU launches of linear layers only (gemm_geglu_kernel.h)
+      static_assert(IA2P_GEMM_TILES[27].bm == 256 && IA2P_GEMM_TILES[27].bn == 320 && IA2P_GEMM_TILES[27].stages == 2 && IA2P_GEMM_TILES[27].pp == 4, "tile table");
+      e = (!CONV && ia2p_geglu320_ok(a)) ? launch_geglu320(a, s) : launch_cfg<256, 160, 3, CONV, 4, 64, 1>(a, s);      // (a launch it does not take -- row map, odd strides -- runs the 256 x 160 ping-pong tile)
+      break;
     case 24:      // halo-staged convolution; a launch it does not take (linear layer, stride 2, ragged patches, more K slices than blocks of 64 channels) runs the same tile shape with the gathered operand
       static_assert(IA2P_GEMM_TILES[24].bm == 256 && IA2P_GEMM_TILES[24].bn == 160 && IA2P_GEMM_TILES[24].halo, "tile table");
       e = halo_site ? launch_halo<160>(a, s) : launch_cfg<256, 160, 3, CONV, 4, 64, 1>(a, s);
@@ -476,6 +484,7 @@ static hipError_t launch_any(const GemmArgs& a0, int v, hipStream_t s, bool with
 
 // the variant whose kernel a launch of plan variant v really is (a.splitk as the caller set it)
 int ia2p_gemm_variant_ran(const GemmArgs& a, bool conv, int v) {
+  if (v >= 0 && v < IA2P_GEMM_NVARIANT && ia2p_tile_geglu_only(IA2P_GEMM_TILES[v].pp)) return (!conv && ia2p_geglu320_ok(a)) ? v : 18;
   if (v < 0 || v >= IA2P_GEMM_NVARIANT || !IA2P_GEMM_TILES[v].halo) return v;
   const bool halo_site = conv && ia2p_conv_halo_ok(a) && ia2p_conv_gn_ok(a) && a.splitk <= a.Cin / 64;
   return halo_site ? v : (v == 24 ? 18 : v == 25 ? 12 : 16);

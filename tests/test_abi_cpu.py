@@ -88,6 +88,7 @@ def test_gemm_plan_is_a_pure_host_function_and_the_plan_table_round_trips(lib):
     from tests.test_ops_gpu import NTILES
     assert len(tiles) == NTILES and lib.ia2p_debug_gemm_tile_info(-1, t) == -1
     assert tiles[0] == (128, 128, 2, 0) and tiles[18] == (256, 160, 3, 1) and tiles[22] == (256, 256, 2, 2) and tiles[24] == (256, 160, 3, 3) and tiles[26] == (256, 80, 3, 3)      # (schedule 3: halo-staged convolution)
+    assert tiles[27] == (256, 320, 2, 4)                                     # (schedule 4: ping-pong on 32-deep sub-steps, GEGLU launches of linear layers in whole tiles only)
     bn = [x[1] for x in tiles]
     for shape in [(2048, 1280, 1280), (8192, 640, 640), (64, 64, 64), (616, 166400, 2048), (37, 132, 128), (256, 1280, 5120), (4096, 4096, 4096)]:
         v, s = plan(*shape)
@@ -105,8 +106,17 @@ def test_gemm_plan_is_a_pure_host_function_and_the_plan_table_round_trips(lib):
     buf = C.create_string_buffer(n + 1)
     lib.ia2p_plan_export(buf, n + 1)
     assert sorted(buf.value.split(b";")) == sorted(text.split(b";"))
-    for bad in [b"garbage", b"2048,1280,1280,0,0,99,1;", b"2048,1280,1280,0,0,0,999;", b"2048,10240,1280,0,1,0,2;", b"2048,1280,1280,0,0,24,1;"]:      # (the last one: a halo-staged convolution tile for a linear layer)
+    for bad in [b"garbage", b"2048,1280,1280,0,0,99,1;", b"2048,1280,1280,0,0,0,999;", b"2048,10240,1280,0,1,0,2;", b"2048,1280,1280,0,0,24,1;",      # (a halo-staged convolution tile for a linear layer)
+                b"2048,10240,1280,0,0,27,1;", b"130,10240,1280,0,1,27,1;", b"2048,10304,1280,0,1,27,1;"]:      # the GEGLU tile for a plain linear layer / for ragged rows / ragged columns
         assert lib.ia2p_plan_import(bad) == -1
+    assert lib.ia2p_plan_import(b"2048,10240,1280,0,1,27,1;") == 1 and plan(2048, 10240, 1280, 0, 1) == (27, 1)
+    lib.ia2p_plan_clear()
+    assert plan(2048, 10240, 1280, 0, 1)[0] != 27                            # the cost model never picks it: by measurement only
+    lib.ia2p_debug_set_gemm_tile(27)                                         # forced: taken where the shape allows, ignored elsewhere
+    try:
+        assert plan(2048, 10240, 1280, 0, 1) == (27, 1) and plan(2048, 1280, 1280)[0] != 27 and plan(130, 1024, 128, 0, 1)[0] != 27
+    finally:
+        lib.ia2p_debug_set_gemm_tile(-1)
     lib.ia2p_plan_clear()
     assert lib.ia2p_plan_export(None, 0) == 0
 

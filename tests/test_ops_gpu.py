@@ -9,7 +9,7 @@ import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
-NTILES = 27      # entries of IA2P_GEMM_TILES (csrc/common.h); tests/test_abi_cpu.py checks it against the library's table
+NTILES = 28      # entries of IA2P_GEMM_TILES (csrc/common.h); tests/test_abi_cpu.py checks it against the library's table
 
 
 @pytest.fixture(scope="module")
@@ -237,6 +237,61 @@ def test_layernorm_fold_bits_do_not_depend_on_the_tile(L):
         L.ia2p_debug_set_gemm_tile(-1)
     for i, o in enumerate(outs[1:]):
         assert torch.equal(o, outs[0]), i + 1
+
+
+@pytest.mark.parametrize("M,C_,ln", [(2048, 640, True), (512, 1280, True), (256, 640, False), (1024, 320, True)])
+def test_geglu_projection_on_the_256x320_tile(L, M, C_, ln):
+    """Round 6: `ff.net.0` (GEGLU projection, norm3 folded in; diffusers FeedForward / GEGLU behind pnp_pipeline.py:253-260, in-tree twin
+    llm/model/vae/modules/attention.py:37-44) on tile variant 27 -- 256 x 320, 8 waves of 64 x 160, ping-pong on 32-deep sub-steps over two k-tile slots, the epilogue in
+    two column halves -- against fp32 torch and BIT-IDENTICAL to the other GEGLU-capable tiles (128 x 160, 256 x 160 ping-pong, 128 x 160 ping-pong, 8-phase 256 x 256):
+    same 32-deep accumulation order, same epilogue formulas. With and without the folded LayerNorm (plain bias); K from 5 to 20 k-tiles."""
+    f, X, Wp, R, gamma, beta, W, b, _, _, _ = _ln_fold_setup(L, M, C_, 8 * C_, seed=170 + C_ // 64)
+    N = 8 * C_
+    Wpk, bpk = torch.empty_like(W), torch.empty_like(b)
+    run(L, "ia2p_pack_geglu", f.ptr(W), f.ptr(Wpk), N, C_)
+    run(L, "ia2p_pack_geglu", f.ptr(b), f.ptr(bpk), N, 1)
+    t = (X.float() * 2 + 0.25).half()
+    if ln:
+        Wf = torch.empty_like(W)
+        cs, fb = torch.empty(N, dtype=torch.float32, device="cuda"), torch.empty(N, dtype=torch.float32, device="cuda")
+        run(L, "ia2p_fold_layernorm", f.ptr(Wpk), f.ptr(gamma), f.ptr(beta), f.ptr(bpk), f.ptr(Wf), f.ptr(cs), f.ptr(fb), N, C_)
+        tf = t.float()
+        slots = C_ // 64
+        st = torch.stack([tf.view(M, slots, 64).sum(2), (tf * tf).view(M, slots, 64).sum(2)], dim=2).permute(1, 0, 2).contiguous()
+        lnc = f.LnFoldC(st.data_ptr(), slots, cs.data_ptr(), fb.data_ptr(), 1e-5)
+        h = F.layer_norm(t.float(), (C_,), gamma.float(), beta.float(), 1e-5) @ W.float().t() + b.float()
+    else:
+        h = t.float() @ W.float().t() + b.float()
+    a, g = h.chunk(2, dim=-1)
+    ref = a * F.gelu(g)
+    info = (C.c_int * 4)()
+    assert L.ia2p_debug_gemm_tile_info(27, info) == 0 and tuple(info) == (256, 320, 2, 4)
+    outs = {}
+    try:
+        for tile in (27, 8, 18, 19, 22):
+            out = torch.full((M, N // 2), float("nan"), dtype=torch.half, device="cuda")
+            L.ia2p_debug_set_gemm_tile(tile)
+            v, sk = C.c_int(-1), C.c_int(-1)
+            L.ia2p_debug_gemm_plan(M, N, C_, 0, 1, C.addressof(v), C.addressof(sk))
+            assert (v.value, sk.value) == (tile, 1)                      # the forced tile is what runs (whole tiles: the GEGLU tile takes the launch)
+            if ln:
+                run(L, "ia2p_gemm_ex", f.ptr(t), f.ptr(Wf), None, None, f.ptr(out), M, N, C_, 1, C.addressof(lnc), None, None, 1, None)
+            else:
+                run(L, "ia2p_gemm_ex", f.ptr(t), f.ptr(Wpk), f.ptr(bpk), None, f.ptr(out), M, N, C_, 1, None, None, None, 1, None)
+            outs[tile] = out
+        # a launch the tile does not take (rows not a multiple of 256): the force is ignored, the plan falls back to the table / the cost model
+        L.ia2p_debug_set_gemm_tile(27)
+        v = C.c_int(-1)
+        L.ia2p_debug_gemm_plan(130, N, C_, 0, 1, C.addressof(v), None)
+        assert v.value != 27 and v.value >= 0
+        L.ia2p_debug_gemm_plan(M, N, C_, 0, 0, C.addressof(v), None)       # ... and so is a non-GEGLU launch of the same shape
+        assert v.value != 27 and v.value >= 0
+    finally:
+        L.ia2p_debug_set_gemm_tile(-1)
+    assert torch.isfinite(outs[27]).all()
+    assert rel_l2(outs[27], ref) < 2e-3, rel_l2(outs[27], ref)
+    for tile, o in outs.items():
+        assert torch.equal(o, outs[27]), (tile, int((o != outs[27]).sum()))
 
 
 @pytest.mark.parametrize("M,C_", [(2048, 640), (130, 128)])
