@@ -671,6 +671,8 @@ def roofline_summary(rb):
             "traffic_over_algorithmic", "traffic_minus_prefetch_over_algorithmic", "avg_launch_us", "launches_per_step", "flops_per_launch", "share_of_step",
             "launches_per_step_all_kernels", "mfma_busy_frac")
     out = {k: rb[k] for k in keep if k in rb}
+    if not out.get("prefetch_bytes_per_launch"):      # (the role records carry no prefetch bytes: the two prefetch-corrected figures would only repeat the plain ones)
+        out.pop("prefetch_bytes_per_launch", None); out.pop("traffic_minus_prefetch_over_algorithmic", None)
     if out.get("traffic_source"):
         out["traffic_source"] = out["traffic_source"].split(" (")[0] + "; NOT measured in this run"
     main_k = max(rb["kernels_of_role"], key=lambda q: rb["kernels_of_role"][q]["ms_per_step"]) if rb.get("kernels_of_role") else None
@@ -797,7 +799,7 @@ def main():
         text = "".join(l for l in open(path).read().splitlines() if not l.startswith("#")).strip()
         import_plans(text)
         import hashlib
-        plans = f"committed table {os.path.relpath(path, ROOT)} sha256:{hashlib.sha256(text.encode()).hexdigest()[:12]} ({text.count(';')} shapes; --tune measures in place)"
+        plans = f"{'imported from' if args.plans else 'committed table'} {os.path.relpath(path, ROOT)} sha256:{hashlib.sha256(text.encode()).hexdigest()[:12]} ({text.count(';')} shapes; --tune measures in place)"
     elif not args.no_autotune:
         tuning = True
         plans = f"measured in place at start-up ({tune(wl, 'headline').count(';')} shapes)"

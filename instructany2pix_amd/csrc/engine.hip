@@ -492,6 +492,17 @@ static void run_gemm(RunCtx* c, GemmArgs& a, bool conv, const char* what, double
       a.gn_out = (double*)gw->out.buf.p;
     }
   }
+#ifdef IA2P_CLOCK_STAMP
+  if (c->stamp_buf && c->role == c->stamp_role && pl.splitk <= 1 && !c->dry && !c->tuning && c->stamp_n < c->stamp_cap) {
+    const GemmTile& t = IA2P_GEMM_TILES[pl.variant];
+    const int tiles = ((a.M + t.bm - 1) / t.bm) * ((a.N + t.bn - 1) / t.bn);
+    if (tiles <= RunCtx::STAMP_WG && !t.halo) {
+      a.partial = (float*)(c->stamp_buf + (size_t)c->stamp_n * RunCtx::STAMP_WG * 8);
+      c->stamp_meta.push_back({a.M, a.N, a.K, pl.variant, tiles});
+      ++c->stamp_n;
+    }
+  }
+#endif
   {
     ProfScope ps(c, (conv ? PK_CONV0 : PK_GEMM0) + pl.variant, flops, bytes);
     ps.pf = a.pf ? (double)a.pf_bytes : 0.0;
@@ -1488,6 +1499,24 @@ ia2p_status ia2p_layernorm(void* stream, const void* x, void* y, const void* gam
   hipError_t e = ia2p_launch_layernorm((const half_t*)x, C, (half_t*)y, C, (const half_t*)gamma, (const half_t*)beta, M, C, eps, (hipStream_t)stream);
   RET_HIP(e, "layernorm");
 }
+#ifdef IA2P_CLOCK_STAMP
+// Diagnostic builds only (IA2P_EXTRA_FLAGS=-DIA2P_CLOCK_STAMP; not declared in the headers, not part of the product library): in-kernel s_memrealtime stamps of the
+// launches of one layer role INSIDE a step. buf: device memory, `launch_slots` x STAMP_WG x 8 u64, zeroed by the caller; role: ROLE_* index (ia2p_profile_read_role).
+int ia2p_debug_stamp_begin(ia2p_ctx* c, int role, void* buf, int launch_slots) {
+  if (!c) return -1;
+  c->stamp_buf = (unsigned long long*)buf; c->stamp_role = role; c->stamp_cap = buf ? launch_slots : 0; c->stamp_n = 0; c->stamp_meta.clear();
+  return RunCtx::STAMP_WG;
+}
+// launches stamped since begin; meta (optional): 5 ints per launch {M, N, K, variant, tiles}
+int ia2p_debug_stamp_read(ia2p_ctx* c, int* meta, int max_launches) {
+  if (!c) return -1;
+  for (int i = 0; meta && i < (int)c->stamp_meta.size() && i < max_launches; ++i) {
+    const auto& m = c->stamp_meta[i];
+    meta[5 * i] = m.M; meta[5 * i + 1] = m.N; meta[5 * i + 2] = m.K; meta[5 * i + 3] = m.variant; meta[5 * i + 4] = m.tiles;
+  }
+  return (int)c->stamp_meta.size();
+}
+#endif
 ia2p_status ia2p_gemm(void* stream, const void* A, const void* W, const void* bias, const void* residual, void* C, int M, int N, int K, int geglu) {
   if (!A || !W || !C) return fail(nullptr, IA2P_ERR_INVALID, "gemm: null argument");
   if (K % 64 || N % 4 || (geglu && (N % 32 || !bias))) return fail(nullptr, IA2P_ERR_SHAPE, "gemm: K=%d must be a multiple of 64, N=%d of 4 (GEGLU: 32, with bias)", K, N);
@@ -1540,6 +1569,9 @@ ia2p_status ia2p_gemm_ex(void* stream, const void* A, const void* W, const void*
   if (ln) { a.ln_stats = ln->stats; a.ln_slots = ln->slots; a.ln_cs = ln->colsum; a.ln_bias = ln->fbias; a.ln_eps = ln->eps; }
   a.stats_out = stats_out;
   if (splitk > 1) { a.splitk = splitk; a.partial = partial; }
+#ifdef IA2P_CLOCK_STAMP
+  else if (partial) a.partial = partial;      // (diagnostic builds: the in-kernel stamps of an unsplit launch go to the caller's buffer, tools/insitu_stamps.py)
+#endif
   int pick = 0, combined = 0;
   hipError_t e = ia2p_launch_gemm(a, false, (hipStream_t)stream, &pick, &combined);
   if (stats_slots && pick >= 0 && pick < IA2P_GEMM_NVARIANT) *stats_slots = (splitk > 1 && !combined) ? 1 : (N + IA2P_GEMM_TILES[pick].bn - 1) / IA2P_GEMM_TILES[pick].bn;

@@ -164,6 +164,15 @@ struct RunCtx {
   bool sattn_fuse = true;    // QKV projection + self-attention as one launch at 256 tokens per image (follows IA2P_XATTN_FUSE=0; IA2P_SATTN_FUSE in experiment builds)
   bool ln_fold = true;       // LayerNorms folded into their consumer GEMMs (IA2P_LN_FOLD=0: separate layernorm_kernel launches, for A/B runs)
   bool prof = false;
+#ifdef IA2P_CLOCK_STAMP
+  // diagnostic builds (tools/insitu_stamps.py): the launches of ONE layer role get a stamp buffer (GemmArgs.partial carries it, see gemm_tile.h IA2P_STAMP): 8 x u64 per workgroup,
+  // STAMP_WG workgroups per launch slot, launches of the role in executor order
+  static constexpr int STAMP_WG = 2048;
+  unsigned long long* stamp_buf = nullptr;
+  int stamp_role = -1, stamp_cap = 0, stamp_n = 0;
+  struct StampMeta { int M, N, K, variant, tiles; };
+  std::vector<StampMeta> stamp_meta;
+#endif
   // autotune pass (ia2p_autotune): every GEMM / conv site of an unmeasured shape times its candidate plans in place
   bool tuning = false;
   int tune_reps = 5, tune_sites = 0;

@@ -275,7 +275,7 @@ __device__ __forceinline__ void tile_epilogue(f4 (&acc)[BM / WGM / 16][BN / WGN 
       }
     }
     __syncthreads();
-    IA2P_STAMP(stamp_put(p, nsplit, 7);)      // the fp16 tile is in LDS
+    IA2P_STAMP(if (IA2P_STAMP_AT != 4) stamp_put(p, nsplit, 7);)      // the fp16 tile is in LDS (IA2P_STAMP_AT == 4: slot 7 is the k-loop's "first k-tile has landed")
     auto rowm = [&](int r) { return row_m(r); };
     if (p.geglu) {                    // packed columns: 32-wide blocks [16 values | 16 gates]; out[m][n/2] = a * gelu(g)
       constexpr int GPR = BN / 16, TOTAL = BM * GPR, U = 2, ITER = (TOTAL + NT * U - 1) / (NT * U);      // groups of 8 OUTPUT columns per row

@@ -577,6 +577,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
     const int ahead = nk - 1 - kt;    // tiles issued after tile kt that may remain in flight
     // tiles kt+1 .. kt+NSTAGE-2 were issued before this wait and may stay in flight (fewer at the tail): vmcnt counts this wave's pieces
     wait_ring<NSTAGE - 2, LPS>(ahead < NSTAGE - 2 ? ahead : NSTAGE - 2);
+    IA2P_STAMP(if (IA2P_STAMP_AT == 4 && kt == 0) stamp_put(p, nsplit, 7);)      // the first k-tile has landed for every wave (tools/insitu_stamps.py: what a launch's cold start costs)
     // every wave has passed the barrier => tile kt has landed for all, and slot `nxt` (read in step kt-1) is free
     if (kt + NSTAGE - 1 < nk) stage(kt + NSTAGE - 1, nxt);
     if constexpr (XA != 0 && XA != 4) {
