@@ -33,7 +33,7 @@ struct Geglu320 {
   static constexpr int BM = 256, BN = 320, BK = 64, NWAVE = 8, WGN = 2, WM = 64, WN = 160, MR = 4, NR = 10;
   static constexpr int ROWB = 128, RPP = 8, A_PW = 4, B_PW = 5;               // row bytes of a k-tile, rows per 1-KiB staging piece, pieces per wave and k-tile
   static constexpr int STAGE = (BM + BN) * ROWB, RING = 2 * STAGE;           // 73 728 B per k-tile slot
-  // epilogue: ONE column half (160 columns) of the fp16 tile at a time (both: 168 KiB), rows padded by 16 B; row / column constants; the normal-CDF table of the gate
+  // epilogue: the OUTPUT tile (BM x 160 fp16: the GEGLU happens in registers), rows padded by 16 B; column constants; the normal-CDF table of the gate
   static constexpr int HN = BN / 2, P16 = HN * 2 + 16, T16_BYTES = BM * P16;
   static constexpr int CONST_BYTES = 2 * BN * 4, LUT_BYTES = (IA2P_PHI_LUT_N * 8 + 15) & ~15, LNROW_BYTES = 2 * BM * 4;      // (row mean / rstd: behind the ring, written in the prologue)
   static_assert(T16_BYTES + CONST_BYTES + LUT_BYTES <= RING, "the epilogue lives inside the ring");
@@ -168,14 +168,31 @@ __global__ __launch_bounds__(512, 2) void gemm_geglu_f16_kernel(const half_t* hA
   using K0 = std::integral_constant<int, 0>;
   using K1 = std::integral_constant<int, 1>;
   // barriers as opaque statements ("memory": no LDS access or DMA issue moves across), pinned against the scheduler on both sides
+#ifndef IA2P_G320_PHASES
 #define IA2P_G320_BAR(text)                          \
   do {                                               \
     __builtin_amdgcn_sched_barrier(0);               \
     asm volatile(text "\n\ts_barrier" ::: "memory"); \
     __builtin_amdgcn_sched_barrier(0);               \
   } while (0)
+#define IA2P_G320_PH(k)
+#else      // diagnostic build (tools/micro/geglu_clock.hip): per interval of a k-tile, the cycles a wave WORKS (up to its own counted wait) and the cycles it then WAITS in the barrier
+  unsigned long long ph_prev = 0, ph_arrive = 0, ph_work[4] = {0, 0, 0, 0}, ph_wait[4] = {0, 0, 0, 0};
+#define IA2P_G320_BAR(text)                            \
+  do {                                                 \
+    __builtin_amdgcn_sched_barrier(0);                 \
+    asm volatile(text ::: "memory");                   \
+    ph_arrive = __builtin_amdgcn_s_memtime();          \
+    asm volatile("s_barrier" ::: "memory");            \
+    __builtin_amdgcn_sched_barrier(0);                 \
+  } while (0)
+#define IA2P_G320_PH(k) do { const unsigned long long now = __builtin_amdgcn_s_memtime(); ph_work[k] += ph_arrive - ph_prev; ph_wait[k] += now - ph_arrive; ph_prev = now; } while (0)
+#endif
   IA2P_STAMP(const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();)
   IA2P_G320_BAR("s_waitcnt vmcnt(0)");               // b(0): k-tile 0 has landed for every wave
+#ifdef IA2P_G320_PHASES
+  ph_prev = __builtin_amdgcn_s_memtime();
+#endif
   if (wave < 4) {
     auto step = [&](int t, int slot, auto first_tag) {
       const bool more = t + 1 < nk;
@@ -183,15 +200,19 @@ __global__ __launch_bounds__(512, 2) void gemm_geglu_f16_kernel(const half_t* hA
       __builtin_amdgcn_sched_barrier(0);
       if (more) issue_w(slot ^ 1, (t + 1) * ROWB);
       IA2P_G320_BAR("s_waitcnt lgkmcnt(0)");         // b(4t+1)
+      IA2P_G320_PH(0);
       mm(first_tag);
       IA2P_G320_BAR("");                             // b(4t+2)
+      IA2P_G320_PH(1);
       rd(slot, K1{});
       __builtin_amdgcn_sched_barrier(0);
       if (more) issue_a(slot ^ 1, (t + 1) * ROWB);
       IA2P_G320_BAR("s_waitcnt lgkmcnt(0)");         // b(4t+3)
+      IA2P_G320_PH(2);
       mm(Next{});
       if (more) IA2P_G320_BAR("s_waitcnt vmcnt(0)"); // b(4t+4): this wave's pieces of tile t+1 have landed
       else IA2P_G320_BAR("s_nop 7\n\ts_nop 7\n\ts_nop 7");      // ... behind the last sub-step: the wait states of `settle`, in front of whatever the allocator places on the loop's exit edge
+      IA2P_G320_PH(3);
     };
     step(0, 0, First{});
     for (int t = 1, slot = 1; t < nk; ++t, slot ^= 1) step(t, slot, Next{});
@@ -200,18 +221,22 @@ __global__ __launch_bounds__(512, 2) void gemm_geglu_f16_kernel(const half_t* hA
     auto step = [&](int t, int slot, auto first_tag) {
       const bool more = t + 1 < nk;
       IA2P_G320_BAR("s_waitcnt vmcnt(0)");           // b(4t+1): this wave's A rows of tile t (issued in I(4t-1)) have landed
+      IA2P_G320_PH(0);                               // (interval I(4t): group 1 multiplied (t-1, kk 1), or idled in the first k-tile)
       rd(slot, K0{});
       __builtin_amdgcn_sched_barrier(0);
       if (more) issue_w(slot ^ 1, (t + 1) * ROWB);
       IA2P_G320_BAR("s_waitcnt lgkmcnt(0)");         // b(4t+2)
+      IA2P_G320_PH(1);
       mm(first_tag);
       IA2P_G320_BAR("");                             // b(4t+3)
+      IA2P_G320_PH(2);
       rd(slot, K1{});
       __builtin_amdgcn_sched_barrier(0);
       if (more) issue_a(slot ^ 1, (t + 1) * ROWB);
       // b(4t+4): the reads of (t, kk 1) are retired (group 0 re-stages this slot's weights next), the W pieces of tile t+1 have landed (the 4 younger A pieces may fly)
       if (more) IA2P_G320_BAR("s_waitcnt vmcnt(4) lgkmcnt(0)");
       else IA2P_G320_BAR("s_waitcnt vmcnt(0) lgkmcnt(0)");
+      IA2P_G320_PH(3);
     };
     step(0, 0, First{});
     for (int t = 1, slot = 1; t < nk; ++t, slot ^= 1) {
@@ -222,6 +247,14 @@ __global__ __launch_bounds__(512, 2) void gemm_geglu_f16_kernel(const half_t* hA
     settle();
   }
 #undef IA2P_G320_BAR
+#ifdef IA2P_G320_PHASES
+  if ((tid == 0 || tid == 256) && p.partial) {      // wave 0 (group 0) / wave 4 (group 1): behind the workgroups' 8-slot records
+    unsigned long long* o = (unsigned long long*)p.partial + 8 * gridDim.x + 16 * blockIdx.x + (tid ? 8 : 0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { o[k] = ph_work[k]; o[4 + k] = ph_wait[k]; }
+  }
+#endif
+#undef IA2P_G320_PH
   IA2P_STAMP(
     if (tid == 0 && p.partial) {      // (the stamps go to a buffer nothing else reads: GEGLU launches have no slabs)
       unsigned long long* o = (unsigned long long*)p.partial + 8 * blockIdx.x;
@@ -230,9 +263,13 @@ __global__ __launch_bounds__(512, 2) void gemm_geglu_f16_kernel(const half_t* hA
     }
   )
 
-  // ---- epilogue: the register route of gemm_epilogue.h (bias / folded LayerNorm on the accumulators in the MFMA layout, ONE rounding to fp16, one pass through LDS,
-  //      read out row-major 16 B per thread, values x GELU(gates) through the normal-CDF table, whole-line stores), one 160-column half of the tile at a time
-  char* t16 = smem;
+  // ---- epilogue. The formulas are gemm_epilogue.h's register route -- bias / folded LayerNorm on the accumulators, ONE rounding to fp16 (the projection's output is an
+  //      fp16 tensor), out = fp16(value x GELU(gate)) through the normal-CDF table -- but the GEGLU happens IN REGISTERS: in the packed column order a 32-wide block is
+  //      [16 values | 16 gates], i.e. fragment column 2 b holds the values and 2 b + 1 the gates of block b, and the MFMA layout gives a lane the same 4 columns of both:
+  //      value and gate of an output sit in the same lane, acc[i][2 b][e] and acc[i][2 b + 1][e]. All eight waves work at once, only the OUTPUT tile (256 x 160 fp16: half
+  //      the bytes) crosses the LDS, once, to leave as whole 128-byte lines. (The first version sent the projected tile through the LDS in two 160-column halves, four waves
+  //      converting while four waited: 11.0 us from the k-loop's end to the last store drained, tools/micro/geglu_clock.hip.)
+  char* t16 = smem;                                          // output tile [BM][160] fp16, rows padded by 16 B
   float* ln_cs = (float*)(smem + G::T16_BYTES);              // BN column sums, BN folded biases
   float* ln_lb = ln_cs + BN;
   float2* phi = (float2*)(ln_lb + BN);
@@ -263,86 +300,68 @@ __global__ __launch_bounds__(512, 2) void gemm_geglu_f16_kernel(const half_t* hA
   for (int i = tid; i < IA2P_PHI_LUT_N; i += NT) phi[i] = ((const float2*)p.phi_lut)[i];
   const float e_as = p.acc_scale == 0.f ? 1.f : p.acc_scale, e_bs = p.bias_scale == 0.f ? 1.f : p.bias_scale;
   const __amdgpu_buffer_rsrc_t c_rsrc = wt_rsrc((void*)p.C, (size_t)hM * p.ldc * 2);
-  __syncthreads();                    // row / column constants and the table are in LDS
-  // a wave rounds its 64 x 160 accumulators to fp16 when its column half is due (they wait in the ACC registers meanwhile: no pressure on the read-out loop)
-  auto convert = [&](auto ln_tag) {
+  __syncthreads();                    // column constants and the table are in LDS (the row constants since the prologue)
+  auto geglu_regs = [&](auto ln_tag) {
     constexpr bool LN = decltype(ln_tag)::value;
     float mu[MR], rs[MR];
 #pragma unroll
     for (int i = 0; i < MR; ++i) { mu[i] = LN ? ln_rows[wm0 + i * 16 + frow] : 0.f; rs[i] = LN ? ln_rows[BM + wm0 + i * 16 + frow] : 1.f; }
 #pragma unroll
-    for (int j = 0; j < NR; ++j) {
-      const int cl = j * 16 + fq * 4;                                // column inside the half of acc[.][j][0]
-      f4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};       // folded LayerNorm: column sums, folded biases; else: bias, -
-      if constexpr (LN) { c0 = *(const f4*)(ln_cs + wn0 + cl); c1 = *(const f4*)(ln_lb + wn0 + cl); }
+    for (int b = 0; b < NR / 2; ++b) {                                // 32-wide packed block b of this wave's 160 columns: fragment column 2 b = values, 2 b + 1 = gates
+      f4 ca0 = {0.f, 0.f, 0.f, 0.f}, ca1 = {0.f, 0.f, 0.f, 0.f}, cg0 = {0.f, 0.f, 0.f, 0.f}, cg1 = {0.f, 0.f, 0.f, 0.f};      // folded LayerNorm: column sums, folded biases; else: bias, -
+      const int cl = wn0 + b * 32 + fq * 4;                           // tile column of this lane's 4 values (their gates: + 16)
+      if constexpr (LN) { ca0 = *(const f4*)(ln_cs + cl); ca1 = *(const f4*)(ln_lb + cl); cg0 = *(const f4*)(ln_cs + cl + 16); cg1 = *(const f4*)(ln_lb + cl + 16); }
       else {
-        const h4 hb = *(const h4*)(p.bias + min(bn0 + wn0 + cl, hN - 4));
+        const h4 ha = *(const h4*)(p.bias + min(bn0 + cl, hN - 4)), hg = *(const h4*)(p.bias + min(bn0 + cl + 16, hN - 4));
 #pragma unroll
-        for (int e = 0; e < 4; ++e) c0[e] = (float)hb[e];
+        for (int e = 0; e < 4; ++e) { ca0[e] = (float)ha[e]; cg0[e] = (float)hg[e]; }
       }
 #pragma unroll
       for (int i = 0; i < MR; ++i) {
-        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-        if constexpr (LN) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = ln_fold_f(v[e], mu[i], rs[i], c0[e], c1[e]);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaf(c0[e], e_bs, v[e] * e_as);
-        }
         h4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (half_t)v[e];
-        *(h4*)(t16 + (wm0 + i * 16 + frow) * G::P16 + cl * 2) = o;
+        for (int e = 0; e < 4; ++e) {
+          float va = acc[i][2 * b][e], vg = acc[i][2 * b + 1][e];
+          if constexpr (LN) { va = ln_fold_f(va, mu[i], rs[i], ca0[e], ca1[e]); vg = ln_fold_f(vg, mu[i], rs[i], cg0[e], cg1[e]); }
+          else { va = fmaf(ca0[e], e_bs, va * e_as); vg = fmaf(cg0[e], e_bs, vg * e_as); }
+          va = (float)(half_t)va; vg = (float)(half_t)vg;             // (the projection's output is an fp16 tensor: the rounding every other tile makes on its way through the LDS)
+          o[e] = (half_t)(va * gelu_lut_f(vg, phi));
+        }
+        *(h4*)(t16 + (wm0 + i * 16 + frow) * G::P16 + ((wn0 >> 1) + b * 16 + fq * 4) * 2) = o;
       }
-      __builtin_amdgcn_sched_barrier(0);      // one fragment column at a time (constant loads of all ten columns hoisted to the top would cost 80 registers)
+      __builtin_amdgcn_sched_barrier(0);      // one block at a time (constant loads of all five blocks hoisted to the top would cost 80 registers)
     }
   };
-  // packed columns: 32-wide blocks [16 values | 16 gates]; out[m][n / 2] = a * gelu(g). Groups of 8 OUTPUT columns: 10 per row and half.
-  auto readout = [&](int h) {
-    constexpr int GPR = G::HN / 16, TOTAL = BM * GPR, U = 2, ITER = (TOTAL + NT * U - 1) / (NT * U);
+  if (p.ln_stats) geglu_regs(std::true_type{});
+  else geglu_regs(std::false_type{});
+  __syncthreads();
+  IA2P_STAMP(if (tid == 0 && p.partial) ((unsigned long long*)p.partial)[8 * blockIdx.x + 7] = __builtin_amdgcn_s_memrealtime();)      // the output tile is in LDS
+  {
+    // read out row-major, 16 B = 8 outputs per thread: 20 groups per row, 5 120 in all = 10 per thread; whole-line write-through stores
+    constexpr int GPR = G::HN / 8, TOTAL = BM * GPR, U = 5, ITER = TOTAL / (NT * U);
+    static_assert(TOTAL % (NT * U) == 0, "read-out: whole rounds");
 #pragma unroll 1
     for (int k = 0; k < ITER; ++k) {
-      h8 ha[U], hg[U];
+      h8 hv[U];
       int rr[U], gg[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int idx = min(tid + (k * U + u) * NT, TOTAL - 1);
+        const int idx = tid + (k * U + u) * NT;
         const int r = idx / GPR, g = idx - r * GPR;
         rr[u] = r; gg[u] = g;
-        const char* q = t16 + r * G::P16 + ((g >> 1) * 32 + (g & 1) * 8) * 2;      // 8 values; their gates 16 columns on
-        ha[u] = *(const h8*)q; hg[u] = *(const h8*)(q + 32);
+        hv[u] = *(const h8*)(t16 + r * G::P16 + g * 16);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int r = rr[u], g = gg[u] + h * GPR;                    // group index inside the whole tile
-        h8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (half_t)((float)ha[u][e] * gelu_lut_f((float)hg[u][e], phi));
-        const bool live = tid + (k * U + u) * NT < TOTAL && bm0 + r < hM && bn0 + (g >> 1) * 32 < hN;
+        const bool live = bm0 + rr[u] < hM && bn0 + gg[u] * 16 < hN;
         if (live) {
-          const size_t elem = (size_t)(bm0 + r) * p.ldc + (bn0 >> 1) + (g >> 1) * 16 + (g & 1) * 8;
-          if (p.c_wt) store16_wt(c_rsrc, elem * 2, o);
-          else *(h8*)(p.C + elem) = o;
+          const size_t elem = (size_t)(bm0 + rr[u]) * p.ldc + (bn0 >> 1) + gg[u] * 8;
+          if (p.c_wt) store16_wt(c_rsrc, elem * 2, hv[u]);
+          else *(h8*)(p.C + elem) = hv[u];
         }
       }
     }
-  };
-  // (the two halves spelled out: inside a two-trip loop the compiler moved the whole accumulator array to scratch at the loop's head)
-  if ((wave & 1) == 0) {              // the four waves that hold the first column half
-    if (p.ln_stats) convert(std::true_type{});
-    else convert(std::false_type{});
   }
-  __syncthreads();
-  IA2P_STAMP(if (tid == 0 && p.partial) ((unsigned long long*)p.partial)[8 * blockIdx.x + 7] = __builtin_amdgcn_s_memrealtime();)      // the first half is in LDS
-  readout(0);
-  __syncthreads();                    // the half has been read out: the other four waves may overwrite it
-  if ((wave & 1) == 1) {
-    if (p.ln_stats) convert(std::true_type{});
-    else convert(std::false_type{});
-  }
-  __syncthreads();
-  readout(1);
   asm volatile("" ::"v"(pfacc), "v"(pfv[0]), "v"(pfv[1]), "v"(pfv[2]), "v"(pfv[3]), "v"(pfv[4]), "v"(pfv[5]), "v"(pfv[6]), "v"(pfv[7]));      // keep the prefetch loads alive up to here
   IA2P_STAMP(
     if (tid == 0 && p.partial) ((unsigned long long*)p.partial)[8 * blockIdx.x + 6] = __builtin_amdgcn_s_memrealtime();      // this wave has ISSUED its last C store
