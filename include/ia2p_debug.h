@@ -25,6 +25,9 @@ void ia2p_debug_set_gemm_tile(int variant);   /* -1 auto; else index into IA2P_G
 /* fused to_q + cross-attention: contexts created AFTER this call fuse launches of at least `tiles` 128-query x head tiles (-1: the built-in 128). Tests only:
  * lets a tiny model take the fused path. */
 void ia2p_debug_set_xattn_min_tiles(int tiles);
+/* IP-Adapter cross-attention (reference attention_processor.py:371,387,397): 1 = the image-token keys ride in the free slots of the last text-key tile (81 keys = two tiles), 0 = a tile of
+ * their own (three), -1 = IA2P_ATTN_FOLD or the default (1). Tests: the two forms agree to one fp16 ulp (the two softmaxes are the same numbers; sums of the probabilities differ in order). */
+void ia2p_debug_set_attn_fold(int mode);
 /* the tile table (tests / tools): out[4] = {tile rows, tile columns, LDS ring stages, schedule: 0 plain, 1 ping-pong, 2 eight-phase, 3 halo-staged 3x3 convolution (ping-pong over 16 x 16 pixel patches)}; 0, or -1 past the last variant */
 int ia2p_debug_gemm_tile_info(int variant, int* out);
 /* the tile variant and K-split the library picks for a problem (pure function of the shape; host-only, no GPU needed) */

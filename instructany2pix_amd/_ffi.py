@@ -107,6 +107,7 @@ SIGNATURES = {
     "ia2p_debug_set_gemm_tile": (None, [_I]),
     "ia2p_debug_gemm_tile_info": (_I, [_I, _P]),
     "ia2p_debug_set_xattn_min_tiles": (None, [_I]),
+    "ia2p_debug_set_attn_fold": (None, [_I]),
     "ia2p_debug_set_splitk_inkernel": (None, [C.c_longlong]),
     "ia2p_debug_invalidate_splitk_counters": (None, []),
     "ia2p_debug_fill_splitk_counters": (_I, [_P, _I]),

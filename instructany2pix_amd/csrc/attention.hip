@@ -65,6 +65,13 @@ __global__ __launch_bounds__(256, 2) void attention_f16_kernel(const half_t* aQ,
   attn_store_o(otot, p.O, (size_t)p.B * p.Nq * p.ldo, b, q0, hd, p.Nq, p.ldo, smem + wave * 4096, lane, (p.xcd_map & 2) != 0);
 }
 
+static int g_attn_fold = -1;      // test / A-B hook (ia2p_debug_set_attn_fold): -1 = IA2P_ATTN_FOLD or the default (fold)
+extern "C" void ia2p_debug_set_attn_fold(int v) { g_attn_fold = v; }
+bool ia2p_attn_fold_enabled() {
+  static const int env = getenv("IA2P_ATTN_FOLD") ? atoi(getenv("IA2P_ATTN_FOLD")) : 1;
+  return (g_attn_fold >= 0 ? g_attn_fold : env) != 0;
+}
+
 hipError_t ia2p_launch_attention(const AttnArgs& a, hipStream_t s) {
   dim3 grid(((a.Nq + 127) / 128) * a.heads * a.B);
   static bool attr_set[64] = {false};     // per device (the attribute is)
@@ -79,7 +86,7 @@ hipError_t ia2p_launch_attention(const AttnArgs& a, hipStream_t s) {
   }
   static const int xcd_map = ia2p_exp_env("IA2P_ATTN_XCD") ? atoi(ia2p_exp_env("IA2P_ATTN_XCD")) : 1;     // A/B switch
   AttnArgs b = a;
-  b.xcd_map = (xcd_map ? 1 : 0) | (((ia2p_wt_mask() & 8) && (size_t)a.B * a.Nq * a.ldo * 2 < (size_t)0x7ffffff0) ? 2 : 0);
+  b.xcd_map = (xcd_map ? 1 : 0) | (((ia2p_wt_mask() & 8) && (size_t)a.B * a.Nq * a.ldo * 2 < (size_t)0x7ffffff0) ? 2 : 0) | (ia2p_attn_fold_enabled() ? 0 : 4);
   // mode: 0 = one key segment; 1 = two segments with a second one of <= 64 keys and a non-zero first weight (the IP-Adapter call: merged
   // accumulator); 2 = any other two-segment call
   const int mode = b.nseg == 1 ? 0 : (b.seg[1].nkeys <= 64 && b.seg[0].weight != 0.f) ? 1 : 2;

@@ -39,11 +39,20 @@ __device__ __forceinline__ void stage_kv(const half_t* Kb, const half_t* Vb, int
   }
 }
 
+// FOLD (round 6): the image-token keys of an IP-Adapter call ride in the FREE slots of the last text-key tile -- 77 text + 4 image tokens are 64 + (13 + 4) keys = two
+// tiles, the second a single live half -- instead of a tile of their own (reference attention_processor.py:371, :387, :397: two scaled_dot_product_attention calls over
+// the same queries, `text + scale * ip`; the two softmaxes stay two: a key-index mask selects which running (max, sum) pair a score feeds). Taken when the last text tile
+// is partial and has room: (n0 % 64) + n1 <= 64, n1 <= 32 (one staging chunk).
+__device__ __host__ __forceinline__ bool attn_fold_ok(int n0, int n1) { return (n0 & 63) != 0 && n1 > 0 && n1 <= 32 && (n0 & 63) + n1 <= 64; }
+// launcher-side switch (attention.hip): IA2P_ATTN_FOLD=0 / ia2p_debug_set_attn_fold(0) keep the image-token keys in a tile of their own (A/B runs, the test's reference);
+// it travels in AttnArgs.xcd_map bit 2 (4 = do not fold)
+bool ia2p_attn_fold_enabled();
+
 // Both key segments of a short-context cross-attention (e.g. 77 text + 4 image-token keys = 2 + 1 tiles) staged in ONE
-// load phase: tiles [0, nt0) hold segment 0, tiles [nt0, NT) segment 1.
+// load phase: tiles [0, nt0) hold segment 0, tiles [nt0, NT) segment 1 -- or, `fold`, segment 1's rows follow segment 0's last row inside tile nt0 - 1.
 template <int NT>
 __device__ __forceinline__ void stage_kv2(const half_t* K0, const half_t* V0, int ld0, int n0, const half_t* K1, const half_t* V1,
-                                          int ld1, int n1, int nt0, int tid, char* sK, char* sV) {
+                                          int ld1, int n1, int nt0, int tid, char* sK, char* sV, bool fold = false) {
   typedef unsigned int u4 __attribute__((ext_vector_type(4)));
   u4 kreg[2 * NT], vreg[2 * NT];
 #pragma unroll
@@ -57,10 +66,19 @@ __device__ __forceinline__ void stage_kv2(const half_t* K0, const half_t* V0, in
 #pragma unroll
   for (int u = 0; u < 2 * NT; ++u) {
     const bool s1 = (u >> 1) >= nt0;
-    const int c = tid + 256 * u, lrow = c >> 3, row = lrow - (s1 ? nt0 * 64 : 0), pos = c & 7;
+    const int c = tid + 256 * u, pos = c & 7;
+    int lrow = c >> 3;
+    const int row = lrow - (s1 ? nt0 * 64 : 0);
     const unsigned keep = row < (s1 ? n1 : n0) ? 0xFFFFFFFFu : 0u;
-    *(u4*)(sK + lrow * 128 + ((pos ^ ((lrow >> 1) & 7)) << 4)) = kreg[u] & keep;
-    *(u4*)(sV + lrow * 128 + ((pos ^ (((lrow >> 1) & 1) << 2)) << 4)) = vreg[u] & keep;
+    bool write = true;
+    if (fold) {                      // (wave-uniform) image-token rows land behind the last text row; the text chunks leave those rows alone (two threads must not write one row)
+      if (s1) { write = u == 2 * nt0 && row < n1; lrow = n0 + row; }
+      else write = lrow < n0 || lrow >= n0 + n1;
+    }
+    if (write) {
+      *(u4*)(sK + lrow * 128 + ((pos ^ ((lrow >> 1) & 7)) << 4)) = kreg[u] & keep;
+      *(u4*)(sV + lrow * 128 + ((pos ^ (((lrow >> 1) & 1) << 2)) << 4)) = vreg[u] & keep;
+    }
   }
 }
 
@@ -91,18 +109,29 @@ __device__ __forceinline__ void attn_kv_load(const AttnArgs& p, int b, int hd, i
     rg.v[u] = *(const u4*)((s1 ? V1 : V0) + off);
   }
 }
+template <bool FOLD = false>
 __device__ __forceinline__ void attn_kv_store(const AttnArgs& p, int tid, const AttnKvRegs& rg, char* sK, char* sV) {
   typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-  const int n1 = p.nseg == 2 ? p.seg[1].nkeys : 0;
-  const int nt0 = (p.seg[0].nkeys + 63) >> 6, nt = nt0 + ((n1 + 63) >> 6);
+  const int n0 = p.seg[0].nkeys, n1 = p.nseg == 2 ? p.seg[1].nkeys : 0;
+  const int nt0 = (n0 + 63) >> 6, nt = nt0 + ((n1 + 63) >> 6);
+  const bool fold = FOLD && !(p.xcd_map & 4) && n1 > 0 && attn_fold_ok(n0, n1);      // (wave-uniform; FOLD: the caller runs attn_core<1>, the only mode that folds)
 #pragma unroll
   for (int u = 0; u < 2 * ATTN_PRE_TILES; ++u) {
-    if ((u >> 1) >= nt) break;                             // wave-uniform
+    if ((u >> 1) >= nt || (fold && u > 2 * nt0)) break;     // wave-uniform
     const bool s1 = (u >> 1) >= nt0;
-    const int c = tid + 256 * u, lrow = c >> 3, row = lrow - (s1 ? nt0 * 64 : 0), pos = c & 7;
-    const unsigned keep = row < (s1 ? n1 : p.seg[0].nkeys) ? 0xFFFFFFFFu : 0u;
-    *(u4*)(sK + lrow * 128 + ((pos ^ ((lrow >> 1) & 7)) << 4)) = rg.k[u] & keep;
-    *(u4*)(sV + lrow * 128 + ((pos ^ (((lrow >> 1) & 1) << 2)) << 4)) = rg.v[u] & keep;
+    const int c = tid + 256 * u, pos = c & 7;
+    int lrow = c >> 3;
+    const int row = lrow - (s1 ? nt0 * 64 : 0);
+    const unsigned keep = row < (s1 ? n1 : n0) ? 0xFFFFFFFFu : 0u;
+    bool write = true;
+    if (fold) {
+      if (s1) { write = row < n1; lrow = n0 + row; }
+      else write = lrow < n0 || lrow >= n0 + n1;
+    }
+    if (write) {
+      *(u4*)(sK + lrow * 128 + ((pos ^ ((lrow >> 1) & 7)) << 4)) = rg.k[u] & keep;
+      *(u4*)(sV + lrow * 128 + ((pos ^ (((lrow >> 1) & 1) << 2)) << 4)) = rg.v[u] & keep;
+    }
   }
 }
 
@@ -127,15 +156,18 @@ __device__ __forceinline__ void attn_core(const AttnArgs& p, int b, int hd, cons
   // short two-segment contexts: everything resident after one load phase and one barrier
   const int nt0 = (p.seg[0].nkeys + 63) >> 6, nt1 = p.nseg == 2 ? (p.seg[1].nkeys + 63) >> 6 : 0;
   const bool resident = PRE || (MODE != 0 && nt0 + nt1 <= 4);
+  // MODE 1, resident context: the image-token keys folded into the free slots of the last text tile (attn_fold_ok; the staging put them there)
+  const int n0 = p.seg[0].nkeys, n1 = p.nseg == 2 ? p.seg[1].nkeys : 0;
+  const bool fold = MODE == 1 && resident && !(p.xcd_map & 4) && attn_fold_ok(n0, n1);
   if (resident && !PRE) {
     const half_t* K0 = p.seg[0].K + (size_t)b * p.seg[0].rows_per_batch * p.seg[0].ld + hd * 64;
     const half_t* V0 = p.seg[0].V + (size_t)b * p.seg[0].rows_per_batch * p.seg[0].ld + hd * 64;
     const half_t* K1 = p.seg[1].K + (size_t)b * p.seg[1].rows_per_batch * p.seg[1].ld + hd * 64;
     const half_t* V1 = p.seg[1].V + (size_t)b * p.seg[1].rows_per_batch * p.seg[1].ld + hd * 64;
     switch (nt0 + nt1) {
-      case 2: stage_kv2<2>(K0, V0, p.seg[0].ld, p.seg[0].nkeys, K1, V1, p.seg[1].ld, p.seg[1].nkeys, nt0, tid, sK, sV); break;
-      case 3: stage_kv2<3>(K0, V0, p.seg[0].ld, p.seg[0].nkeys, K1, V1, p.seg[1].ld, p.seg[1].nkeys, nt0, tid, sK, sV); break;
-      default: stage_kv2<4>(K0, V0, p.seg[0].ld, p.seg[0].nkeys, K1, V1, p.seg[1].ld, p.seg[1].nkeys, nt0, tid, sK, sV); break;
+      case 2: stage_kv2<2>(K0, V0, p.seg[0].ld, p.seg[0].nkeys, K1, V1, p.seg[1].ld, p.seg[1].nkeys, nt0, tid, sK, sV, fold); break;
+      case 3: stage_kv2<3>(K0, V0, p.seg[0].ld, p.seg[0].nkeys, K1, V1, p.seg[1].ld, p.seg[1].nkeys, nt0, tid, sK, sV, fold); break;
+      default: stage_kv2<4>(K0, V0, p.seg[0].ld, p.seg[0].nkeys, K1, V1, p.seg[1].ld, p.seg[1].nkeys, nt0, tid, sK, sV, fold); break;
     }
     __syncthreads();
   }
@@ -143,6 +175,7 @@ __device__ __forceinline__ void attn_core(const AttnArgs& p, int b, int hd, cons
   constexpr int NSEG = MODE == 0 ? 1 : 2;
 #pragma unroll 1
   for (int sg = 0; sg < NSEG; ++sg) {
+    if (MODE == 1 && fold && sg == 1) break;             // the image-token keys went through the last text tile
     AttnSeg seg = sg == 0 ? p.seg[0] : p.seg[1];         // (a runtime index into the by-value argument would push it to scratch)
     if (sg == 1 && p.w1_b) seg.weight = p.w1_b[b];       // per-request IP-Adapter scale
     const half_t* Kb = seg.K + (size_t)b * seg.rows_per_batch * seg.ld + hd * 64;
@@ -203,7 +236,7 @@ __device__ __forceinline__ void attn_core(const AttnArgs& p, int b, int hd, cons
       auto qk = [&](int tl, f16v (&st)[2]) {       // S^T[key][q] for the two 32-key halves of tile tl; K fragments read ahead of the MFMAs
         const char* sKt = sKs + (tbase + tl) * 8192;
         // short contexts end in short tiles (77 text keys = 64 + 13, 4 image-token keys): a tile with <= 32 live keys is ONE half
-        const int nkh = ((MODE != 0 || PRE) && seg.nkeys - (s0 + tl * 64) <= 32) ? 1 : 2;       // wave-uniform
+        const int nkh = ((MODE != 0 || PRE) && (fold ? n0 + n1 : seg.nkeys) - (s0 + tl * 64) <= 32) ? 1 : 2;       // wave-uniform
         h8 kf[2][4];
 #pragma unroll
         for (int kh = 0; kh < 2; ++kh) {
@@ -227,7 +260,9 @@ __device__ __forceinline__ void attn_core(const AttnArgs& p, int b, int hd, cons
       };
       auto soft_pv = [&](int tl, f16v (&st)[2]) {
         const int k0 = s0 + tl * 64;
-        const int nkh = ((MODE != 0 || PRE) && seg.nkeys - k0 <= 32) ? 1 : 2;                   // as in qk
+        const int live_end = (MODE == 1 && fold) ? n0 + n1 : seg.nkeys;                            // keys of this segment's tiles that exist (folded: text keys, then the image-token keys)
+        const bool merged = MODE == 1 && fold && k0 + 64 > n0;                                     // the last text tile carries the image-token keys too (wave-uniform)
+        const int nkh = ((MODE != 0 || PRE) && live_end - k0 <= 32) ? 1 : 2;                     // as in qk
         const char* sVt = sVs + (tbase + tl) * 8192;
         // V^T fragments of the whole tile: issued now, their latency hides under the softmax arithmetic below
         const int gi = (lane >> 4) & 1, li = lane & 15;
@@ -253,6 +288,8 @@ __device__ __forceinline__ void attn_core(const AttnArgs& p, int b, int hd, cons
         __builtin_amdgcn_sched_barrier(0);
         // st[kh][r] <-> key = k0 + 32kh + (r&3) + 8(r>>2) + 4*hh, query = q0 + lane%32
         // softmax on RAW scores: max commutes with the positive scale, and exp2(c*s - c*m) is one FMA + one v_exp_f32
+        // merged tile: the image-token scores leave `st` for `si` (their own softmax below); what stays in `st` is the text softmax's, exactly as in a tile of its own
+        f16v si[2];
         if (k0 + 64 > seg.nkeys) {        // only the last, partial tile of a segment needs masking (wave-uniform)
 #pragma unroll
           for (int kh = 0; kh < 2; ++kh) {
@@ -260,6 +297,7 @@ __device__ __forceinline__ void attn_core(const AttnArgs& p, int b, int hd, cons
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int key = k0 + kh * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+              if (merged) si[kh][r] = (key >= n0 && key < live_end) ? st[kh][r] : MASKED;
               if (key >= seg.nkeys) st[kh][r] = MASKED;
             }
           }
@@ -310,6 +348,41 @@ __device__ __forceinline__ void attn_core(const AttnArgs& p, int b, int hd, cons
             mrun = mnew;
           }
           lrun += psum;
+          if (merged) {
+            // the image-token keys of this tile: their own softmax (reference attention_processor.py:387), scaled as the stand-alone image-token tile scales it --
+            // (w_ip / w_text) * l_text / l_ip, with l_text final now (this IS the last text tile) -- and dropped into the probability slots the text softmax left at zero
+            lt = lrun + __shfl_xor(lrun, 32, 64);
+            float mxi = si[0][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mxi = fmaxf(mxi, si[0][r]);
+            if (nkh == 2) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) mxi = fmaxf(mxi, si[1][r]);
+            }
+            mxi = fmaxf(mxi, __shfl_xor(mxi, 32, 64));
+            const float mci = mxi * p.scale_log2e;
+            float psi = 0.f;
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+              if (kh >= nkh) break;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) { si[kh][r] = __builtin_amdgcn_exp2f(fmaf(si[kh][r], p.scale_log2e, -mci)); psi += si[kh][r]; }
+            }
+            const float li = psi + __shfl_xor(psi, 32, 64);
+            const float w_ip = p.w1_b ? p.w1_b[b] : p.seg[1].weight;
+            const float ci = w_ip / p.seg[0].weight * lt / li;
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+              if (kh >= nkh) break;
+#pragma unroll
+              for (int r = 0; r < 16; r += 2) {
+                const h2 pr = __builtin_convertvector((f2v){si[kh][r] * ci, si[kh][r + 1] * ci}, h2);
+                const int key = k0 + kh * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;      // (r even: r and r + 1 are keys key, key + 1)
+                if (key >= n0) pf[kh][r >> 3][r & 7] = pr[0];
+                if (key + 1 >= n0) pf[kh][r >> 3][(r & 7) + 1] = pr[1];
+              }
+            }
+          }
         } else {
           // image-token tile (MODE 1): its own softmax over its <= 64 keys, all of them in this tile. `o` already holds sum_t e^(s_t - m_t) v_t
           // of the text keys, to be divided by l_t at the end: scale these probabilities by (w_ip / w_text) * l_t / l_ip so that the common

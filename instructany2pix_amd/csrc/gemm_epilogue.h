@@ -215,7 +215,7 @@ __device__ __forceinline__ void tile_epilogue(f4 (&acc)[BM / WGM / 16][BN / WGN 
     const AttnArgs& ap = *xa;
     const int b = bm0 / ap.Nq, q0 = bm0 - b * ap.Nq + wave * 32, hd = tn;
     f16v otot[2];
-    attn_kv_store(ap, tid, kvr, smem, smem + 32768);     // only short contexts are fused (the launcher checks): their K / V are in registers by now
+    attn_kv_store<XA - 1 == 1>(ap, tid, kvr, smem, smem + 32768);     // only short contexts are fused (the launcher checks): their K / V are in registers by now
     __syncthreads();
     IA2P_STAMP(if (tid == 0 && xo) xo[6] = __builtin_amdgcn_s_memrealtime();)      // Q fragments built, K / V images in LDS
     attn_core<XA - 1, true>(ap, b, hd, qf, smem, smem + 32768, tid, otot);

@@ -53,7 +53,7 @@ hipError_t ia2p_launch_qproj_xattn(const GemmArgs& a, const AttnArgs& x, hipStre
 #endif
   b.group_w = ia2p_tile_group_w(tiles, tiles_n, SMEM, BM, BN);
   AttnArgs y = x;
-  y.xcd_map = ((ia2p_wt_mask() & 8) && (size_t)x.B * x.Nq * x.ldo * 2 < (size_t)0x7ffffff0) ? 2 : 0;      // bit 1: write-through O
+  y.xcd_map = (((ia2p_wt_mask() & 8) && (size_t)x.B * x.Nq * x.ldo * 2 < (size_t)0x7ffffff0) ? 2 : 0) | (ia2p_attn_fold_enabled() ? 0 : 4);      // bit 1: write-through O; bit 2: image-token keys NOT folded into the last text tile
   const int extra = (a.pf && a.pf_bytes >= 4096) ? a.pf_blocks : 0;
   const int mode = y.nseg == 1 ? 0 : (y.seg[1].nkeys <= 64 && y.seg[0].weight != 0.f) ? 1 : 2;     // as ia2p_launch_attention
 #define IA2P_QX_LAUNCH(MODE)                                                                                                                   \

@@ -716,6 +716,66 @@ def test_cross_attention_two_softmaxes(L, Lt, Li, scale):
     assert rel_l2(out, ref) < 2e-3, rel_l2(out, ref)
 
 
+@pytest.mark.parametrize("Lt,Li,scale,folds", [(77, 4, 1.0, True), (73, 4, 0.5, True), (77, 4, 0.0, True), (13, 4, 0.9, True), (141, 16, 0.7, True), (100, 28, 1.2, True), (60, 4, 1.0, True),
+                                               (64, 4, 1.0, False), (77, 33, 1.0, False), (120, 16, 0.8, False), (300, 4, 0.9, False)])
+def test_image_token_keys_fold_into_the_last_text_tile(L, Lt, Li, scale, folds):
+    """Round 6: IPAttnProcessor2_0's two scaled_dot_product_attention calls (reference attention_processor.py:371 text, :387 image tokens, :397
+    `text + scale * ip`) walk 81 keys as TWO key tiles -- the 4 image-token keys ride in the free slots of the second text tile, a key-index mask keeps the two softmaxes
+    apart -- instead of three. Against fp32 torch, and against the three-tile form (ia2p_debug_set_attn_fold(0)) to one fp16 ulp: the softmaxes are the same numbers, the
+    probability sums and the P.V products are added up in another order. Stand-alone kernel and the fused to_q + cross-attention launch; per-request scales too.
+    Shapes that do not fold (a full last text tile, more than 32 image tokens, no room, a non-resident context) must not change at all."""
+    f = _ffi()
+    B, heads, N = 2, 4, 256
+    C_ = heads * 64
+    q, kv, kvi = rnd(B, N, C_, seed=118), rnd(B, Lt, 2 * C_, seed=119), rnd(B, Li, 2 * C_, seed=120)
+    sp = lambda t: t.reshape(B, -1, heads, 64).transpose(1, 2)
+    ref = (_sdpa(sp(q), sp(kv[..., :C_]), sp(kv[..., C_:])) + scale * _sdpa(sp(q), sp(kvi[..., :C_]), sp(kvi[..., C_:]))).transpose(1, 2).reshape(B, N, C_)
+    segs = (2, f.ptr(kv), C.c_void_p(kv.data_ptr() + 2 * C_), 2 * C_, Lt, 1.0, f.ptr(kvi), C.c_void_p(kvi.data_ptr() + 2 * C_), 2 * C_, Li, scale)
+    outs = {}
+    X, W, b = rnd(B * N, C_, seed=133), rnd(C_, C_, seed=134, scale=C_ ** -0.5), rnd(C_, seed=135, scale=0.3)
+    fused_ok = (Lt + 63) // 64 + (Li + 63) // 64 <= 3            # (the fused launch keeps a resident context of at most three key tiles)
+    try:
+        for mode in (1, 0):
+            L.ia2p_debug_set_attn_fold(mode)
+            out = torch.full((B, N, C_), float("nan"), dtype=torch.half, device="cuda")
+            run(L, "ia2p_attention", f.ptr(q), C_, f.ptr(out), C_, B, heads, N, *segs)
+            outs[("attention", mode)] = out
+            if fused_ok:
+                o2 = torch.full((B, N, C_), float("nan"), dtype=torch.half, device="cuda")
+                run(L, "ia2p_qproj_attention", f.ptr(X), f.ptr(W), f.ptr(b), None, f.ptr(o2), C_, B, heads, N, C_, *segs)
+                outs[("fused", mode)] = o2
+    finally:
+        L.ia2p_debug_set_attn_fold(-1)
+    assert rel_l2(outs[("attention", 1)], ref) < 2e-3 and rel_l2(outs[("attention", 0)], ref) < 2e-3
+    kinds = ["attention"] + (["fused"] if fused_ok else [])
+    for kind in kinds:
+        a, c = outs[(kind, 1)], outs[(kind, 0)]
+        assert torch.isfinite(a).all()
+        if not folds:
+            assert torch.equal(a, c), kind                                          # nothing to fold: the switch changes nothing
+            continue
+        # one fp16 ulp at the scale of the query's output: |a - c| <= the spacing of fp16 numbers at the largest |O| of the query's head (an output is a sum of
+        # probability x value terms whose probabilities are rounded to fp16 before the P.V product: where the image tokens' probabilities round the other way -- their
+        # common factor l_text / l_ip is summed in another order -- an output moves by 2^-11 of a TERM, which is many ulps of an output that cancels to near zero)
+        d = (a.float() - c.float()).abs().reshape(B, N, heads, 64)
+        scale_ = torch.maximum(a.float().abs(), c.float().abs()).reshape(B, N, heads, 64).amax(dim=-1, keepdim=True).clamp_min(2.0 ** -14)
+        ulp = torch.exp2(torch.floor(torch.log2(scale_)) - 10)
+        assert bool((d <= ulp).all()), (kind, float((d / ulp).max()))
+        assert rel_l2(a, c) < 2e-4, (kind, rel_l2(a, c))
+        assert float((a != c).float().mean()) < 0.25, kind                          # ... and most outputs are the same bits
+    if fused_ok:
+        qref = (X.float() @ W.float().t() + b.float()).half()
+        two = torch.empty(B, N, C_, dtype=torch.half, device="cuda")
+        L.ia2p_debug_set_gemm_tile(2)
+        try:
+            qq = torch.empty(B * N, C_, dtype=torch.half, device="cuda")
+            run(L, "ia2p_gemm_ex", f.ptr(X), f.ptr(W), f.ptr(b), None, f.ptr(qq), B * N, C_, C_, 0, None, None, None, 1, None)
+            run(L, "ia2p_attention", f.ptr(qq), C_, f.ptr(two), C_, B, heads, N, *segs)
+        finally:
+            L.ia2p_debug_set_gemm_tile(-1)
+        assert torch.equal(two, outs[("fused", 1)])                                  # fused and two-launch forms share the core: same bits, folded or not
+
+
 @pytest.mark.parametrize("folded", [True, False])
 @pytest.mark.parametrize("B,heads,Nq,Lt,Li,scale", [(2, 4, 256, 77, 4, 1.0), (1, 20, 256, 77, 4, 0.6), (1, 10, 1024, 77, 0, 0.0), (2, 2, 128, 128, 4, 0.9),
                                                     (1, 3, 384, 64, 65, 2.0), (1, 2, 256, 77, 64, 1.3), (1, 2, 256, 13, 0, 0.0), (1, 1, 128, 192, 0, 0.0)])
