@@ -48,7 +48,11 @@ constexpr int IA2P_PHI_LUT_N = 513;
 __device__ __forceinline__ float gelu_lut_f(float g, const float2* lut) {
   const float f = fmaf(__builtin_amdgcn_fmed3f(g, -8.0f, 7.99f), 32.0f, 256.0f);
   const float fl = floorf(f);
+#ifdef IA2P_TIMING_NOLUT      // (timing experiments only, tools/micro/geglu_clock.hip: what the table gather costs; results are wrong)
+  const float2 e = lut[threadIdx.x & 63];
+#else
   const float2 e = lut[(int)fl];
+#endif
   return g * fmaf(f - fl, e.y, e.x);
 }
 __device__ __forceinline__ float quick_gelu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x)); }

@@ -270,11 +270,14 @@ def test_measured_plans_are_the_verified_configuration(full):
     the cost model's plans. Tiles never change the bits, but a different K split sums fp32 partials in a different order -- so the configuration the
     headline number is measured on is checked here too: cfg 3 (batch 8, 81 tokens) and cfg 2 (batch 1, 77 tokens: the 32-row tiles) autotuned exactly
     as bench.py does, then one evaluation each against the oracle (requests 0 and 7 of the batch), and against the cost-model run of the same inputs."""
-    from bench import make_inputs
-    from instructany2pix_amd.unet import clear_plans, export_plans
+    from bench import make_inputs, DEFAULT_PLANS
+    from instructany2pix_amd.unet import clear_plans, export_plans, import_plans
     cfg, hip, ref, ip_procs, oracle = full
+    want_cache = {}
     try:
-        for B, L, cfg_id, sel in ((8, 81, 3, [0, 7]), (1, 77, 2, [0])):
+        # round 6 (VERDICT round 5 item 6): bench.py's DEFAULT is the committed plan table (instructany2pix_amd/plans/mi355x_bench.plans) -- the configuration the driver
+        # times -- so it is verified first, exactly as committed; then the plans this box's tuner measures (`bench.py --tune`)
+        for source, B, L, cfg_id, sel in (("committed", 8, 81, 3, [0, 7]), ("committed", 1, 77, 2, [0]), ("tuned", 8, 81, 3, [0, 7]), ("tuned", 1, 77, 2, [0])):
             clear_plans()
             if L > 77:
                 _set_ip(hip, ref, ip_procs, 1.0)
@@ -284,14 +287,21 @@ def test_measured_plans_are_the_verified_configuration(full):
             added = dict(text_embeds=pooled, time_ids=tid)
             hip.cache_context_kv = False             # the reference's schedule: the context projection inside the evaluation
             base = hip(lat, 981, encoder_hidden_states=ctx, added_cond_kwargs=added)[0].clone()
-            n = hip.autotune(lat, 981, ctx, added)
-            assert n >= 20 and export_plans().count(";") >= 20, n
+            if source == "committed":
+                text = "".join(l for l in open(DEFAULT_PLANS).read().splitlines() if not l.startswith("#")).strip()
+                assert import_plans(text) >= 100 and text.count(";") == export_plans().count(";")
+            else:
+                n = hip.autotune(lat, 981, ctx, added)
+                assert n >= 20 and export_plans().count(";") >= 20, n
             hip.profile(True)
             out = hip(lat, 981, encoder_hidden_states=ctx, added_cond_kwargs=added)[0].clone()
             torch.cuda.synchronize()
             roles = hip.profile_read_roles()
             hip.profile(False)
             assert torch.isfinite(out).all()
+            if source == "committed" and B == 8:      # the committed table runs the GEGLU projections on the 256 x 320 tile of round 6 (tile variant 27): all 70 of them
+                ff = [v for k, v in roles.items() if k.startswith("ff_in")][0]
+                assert ff["launches"] == 70 and set(ff["kernels"]) == {"gemm_geglu_f16_kernel"}, ff
             # the headline loop (bench.py) projects the context once per request and reads the buffer in the other steps: the same bits, at full size
             hip.cache_context_kv = True
             hip.invalidate_context_kv()
@@ -335,12 +345,14 @@ def test_measured_plans_are_the_verified_configuration(full):
                 assert gn_all <= 16, gn_all      # the 11 Transformer2DModel norms, conv_norm_out, the statistics pass behind conv_in (+ sites whose plan is not a halo-staged tile)
             assert rel_l2(out, base) < 2e-3, rel_l2(out, base)          # same arithmetic up to the K-split summation order
             f = lambda t_: t_[sel].float().cpu()
-            with torch.no_grad():
-                want = ref(f(lat), 981, f(ctx), added_cond_kwargs=dict(text_embeds=f(pooled), time_ids=f(tid)))[0]
+            if cfg_id not in want_cache:          # (the oracle's answer does not depend on the plans: once per shape)
+                with torch.no_grad():
+                    want_cache[cfg_id] = ref(f(lat), 981, f(ctx), added_cond_kwargs=dict(text_embeds=f(pooled), time_ids=f(tid)))[0]
+            want = want_cache[cfg_id]
             for i, r in enumerate(sel):
                 e = rel_l2(out[r], want[i])
-                assert e < 5e-3, (B, r, e)
-                assert float((out[r].float().cpu() - want[i]).abs().max()) < 2e-2 * float(want[i].abs().max()), (B, r)
+                assert e < 5e-3, (source, B, r, e)
+                assert float((out[r].float().cpu() - want[i]).abs().max()) < 2e-2 * float(want[i].abs().max()), (source, B, r)
     finally:
         clear_plans()
         hip.cache_context_kv = True

@@ -355,3 +355,18 @@ def test_denoise_batch_validates_guidance_and_group_before_touching_the_device()
             denoise_batch(pipe, [req(7.5)], group=g)
     with pytest.raises(ValueError, match="at least one request"):
         denoise_batch(pipe, [])
+
+
+def test_the_reference_import_name_resolves_to_the_native_pipeline():
+    """the call surface to keep starts at `from instructany2pix import InstructAny2PixPipeline` (reference instructany2pix/__init__.py:1). The alias package
+    forwards every name to instructany2pix_amd, lazily: importing it loads neither torch-side modules nor the HIP library."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; import instructany2pix; assert 'instructany2pix_amd.pipeline' not in sys.modules and 'torch' not in sys.modules; "
+            "from instructany2pix import InstructAny2PixPipeline, DDIMScheduler; import instructany2pix_amd.pipeline as p, instructany2pix_amd.scheduler as s; "
+            "assert InstructAny2PixPipeline is p.InstructAny2PixPipeline and DDIMScheduler is s.DDIMScheduler; "
+            "import inspect; sig = inspect.signature(InstructAny2PixPipeline.__call__); "
+            "assert [k for k in sig.parameters][:3] == ['self', 'inst', 'mm_data'] and sig.parameters['num_inference_steps'].default == 25 and sig.parameters['cfg'].default == 10")
+    subprocess.run([sys.executable, "-c", code], check=True, cwd=root)
