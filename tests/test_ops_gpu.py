@@ -294,6 +294,33 @@ def test_geglu_projection_on_the_256x320_tile(L, M, C_, ln):
         assert torch.equal(o, outs[27]), (tile, int((o != outs[27]).sum()))
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 640, 64), (512, 320, 128), (256, 960, 192)])
+def test_geglu_tile_shortest_k_loops(L, M, N, K):
+    """the 256 x 320 GEGLU tile with ONE, two and three k-tiles (its k-loop peels the first sub-step -- the MFMAs that define the accumulators -- and the last one: the
+    shortest loops run only peeled code), plain bias: same bits as the 128 x 160 tile, fp32 torch within tolerance"""
+    f = _ffi()
+    A, W, b = rnd(M, K, seed=201), rnd(N, K, seed=202, scale=K ** -0.5), rnd(N, seed=203, scale=0.3)
+    Wpk, bpk = torch.empty_like(W), torch.empty_like(b)
+    run(L, "ia2p_pack_geglu", f.ptr(W), f.ptr(Wpk), N, K)
+    run(L, "ia2p_pack_geglu", f.ptr(b), f.ptr(bpk), N, 1)
+    outs = {}
+    try:
+        for tile in (27, 8):
+            out = torch.full((M, N // 2), float("nan"), dtype=torch.half, device="cuda")
+            L.ia2p_debug_set_gemm_tile(tile)
+            v = C.c_int(-1)
+            L.ia2p_debug_gemm_plan(M, N, K, 0, 1, C.addressof(v), None)
+            assert v.value == tile
+            run(L, "ia2p_gemm_ex", f.ptr(A), f.ptr(Wpk), f.ptr(bpk), None, f.ptr(out), M, N, K, 1, None, None, None, 1, None)
+            outs[tile] = out
+    finally:
+        L.ia2p_debug_set_gemm_tile(-1)
+    h = A.float() @ W.float().t() + b.float()
+    a, g = h.chunk(2, dim=-1)
+    assert torch.isfinite(outs[27]).all() and rel_l2(outs[27], a * F.gelu(g)) < 2e-3
+    assert torch.equal(outs[27], outs[8])
+
+
 @pytest.mark.parametrize("M,C_", [(2048, 640), (130, 128)])
 def test_layernorm_folded_into_geglu(L, M, C_):
     f, X, Wp, R, gamma, beta, W, b, _, _, _ = _ln_fold_setup(L, M, C_, 8 * C_, seed=70)
