@@ -321,6 +321,43 @@ def test_geglu_tile_shortest_k_loops(L, M, N, K):
     assert torch.equal(outs[27], outs[8])
 
 
+def test_geglu_tile_gate_range_and_special_values_match_the_family(L):
+    """the in-register GEGLU of the 256 x 320 tile on gates anywhere in [-12, 12] (exactly +-8, the table's last cell, beyond it) and on NaN / +-Inf in a value or a gate:
+    the same bits as the 128 x 160 tile, which sends the projected tile through the LDS (test_geglu_gate_table_range_and_special_values pins that route to exact-erf GELU);
+    NaN / Inf never come out as a finite number. One row of A selects one (value, gate) pair."""
+    f = _ffi()
+    M, N, K = 256, 320, 64
+    gates = torch.tensor([-12.0, -9.5, -8.0, -7.99, -7.5, -4.0, -1.0, -0.03125, 0.0, 0.015625, 1.0, 3.0, 6.0, 7.96875, 7.99, 8.0, 9.5, 12.0])
+    gates = torch.cat([gates, torch.linspace(-12, 12, 64 - len(gates))])
+    vals = torch.linspace(-3.0, 3.0, 64)
+    A = torch.eye(64, K).repeat(4, 1).half().cuda()                            # row m selects k = m % 64
+    W = torch.zeros(N, K)
+    for blk in range(N // 32):
+        W[blk * 32:blk * 32 + 16, :] = vals
+        W[blk * 32 + 16:blk * 32 + 32, :] = gates
+    bias = torch.zeros(N).half().cuda()
+    for special, row, col in ((None, 0, 0), (float("nan"), 16, 5), (float("nan"), 0, 5), (float("inf"), 16, 7), (float("-inf"), 16, 9), (float("inf"), 0, 11), (float("nan"), 9 * 32 + 31, 63)):
+        W2 = W.clone()
+        if special is not None:
+            W2[row, col] = special
+        W2 = W2.half().cuda()
+        outs = {}
+        try:
+            for tile in (27, 8):
+                out = torch.zeros(M, N // 2, dtype=torch.half, device="cuda")
+                L.ia2p_debug_set_gemm_tile(tile)
+                run(L, "ia2p_gemm", f.ptr(A), f.ptr(W2), f.ptr(bias), None, f.ptr(out), M, N, K, 1)
+                outs[tile] = out
+        finally:
+            L.ia2p_debug_set_gemm_tile(-1)
+        a, b = outs[27], outs[8]
+        assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(torch.nan_to_num(a.float(), nan=7.0), torch.nan_to_num(b.float(), nan=7.0)), (special, row, col)
+        if special is not None:
+            oc = (row // 32) * 16 + (row % 16)                                  # the output column the touched value / gate row feeds
+            hit = a[col::64, oc].float()
+            assert not torch.isfinite(hit).any(), (special, row, col, hit)      # NaN / Inf propagate (Inf in a far-negative... the rows chosen have finite non-zero partners)
+
+
 @pytest.mark.parametrize("M,C_", [(2048, 640), (130, 128)])
 def test_layernorm_folded_into_geglu(L, M, C_):
     f, X, Wp, R, gamma, beta, W, b, _, _, _ = _ln_fold_setup(L, M, C_, 8 * C_, seed=70)
