@@ -152,6 +152,9 @@ struct GemmArgs {
   // splitk_reduce_kernel then sums them in slab order (deterministic) and applies the epilogue
   int splitk;            // 0/1 = off
   float* partial;
+#ifdef IA2P_CLOCK_STAMP
+  unsigned long long* stamp;      // diagnostic builds only: the stamp records of a launch WITH a K split (its `partial` holds the slabs); unsplit launches pass the buffer in `partial`
+#endif
   int* sk_counters;      // set by the launcher: per-tile ticket counters of the in-launch combine (null: a separate splitk_reduce_kernel launch finishes)
   // range extension (VAE executor): out = acc * acc_scale + (bias + rowvec) * bias_scale + residual; 0 = 1.0. The VAE keeps its residual
   // stream multiplied by a power of two < 1 so that fp16 storage does not overflow where the reference upcasts to fp32 (vae_engine.hip)

@@ -493,12 +493,14 @@ static void run_gemm(RunCtx* c, GemmArgs& a, bool conv, const char* what, double
     }
   }
 #ifdef IA2P_CLOCK_STAMP
-  if (c->stamp_buf && c->role == c->stamp_role && pl.splitk <= 1 && !c->dry && !c->tuning && c->stamp_n < c->stamp_cap) {
+  if (c->stamp_buf && c->role == c->stamp_role && (pl.splitk <= 1 || combined) && !c->dry && !c->tuning && c->stamp_n < c->stamp_cap) {
     const GemmTile& t = IA2P_GEMM_TILES[pl.variant];
-    const int tiles = ((a.M + t.bm - 1) / t.bm) * ((a.N + t.bn - 1) / t.bn);
+    const int tiles = ((a.M + t.bm - 1) / t.bm) * ((a.N + t.bn - 1) / t.bn) * (pl.splitk > 1 ? pl.splitk : 1);      // (workgroups: a K split launches one per tile and slice)
     if (tiles <= RunCtx::STAMP_WG && !t.halo) {
-      a.partial = (float*)(c->stamp_buf + (size_t)c->stamp_n * RunCtx::STAMP_WG * 8);
-      c->stamp_meta.push_back({a.M, a.N, a.K, pl.variant, tiles});
+      unsigned long long* rec = c->stamp_buf + (size_t)c->stamp_n * RunCtx::STAMP_WG * 8;
+      if (pl.splitk > 1) a.stamp = rec;
+      else a.partial = (float*)rec;
+      c->stamp_meta.push_back({a.M, a.N, a.K, pl.splitk > 1 ? -100 * pl.splitk - pl.variant : pl.variant, tiles});
       ++c->stamp_n;
     }
   }
@@ -789,6 +791,13 @@ static void op_qkv_sattn(RunCtx* c, const half_t* A, int lda, const half_t* W, c
   a.rows_per_batch = 1;
   set_prefetch(c, a, W, (size_t)3 * C * C * sizeof(half_t));
   RoleScope role(c, ROLE_QKV_SATTN);
+#ifdef IA2P_CLOCK_STAMP
+  if (c->stamp_buf && c->role == c->stamp_role && !c->dry && !c->tuning && c->stamp_n < c->stamp_cap && x.B * x.heads <= RunCtx::STAMP_WG) {
+    a.partial = (float*)(c->stamp_buf + (size_t)c->stamp_n * RunCtx::STAMP_WG * 8);
+    c->stamp_meta.push_back({a.M, a.N, a.K, -4, x.B * x.heads});      // (variant -4: the fused QKV + self-attention tile)
+    ++c->stamp_n;
+  }
+#endif
   ProfScope ps(c, PK_QKVATTN, 2.0 * M * 3.0 * C * C + 4.0 * x.B * x.heads * (double)x.Nq * x.Nq * 64, 2.0 * ((double)M * C + 3.0 * C * C + (double)M * C));
   ps.pf = a.pf ? (double)a.pf_bytes : 0.0;
   CHECK_LAUNCH(c, ia2p_launch_qkv_sattn(a, x, c->stream), "qkv projection + self-attention");

@@ -165,6 +165,7 @@ __device__ __forceinline__ void tile_epilogue(f4 (&acc)[BM / WGM / 16][BN / WGN 
       }
     }
     __syncthreads();
+    IA2P_STAMP(if (tid == 0 && p.partial) ((unsigned long long*)p.partial)[8 * blockIdx.x + 7] = __builtin_amdgcn_s_memrealtime();)      // Q / K / V images in LDS
     const int r31 = lane & 31, hh = lane >> 5;
     h8 qf[4];
     {
@@ -175,7 +176,13 @@ __device__ __forceinline__ void tile_epilogue(f4 (&acc)[BM / WGM / 16][BN / WGN 
     const AttnArgs& ap = *xa;
     f16v otot[2];
     attn_core<0, true>(ap, tm, tn, qf, sK, sV, tid, otot);       // this wave's 32 queries over the image's 256 keys (no workgroup barrier inside: resident images)
+    IA2P_STAMP(if (tid == 0 && p.partial) ((unsigned long long*)p.partial)[8 * blockIdx.x + 6] = __builtin_amdgcn_s_memrealtime();)      // wave 0's attention core done
     attn_store_o(otot, ap.O, (size_t)ap.B * ap.Nq * ap.ldo, tm, wave * 32, tn, ap.Nq, ap.ldo, sQ + wave * 4096, lane, (ap.xcd_map & 2) != 0);
+    IA2P_STAMP(
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0 && p.partial) ((unsigned long long*)p.partial)[8 * blockIdx.x + 5] = __builtin_amdgcn_s_memrealtime();
+    )
     return;
   } else if constexpr (XA != 0) {
     // ---- fused to_q + cross-attention (reference attention_processor.py:344 `attn.to_q`, :371 / :387 the two SDPA calls, :397 `text + scale * ip`):
@@ -452,6 +459,7 @@ __device__ __forceinline__ void tile_epilogue(f4 (&acc)[BM / WGM / 16][BN / WGN 
     if (!p.sk_counters) { pf_sink(); return; }      // finished by a separate splitk_reduce_kernel launch (A/B switch)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // EVERY storing wave drains its write-through stores ...
     __syncthreads();                                       // ... before ONE lane signals for the workgroup
+    IA2P_STAMP(stamp_put(p, nsplit, 0);)                   // K-split launches: slot 0 = this slice's slab has drained (slots 5 / 6 stay 0 for a slice that is not the last arriver)
     if (tid == 0) *sk_flag = __hip_atomic_fetch_add(p.sk_counters + (tm * tiles_n + tn), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (*sk_flag != nsplit - 1) { pf_sink(); return; }

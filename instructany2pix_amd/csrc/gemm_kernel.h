@@ -632,8 +632,8 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   tc.hM = hM; tc.hN = hN; tc.hK = hK; tc.tm = tm; tc.tn = tn; tc.bm0 = bm0; tc.bn0 = bn0; tc.tiles_m = tiles_m; tc.tiles_n = tiles_n; tc.split = split; tc.nsplit = nsplit;
   tc.h_m0 = 0; tc.ln_s1 = ln_s1; tc.ln_s2 = ln_s2;
   IA2P_STAMP(
-    if (tid == 0 && p.partial && nsplit == 1) {      // (the stamps go to a buffer nothing else reads)
-      unsigned long long* o = (unsigned long long*)p.partial + 8 * blockIdx.x;
+    if (tid == 0 && stamp_base(p, nsplit)) {      // (the stamps go to a buffer nothing else reads)
+      unsigned long long* o = stamp_base(p, nsplit) + 8 * blockIdx.x;
       const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
       o[0] = __builtin_amdgcn_s_memtime() - stamp_c0; o[1] = r1 - stamp_r0; o[2] = stamp_entry; o[3] = stamp_r0; o[4] = r1;
     }

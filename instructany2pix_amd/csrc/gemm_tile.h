@@ -98,8 +98,12 @@ struct EpiCfg {
 #ifndef IA2P_STAMP_AT
 #define IA2P_STAMP_AT 0
 #endif
+__device__ __forceinline__ unsigned long long* stamp_base(const GemmArgs& p, int nsplit) {      // (a launch with a K split carries its records in p.stamp: p.partial holds the slabs)
+  return p.stamp ? p.stamp : (nsplit == 1 ? (unsigned long long*)p.partial : nullptr);
+}
 __device__ __forceinline__ void stamp_put(const GemmArgs& p, int nsplit, int slot) {
-  if (threadIdx.x == 0 && p.partial && nsplit == 1) ((unsigned long long*)p.partial)[8 * blockIdx.x + slot] = __builtin_amdgcn_s_memrealtime();
+  unsigned long long* b = stamp_base(p, nsplit);
+  if (threadIdx.x == 0 && b) b[8 * blockIdx.x + slot] = __builtin_amdgcn_s_memrealtime();
 }
 #else
 #define IA2P_STAMP(...)

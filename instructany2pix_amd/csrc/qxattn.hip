@@ -102,7 +102,10 @@ hipError_t ia2p_launch_qkv_sattn(const GemmArgs& a, const AttnArgs& x, hipStream
   }
   const int tiles_n = x.heads, tiles = x.B * tiles_n;
   GemmArgs b = a;
-  b.vec8 = 1; b.splitk = 0; b.sk_counters = nullptr; b.partial = nullptr;
+  b.vec8 = 1; b.splitk = 0; b.sk_counters = nullptr;
+#ifndef IA2P_CLOCK_STAMP
+  b.partial = nullptr;      // (diagnostic builds: the field carries the stamp buffer, tools/insitu_stamps.py)
+#endif
   b.m_fastest = 0;
   b.group_w = ia2p_tile_group_w(tiles, tiles_n, SMEM, 256, 192);
   AttnArgs y = x;

@@ -63,15 +63,62 @@ def breakdown(rec, tiles):
             "loop_end_to_last_store": med(issued - l1), "drain": med(left - issued), "wg_lifetime": med(left - entry), "exit_skew": float(left.max() - left.min())}
 
 
+def breakdown_fused(rec, tiles):
+    """the fused QKV + self-attention tile (variant -4): slot 7 = Q / K / V images in LDS, slot 6 = attention core done (wave 0), slot 5 = O stored and drained"""
+    r = rec[:tiles].double() * 0.01
+    r = r[rec[:tiles, 3] != 0]
+    if r.shape[0] == 0:
+        return None
+    entry, l0, l1, left, core, img = r[:, 2], r[:, 3], r[:, 4], r[:, 5], r[:, 6], r[:, 7]
+    med = lambda t: float(t.median())
+    return {"wgs": int(r.shape[0]), "span": float(left.max() - entry.min()), "entry_ramp": float(entry.max() - entry.min()), "entry_to_loop": med(l0 - entry), "k_loop": med(l1 - l0),
+            "loop_end_to_images": med(img - l1), "attention_core": med(core - img), "store_O": med(left - core), "wg_lifetime": med(left - entry), "exit_skew": float(left.max() - left.min())}
+
+
+def breakdown_split(rec, tiles):
+    """a launch with an in-launch K split (variant -(100 * split + v)): slot 0 = this slice's slab has drained (in front of the ticket); slots 6 / 5 are written by the LAST
+    arriver of a tile only (epilogue's last store issued / drained), 0 for the slices that leave behind the ticket"""
+    r = rec[:tiles].double() * 0.01
+    r = r[rec[:tiles, 3] != 0]
+    if r.shape[0] == 0:
+        return None
+    slab, entry, l0, l1, left, issued, first = r[:, 0], r[:, 2], r[:, 3], r[:, 4], r[:, 5], r[:, 6], r[:, 7]
+    last = left > 0
+    med = lambda t: float(t.median()) if t.numel() else float("nan")
+    end = torch.where(last, left, slab)
+    return {"wgs": int(r.shape[0]), "last_arrivers": int(last.sum()), "span": float(end.max() - entry.min()), "entry_ramp": float(entry.max() - entry.min()), "entry_to_loop": med(l0 - entry),
+            "loop_to_first_tile": med(first - l0) if float(first.min()) > 0 and float((l1 - first).min()) > 0 else float("nan"), "k_loop": med(l1 - l0), "k_loop_p90": float((l1 - l0).quantile(0.9)),
+            "loop_end_to_slab_drained": med(slab - l1), "last_arriver_ticket_to_last_store": med((issued - slab)[last]),
+            "last_arriver_ticket_to_tile_in_lds(fp32 route, STAMP_AT=1: slabs summed; register route, STAMP_AT=0: fp16 tile written)": med((first - slab)[last]) if last.any() and float((first - l1)[last].min()) > 0 else float("nan"), "last_arriver_drain": med((left - issued)[last]),
+            "lifetime_slice_that_leaves": med((slab - entry)[~last]), "lifetime_last_arriver": med((left - entry)[last]), "first_exit": float(end.min() - entry.min())}
+
+
 cols = ("wgs", "span", "entry_ramp", "entry_to_loop", "loop_to_first_tile", "first_tile_to_loop_end", "loop_end_to_last_store", "drain", "wg_lifetime", "exit_skew")
 print(f"# role {role}: {n} launches stamped inside one step (batch 8, 512 x 512, 81-token context); us; medians over the launch's workgroups unless noted")
 print("# span = first workgroup entry -> last workgroup's stores drained; entry_ramp = first -> last workgroup entry; exit_skew = first -> last workgroup exit")
 by_shape = {}
+fused = {}
+split = {}
 for i in range(min(n, SLOTS)):
     M, N, K, v, tiles = meta[5 * i:5 * i + 5]
+    if v == -4:
+        b = breakdown_fused(h[i], tiles)
+        if b:
+            fused.setdefault((M, N, K), []).append(b)
+        continue
+    if v <= -100:
+        b = breakdown_split(h[i], tiles)
+        if b:
+            split.setdefault((M, N, K, (-v) // 100, (-v) % 100), []).append(b)
+        continue
     b = breakdown(h[i], tiles)
     if b:
         by_shape.setdefault((M, N, K, v), []).append(b)
+for (M, N, K, sk, v), bs in sorted(split.items()):
+    print(f"K split {sk} in the launch (tile variant {v}), {M} x {N} x {K}, {len(bs)} launches in the step: " + ", ".join(f"{c} {statistics.median(b[c] for b in bs):.2f}" for c in bs[0]))
+for (M, N, K), bs in sorted(fused.items()):
+    fc = list(bs[0])
+    print(f"fused QKV projection + self-attention (256 x 192 tile per image and head), {M} x {N} x {K}, {len(bs)} launches in the step: " + ", ".join(f"{c} {statistics.median(b[c] for b in bs):.2f}" for c in fc))
 print(f"{'where':28s} {'M x N x K (variant)':28s} {'n':>4s} " + " ".join(f"{c:>22s}" for c in cols))
 for (M, N, K, v), bs in sorted(by_shape.items()):
     print(f"{'in the step':28s} {f'{M} x {N} x {K} ({v})':28s} {len(bs):4d} " + " ".join(f"{statistics.median(b[c] for b in bs):22.2f}" for c in cols))
