@@ -469,6 +469,7 @@ __device__ __forceinline__ void tile_epilogue(f4 (&acc)[BM / WGM / 16][BN / WGN 
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
+    IA2P_STAMP(if (IA2P_STAMP_AT == 5) stamp_put(p, nsplit, 7);)      // the last arriver is through its ticket and the acquire fence
     from_slabs = true;
   }
 #pragma unroll(PP == 2 ? 2 : 1)

@@ -89,7 +89,7 @@ def breakdown_split(rec, tiles):
     return {"wgs": int(r.shape[0]), "last_arrivers": int(last.sum()), "span": float(end.max() - entry.min()), "entry_ramp": float(entry.max() - entry.min()), "entry_to_loop": med(l0 - entry),
             "loop_to_first_tile": med(first - l0) if float(first.min()) > 0 and float((l1 - first).min()) > 0 else float("nan"), "k_loop": med(l1 - l0), "k_loop_p90": float((l1 - l0).quantile(0.9)),
             "loop_end_to_slab_drained": med(slab - l1), "last_arriver_ticket_to_last_store": med((issued - slab)[last]),
-            "last_arriver_ticket_to_tile_in_lds(fp32 route, STAMP_AT=1: slabs summed; register route, STAMP_AT=0: fp16 tile written)": med((first - slab)[last]) if last.any() and float((first - l1)[last].min()) > 0 else float("nan"), "last_arriver_drain": med((left - issued)[last]),
+            "last_arriver_slab_drained_to_slot7(STAMP_AT=1: slabs summed; STAMP_AT=5: through the ticket and the acquire fence)": med((first - slab)[last]) if last.any() and float((first - l1)[last].min()) > 0 else float("nan"), "last_arriver_drain": med((left - issued)[last]),
             "lifetime_slice_that_leaves": med((slab - entry)[~last]), "lifetime_last_arriver": med((left - entry)[last]), "first_exit": float(end.min() - entry.min())}
 
 
