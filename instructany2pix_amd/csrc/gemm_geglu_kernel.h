@@ -35,9 +35,11 @@ struct Geglu320 {
   static constexpr int STAGE = (BM + BN) * ROWB, RING = 2 * STAGE;           // 73 728 B per k-tile slot
   // epilogue: the OUTPUT tile (BM x 160 fp16: the GEGLU happens in registers), rows padded by 16 B; column constants; the normal-CDF table of the gate
   static constexpr int HN = BN / 2, P16 = HN * 2 + 16, T16_BYTES = BM * P16;
-  static constexpr int CONST_BYTES = 2 * BN * 4, LUT_BYTES = (IA2P_PHI_LUT_N * 8 + 15) & ~15, LNROW_BYTES = 2 * BM * 4;      // (row mean / rstd: behind the ring, written in the prologue)
-  static_assert(T16_BYTES + CONST_BYTES + LUT_BYTES <= RING, "the epilogue lives inside the ring");
-  static constexpr int SMEM = RING + LNROW_BYTES;
+  // behind the ring, written in the PROLOGUE (their global loads fly beside the first k-tile's DMA; fetched at the epilogue's start they cost every workgroup a cold
+  // round trip between its last MFMA and its first conversion): row mean / rstd, the column constants, the table
+  static constexpr int CONST_BYTES = 2 * BN * 4, LUT_BYTES = (IA2P_PHI_LUT_N * 8 + 15) & ~15, LNROW_BYTES = 2 * BM * 4;
+  static_assert(T16_BYTES <= RING, "the output tile lives inside the ring");
+  static constexpr int SMEM = RING + LNROW_BYTES + CONST_BYTES + LUT_BYTES;
   static_assert(SMEM <= 160 * 1024 && A_PW * NWAVE * RPP == BM && B_PW * NWAVE * RPP == BN, "LDS budget / staging split");
 };
 
@@ -94,6 +96,19 @@ __global__ __launch_bounds__(512, 2) void gemm_geglu_f16_kernel(const half_t* hA
   // folded LayerNorm (consumer): thread r < BM collects the {sum, sum of squares} partials of tile row r behind the prologue DMA, all slots in flight at once, and parks
   // the row's mean / rstd in the 2 KiB of LDS behind the ring (nothing is carried through the k-loop in registers)
   float* ln_rows = (float*)(smem + G::RING);                 // [0, BM): mean, [BM, 2 BM): rstd
+  float* ln_cs = ln_rows + 2 * BM;                           // BN column sums, BN folded biases
+  float* ln_lb = ln_cs + BN;
+  float2* phi = (float2*)(ln_lb + BN);                       // the normal-CDF table of the gate activation (gelu_lut_f)
+  {
+    f4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+    const bool ccol = p.ln_stats && tid < BN / 4;           // (whole tiles: every column is in range)
+    if (ccol) { c0 = *(const f4*)(p.ln_cs + bn0 + tid * 4); c1 = *(const f4*)(p.ln_bias + bn0 + tid * 4); }
+    const float2 t0 = ((const float2*)p.phi_lut)[tid], t1 = ((const float2*)p.phi_lut)[min(tid + NT, IA2P_PHI_LUT_N - 1)];
+    static_assert(IA2P_PHI_LUT_N > NT && IA2P_PHI_LUT_N <= 2 * NT, "table copy: two entries per thread");
+    if (ccol) { *(f4*)(ln_cs + tid * 4) = c0; *(f4*)(ln_lb + tid * 4) = c1; }
+    phi[tid] = t0;
+    if (tid + NT < IA2P_PHI_LUT_N) phi[tid + NT] = t1;
+  }
   if (p.ln_stats && tid < BM) {
     float ln_s1 = 0.f, ln_s2 = 0.f;
     const float2* st = (const float2*)p.ln_stats + (bm0 + tid);
@@ -270,17 +285,8 @@ __global__ __launch_bounds__(512, 2) void gemm_geglu_f16_kernel(const half_t* hA
   //      the bytes) crosses the LDS, once, to leave as whole 128-byte lines. (The first version sent the projected tile through the LDS in two 160-column halves, four waves
   //      converting while four waited: 11.0 us from the k-loop's end to the last store drained, tools/micro/geglu_clock.hip.)
   char* t16 = smem;                                          // output tile [BM][160] fp16, rows padded by 16 B
-  float* ln_cs = (float*)(smem + G::T16_BYTES);              // BN column sums, BN folded biases
-  float* ln_lb = ln_cs + BN;
-  float2* phi = (float2*)(ln_lb + BN);
   __syncthreads();                    // every wave has finished reading the stage buffers
-  if (p.ln_stats) {
-    if (tid < BN / 4 && bn0 + tid * 4 < hN) {
-      *(f4*)(ln_cs + tid * 4) = *(const f4*)(p.ln_cs + bn0 + tid * 4);
-      *(f4*)(ln_lb + tid * 4) = *(const f4*)(p.ln_bias + bn0 + tid * 4);
-    }
-  }
-  // this workgroup's slice of the NEXT contraction's weights (a workgroup owns its CU's LDS: no separate prefetch workgroups), issued behind the constant loads and
+  // this workgroup's slice of the NEXT contraction's weights (a workgroup owns its CU's LDS: no separate prefetch workgroups), issued here and
   // consumed at the kernel's end
   unsigned pfacc = 0, pfv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (p.pf) {
@@ -297,10 +303,9 @@ __global__ __launch_bounds__(512, 2) void gemm_geglu_f16_kernel(const half_t* hA
         for (int u = 0; u < 8; ++u) pfv[u] = *(const unsigned*)(src + min(o + u * SW, hi - 16));
       }
   }
-  for (int i = tid; i < IA2P_PHI_LUT_N; i += NT) phi[i] = ((const float2*)p.phi_lut)[i];
   const float e_as = p.acc_scale == 0.f ? 1.f : p.acc_scale, e_bs = p.bias_scale == 0.f ? 1.f : p.bias_scale;
   const __amdgpu_buffer_rsrc_t c_rsrc = wt_rsrc((void*)p.C, (size_t)hM * p.ldc * 2);
-  __syncthreads();                    // column constants and the table are in LDS (the row constants since the prologue)
+  // (row / column constants and the table have been in LDS since the prologue)
   auto geglu_regs = [&](auto ln_tag) {
     constexpr bool LN = decltype(ln_tag)::value;
     float mu[MR], rs[MR];
