@@ -824,6 +824,13 @@ static void op_qxattn(RunCtx* c, const half_t* A, int lda, const half_t* W, cons
   double keys = 0;
   for (int s = 0; s < x.nseg; ++s) keys += x.seg[s].nkeys;
   RoleScope role(c, ROLE_Q_XATTN);
+#ifdef IA2P_CLOCK_STAMP
+  if (c->stamp_buf && c->role == c->stamp_role && !c->dry && !c->tuning && c->stamp_n < c->stamp_cap && (M / 128) * (N / 64) <= RunCtx::STAMP_WG) {
+    a.partial = (float*)(c->stamp_buf + (size_t)c->stamp_n * RunCtx::STAMP_WG * 8);
+    c->stamp_meta.push_back({a.M, a.N, a.K, -5, (M / 128) * (N / 64)});      // (variant -5: the fused to_q + cross-attention tile, 128 x 64)
+    ++c->stamp_n;
+  }
+#endif
   ProfScope ps(c, PK_QXATTN, 2.0 * M * N * K + 4.0 * x.B * x.heads * (double)x.Nq * keys * 64,
                2.0 * ((double)M * K + (double)N * K + (double)M * N + 2.0 * x.B * keys * x.heads * 64));
   CHECK_LAUNCH(c, ia2p_launch_qproj_xattn(a, x, c->stream), "to_q + cross-attention");

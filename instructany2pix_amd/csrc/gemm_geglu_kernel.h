@@ -91,35 +91,46 @@ __global__ __launch_bounds__(512, 2) void gemm_geglu_f16_kernel(const half_t* hA
   const int a_off = (wm0 + frow) * ROWB, w_off = BM * ROWB + (wn0 + frow) * ROWB;
 
   const int nk = hK / 64;
+  // folded LayerNorm (consumer): thread r < BM collects the {sum, sum of squares} partials of tile row r. The loads go out AHEAD of the prologue DMA and are folded behind
+  // it (vmcnt retires in order: behind the DMA their wait would also be a wait for the whole first k-tile, and then for their own round trip on top; gemm_kernel.h)
+  constexpr int MAXS = 24;
+  float2 ln_v[MAXS];
+  const bool ln_wide = p.ln_stats && tid < BM && p.ln_slots <= MAXS;
+  if (ln_wide) {
+    const float2* st = (const float2*)p.ln_stats + (bm0 + tid);
+#pragma unroll
+    for (int u = 0; u < MAXS; ++u) ln_v[u] = st[(size_t)min(u, p.ln_slots - 1) * hM];
+  }
+  // ... and so do the loads of the column constants and of the gate table (into the LDS behind the ring)
+  f4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+  const bool ccol = p.ln_stats && tid < BN / 4;             // (whole tiles: every column is in range)
+  if (ccol) { c0 = *(const f4*)(p.ln_cs + bn0 + tid * 4); c1 = *(const f4*)(p.ln_bias + bn0 + tid * 4); }
+  const float2 t0 = ((const float2*)p.phi_lut)[tid], t1 = ((const float2*)p.phi_lut)[min(tid + NT, IA2P_PHI_LUT_N - 1)];
+  static_assert(IA2P_PHI_LUT_N > NT && IA2P_PHI_LUT_N <= 2 * NT, "table copy: two entries per thread");
+  __builtin_amdgcn_sched_barrier(0);
   issue_a(0, 0);            // k-tile 0, whole, into slot 0
   issue_w(0, 0);
-  // folded LayerNorm (consumer): thread r < BM collects the {sum, sum of squares} partials of tile row r behind the prologue DMA, all slots in flight at once, and parks
-  // the row's mean / rstd in the 2 KiB of LDS behind the ring (nothing is carried through the k-loop in registers)
+  __builtin_amdgcn_sched_barrier(0);
+  // the row's mean / rstd are parked in the 2 KiB of LDS behind the ring (nothing is carried through the k-loop in registers)
   float* ln_rows = (float*)(smem + G::RING);                 // [0, BM): mean, [BM, 2 BM): rstd
   float* ln_cs = ln_rows + 2 * BM;                           // BN column sums, BN folded biases
   float* ln_lb = ln_cs + BN;
   float2* phi = (float2*)(ln_lb + BN);                       // the normal-CDF table of the gate activation (gelu_lut_f)
-  {
-    f4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
-    const bool ccol = p.ln_stats && tid < BN / 4;           // (whole tiles: every column is in range)
-    if (ccol) { c0 = *(const f4*)(p.ln_cs + bn0 + tid * 4); c1 = *(const f4*)(p.ln_bias + bn0 + tid * 4); }
-    const float2 t0 = ((const float2*)p.phi_lut)[tid], t1 = ((const float2*)p.phi_lut)[min(tid + NT, IA2P_PHI_LUT_N - 1)];
-    static_assert(IA2P_PHI_LUT_N > NT && IA2P_PHI_LUT_N <= 2 * NT, "table copy: two entries per thread");
-    if (ccol) { *(f4*)(ln_cs + tid * 4) = c0; *(f4*)(ln_lb + tid * 4) = c1; }
-    phi[tid] = t0;
-    if (tid + NT < IA2P_PHI_LUT_N) phi[tid + NT] = t1;
-  }
+  if (ccol) { *(f4*)(ln_cs + tid * 4) = c0; *(f4*)(ln_lb + tid * 4) = c1; }
+  phi[tid] = t0;
+  if (tid + NT < IA2P_PHI_LUT_N) phi[tid + NT] = t1;
   if (p.ln_stats && tid < BM) {
     float ln_s1 = 0.f, ln_s2 = 0.f;
     const float2* st = (const float2*)p.ln_stats + (bm0 + tid);
-    constexpr int MAXS = 24;
-    if (p.ln_slots <= MAXS) {
-      float2 v[MAXS];
+    if (ln_wide) {
 #pragma unroll
-      for (int u = 0; u < MAXS; ++u) v[u] = st[(size_t)min(u, p.ln_slots - 1) * hM];
+      for (int u = 0; u < MAXS; u += 12)      // (opaque to the optimizer: the first addition must not be hoisted to right behind the loads, ahead of the DMA issue)
+        asm volatile("" : "+v"(ln_v[u].x), "+v"(ln_v[u].y), "+v"(ln_v[u + 1].x), "+v"(ln_v[u + 1].y), "+v"(ln_v[u + 2].x), "+v"(ln_v[u + 2].y), "+v"(ln_v[u + 3].x), "+v"(ln_v[u + 3].y),
+                          "+v"(ln_v[u + 4].x), "+v"(ln_v[u + 4].y), "+v"(ln_v[u + 5].x), "+v"(ln_v[u + 5].y), "+v"(ln_v[u + 6].x), "+v"(ln_v[u + 6].y), "+v"(ln_v[u + 7].x), "+v"(ln_v[u + 7].y),
+                          "+v"(ln_v[u + 8].x), "+v"(ln_v[u + 8].y), "+v"(ln_v[u + 9].x), "+v"(ln_v[u + 9].y), "+v"(ln_v[u + 10].x), "+v"(ln_v[u + 10].y), "+v"(ln_v[u + 11].x), "+v"(ln_v[u + 11].y));
 #pragma unroll
       for (int u = 0; u < MAXS; ++u)
-        if (u < p.ln_slots) { ln_s1 += v[u].x; ln_s2 += v[u].y; }
+        if (u < p.ln_slots) { ln_s1 += ln_v[u].x; ln_s2 += ln_v[u].y; }
     } else {
       for (int sl = 0; sl < p.ln_slots; ++sl) { const float2 v = st[(size_t)sl * hM]; ln_s1 += v.x; ln_s2 += v.y; }
     }

@@ -297,21 +297,39 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   //      Ping-pong tile: loaded AHEAD of the first tiles and folded at once (48 registers carried through the loop would spill, and a spill
   //      reload in the loop waits for vmcnt, i.e. drains the DMA queue); the prologue DMA stays in flight behind them.
   float ln_s1 = 0.f, ln_s2 = 0.f;
-  auto load_ln = [&]() {
-  if (p.ln_stats && tid < BM && bm0 + tid < hM) {
+  constexpr int LN_MAXS = 24;
+  float2 ln_v[LN_MAXS];
+#ifdef IA2P_TIMING_NOSTATS      // (timing experiments only: what the statistics' loads cost a workgroup's start; results are wrong)
+  const bool ln_row = false;
+#else
+  const bool ln_row = p.ln_stats && tid < BM && bm0 + tid < hM;
+#endif
+  const bool ln_wide = ln_row && p.ln_slots <= LN_MAXS;
+  // Round 6: the loads are ISSUED ahead of the prologue DMA and FOLDED behind it. vmcnt retires in order: issued behind the DMA (rounds 3-5), their wait was also a
+  // wait for every piece of the prologue and then for their own round trip on top -- in the step 1.4 us (to_q + cross-attention) to 1.9 us (QKV + self-attention) per
+  // workgroup start (timing build without the statistics: profiles/r06ad_nostats_timing.txt); issued first and waited for at once (round 2) the DMA started a round trip
+  // late. Now both fly together and the counted wait of the fold leaves the younger DMA pieces in flight.
+  if (ln_wide) {
     const float2* st = (const float2*)p.ln_stats + (bm0 + tid);
-    constexpr int MAXS = 24;
-    if (p.ln_slots <= MAXS) {
-      float2 v[MAXS];
 #pragma unroll
-      for (int u = 0; u < MAXS; ++u) v[u] = st[(size_t)min(u, p.ln_slots - 1) * hM];
+    for (int u = 0; u < LN_MAXS; ++u) ln_v[u] = st[(size_t)min(u, p.ln_slots - 1) * hM];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  auto fold_ln = [&]() {
+    if (ln_wide) {
+      // (opaque to the optimizer: without it the first addition -- and with it a full round trip's wait -- is hoisted to right behind the loads, ahead of the DMA issue)
 #pragma unroll
-      for (int u = 0; u < MAXS; ++u)
-        if (u < p.ln_slots) { ln_s1 += v[u].x; ln_s2 += v[u].y; }
-    } else {
+      for (int u = 0; u < LN_MAXS; u += 12)
+        asm volatile("" : "+v"(ln_v[u].x), "+v"(ln_v[u].y), "+v"(ln_v[u + 1].x), "+v"(ln_v[u + 1].y), "+v"(ln_v[u + 2].x), "+v"(ln_v[u + 2].y), "+v"(ln_v[u + 3].x), "+v"(ln_v[u + 3].y),
+                          "+v"(ln_v[u + 4].x), "+v"(ln_v[u + 4].y), "+v"(ln_v[u + 5].x), "+v"(ln_v[u + 5].y), "+v"(ln_v[u + 6].x), "+v"(ln_v[u + 6].y), "+v"(ln_v[u + 7].x), "+v"(ln_v[u + 7].y),
+                          "+v"(ln_v[u + 8].x), "+v"(ln_v[u + 8].y), "+v"(ln_v[u + 9].x), "+v"(ln_v[u + 9].y), "+v"(ln_v[u + 10].x), "+v"(ln_v[u + 10].y), "+v"(ln_v[u + 11].x), "+v"(ln_v[u + 11].y));
+#pragma unroll
+      for (int u = 0; u < LN_MAXS; ++u)
+        if (u < p.ln_slots) { ln_s1 += ln_v[u].x; ln_s2 += ln_v[u].y; }
+    } else if (ln_row) {
+      const float2* st = (const float2*)p.ln_stats + (bm0 + tid);
       for (int sl = 0; sl < p.ln_slots; ++sl) { const float2 v = st[(size_t)sl * hM]; ln_s1 += v.x; ln_s2 += v.y; }
     }
-  }
   };
   const int nk = kt1 - kt0;
   constexpr int LPS = A_PW + B_PW;   // LDS-DMA pieces this wave issues per k-tile
@@ -326,8 +344,9 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
     for (int s = 0; s < NSTAGE - 1; ++s)
       if (s < nk) stage(s, s);
   }
-  load_ln();               // behind the prologue DMA: the statistics' round trip overlaps the first tiles' (the ping-pong tile used to load them AHEAD of
-  if (PP) asm volatile("" : "+v"(ln_s1), "+v"(ln_s2));      //  its prologue -- a serial 1-2 us at every workgroup start; folded here, before the loop, they still cost it no registers)
+  __builtin_amdgcn_sched_barrier(0);
+  fold_ln();               // (folded here, before the loop: 48 registers carried through it would spill)
+  if (PP) asm volatile("" : "+v"(ln_s1), "+v"(ln_s2));
   // fused cross-attention: the context K / V of this tile's (batch element, head) travel to registers while the projection runs
   AttnKvRegs kvr;       // loaded inside the k-loop, behind the first tile     // folds now; the counted wait leaves the prologue DMA in flight
   IA2P_STAMP(const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();)      // (tools/micro/gemm_clock.hip: in-kernel clock = d(s_memtime) / d(s_memrealtime) x 100 MHz around the k-loop)

@@ -75,6 +75,19 @@ def breakdown_fused(rec, tiles):
             "loop_end_to_images": med(img - l1), "attention_core": med(core - img), "store_O": med(left - core), "wg_lifetime": med(left - entry), "exit_skew": float(left.max() - left.min())}
 
 
+def breakdown_xattn(rec, tiles):
+    """the fused to_q + cross-attention tile (variant -5): slot 6 = Q fragments built, K / V images in LDS, slot 7 = attention core done, slot 5 = O stored and drained"""
+    r = rec[:tiles].double() * 0.01
+    r = r[rec[:tiles, 3] != 0]
+    if r.shape[0] == 0:
+        return None
+    entry, l0, l1, left, img, core = r[:, 2], r[:, 3], r[:, 4], r[:, 5], r[:, 6], r[:, 7]
+    med = lambda t: float(t.median())
+    return {"wgs": int(r.shape[0]), "span": float(left.max() - entry.min()), "entry_ramp": float(entry.max() - entry.min()), "entry_to_loop": med(l0 - entry), "k_loop": med(l1 - l0),
+            "k_loop_p90": float((l1 - l0).quantile(0.9)), "loop_end_to_q_and_kv_images": med(img - l1), "attention_core": med(core - img), "store_O": med(left - core),
+            "wg_lifetime": med(left - entry), "wg_lifetime_p90": float((left - entry).quantile(0.9)), "exit_skew": float(left.max() - left.min())}
+
+
 def breakdown_split(rec, tiles):
     """a launch with an in-launch K split (variant -(100 * split + v)): slot 0 = this slice's slab has drained (in front of the ticket); slots 6 / 5 are written by the LAST
     arriver of a tile only (epilogue's last store issued / drained), 0 for the slices that leave behind the ticket"""
@@ -99,12 +112,18 @@ print("# span = first workgroup entry -> last workgroup's stores drained; entry_
 by_shape = {}
 fused = {}
 split = {}
+xat = {}
 for i in range(min(n, SLOTS)):
     M, N, K, v, tiles = meta[5 * i:5 * i + 5]
     if v == -4:
         b = breakdown_fused(h[i], tiles)
         if b:
             fused.setdefault((M, N, K), []).append(b)
+        continue
+    if v == -5:
+        b = breakdown_xattn(h[i], tiles)
+        if b:
+            xat.setdefault((M, N, K), []).append(b)
         continue
     if v <= -100:
         b = breakdown_split(h[i], tiles)
@@ -114,6 +133,8 @@ for i in range(min(n, SLOTS)):
     b = breakdown(h[i], tiles)
     if b:
         by_shape.setdefault((M, N, K, v), []).append(b)
+for (M, N, K), bs in sorted(xat.items()):
+    print(f"fused to_q + cross-attention (128 x 64 tile), {M} x {N} x {K}, {len(bs)} launches in the step: " + ", ".join(f"{c} {statistics.median(b[c] for b in bs):.2f}" for c in bs[0]))
 for (M, N, K, sk, v), bs in sorted(split.items()):
     print(f"K split {sk} in the launch (tile variant {v}), {M} x {N} x {K}, {len(bs)} launches in the step: " + ", ".join(f"{c} {statistics.median(b[c] for b in bs):.2f}" for c in bs[0]))
 for (M, N, K), bs in sorted(fused.items()):
