@@ -15,7 +15,7 @@
 // into the Q fragments of the attention core (attention_core.h, MODE = XA - 1) and writes the cross-attention output instead.
 template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int BK = 64, int PP = 0, int WGN = 2, int XA = 0>
 __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* hW, const half_t* hzero, int hM, int hN, int hK, int hlda, int hldw, int hrpb, int hbstride,
-                                               int hroff, int hsplitk, int hgroup_w, const GemmArgs& p, const AttnArgs* xa) {
+                                               int hroff, int hsplitk, int hgroup_w, const GemmArgs& p, const AttnArgs* xa, const float* pre_ln_stats = nullptr, int pre_ln_slots = 0) {
   // The leading 16 dwords of the argument list are what the prologue needs; built with -amdgpu-kernarg-preload-count=16 the command processor
   // hands them over in SGPRs, so the first tile loads go out without waiting for a cold read of the argument block (which costs every launch
   // ~1 us: tools/micro/launch_floor2.hip). The rest of GemmArgs (epilogue, conv geometry) arrives while those loads fly.   // >= 2 waves/SIMD: big tiles must fit 256 registers
@@ -299,20 +299,23 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   float ln_s1 = 0.f, ln_s2 = 0.f;
   constexpr int LN_MAXS = 24;
   float2 ln_v[LN_MAXS];
+  // (fused attention tiles: pointer and slot count from the preloaded arguments of their kernels, qxattn.hip -- the same values as in `p`, without the argument block's round trip)
+  const float* const ln_stats_p = XA != 0 ? pre_ln_stats : p.ln_stats;
+  const int ln_nslots = XA != 0 ? pre_ln_slots : p.ln_slots;
 #ifdef IA2P_TIMING_NOSTATS      // (timing experiments only: what the statistics' loads cost a workgroup's start; results are wrong)
   const bool ln_row = false;
 #else
-  const bool ln_row = p.ln_stats && tid < BM && bm0 + tid < hM;
+  const bool ln_row = ln_stats_p && tid < BM && bm0 + tid < hM;
 #endif
-  const bool ln_wide = ln_row && p.ln_slots <= LN_MAXS;
+  const bool ln_wide = ln_row && ln_nslots <= LN_MAXS;
   // Round 6: the loads are ISSUED ahead of the prologue DMA and FOLDED behind it. vmcnt retires in order: issued behind the DMA (rounds 3-5), their wait was also a
   // wait for every piece of the prologue and then for their own round trip on top -- in the step 1.4 us (to_q + cross-attention) to 1.9 us (QKV + self-attention) per
   // workgroup start (timing build without the statistics: profiles/r06ad_nostats_timing.txt); issued first and waited for at once (round 2) the DMA started a round trip
   // late. Now both fly together and the counted wait of the fold leaves the younger DMA pieces in flight.
   if (ln_wide) {
-    const float2* st = (const float2*)p.ln_stats + (bm0 + tid);
+    const float2* st = (const float2*)ln_stats_p + (bm0 + tid);
 #pragma unroll
-    for (int u = 0; u < LN_MAXS; ++u) ln_v[u] = st[(size_t)min(u, p.ln_slots - 1) * hM];
+    for (int u = 0; u < LN_MAXS; ++u) ln_v[u] = st[(size_t)min(u, ln_nslots - 1) * hM];
   }
   __builtin_amdgcn_sched_barrier(0);
   auto fold_ln = [&]() {
@@ -325,10 +328,10 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
                           "+v"(ln_v[u + 8].x), "+v"(ln_v[u + 8].y), "+v"(ln_v[u + 9].x), "+v"(ln_v[u + 9].y), "+v"(ln_v[u + 10].x), "+v"(ln_v[u + 10].y), "+v"(ln_v[u + 11].x), "+v"(ln_v[u + 11].y));
 #pragma unroll
       for (int u = 0; u < LN_MAXS; ++u)
-        if (u < p.ln_slots) { ln_s1 += ln_v[u].x; ln_s2 += ln_v[u].y; }
+        if (u < ln_nslots) { ln_s1 += ln_v[u].x; ln_s2 += ln_v[u].y; }
     } else if (ln_row) {
-      const float2* st = (const float2*)p.ln_stats + (bm0 + tid);
-      for (int sl = 0; sl < p.ln_slots; ++sl) { const float2 v = st[(size_t)sl * hM]; ln_s1 += v.x; ln_s2 += v.y; }
+      const float2* st = (const float2*)ln_stats_p + (bm0 + tid);
+      for (int sl = 0; sl < ln_nslots; ++sl) { const float2 v = st[(size_t)sl * hM]; ln_s1 += v.x; ln_s2 += v.y; }
     }
   };
   const int nk = kt1 - kt0;

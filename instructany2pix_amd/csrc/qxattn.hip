@@ -15,16 +15,18 @@
 #define IA2P_QX_STAGES 2      // LDS ring depth of the projection loop (build-time knob for A/B builds)
 #endif
 template <int MODE>      // attention core mode: 0 one key segment; 1 text + <= 64 image-token keys; 2 generic two segments
-__global__ __launch_bounds__(256, 2) void qproj_xattn_kernel(const half_t* hA, const half_t* hW, const half_t* hzero, int hM, int hN, int hK, int hlda, int hldw, int hrpb,
-                                                             int hbstride, int hroff, int hsplitk, int hgroup_w, const GemmArgs p, const AttnArgs xa) {
-  gemm_tile_body<128, 64, IA2P_QX_STAGES, false, 2, 64, 0, 2, MODE + 1>(hA, hW, hzero, hM, hN, hK, hlda, hldw, hrpb, hbstride, hroff, hsplitk, hgroup_w, p, &xa);
+// (the fused tiles take no row map and no K split: the four preloaded argument dwords those would use carry the folded LayerNorm's statistics pointer and slot count --
+//  read from `p`, a cold scalar load of the argument block stood between the workgroup's entry and its statistics loads; gemm_geglu_kernel.h)
+__global__ __launch_bounds__(256, 2) void qproj_xattn_kernel(const half_t* hA, const half_t* hW, const half_t* hzero, int hM, int hN, int hK, int hlda, int hldw,
+                                                             const float* h_ln_stats, int h_ln_slots, int hgroup_w, const GemmArgs p, const AttnArgs xa) {
+  gemm_tile_body<128, 64, IA2P_QX_STAGES, false, 2, 64, 0, 2, MODE + 1>(hA, hW, hzero, hM, hN, hK, hlda, hldw, 0, 0, 0, 0, hgroup_w, p, &xa, h_ln_stats, h_ln_slots);
 }
 
 // Q = epilogue(A . W^T) is [B * Nq, heads * 64]; x.Q / x.ldq are ignored (Q stays on chip). Requires Nq % 128 == 0 (a tile must not straddle
 // two batch elements), N = heads * 64, no K-split, no GEGLU / residual / row vector / statistics output; the context must fit
 // ATTN_PRE_TILES key tiles of 64 (77 text + 4 image tokens: 2 + 1).
 bool ia2p_qproj_xattn_ok(const GemmArgs& a, const AttnArgs& x) {
-  return x.Nq > 0 && x.Nq % 128 == 0 && a.M == x.B * x.Nq && a.N == x.heads * 64 && a.K >= 64 && a.K % 64 == 0 && a.splitk <= 1 && !a.geglu && !a.residual && !a.rowvec &&
+  return x.Nq > 0 && x.Nq % 128 == 0 && a.M == x.B * x.Nq && a.N == x.heads * 64 && a.K >= 64 && a.K % 64 == 0 && a.splitk <= 1 && !a.rpb && !a.geglu && !a.residual && !a.rowvec &&
          !a.stats_out && !a.act && x.nseg >= 1 && x.nseg <= 2 && x.seg[0].nkeys > 0 && (x.nseg == 1 || x.seg[1].nkeys > 0) &&
          (!a.bias || ((((uintptr_t)a.bias) & 15) == 0 && a.N % 8 == 0)) && x.ldo % 8 == 0 && ((((uintptr_t)x.O) & 15) == 0) &&
          ia2p_fits_buffer(a.rpb ? ((size_t)a.M / a.rpb + 1) * (size_t)(a.bstride > 0 ? a.bstride : 0) + a.roff + a.rpb : (size_t)a.M, a.lda) && ia2p_fits_buffer(a.N, a.ldw) &&
@@ -57,8 +59,8 @@ hipError_t ia2p_launch_qproj_xattn(const GemmArgs& a, const AttnArgs& x, hipStre
   const int extra = (a.pf && a.pf_bytes >= 4096) ? a.pf_blocks : 0;
   const int mode = y.nseg == 1 ? 0 : (y.seg[1].nkeys <= 64 && y.seg[0].weight != 0.f) ? 1 : 2;     // as ia2p_launch_attention
 #define IA2P_QX_LAUNCH(MODE)                                                                                                                   \
-  hipLaunchKernelGGL(qproj_xattn_kernel<MODE>, dim3(tiles + extra), dim3(256), SMEM, s, b.A, b.W, b.zero, b.M, b.N, b.K, b.lda, b.ldw, b.rpb, \
-                     b.bstride, b.roff, b.splitk, b.group_w, b, y)
+  hipLaunchKernelGGL(qproj_xattn_kernel<MODE>, dim3(tiles + extra), dim3(256), SMEM, s, b.A, b.W, b.zero, b.M, b.N, b.K, b.lda, b.ldw, b.ln_stats, \
+                     b.ln_slots, b.group_w, b, y)
   if (mode == 0) IA2P_QX_LAUNCH(0);
   else if (mode == 1) IA2P_QX_LAUNCH(1);
   else IA2P_QX_LAUNCH(2);
@@ -73,12 +75,12 @@ hipError_t ia2p_launch_qproj_xattn(const GemmArgs& a, const AttnArgs& x, hipStre
 // ONE head = everything that head's attention needs. The tile body (gemm_kernel.h, XA = 4) turns its accumulators into the K / V images and Q fragments of the
 // attention core and writes only O: no QKV tensor (15.7 MB per layer at batch 8), no second launch. Same arithmetic in the same order as the stand-alone
 // pair: bit-identical to `ia2p_gemm_ex` + `ia2p_attention` (tests/test_ops_gpu.py).
-__global__ __launch_bounds__(512, 2) void qkv_sattn_kernel(const half_t* hA, const half_t* hW, const half_t* hzero, int hM, int hN, int hK, int hlda, int hldw, int hrpb,
-                                                           int hbstride, int hroff, int hsplitk, int hgroup_w, const GemmArgs p, const AttnArgs xa) {
+__global__ __launch_bounds__(512, 2) void qkv_sattn_kernel(const half_t* hA, const half_t* hW, const half_t* hzero, int hM, int hN, int hK, int hlda, int hldw,
+                                                           const float* h_ln_stats, int h_ln_slots, int hgroup_w, const GemmArgs p, const AttnArgs xa) {
 #ifndef IA2P_SATTN_PP
 #define IA2P_SATTN_PP 3      // k-loop schedule of the fused QKV + self-attention tile: 3 = two-slot ping-pong, 0 = plain loop (one barrier per k-step); A/B builds
 #endif
-  gemm_tile_body<256, 192, 2, false, 4, 64, IA2P_SATTN_PP, 2, 4>(hA, hW, hzero, hM, hN, hK, hlda, hldw, hrpb, hbstride, hroff, hsplitk, hgroup_w, p, &xa);
+  gemm_tile_body<256, 192, 2, false, 4, 64, IA2P_SATTN_PP, 2, 4>(hA, hW, hzero, hM, hN, hK, hlda, hldw, 0, 0, 0, 0, hgroup_w, p, &xa, h_ln_stats, h_ln_slots);
 }
 
 // A [B * 256, K] (un-normalised rows with a.ln_*, or plain), W the stacked [3 * heads * 64, K] projection; x: O / ldo / B / heads / Nq = 256.
@@ -112,7 +114,7 @@ hipError_t ia2p_launch_qkv_sattn(const GemmArgs& a, const AttnArgs& x, hipStream
   y.seg[0].nkeys = 256; y.seg[0].weight = 1.f; y.nseg = 1;
   y.xcd_map = ((ia2p_wt_mask() & 8) && (size_t)x.B * x.Nq * x.ldo * 2 < (size_t)0x7ffffff0) ? 2 : 0;      // bit 1: write-through O
   const int extra = (a.pf && a.pf_bytes >= 4096) ? a.pf_blocks : 0;
-  hipLaunchKernelGGL(qkv_sattn_kernel, dim3(tiles + extra), dim3(512), SMEM, s, b.A, b.W, b.zero, b.M, b.N, b.K, b.lda, b.ldw, b.rpb, b.bstride, b.roff, b.splitk,
+  hipLaunchKernelGGL(qkv_sattn_kernel, dim3(tiles + extra), dim3(512), SMEM, s, b.A, b.W, b.zero, b.M, b.N, b.K, b.lda, b.ldw, b.ln_stats, b.ln_slots,
                      b.group_w, b, y);
   return hipGetLastError();
 }
