@@ -16,7 +16,8 @@ SOURCES = ["gemm.hip", "qxattn.hip", "attention.hip", "norm.hip", "misc.hip", "e
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result"] + os.environ.get("IA2P_EXTRA_FLAGS", "").split()    # (A/B builds of compile-time knobs)
 # attention: MFMA results feed VALU softmax directly; the VGPR form avoids ~250 v_accvgpr_read/write per key tile
-# kernarg preload: the first 16 dwords of a kernel's (scalar) arguments arrive in SGPRs instead of through a cold read of the argument block
+# kernarg preload: the leading dwords of a kernel's (scalar) arguments arrive in SGPRs instead of through a cold read of the argument block -- FOURTEEN of them
+# (16 user SGPRs less the argument block's address: `.amdhsa_user_sgpr_kernarg_preload_length 14` whatever count is asked for; the kernels' leading arguments are packed to fit)
 PRELOAD = ["-mllvm", "-amdgpu-kernarg-preload-count=16"]
 FILE_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"] + PRELOAD, "qxattn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"] + PRELOAD, "gemm.hip": PRELOAD, "norm.hip": PRELOAD}
 

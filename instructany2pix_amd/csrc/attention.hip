@@ -20,7 +20,7 @@ template <int MODE>      // 0: one key segment; 1: two segments, the second <= 6
 __global__ __launch_bounds__(256, 2) void attention_f16_kernel(const half_t* aQ, half_t* aO, int aldq, int aldo, int aB, int aheads, int aNq, int anseg, float ascale,
                                                             int axcd, const half_t* aK0, const half_t* aV0, int an0, int ald0, int arpb0, float aw0,
                                                             const half_t* aK1, const half_t* aV1, int an1, int ald1, int arpb1, float aw1, const float* aw1b) {
-  // scalar arguments (the first 16 dwords are preloaded into SGPRs: build.py PRELOAD), re-assembled into the descriptor the body uses
+  // scalar arguments (the first 14 dwords are preloaded into SGPRs: build.py PRELOAD), re-assembled into the descriptor the body uses
   AttnArgs p;
   p.Q = aQ; p.O = aO; p.ldq = aldq; p.ldo = aldo; p.B = aB; p.heads = aheads; p.Nq = aNq; p.nseg = anseg; p.scale_log2e = ascale; p.xcd_map = axcd;
   p.seg[0].K = aK0; p.seg[0].V = aV0; p.seg[0].nkeys = an0; p.seg[0].ld = ald0; p.seg[0].rows_per_batch = arpb0; p.seg[0].weight = aw0;

@@ -48,7 +48,8 @@ constexpr GnOp GN_OPS[GN_NOPS] = {{0, 0}, {0, 1}, {0, 2}, {1, 0}, {0, 3}, {1, 1}
                                   {1, 4}, {2, 3}, {3, 2}, {0, 7}, {1, 5}, {2, 4}, {3, 3}, {1, 6}, {2, 5}, {3, 4}, {1, 7}, {2, 6}, {3, 5}, {2, 7}, {3, 6}, {3, 7}};
 
 template <int BN, int GN>
-__device__ __forceinline__ void conv_halo_tile_body(const half_t* hA, const half_t* hW, int hM, int hN, int hK, int hlda, int hldw, int hsplitk, int hgroup_w, const GemmArgs& p) {
+__device__ __forceinline__ void conv_halo_tile_body(const half_t* hA, const half_t* hW, int hM, int hN, int hK, int hlda, int hldw, int hsplitk, int hgroup_w, int gHo, int gWo, int gHs, int gWs,
+                                                    int gUp, int gCin, int gCin2, const GemmArgs& p) {
   constexpr int BM = 256, BK = 64, NSTAGE = 3, PP = 1, WGM = HaloWaves<BN>::WGM, WGN = HaloWaves<BN>::WGN;
   constexpr int NWAVE = WGM * WGN;
   static_assert(NWAVE == 8, "ping-pong schedule: 8 waves (two groups of 4 by tile rows)");
@@ -83,12 +84,12 @@ __device__ __forceinline__ void conv_halo_tile_body(const half_t* hA, const half
   int tm, tn;
   tile_order(bid, tiles_m, tiles_n, hgroup_w, p.m_fastest, tm, tn);
   const int bm0 = tm * BM, bn0 = tn * BN;
-  const int tpr = p.Wo >> 4, tpi = (p.Ho >> 4) * tpr;
+  const int tpr = gWo >> 4, tpi = (gHo >> 4) * tpr;
   const int h_img = tm / tpi;
   const int h_rem = tm - h_img * tpi, h_ty = h_rem / tpr;
   const int h_y0 = h_ty * 16, h_x0 = (h_rem - h_ty * tpr) * 16;
-  const int h_m0 = (h_img * p.Ho + h_y0) * p.Wo + h_x0;
-  auto row_m = [&](int r) { return h_m0 + (r >> 4) * p.Wo + (r & 15); };
+  const int h_m0 = (h_img * gHo + h_y0) * gWo + h_x0;
+  auto row_m = [&](int r) { return h_m0 + (r >> 4) * gWo + (r & 15); };
 
   // ---- staging addresses. Halo image: DMA piece (slot * NWAVE + wave), lane -> 16-byte chunk j = piece * 64 + lane = (halo pixel j / 9, chunk j % 9);
   //      h_voff = byte offset of that chunk inside the source tensor (channel block 0), or OOB: pad chunk / outside the image / past the image's last pixel
@@ -102,10 +103,10 @@ __device__ __forceinline__ void conv_halo_tile_body(const half_t* hA, const half
     const int hp = j / 9, c = j - hp * 9;
     const int hy = hp / 18, hx = hp - hy * 18;
     const int y = h_y0 - 1 + hy, x = h_x0 - 1 + hx;
-    const bool ok = c < 8 && hp < 18 * 18 && (unsigned)y < (unsigned)p.Ho && (unsigned)x < (unsigned)p.Wo;
+    const bool ok = c < 8 && hp < 18 * 18 && (unsigned)y < (unsigned)gHo && (unsigned)x < (unsigned)gWo;
     // (nearest-x2 upsampled view: the image in LDS IS the upsampled patch -- pixel (y, x) of it comes from source pixel (y / 2, x / 2), fetched up to four times out of L2)
-    h_voff[sl] = ok ? (((h_img * p.Hs + (y >> p.up)) * p.Ws + (x >> p.up)) * hlda + c * 8) * 2 : OOB;
-    if constexpr (GN != 0) h_voff2[sl] = ok ? (((h_img * p.Hs + y) * p.Ws + x) * p.lda1b + c * 8) * 2 : OOB;      // (second source of a GroupNorm-fused launch: its own row stride; no upsampled view there)
+    h_voff[sl] = ok ? (((h_img * gHs + (y >> gUp)) * gWs + (x >> gUp)) * hlda + c * 8) * 2 : OOB;
+    if constexpr (GN != 0) h_voff2[sl] = ok ? (((h_img * gHs + y) * gWs + x) * p.lda1b + c * 8) * 2 : OOB;      // (second source of a GroupNorm-fused launch: its own row stride; no upsampled view there)
   }
   // this wave's weight pieces: [b_pi0, b_pi0 + b_npw); piece `pi` covers tile columns pi*8 .. pi*8+7: lane -> (row pi*8 + lane/8, LDS chunk lane%8 holding global chunk (lane%8) ^ swz(row))
   int w_voff[B_PW];
@@ -122,7 +123,7 @@ __device__ __forceinline__ void conv_halo_tile_body(const half_t* hA, const half
 
   const int nk_all = hK / BK;
   const int kt0 = (int)((long)split * nk_all / nsplit), kt1 = (int)((long)(split + 1) * nk_all / nsplit);   // this workgroup's k-tiles
-  int cin_main = p.Cin, cin_extra = p.Cin2;                 // (two named scalars: a select between two argument FIELDS became a 2-entry table in scratch)
+  int cin_main = gCin, cin_extra = gCin2;                 // (two named scalars: a select between two argument FIELDS became a 2-entry table in scratch)
   asm volatile("" : "+s"(cin_main), "+s"(cin_extra));
 
   // ---- fragment read offsets (wave tile origin is a multiple of 16, so swz(row) = (lane>>1)&7)
@@ -159,7 +160,7 @@ __device__ __forceinline__ void conv_halo_tile_body(const half_t* hA, const half
   const int blk0 = k0 < nk_main ? k0 / 9 : nb_main, blk1 = min(k1, nk_main) / 9 > blk0 ? min(k1, nk_main) / 9 : blk0;      // its blocks of the 3x3 part
   const int n2 = nkt - 9 * (blk1 - blk0);                                                                               // its tiles of the appended 1x1 blocks
   auto mk_rsrc = [](const void* q, size_t bytes) { return __builtin_amdgcn_make_buffer_rsrc((void*)q, 0, (int)min(bytes, (size_t)0x7ffffe00), 0x00020000); };
-  const __amdgpu_buffer_rsrc_t rs_w = mk_rsrc(hW, (size_t)hN * hldw * 2), rs_a = mk_rsrc(hA, (size_t)(hM / (p.Ho * p.Wo)) * p.Hs * p.Ws * hlda * 2), rs_none = mk_rsrc(hW, 0);
+  const __amdgpu_buffer_rsrc_t rs_w = mk_rsrc(hW, (size_t)hN * hldw * 2), rs_a = mk_rsrc(hA, (size_t)(hM / (gHo * gWo)) * gHs * gWs * hlda * 2), rs_none = mk_rsrc(hW, 0);
   // GroupNorm-fused launch: channel blocks [0, nb0) come from A, [nb0, nb_main) from A1b (one source: nb0 = nb_main)
   const int nb0 = GN ? p.gn.C0 / BK : nb_main;
   const __amdgpu_buffer_rsrc_t rs_a1b = GN ? mk_rsrc(p.A1b, p.A1b ? (size_t)(hM / (p.Ho * p.Wo)) * p.Hs * p.Ws * p.lda1b * 2 : 0) : rs_none;
@@ -503,10 +504,12 @@ __device__ __forceinline__ void conv_halo_tile_body(const half_t* hA, const half
 }
 
 template <int BN, int GN = 0>
-__global__ __launch_bounds__(512, 2) void conv_halo_f16_kernel(const half_t* hA, const half_t* hW, const half_t* hzero, int hM, int hN, int hK, int hlda, int hldw, int hrpb, int hbstride,
-                                                                 int hroff, int hsplitk, int hgroup_w, const GemmArgs p) {
-  (void)hzero; (void)hrpb; (void)hbstride; (void)hroff;      // (same leading scalars as gemm_f16_kernel: kernarg preload)
-  conv_halo_tile_body<BN, GN>(hA, hW, hM, hN, hK, hlda, hldw, hsplitk, hgroup_w, p);
+// (leading arguments: 14 preloaded dwords, gemm_kernel.h -- operands, shape, strides, {K split, tile order} and the image geometry the first DMA piece is addressed with:
+//  {Ho, Wo} and {Hs, Ws} in 16 bits each, {upsampled view, Cin}, Cin2)
+__global__ __launch_bounds__(512, 2) void conv_halo_f16_kernel(const half_t* hA, const half_t* hW, int hM, int hN, int hK, int hlda, int hldw, int hsk_gw, int hHoWo, int hHsWs, int hUpCin,
+                                                                 int hCin2, const GemmArgs p) {
+  conv_halo_tile_body<BN, GN>(hA, hW, hM, hN, hK, hlda, hldw, hsk_gw & 0xff, (int)((unsigned)hsk_gw >> 8), hHoWo & 0xffff, (int)((unsigned)hHoWo >> 16), hHsWs & 0xffff,
+                              (int)((unsigned)hHsWs >> 16), hUpCin & 3, (int)((unsigned)hUpCin >> 2), hCin2, p);
 }
 
 template <int BN, int GN>
@@ -525,8 +528,11 @@ static hipError_t launch_halo_gn(const GemmArgs& a, hipStream_t s) {
   ia2p_gemm_prepare(b, smem, 256, BN, true);
   if (b.gn_out && !b.vec8) return hipErrorInvalidValue;      // (the column sums of the output are taken on the 16-byte epilogue routes)
   if (b.sk_counters && tiles > ia2p_sk_counter_capacity()) return hipErrorInvalidValue;
+  int sk_gw, howo, hsws;
+  if (!ia2p_pack_skgw(b.splitk, b.group_w, &sk_gw) || !ia2p_pack_rowmap(b.Ho, b.Wo, &howo) || !ia2p_pack_rowmap(b.Hs, b.Ws, &hsws) || b.up < 0 || b.up > 3 || b.Cin < 0 || b.Cin >= (1 << 29))
+    return hipErrorInvalidValue;
   hipLaunchKernelGGL((conv_halo_f16_kernel<BN, GN>), dim3(tiles * (a.splitk > 1 ? a.splitk : 1)), dim3(512), smem, s,
-                     b.A, b.W, b.zero, b.M, b.N, b.K, b.lda, b.ldw, b.rpb, b.bstride, b.roff, b.splitk, b.group_w, b);
+                     b.A, b.W, b.M, b.N, b.K, b.lda, b.ldw, sk_gw, howo, hsws, (int)((unsigned)b.up | ((unsigned)b.Cin << 2)), b.Cin2, b);
   return hipGetLastError();
 }
 // a.gn.st0 != nullptr: the GroupNorm-fused form (the operand is the raw input of the norm; ia2p_conv_gn_ok)

@@ -43,11 +43,13 @@ struct Geglu320 {
   static_assert(SMEM <= 160 * 1024 && A_PW * NWAVE * RPP == BM && B_PW * NWAVE * RPP == BN, "LDS budget / staging split");
 };
 
-// The leading 16 dwords of the argument list arrive in SGPRs (kernarg preload, build.py); everything in `p` is a scalar load from the argument block, cold at every launch.
+// The leading dwords of the argument list arrive in SGPRs (kernarg preload, build.py); everything in `p` is a scalar load from the argument block, cold at every launch.
 // What a workgroup needs BEFORE its first DMA piece and its statistics loads is therefore spelled out in front of `p`: operands, shape, strides, tile order, and the folded
 // LayerNorm's statistics / column-sum pointers (with the pointers in `p`, the statistics loads left a cold scalar round trip after the DMA and came back that much later).
-__global__ __launch_bounds__(512, 2) void gemm_geglu_f16_kernel(const half_t* hA, const half_t* hW, const float* h_ln_stats, int hM, int hN, int hK, int hlda, int hldw, int h_ln_slots,
-                                                               int hgroup_w, int h_m_fastest, const float* h_ln_cs, const GemmArgs p) {
+// (FOURTEEN dwords are preloaded -- 16 user SGPRs less the argument block's address, gemm_kernel.h: four pointers, five ints, {slots, tile order} packed in one.)
+__global__ __launch_bounds__(512, 2) void gemm_geglu_f16_kernel(const half_t* hA, const half_t* hW, const float* h_ln_stats, const float* h_ln_cs, int hM, int hN, int hK, int hlda, int hldw,
+                                                               int h_slots_gw, const GemmArgs p) {
+  const int h_ln_slots = h_slots_gw & 0xff, hgroup_w = (int)((unsigned)h_slots_gw >> 8), h_m_fastest = p.m_fastest;      // (m_fastest: read only when the launcher set no grouped order)
   using G = Geglu320;
   constexpr int BM = G::BM, BN = G::BN, MR = G::MR, NR = G::NR, ROWB = G::ROWB, RPP = G::RPP, A_PW = G::A_PW, B_PW = G::B_PW, STAGE = G::STAGE, NT = G::NWAVE * 64;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -417,6 +419,8 @@ static hipError_t launch_geglu320(const GemmArgs& a, hipStream_t s) {
   b.partial = nullptr;
 #endif
   const int tiles = ((a.M + G::BM - 1) / G::BM) * ((a.N + G::BN - 1) / G::BN);
-  hipLaunchKernelGGL(gemm_geglu_f16_kernel, dim3(tiles), dim3(512), G::SMEM, s, b.A, b.W, b.ln_stats, b.M, b.N, b.K, b.lda, b.ldw, b.ln_slots, b.group_w, b.m_fastest, b.ln_cs, b);
+  int slots_gw;
+  if (!ia2p_pack_skgw(b.ln_stats ? b.ln_slots : 0, b.group_w, &slots_gw)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(gemm_geglu_f16_kernel, dim3(tiles), dim3(512), G::SMEM, s, b.A, b.W, b.ln_stats, b.ln_cs, b.M, b.N, b.K, b.lda, b.ldw, slots_gw, b);
   return hipGetLastError();
 }

@@ -16,8 +16,8 @@
 template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int BK = 64, int PP = 0, int WGN = 2, int XA = 0>
 __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* hW, const half_t* hzero, int hM, int hN, int hK, int hlda, int hldw, int hrpb, int hbstride,
                                                int hroff, int hsplitk, int hgroup_w, const GemmArgs& p, const AttnArgs* xa, const float* pre_ln_stats = nullptr, int pre_ln_slots = 0) {
-  // The leading 16 dwords of the argument list are what the prologue needs; built with -amdgpu-kernarg-preload-count=16 the command processor
-  // hands them over in SGPRs, so the first tile loads go out without waiting for a cold read of the argument block (which costs every launch
+  // The leading arguments of the kernels are what the prologue needs; built with -amdgpu-kernarg-preload-count=16 the command processor
+  // hands the first 14 dwords over in SGPRs (the kernels pack theirs to fit: gemm_f16_kernel below), so the first tile loads go out without waiting for a cold read of the argument block (which costs every launch
   // ~1 us: tools/micro/launch_floor2.hip). The rest of GemmArgs (epilogue, conv geometry) arrives while those loads fly.   // >= 2 waves/SIMD: big tiles must fit 256 registers
   static_assert(PP != 1 || (WGM * WGN == 8 && (WGM == 4 || WGM == 8) && NSTAGE == 3), "ping-pong schedule: 8 waves (two groups of 4 by tile rows), 3-stage ring");
   static_assert(PP != 3 || (WGM == 4 && NSTAGE == 2 && !CONV), "two-slot ping-pong schedule: 8 waves, 2 k-tile slots");
@@ -664,9 +664,14 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
 }
 
 template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int BK = 64, int PP = 0, int WGN = 2>
-__global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_f16_kernel(const half_t* hA, const half_t* hW, const half_t* hzero, int hM, int hN, int hK, int hlda, int hldw, int hrpb, int hbstride,
-                                                                         int hroff, int hsplitk, int hgroup_w, const GemmArgs p) {
-  gemm_tile_body<BM, BN, NSTAGE, CONV, WGM, BK, PP, WGN, 0>(hA, hW, hzero, hM, hN, hK, hlda, hldw, hrpb, hbstride, hroff, hsplitk, hgroup_w, p, nullptr);
+// Leading arguments = what a workgroup needs before its first DMA piece, in FOURTEEN dwords: that is how many the command processor preloads into SGPRs (16 user SGPRs, two
+// of them the argument block's address; `.amdhsa_user_sgpr_kernarg_preload_length 14`). Rounds 2-5 spelled the row map and the K split / tile order out as five ints, 16 dwords
+// in all: the last two -- hsplitk and hgroup_w, which the tile decode needs first -- were NOT preloaded, and every launch began with a cold scalar read of its argument block.
+// Packed (ia2p_pack_rowmap / ia2p_pack_skgw: the launcher refuses values that do not fit).
+__global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_f16_kernel(const half_t* hA, const half_t* hW, const half_t* hzero, int hM, int hN, int hK, int hlda, int hldw, int hrowmap,
+                                                                         int hbstride, int hsk_gw, const GemmArgs p) {
+  gemm_tile_body<BM, BN, NSTAGE, CONV, WGM, BK, PP, WGN, 0>(hA, hW, hzero, hM, hN, hK, hlda, hldw, hrowmap & 0xffff, hbstride, (int)((unsigned)hrowmap >> 16), hsk_gw & 0xff,
+                                                            (int)((unsigned)hsk_gw >> 8), p, nullptr);
 }
 template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int BK = 64, int PP = 0, int WGN = 2>
 static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
@@ -694,7 +699,9 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
   // b.sk_counters: as the caller (launch_any, gemm.hip) attached them -- null: the K-slices only write their slabs and a splitk_reduce_kernel launch finishes
   if (b.sk_counters && tiles > ia2p_sk_counter_capacity()) return hipErrorInvalidValue;
   const int extra = (!PP && a.pf && a.pf_bytes >= 4096) ? a.pf_blocks : 0;
+  int rowmap, sk_gw;
+  if (!ia2p_pack_rowmap(b.rpb, b.roff, &rowmap) || !ia2p_pack_skgw(b.splitk, b.group_w, &sk_gw)) return hipErrorInvalidValue;
   hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, NSTAGE, CONV, WGM, BK, PP, WGN>), dim3(tiles * (a.splitk > 1 ? a.splitk : 1) + extra), dim3(WGM * WGN * 64), smem, s,
-                     b.A, b.W, b.zero, b.M, b.N, b.K, b.lda, b.ldw, b.rpb, b.bstride, b.roff, b.splitk, b.group_w, b);
+                     b.A, b.W, b.zero, b.M, b.N, b.K, b.lda, b.ldw, rowmap, b.bstride, sk_gw, b);
   return hipGetLastError();
 }

@@ -156,6 +156,19 @@ static inline int ia2p_tile_group_w(int tiles, int tiles_n, int smem, double a_o
 }
 static inline int ia2p_tile_group_w(int tiles, int tiles_n, int smem, int BM, int BN) { return ia2p_tile_group_w(tiles, tiles_n, smem, (double)BM / BN); }
 
+// packed leading kernel arguments (gemm_kernel.h: 14 preloaded dwords): row map {rows per batch, row offset} in 16 bits each; {K split, grouped tile order} in 8 + 24 bits;
+// fused LayerNorm consumers of their own kernels: {statistics slots, tile order} likewise. false: the value does not fit (the launcher returns hipErrorInvalidValue)
+static inline bool ia2p_pack_rowmap(int rpb, int roff, int* out) {
+  if (rpb < 0 || rpb > 0xffff || roff < 0 || roff > 0xffff) return false;
+  *out = (int)((unsigned)rpb | ((unsigned)roff << 16));
+  return true;
+}
+static inline bool ia2p_pack_skgw(int lo8, int group_w, int* out) {
+  if (lo8 < 0 || lo8 > 0xff || group_w < 0 || group_w > 0x7fffff) return false;
+  *out = (int)((unsigned)lo8 | ((unsigned)group_w << 8));
+  return true;
+}
+
 // launcher-side fields of a launch description: epilogue access width, write-through C, grouped tile order
 static inline void ia2p_gemm_prepare(GemmArgs& b, int smem, int BM, int BN, bool conv = false) {
   // 16-byte epilogue accesses need 8-element row strides and 16-byte-aligned bases; otherwise the epilogue falls back to 8-byte pieces

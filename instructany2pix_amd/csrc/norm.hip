@@ -32,7 +32,7 @@ struct GNArgs {
 template <int V>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* ax, half_t* ay, const half_t* agamma, const half_t* abeta, float* apartial, int aB, int aHW, int aC, int aG,
                                                            int achunks, int arows_, int aarows, int aldx, int aldy, float aeps, int asilu, const half_t* ax2, int aldx2, int aCa) {
-  // scalar arguments (the first 16 dwords are preloaded into SGPRs: build.py PRELOAD), re-assembled into the descriptor the body uses
+  // scalar arguments (the first 14 dwords are preloaded into SGPRs: build.py PRELOAD), re-assembled into the descriptor the body uses
   GNArgs p;
   p.x = ax; p.y = ay; p.gamma = agamma; p.beta = abeta; p.partial = apartial; p.B = aB; p.HW = aHW; p.C = aC; p.G = aG; p.chunks = achunks;
   p.rows = arows_; p.arows = aarows; p.ldx = aldx; p.ldy = aldy; p.eps = aeps; p.silu = asilu; p.x2 = ax2; p.ldx2 = aldx2; p.Ca = aCa;
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* ax, half_t*
 template <int V>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* ax, half_t* ay, const half_t* agamma, const half_t* abeta, float* apartial, int aB, int aHW, int aC, int aG,
                                                            int achunks, int arows_, int aarows, int aldx, int aldy, float aeps, int asilu, const half_t* ax2, int aldx2, int aCa) {
-  // scalar arguments (the first 16 dwords are preloaded into SGPRs: build.py PRELOAD), re-assembled into the descriptor the body uses
+  // scalar arguments (the first 14 dwords are preloaded into SGPRs: build.py PRELOAD), re-assembled into the descriptor the body uses
   GNArgs p;
   p.x = ax; p.y = ay; p.gamma = agamma; p.beta = abeta; p.partial = apartial; p.B = aB; p.HW = aHW; p.C = aC; p.G = aG; p.chunks = achunks;
   p.rows = arows_; p.arows = aarows; p.ldx = aldx; p.ldy = aldy; p.eps = aeps; p.silu = asilu & 1; p.x2 = ax2; p.ldx2 = aldx2; p.Ca = aCa;
