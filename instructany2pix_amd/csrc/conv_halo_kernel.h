@@ -48,7 +48,7 @@ constexpr GnOp GN_OPS[GN_NOPS] = {{0, 0}, {0, 1}, {0, 2}, {1, 0}, {0, 3}, {1, 1}
                                   {1, 4}, {2, 3}, {3, 2}, {0, 7}, {1, 5}, {2, 4}, {3, 3}, {1, 6}, {2, 5}, {3, 4}, {1, 7}, {2, 6}, {3, 5}, {2, 7}, {3, 6}, {3, 7}};
 
 template <int BN, int GN>
-__device__ __forceinline__ void conv_halo_tile_body(const half_t* hA, const half_t* hW, int hM, int hN, int hK, int hlda, int hldw, int hsplitk, int hgroup_w, int gHo, int gWo, int gHs, int gWs,
+__device__ __forceinline__ void conv_halo_tile_body(const half_t* hA, const half_t* hW, int hM, int hN, int hK, int hlda, int hldw, int hsplitk, int hgroup_w, int hmfast, int gHo, int gWo, int gHs, int gWs,
                                                     int gUp, int gCin, int gCin2, const GemmArgs& p) {
   constexpr int BM = 256, BK = 64, NSTAGE = 3, PP = 1, WGM = HaloWaves<BN>::WGM, WGN = HaloWaves<BN>::WGN;
   constexpr int NWAVE = WGM * WGN;
@@ -82,7 +82,7 @@ __device__ __forceinline__ void conv_halo_tile_body(const half_t* hA, const half
   const int split = bid / (tiles_m * tiles_n);
   bid -= split * tiles_m * tiles_n;
   int tm, tn;
-  tile_order(bid, tiles_m, tiles_n, hgroup_w, p.m_fastest, tm, tn);
+  tile_order(bid, tiles_m, tiles_n, hgroup_w, hmfast, tm, tn);
   const int bm0 = tm * BM, bn0 = tn * BN;
   const int tpr = gWo >> 4, tpi = (gHo >> 4) * tpr;
   const int h_img = tm / tpi;
@@ -508,7 +508,7 @@ template <int BN, int GN = 0>
 //  {Ho, Wo} and {Hs, Ws} in 16 bits each, {upsampled view, Cin}, Cin2)
 __global__ __launch_bounds__(512, 2) void conv_halo_f16_kernel(const half_t* hA, const half_t* hW, int hM, int hN, int hK, int hlda, int hldw, int hsk_gw, int hHoWo, int hHsWs, int hUpCin,
                                                                  int hCin2, const GemmArgs p) {
-  conv_halo_tile_body<BN, GN>(hA, hW, hM, hN, hK, hlda, hldw, hsk_gw & 0xff, (int)((unsigned)hsk_gw >> 8), hHoWo & 0xffff, (int)((unsigned)hHoWo >> 16), hHsWs & 0xffff,
+  conv_halo_tile_body<BN, GN>(hA, hW, hM, hN, hK, hlda, hldw, IA2P_SKGW_LO8(hsk_gw), IA2P_SKGW_GW(hsk_gw), IA2P_SKGW_FLAGS(hsk_gw) & 1, hHoWo & 0xffff, (int)((unsigned)hHoWo >> 16), hHsWs & 0xffff,
                               (int)((unsigned)hHsWs >> 16), hUpCin & 3, (int)((unsigned)hUpCin >> 2), hCin2, p);
 }
 
@@ -529,7 +529,7 @@ static hipError_t launch_halo_gn(const GemmArgs& a, hipStream_t s) {
   if (b.gn_out && !b.vec8) return hipErrorInvalidValue;      // (the column sums of the output are taken on the 16-byte epilogue routes)
   if (b.sk_counters && tiles > ia2p_sk_counter_capacity()) return hipErrorInvalidValue;
   int sk_gw, howo, hsws;
-  if (!ia2p_pack_skgw(b.splitk, b.group_w, &sk_gw) || !ia2p_pack_rowmap(b.Ho, b.Wo, &howo) || !ia2p_pack_rowmap(b.Hs, b.Ws, &hsws) || b.up < 0 || b.up > 3 || b.Cin < 0 || b.Cin >= (1 << 29))
+  if (!ia2p_pack_skgw(b.splitk, b.group_w, b.m_fastest, false, &sk_gw) || !ia2p_pack_rowmap(b.Ho, b.Wo, &howo) || !ia2p_pack_rowmap(b.Hs, b.Ws, &hsws) || b.up < 0 || b.up > 3 || b.Cin < 0 || b.Cin >= (1 << 29))
     return hipErrorInvalidValue;
   hipLaunchKernelGGL((conv_halo_f16_kernel<BN, GN>), dim3(tiles * (a.splitk > 1 ? a.splitk : 1)), dim3(512), smem, s,
                      b.A, b.W, b.M, b.N, b.K, b.lda, b.ldw, sk_gw, howo, hsws, (int)((unsigned)b.up | ((unsigned)b.Cin << 2)), b.Cin2, b);

@@ -49,7 +49,7 @@ struct Geglu320 {
 // (FOURTEEN dwords are preloaded -- 16 user SGPRs less the argument block's address, gemm_kernel.h: four pointers, five ints, {slots, tile order} packed in one.)
 __global__ __launch_bounds__(512, 2) void gemm_geglu_f16_kernel(const half_t* hA, const half_t* hW, const float* h_ln_stats, const float* h_ln_cs, int hM, int hN, int hK, int hlda, int hldw,
                                                                int h_slots_gw, const GemmArgs p) {
-  const int h_ln_slots = h_slots_gw & 0xff, hgroup_w = (int)((unsigned)h_slots_gw >> 8), h_m_fastest = p.m_fastest;      // (m_fastest: read only when the launcher set no grouped order)
+  const int h_ln_slots = IA2P_SKGW_LO8(h_slots_gw), hgroup_w = IA2P_SKGW_GW(h_slots_gw), h_m_fastest = IA2P_SKGW_FLAGS(h_slots_gw) & 1;
   using G = Geglu320;
   constexpr int BM = G::BM, BN = G::BN, MR = G::MR, NR = G::NR, ROWB = G::ROWB, RPP = G::RPP, A_PW = G::A_PW, B_PW = G::B_PW, STAGE = G::STAGE, NT = G::NWAVE * 64;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -105,16 +105,16 @@ __global__ __launch_bounds__(512, 2) void gemm_geglu_f16_kernel(const half_t* hA
 #pragma unroll
     for (int u = 0; u < MAXS; ++u) ln_v[u] = st[(size_t)min(u, h_ln_slots - 1) * hM];
   }
-  // ... and so do the loads of the column constants and of the gate table (into the LDS behind the ring)
+  __builtin_amdgcn_sched_barrier(0);
+  issue_a(0, 0);            // k-tile 0, whole, into slot 0
+  issue_w(0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  // column constants and the gate table: loaded here, behind the DMA issue (their pointers come out of the argument block: ahead of the DMA issue they would hold it up for that cold read), parked in the LDS behind the ring before the first barrier
   f4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
   const bool ccol = h_ln_stats && tid < BN / 4;             // (whole tiles: every column is in range)
   if (ccol) { c0 = *(const f4*)(h_ln_cs + bn0 + tid * 4); c1 = *(const f4*)(p.ln_bias + bn0 + tid * 4); }
   const float2 t0 = ((const float2*)p.phi_lut)[tid], t1 = ((const float2*)p.phi_lut)[min(tid + NT, IA2P_PHI_LUT_N - 1)];
   static_assert(IA2P_PHI_LUT_N > NT && IA2P_PHI_LUT_N <= 2 * NT, "table copy: two entries per thread");
-  __builtin_amdgcn_sched_barrier(0);
-  issue_a(0, 0);            // k-tile 0, whole, into slot 0
-  issue_w(0, 0);
-  __builtin_amdgcn_sched_barrier(0);
   // the row's mean / rstd are parked in the 2 KiB of LDS behind the ring (nothing is carried through the k-loop in registers)
   float* ln_rows = (float*)(smem + G::RING);                 // [0, BM): mean, [BM, 2 BM): rstd
   float* ln_cs = ln_rows + 2 * BM;                           // BN column sums, BN folded biases
@@ -420,7 +420,7 @@ static hipError_t launch_geglu320(const GemmArgs& a, hipStream_t s) {
 #endif
   const int tiles = ((a.M + G::BM - 1) / G::BM) * ((a.N + G::BN - 1) / G::BN);
   int slots_gw;
-  if (!ia2p_pack_skgw(b.ln_stats ? b.ln_slots : 0, b.group_w, &slots_gw)) return hipErrorInvalidValue;
+  if (!ia2p_pack_skgw(b.ln_stats ? b.ln_slots : 0, b.group_w, b.m_fastest, b.ln_stats != nullptr, &slots_gw)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(gemm_geglu_f16_kernel, dim3(tiles), dim3(512), G::SMEM, s, b.A, b.W, b.ln_stats, b.ln_cs, b.M, b.N, b.K, b.lda, b.ldw, slots_gw, b);
   return hipGetLastError();
 }

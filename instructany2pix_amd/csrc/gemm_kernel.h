@@ -15,7 +15,10 @@
 // into the Q fragments of the attention core (attention_core.h, MODE = XA - 1) and writes the cross-attention output instead.
 template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int BK = 64, int PP = 0, int WGN = 2, int XA = 0>
 __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* hW, const half_t* hzero, int hM, int hN, int hK, int hlda, int hldw, int hrpb, int hbstride,
-                                               int hroff, int hsplitk, int hgroup_w, const GemmArgs& p, const AttnArgs* xa, const float* pre_ln_stats = nullptr, int pre_ln_slots = 0) {
+                                               int hroff, int hsplitk, int hgroup_w, int hflags, const GemmArgs& p, const AttnArgs* xa, const float* pre_ln_stats = nullptr, int pre_ln_slots = 0) {
+  // hflags (preloaded with the other leading arguments): bit 0 = p.m_fastest, bit 1 = p.ln_stats != nullptr. Read from `p` they are scalar loads from the cold argument block
+  // whose results stand between the workgroup's entry and its first DMA piece: the tile decode does not even use m_fastest under a grouped order, but the load was in flight
+  // into registers the decode reuses (a wait for it, in every launch), and every launch asked p.ln_stats whether it had statistics to fetch ahead of its DMA.
   // The leading arguments of the kernels are what the prologue needs; built with -amdgpu-kernarg-preload-count=16 the command processor
   // hands the first 14 dwords over in SGPRs (the kernels pack theirs to fit: gemm_f16_kernel below), so the first tile loads go out without waiting for a cold read of the argument block (which costs every launch
   // ~1 us: tools/micro/launch_floor2.hip). The rest of GemmArgs (epilogue, conv geometry) arrives while those loads fly.   // >= 2 waves/SIMD: big tiles must fit 256 registers
@@ -74,7 +77,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
     return;
   }
   int tm, tn;
-  tile_order(bid, tiles_m, tiles_n, hgroup_w, p.m_fastest, tm, tn);
+  tile_order(bid, tiles_m, tiles_n, hgroup_w, hflags & 1, tm, tn);
   const int bm0 = tm * BM, bn0 = tn * BN;
 
   // ---- staging addresses. Piece `pi` covers tile rows pi*8 .. pi*8+7; lane -> (row pi*8 + lane/8, LDS chunk lane%8),
@@ -300,8 +303,17 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   constexpr int LN_MAXS = 24;
   float2 ln_v[LN_MAXS];
   // (fused attention tiles: pointer and slot count from the preloaded arguments of their kernels, qxattn.hip -- the same values as in `p`, without the argument block's round trip)
-  const float* const ln_stats_p = XA != 0 ? pre_ln_stats : p.ln_stats;
-  const int ln_nslots = XA != 0 ? pre_ln_slots : p.ln_slots;
+  // `p` behind a pointer the optimizer cannot see through before the point of the call (the leading arguments fill 14 dwords: `p` sits at byte 56 of the argument block):
+  // scalar loads from the argument block are hoisted and speculated freely, and every one that lands in front of the first DMA piece is a cold round trip there
+  auto p_opaque = [&]() -> const GemmArgs* {
+    int off = 56;
+    asm volatile("" : "+s"(off));
+    return (const GemmArgs*)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + off);
+  };
+  const float* ln_stats_p = nullptr;
+  int ln_nslots = 0;
+  if constexpr (XA != 0) { ln_stats_p = pre_ln_stats; ln_nslots = pre_ln_slots; }
+  else if (hflags & 2) { const GemmArgs* pe = p_opaque(); ln_stats_p = pe->ln_stats; ln_nslots = pe->ln_slots; }      // (consumers only: the others never ask)
 #ifdef IA2P_TIMING_NOSTATS      // (timing experiments only: what the statistics' loads cost a workgroup's start; results are wrong)
   const bool ln_row = false;
 #else
@@ -667,11 +679,11 @@ template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int BK = 64, int P
 // Leading arguments = what a workgroup needs before its first DMA piece, in FOURTEEN dwords: that is how many the command processor preloads into SGPRs (16 user SGPRs, two
 // of them the argument block's address; `.amdhsa_user_sgpr_kernarg_preload_length 14`). Rounds 2-5 spelled the row map and the K split / tile order out as five ints, 16 dwords
 // in all: the last two -- hsplitk and hgroup_w, which the tile decode needs first -- were NOT preloaded, and every launch began with a cold scalar read of its argument block.
-// Packed (ia2p_pack_rowmap / ia2p_pack_skgw: the launcher refuses values that do not fit).
+// Packed (ia2p_pack_rowmap / ia2p_pack_skgw, with the two flags of the prologue: the launcher refuses values that do not fit).
 __global__ __launch_bounds__(WGM * WGN * 64, 2) void gemm_f16_kernel(const half_t* hA, const half_t* hW, const half_t* hzero, int hM, int hN, int hK, int hlda, int hldw, int hrowmap,
                                                                          int hbstride, int hsk_gw, const GemmArgs p) {
-  gemm_tile_body<BM, BN, NSTAGE, CONV, WGM, BK, PP, WGN, 0>(hA, hW, hzero, hM, hN, hK, hlda, hldw, hrowmap & 0xffff, hbstride, (int)((unsigned)hrowmap >> 16), hsk_gw & 0xff,
-                                                            (int)((unsigned)hsk_gw >> 8), p, nullptr);
+  gemm_tile_body<BM, BN, NSTAGE, CONV, WGM, BK, PP, WGN, 0>(hA, hW, hzero, hM, hN, hK, hlda, hldw, hrowmap & 0xffff, hbstride, (int)((unsigned)hrowmap >> 16), IA2P_SKGW_LO8(hsk_gw),
+                                                            IA2P_SKGW_GW(hsk_gw), IA2P_SKGW_FLAGS(hsk_gw), p, nullptr);
 }
 template <int BM, int BN, int NSTAGE, bool CONV, int WGM = 2, int BK = 64, int PP = 0, int WGN = 2>
 static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
@@ -700,7 +712,7 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
   if (b.sk_counters && tiles > ia2p_sk_counter_capacity()) return hipErrorInvalidValue;
   const int extra = (!PP && a.pf && a.pf_bytes >= 4096) ? a.pf_blocks : 0;
   int rowmap, sk_gw;
-  if (!ia2p_pack_rowmap(b.rpb, b.roff, &rowmap) || !ia2p_pack_skgw(b.splitk, b.group_w, &sk_gw)) return hipErrorInvalidValue;
+  if (!ia2p_pack_rowmap(b.rpb, b.roff, &rowmap) || !ia2p_pack_skgw(b.splitk, b.group_w, b.m_fastest, b.ln_stats != nullptr, &sk_gw)) return hipErrorInvalidValue;
   hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, NSTAGE, CONV, WGM, BK, PP, WGN>), dim3(tiles * (a.splitk > 1 ? a.splitk : 1) + extra), dim3(WGM * WGN * 64), smem, s,
                      b.A, b.W, b.zero, b.M, b.N, b.K, b.lda, b.ldw, rowmap, b.bstride, sk_gw, b);
   return hipGetLastError();

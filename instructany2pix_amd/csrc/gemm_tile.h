@@ -163,11 +163,14 @@ static inline bool ia2p_pack_rowmap(int rpb, int roff, int* out) {
   *out = (int)((unsigned)rpb | ((unsigned)roff << 16));
   return true;
 }
-static inline bool ia2p_pack_skgw(int lo8, int group_w, int* out) {
-  if (lo8 < 0 || lo8 > 0xff || group_w < 0 || group_w > 0x7fffff) return false;
-  *out = (int)((unsigned)lo8 | ((unsigned)group_w << 8));
+static inline bool ia2p_pack_skgw(int lo8, int group_w, int m_fastest, bool has_ln, int* out) {      // [7:0] K split (or slots), [8] m_fastest, [9] folded-LayerNorm consumer, [31:10] tile order
+  if (lo8 < 0 || lo8 > 0xff || group_w < 0 || group_w > 0x3fffff) return false;
+  *out = (int)((unsigned)lo8 | (m_fastest ? 0x100u : 0u) | (has_ln ? 0x200u : 0u) | ((unsigned)group_w << 10));
   return true;
 }
+#define IA2P_SKGW_LO8(w) ((w) & 0xff)
+#define IA2P_SKGW_FLAGS(w) (((w) >> 8) & 3)      // bit 0: m_fastest, bit 1: the launch consumes folded-LayerNorm statistics
+#define IA2P_SKGW_GW(w) ((int)((unsigned)(w) >> 10))
 
 // launcher-side fields of a launch description: epilogue access width, write-through C, grouped tile order
 static inline void ia2p_gemm_prepare(GemmArgs& b, int smem, int BM, int BN, bool conv = false) {

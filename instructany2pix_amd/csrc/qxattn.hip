@@ -20,8 +20,8 @@ template <int MODE>      // attention core mode: 0 one key segment; 1 text + <= 
 //  14 dwords are preloaded: four pointers, five ints, {slots, tile order} packed)
 __global__ __launch_bounds__(256, 2) void qproj_xattn_kernel(const half_t* hA, const half_t* hW, const half_t* hzero, const float* h_ln_stats, int hM, int hN, int hK, int hlda, int hldw,
                                                              int h_slots_gw, const GemmArgs p, const AttnArgs xa) {
-  gemm_tile_body<128, 64, IA2P_QX_STAGES, false, 2, 64, 0, 2, MODE + 1>(hA, hW, hzero, hM, hN, hK, hlda, hldw, 0, 0, 0, 0, (int)((unsigned)h_slots_gw >> 8), p, &xa, h_ln_stats,
-                                                                        h_slots_gw & 0xff);
+  gemm_tile_body<128, 64, IA2P_QX_STAGES, false, 2, 64, 0, 2, MODE + 1>(hA, hW, hzero, hM, hN, hK, hlda, hldw, 0, 0, 0, 0, IA2P_SKGW_GW(h_slots_gw), IA2P_SKGW_FLAGS(h_slots_gw), p, &xa, h_ln_stats,
+                                                                        IA2P_SKGW_LO8(h_slots_gw));
 }
 
 // Q = epilogue(A . W^T) is [B * Nq, heads * 64]; x.Q / x.ldq are ignored (Q stays on chip). Requires Nq % 128 == 0 (a tile must not straddle
@@ -60,7 +60,7 @@ hipError_t ia2p_launch_qproj_xattn(const GemmArgs& a, const AttnArgs& x, hipStre
   y.xcd_map = (((ia2p_wt_mask() & 8) && (size_t)x.B * x.Nq * x.ldo * 2 < (size_t)0x7ffffff0) ? 2 : 0) | (ia2p_attn_fold_enabled() ? 0 : 4);      // bit 1: write-through O; bit 2: image-token keys NOT folded into the last text tile
   const int extra = (a.pf && a.pf_bytes >= 4096) ? a.pf_blocks : 0;
   int slots_gw;
-  if (!ia2p_pack_skgw(b.ln_stats ? b.ln_slots : 0, b.group_w, &slots_gw)) return hipErrorInvalidValue;
+  if (!ia2p_pack_skgw(b.ln_stats ? b.ln_slots : 0, b.group_w, b.m_fastest, b.ln_stats != nullptr, &slots_gw)) return hipErrorInvalidValue;
   const int mode = y.nseg == 1 ? 0 : (y.seg[1].nkeys <= 64 && y.seg[0].weight != 0.f) ? 1 : 2;     // as ia2p_launch_attention
 #define IA2P_QX_LAUNCH(MODE)                                                                                                                   \
   hipLaunchKernelGGL(qproj_xattn_kernel<MODE>, dim3(tiles + extra), dim3(256), SMEM, s, b.A, b.W, b.zero, b.ln_stats, b.M, b.N, b.K, b.lda, b.ldw, slots_gw, b, y)
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(512, 2) void qkv_sattn_kernel(const half_t* hA, con
 #ifndef IA2P_SATTN_PP
 #define IA2P_SATTN_PP 3      // k-loop schedule of the fused QKV + self-attention tile: 3 = two-slot ping-pong, 0 = plain loop (one barrier per k-step); A/B builds
 #endif
-  gemm_tile_body<256, 192, 2, false, 4, 64, IA2P_SATTN_PP, 2, 4>(hA, hW, hzero, hM, hN, hK, hlda, hldw, 0, 0, 0, 0, (int)((unsigned)h_slots_gw >> 8), p, &xa, h_ln_stats, h_slots_gw & 0xff);
+  gemm_tile_body<256, 192, 2, false, 4, 64, IA2P_SATTN_PP, 2, 4>(hA, hW, hzero, hM, hN, hK, hlda, hldw, 0, 0, 0, 0, IA2P_SKGW_GW(h_slots_gw), IA2P_SKGW_FLAGS(h_slots_gw), p, &xa, h_ln_stats, IA2P_SKGW_LO8(h_slots_gw));
 }
 
 // A [B * 256, K] (un-normalised rows with a.ln_*, or plain), W the stacked [3 * heads * 64, K] projection; x: O / ldo / B / heads / Nq = 256.
@@ -118,7 +118,7 @@ hipError_t ia2p_launch_qkv_sattn(const GemmArgs& a, const AttnArgs& x, hipStream
   y.xcd_map = ((ia2p_wt_mask() & 8) && (size_t)x.B * x.Nq * x.ldo * 2 < (size_t)0x7ffffff0) ? 2 : 0;      // bit 1: write-through O
   const int extra = (a.pf && a.pf_bytes >= 4096) ? a.pf_blocks : 0;
   int slots_gw;
-  if (!ia2p_pack_skgw(b.ln_stats ? b.ln_slots : 0, b.group_w, &slots_gw)) return hipErrorInvalidValue;
+  if (!ia2p_pack_skgw(b.ln_stats ? b.ln_slots : 0, b.group_w, b.m_fastest, b.ln_stats != nullptr, &slots_gw)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(qkv_sattn_kernel, dim3(tiles + extra), dim3(512), SMEM, s, b.A, b.W, b.zero, b.ln_stats, b.M, b.N, b.K, b.lda, b.ldw, slots_gw, b, y);
   return hipGetLastError();
 }
