@@ -79,7 +79,7 @@ __device__ __forceinline__ void conv_halo_tile_body(const half_t* hA, const half
   const int tiles_m = hM / BM, tiles_n = (hN + BN - 1) / BN;
   int bid = blockIdx.x;
   const int nsplit = hsplitk > 1 ? hsplitk : 1;
-  const int split = bid / (tiles_m * tiles_n);
+  const int split = bid < tiles_m * tiles_n ? 0 : udiv_small(bid, tiles_m * tiles_n);
   bid -= split * tiles_m * tiles_n;
   int tm, tn;
   tile_order(bid, tiles_m, tiles_n, hgroup_w, hmfast, tm, tn);
@@ -122,7 +122,8 @@ __device__ __forceinline__ void conv_halo_tile_body(const half_t* hA, const half
   }
 
   const int nk_all = hK / BK;
-  const int kt0 = (int)((long)split * nk_all / nsplit), kt1 = (int)((long)(split + 1) * nk_all / nsplit);   // this workgroup's k-tiles
+  // this workgroup's k-tiles (no K split: all of them -- the 64-bit divisions this was written with ran in every launch: ~200 instructions of a workgroup's start)
+  const int kt0 = nsplit == 1 ? 0 : udiv_small(split * nk_all, nsplit), kt1 = nsplit == 1 ? nk_all : udiv_small((split + 1) * nk_all, nsplit);
   int cin_main = gCin, cin_extra = gCin2;                 // (two named scalars: a select between two argument FIELDS became a 2-entry table in scratch)
   asm volatile("" : "+s"(cin_main), "+s"(cin_extra));
 

@@ -53,7 +53,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   const int tiles_m = (hM + BM - 1) / BM, tiles_n = (hN + BN - 1) / BN;
   int bid = blockIdx.x;
   const int nsplit = hsplitk > 1 ? hsplitk : 1;
-  const int split = bid / (tiles_m * tiles_n);          // >= nsplit: prefetch workgroup
+  const int split = bid < tiles_m * tiles_n ? 0 : udiv_small(bid, tiles_m * tiles_n);          // >= nsplit: prefetch workgroup (the common case, a tile of an unsplit launch: one comparison)
   if (split < nsplit) bid -= split * tiles_m * tiles_n;
   if (split >= nsplit) {   // prefetch workgroup: touch its slice of the next kernel's weights and leave
     bid -= nsplit * tiles_m * tiles_n;
@@ -146,7 +146,8 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   }
 
   const int nk_all = hK / BK;
-  const int kt0 = (int)((long)split * nk_all / nsplit), kt1 = (int)((long)(split + 1) * nk_all / nsplit);   // this workgroup's k-tiles
+  // this workgroup's k-tiles (no K split: all of them -- the 64-bit divisions this was written with ran in every launch: ~200 instructions of a workgroup's start)
+  const int kt0 = nsplit == 1 ? 0 : udiv_small(split * nk_all, nsplit), kt1 = nsplit == 1 ? nk_all : udiv_small((split + 1) * nk_all, nsplit);
   // conv: K = (tap, channel) is walked TAP-major -- all Cin channels of a filter tap (64 per k-tile, running pointers: the gather of a row is derived once per
   // tap), then the next tap; after the 9 Cin columns of the 3x3 part the appended 1x1 blocks. Weights are packed in that order ([Co][tap][Cin], misc.hip).
   // (The gathered operand walked channel-block-major -- the nine taps of a block of 64 channels, then the next block -- halves the fabric traffic of the large convolutions

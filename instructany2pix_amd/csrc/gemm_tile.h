@@ -112,6 +112,15 @@ __device__ __forceinline__ void stamp_put(const GemmArgs& p, int nsplit, int slo
 // ---- tile of a workgroup. Blocks b, b + 8, ... share an XCD (its L2): every XCD gets a CONTIGUOUS range of the tile order; inside it either plain row / column
 //      major (m_fastest) or, group_w > 0, column panels of group_w tiles walked row-major, so that the range an XCD works on (and the workgroups co-resident on it)
 //      covers a compact rows x cols block: the operand panels its L2 has to fetch shrink with the perimeter.
+// a / b for the tile decode: 0 <= a < 2^21, 0 < b < 2^21 (block and tile counts). One reciprocal, one correction either way: |a * rcp(b) - a / b| < 1 there (fp32 holds
+// both operands exactly, v_rcp_f32 is good to 1 ulp). The compiler's own expansion of a 32-bit signed division is ~60 instructions, and a workgroup's start is bound by
+// instruction issue (one or two waves per SIMD running ~600 dependent instructions before the first DMA piece: ~2 ns apiece); the decode has three of them.
+__device__ __forceinline__ int udiv_small(int a, int b) {
+  int q = (int)((float)a * __builtin_amdgcn_rcpf((float)b));
+  const int r = a - q * b;
+  q += (r >= b ? 1 : 0) - (r < 0 ? 1 : 0);
+  return q;
+}
 __device__ __forceinline__ void tile_order(int bid, int tiles_m, int tiles_n, int group_w, int m_fastest, int& tm, int& tn) {
   {
     const int nwg = tiles_m * tiles_n;
@@ -120,11 +129,11 @@ __device__ __forceinline__ void tile_order(int bid, int tiles_m, int tiles_n, in
   }
   if (group_w > 0) {
     const int per = tiles_m * group_w;
-    const int panel = bid / per, r = bid - panel * per;
+    const int panel = udiv_small(bid, per), r = bid - panel * per;
     const int w = min(group_w, tiles_n - panel * group_w);
-    tm = r / w; tn = panel * group_w + (r - tm * w);
-  } else if (m_fastest) { tn = bid / tiles_m; tm = bid - tn * tiles_m; }
-  else                  { tm = bid / tiles_n; tn = bid - tm * tiles_n; }
+    tm = udiv_small(r, w); tn = panel * group_w + (r - tm * w);
+  } else if (m_fastest) { tn = udiv_small(bid, tiles_m); tm = bid - tn * tiles_m; }
+  else                  { tm = udiv_small(bid, tiles_n); tn = bid - tm * tiles_n; }
 }
 
 // what the epilogue needs to know about the tile whose accumulators it takes over
