@@ -55,7 +55,8 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   const int nsplit = hsplitk > 1 ? hsplitk : 1;
   const int split = bid < tiles_m * tiles_n ? 0 : udiv_small(bid, tiles_m * tiles_n);          // >= nsplit: prefetch workgroup (the common case, a tile of an unsplit launch: one comparison)
   if (split < nsplit) bid -= split * tiles_m * tiles_n;
-  if (split >= nsplit) {   // prefetch workgroup: touch its slice of the next kernel's weights and leave
+  if (__builtin_expect(split >= nsplit, 0)) {   // prefetch workgroup: touch its slice of the next kernel's weights and leave (out of line: a tile workgroup's start should FALL THROUGH -- every
+                                                // taken branch over a cold block is an instruction fetch the sequential prefetcher has not made, a few hundred ns at a launch's start)
     bid -= nsplit * tiles_m * tiles_n;
     const long per = ((p.pf_bytes + p.pf_blocks - 1) / p.pf_blocks + 4095) & ~4095L;
     const long lo = (long)bid * per, hi = min(lo + per, p.pf_bytes & ~15L);
@@ -103,7 +104,7 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
     if (!CONV) {
       if (m < hM) {
         int src = m;
-        if (hrpb) { const int b = m / hrpb; src = b * hbstride + (m - b * hrpb) + hroff; }
+        if (__builtin_expect(hrpb != 0, 0)) { const int b = m / hrpb; src = b * hbstride + (m - b * hrpb) + hroff; }
         a_ptr[i] = hA + (size_t)src * hlda + gch * 8;
         a_inc[i] = BK;
         a_voff[i] = (src * hlda + gch * 8) * 2;
@@ -325,14 +326,14 @@ __device__ __forceinline__ void gemm_tile_body(const half_t* hA, const half_t* h
   // wait for every piece of the prologue and then for their own round trip on top -- in the step 1.4 us (to_q + cross-attention) to 1.9 us (QKV + self-attention) per
   // workgroup start (timing build without the statistics: profiles/r06ad_nostats_timing.txt); issued first and waited for at once (round 2) the DMA started a round trip
   // late. Now both fly together and the counted wait of the fold leaves the younger DMA pieces in flight.
-  if (ln_wide) {
+  if (XA == 0 ? __builtin_expect(ln_wide, 0) : ln_wide) {      // (the shared kernels' launches are mostly NOT consumers: the 24 loads sit out of line there)
     const float2* st = (const float2*)ln_stats_p + (bm0 + tid);
 #pragma unroll
     for (int u = 0; u < LN_MAXS; ++u) ln_v[u] = st[(size_t)min(u, ln_nslots - 1) * hM];
   }
   __builtin_amdgcn_sched_barrier(0);
   auto fold_ln = [&]() {
-    if (ln_wide) {
+    if (XA == 0 ? __builtin_expect(ln_wide, 0) : ln_wide) {
       // (opaque to the optimizer: without it the first addition -- and with it a full round trip's wait -- is hoisted to right behind the loads, ahead of the DMA issue)
 #pragma unroll
       for (int u = 0; u < LN_MAXS; u += 12)
