@@ -194,7 +194,8 @@ ia2p_status ia2p_fold_layernorm(void* stream, const void* W, const void* gamma, 
                                 float* colsum, float* fbias, int N, int K);
 ia2p_status ia2p_gemm_ex(void* stream, const void* A, const void* W, const void* bias, const void* residual, void* C, int M, int N, int K,
                          int geglu, const ia2p_ln_fold* ln, float* stats_out, int* stats_slots, int splitk, float* partial);
-/* same with K split over `splitk` workgroups per tile; partial holds splitk*M*N floats (deterministic slab reduce) */
+/* same with K split over `splitk` workgroups per tile (1 .. min(K / 64, 255): the split rides in 8 bits of a preloaded kernel argument); partial holds splitk*M*N floats
+ * (deterministic slab reduce) */
 ia2p_status ia2p_gemm_splitk(void* stream, const void* A, const void* W, const void* bias, const void* residual, void* C,
                              int M, int N, int K, int splitk, float* partial);
 /* 3x3 conv, pad 1, over channels-last x[B,Hs,Ws,Cin] with W packed by ia2p_pack_conv3x3 ([Co][3][3][Cin]);

@@ -1551,7 +1551,7 @@ ia2p_status ia2p_gemm(void* stream, const void* A, const void* W, const void* bi
 ia2p_status ia2p_ffn(void* stream, const void* X, const void* W1p, const void* b1p, const void* W2, const void* b2, const void* R, void* H, void* out,
                      int M, int C, int splitk, float* partial) {
   if (!X || !W1p || !b1p || !W2 || !H || !out) return fail(nullptr, IA2P_ERR_INVALID, "ffn: null argument");
-  if (C % 64 || (splitk > 1 && (!partial || splitk > 4 * C / 64))) return fail(nullptr, IA2P_ERR_SHAPE, "ffn: C=%d must be a multiple of 64, splitk=%d needs slabs", C, splitk);
+  if (C % 64 || (splitk > 1 && (!partial || splitk > 4 * C / 64 || splitk > 255))) return fail(nullptr, IA2P_ERR_SHAPE, "ffn: C=%d must be a multiple of 64, splitk=%d needs slabs", C, splitk);
   RunCtx rc;
   GemmArgs a = gemm_args(&rc, (const half_t*)X, C, (const half_t*)W1p, (const half_t*)b1p, nullptr, 0, (half_t*)H, 4 * C, M, 8 * C, C, 1, 0, 0, 0, 0, nullptr, nullptr, 0);
   GemmArgs b = gemm_args(&rc, (const half_t*)H, 4 * C, (const half_t*)W2, (const half_t*)b2, (const half_t*)R, C, (half_t*)out, C, M, C, 4 * C, 0, 0, 0, 0, 0, nullptr, nullptr, 0);
@@ -1572,7 +1572,7 @@ ia2p_status ia2p_gemm_ex(void* stream, const void* A, const void* W, const void*
                          const ia2p_ln_fold* ln, float* stats_out, int* stats_slots, int splitk, float* partial) {
   if (!A || !W || !C) return fail(nullptr, IA2P_ERR_INVALID, "gemm_ex: null argument");
   if (K % 64 || N % 4 || (geglu && (N % 32 || (!bias && !ln)))) return fail(nullptr, IA2P_ERR_SHAPE, "gemm_ex: K=%d must be a multiple of 64, N=%d of 4 (GEGLU: 32, with bias)", K, N);
-  if (splitk > 1 && (!partial || geglu || splitk > K / 64)) return fail(nullptr, IA2P_ERR_SHAPE, "gemm_ex: splitk=%d needs a slab, no GEGLU, and <= K/64", splitk);
+  if (splitk > 1 && (!partial || geglu || splitk > K / 64 || splitk > 255)) return fail(nullptr, IA2P_ERR_SHAPE, "gemm_ex: splitk=%d needs a slab, no GEGLU, and <= min(K/64, 255)", splitk);
   if (ln && (!ln->stats || !ln->colsum || !ln->fbias || ln->slots < 1)) return fail(nullptr, IA2P_ERR_INVALID, "gemm_ex: incomplete ia2p_ln_fold");
   if (stats_out && geglu) return fail(nullptr, IA2P_ERR_INVALID, "gemm_ex: row statistics of a GEGLU output are not provided");
   GemmArgs a;
@@ -1596,7 +1596,7 @@ ia2p_status ia2p_gemm_ex(void* stream, const void* A, const void* W, const void*
 ia2p_status ia2p_gemm_splitk(void* stream, const void* A, const void* W, const void* bias, const void* residual, void* C, int M, int N, int K,
                              int splitk, float* partial) {
   if (!A || !W || !C || !partial) return fail(nullptr, IA2P_ERR_INVALID, "gemm_splitk: null argument");
-  if (K % 64 || N % 4 || splitk < 1 || splitk > K / 64) return fail(nullptr, IA2P_ERR_SHAPE, "gemm_splitk: K=%d N=%d splitk=%d", K, N, splitk);
+  if (K % 64 || N % 4 || splitk < 1 || splitk > K / 64 || splitk > 255) return fail(nullptr, IA2P_ERR_SHAPE, "gemm_splitk: K=%d N=%d splitk=%d (1 .. min(K / 64, 255))", K, N, splitk);
   GemmArgs a;
   memset(&a, 0, sizeof a);
   a.pad = 1;
@@ -1625,7 +1625,7 @@ ia2p_status ia2p_conv3x3(void* stream, const void* x, const void* Wp, const void
 ia2p_status ia2p_conv3x3_splitk(void* stream, const void* x, const void* Wp, const void* bias, const void* rowvec, const void* residual, void* y,
                                 int B, int Hs, int Ws, int Cin, int Co, int splitk, float* partial) {
   if (!x || !Wp || !y || (splitk > 1 && !partial)) return fail(nullptr, IA2P_ERR_INVALID, "conv3x3_splitk: null argument (partial is needed for splitk > 1 only)");
-  if (Cin % 64 || Co % 4 || splitk < 1 || splitk > 9 * Cin / 64) return fail(nullptr, IA2P_ERR_SHAPE, "conv3x3_splitk: Cin=%d (mult of 64) Co=%d (mult of 4) splitk=%d (1 .. 9 Cin / 64)", Cin, Co, splitk);
+  if (Cin % 64 || Co % 4 || splitk < 1 || splitk > 9 * Cin / 64 || splitk > 255) return fail(nullptr, IA2P_ERR_SHAPE, "conv3x3_splitk: Cin=%d (mult of 64) Co=%d (mult of 4) splitk=%d (1 .. 9 Cin / 64)", Cin, Co, splitk);
   GemmArgs a;
   memset(&a, 0, sizeof a);
   a.pad = 1;
@@ -1674,7 +1674,7 @@ ia2p_status ia2p_conv3x3_gn(void* stream, const ia2p_conv_gn* d, int* gn_out_row
   if (gn_out_rows) *gn_out_rows = 0;
   if (!d || !d->x0 || !d->Wp || !d->y || (d->splitk > 1 && !d->partial) || (d->Ca > 0 && !d->xa)) return fail(nullptr, IA2P_ERR_INVALID, "conv3x3_gn: null argument");
   const int Cin = d->C0 + (d->st0 ? d->C1 : 0), HW = d->H * d->W;
-  if (Cin % 64 || d->C0 % 64 || d->Co % 8 || d->Ca % 64 || d->B < 1 || HW < 1 || d->splitk < 0 || d->splitk > (9 * Cin + d->Ca) / 64) return fail(nullptr, IA2P_ERR_SHAPE, "conv3x3_gn: C0=%d C1=%d Co=%d Ca=%d splitk=%d", d->C0, d->C1, d->Co, d->Ca, d->splitk);
+  if (Cin % 64 || d->C0 % 64 || d->Co % 8 || d->Ca % 64 || d->B < 1 || HW < 1 || d->splitk < 0 || d->splitk > (9 * Cin + d->Ca) / 64 || d->splitk > 255) return fail(nullptr, IA2P_ERR_SHAPE, "conv3x3_gn: C0=%d C1=%d Co=%d Ca=%d splitk=%d", d->C0, d->C1, d->Co, d->Ca, d->splitk);
   GemmArgs a;
   memset(&a, 0, sizeof a);
   a.pad = 1; a.Ho = a.Hs = d->H; a.Wo = a.Ws = d->W; a.stride = 1;
@@ -1704,7 +1704,7 @@ ia2p_status ia2p_gemm_gnstats(void* stream, const void* A, const void* W, const 
                               int HW, double* gn_out, int* rows) {
   if (rows) *rows = 0;
   if (!A || !W || !C || !gn_out || !rows || (splitk > 1 && !partial)) return fail(nullptr, IA2P_ERR_INVALID, "gemm_gnstats: null argument");
-  if (K % 64 || N % 8 || HW < 16 || M % HW || splitk < 0 || splitk > K / 64) return fail(nullptr, IA2P_ERR_SHAPE, "gemm_gnstats: K=%d N=%d HW=%d splitk=%d", K, N, HW, splitk);
+  if (K % 64 || N % 8 || HW < 16 || M % HW || splitk < 0 || splitk > K / 64 || splitk > 255) return fail(nullptr, IA2P_ERR_SHAPE, "gemm_gnstats: K=%d N=%d HW=%d splitk=%d", K, N, HW, splitk);
   GemmArgs a;
   memset(&a, 0, sizeof a);
   a.pad = 1;
