@@ -133,6 +133,20 @@ for i in range(min(n, SLOTS)):
     b = breakdown(h[i], tiles)
     if b:
         by_shape.setdefault((M, N, K, v), []).append(b)
+# the 256 x 320 GEGLU tile in a -DIA2P_G320_PHASES build: per interval of a k-tile, the cycles a wave works and the cycles it then waits in the barrier (records behind the 8-slot ones)
+if os.environ.get("IA2P_G320_PHASES"):
+    what = (("I(4t)   read kk0 + 5 W pieces", "I(4t+1) 40 MFMAs", "I(4t+2) read kk1 + 4 A pieces", "I(4t+3) 40 MFMAs"),
+            ("I(4t)   40 MFMAs (t-1, kk1)", "I(4t+1) read kk0 + 5 W pieces", "I(4t+2) 40 MFMAs", "I(4t+3) read kk1 + 4 A pieces"))
+    for i in range(min(n, SLOTS)):
+        M, N, K, v, tiles = meta[5 * i:5 * i + 5]
+        if v != 27 or (M, N, K) != (2048, 10240, 1280):
+            continue
+        ph = h[i].reshape(-1)[8 * tiles:8 * tiles + 16 * tiles].reshape(tiles, 16).double() / (K // 64)
+        print(f"launch {i}: {M} x {N} x {K}, cycles per k-tile (median over workgroups)")
+        for grp in range(2):
+            for k in range(4):
+                print(f"    group {grp}  {what[grp][k]:32s} works {float(ph[:, 8 * grp + k].median()):6.0f}, waits in the barrier {float(ph[:, 8 * grp + 4 + k].median()):6.0f}")
+        break
 for (M, N, K), bs in sorted(xat.items()):
     print(f"fused to_q + cross-attention (128 x 64 tile), {M} x {N} x {K}, {len(bs)} launches in the step: " + ", ".join(f"{c} {statistics.median(b[c] for b in bs):.2f}" for c in bs[0]))
 for (M, N, K, sk, v), bs in sorted(split.items()):
