@@ -529,6 +529,7 @@ static hipError_t launch_halo_gn(const GemmArgs& a, hipStream_t s) {
   ia2p_gemm_prepare(b, smem, 256, BN, true);
   if (b.gn_out && !b.vec8) return hipErrorInvalidValue;      // (the column sums of the output are taken on the 16-byte epilogue routes)
   if (b.sk_counters && tiles > ia2p_sk_counter_capacity()) return hipErrorInvalidValue;
+  if ((long)tiles * (a.splitk > 1 ? a.splitk : 1) >= (1L << 21)) return hipErrorInvalidValue;      // (udiv_small in the tile decode: block and tile counts below 2^21)
   int sk_gw, howo, hsws;
   if (!ia2p_pack_skgw(b.splitk, b.group_w, b.m_fastest, false, &sk_gw) || !ia2p_pack_rowmap(b.Ho, b.Wo, &howo) || !ia2p_pack_rowmap(b.Hs, b.Ws, &hsws) || b.up < 0 || b.up > 3 || b.Cin < 0 || b.Cin >= (1 << 29))
     return hipErrorInvalidValue;

@@ -419,6 +419,7 @@ static hipError_t launch_geglu320(const GemmArgs& a, hipStream_t s) {
   b.partial = nullptr;
 #endif
   const int tiles = ((a.M + G::BM - 1) / G::BM) * ((a.N + G::BN - 1) / G::BN);
+  if (tiles >= (1 << 21)) return hipErrorInvalidValue;      // (udiv_small in the tile decode)
   int slots_gw;
   if (!ia2p_pack_skgw(b.ln_stats ? b.ln_slots : 0, b.group_w, b.m_fastest, b.ln_stats != nullptr, &slots_gw)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(gemm_geglu_f16_kernel, dim3(tiles), dim3(512), G::SMEM, s, b.A, b.W, b.ln_stats, b.ln_cs, b.M, b.N, b.K, b.lda, b.ldw, slots_gw, b);

@@ -713,6 +713,7 @@ static hipError_t launch_cfg(const GemmArgs& a, hipStream_t s) {
   // b.sk_counters: as the caller (launch_any, gemm.hip) attached them -- null: the K-slices only write their slabs and a splitk_reduce_kernel launch finishes
   if (b.sk_counters && tiles > ia2p_sk_counter_capacity()) return hipErrorInvalidValue;
   const int extra = (!PP && a.pf && a.pf_bytes >= 4096) ? a.pf_blocks : 0;
+  if ((long)tiles * (a.splitk > 1 ? a.splitk : 1) + extra >= (1L << 21)) return hipErrorInvalidValue;      // (udiv_small in the tile decode: block and tile counts below 2^21)
   int rowmap, sk_gw;
   if (!ia2p_pack_rowmap(b.rpb, b.roff, &rowmap) || !ia2p_pack_skgw(b.splitk, b.group_w, b.m_fastest, b.ln_stats != nullptr, &sk_gw)) return hipErrorInvalidValue;
   hipLaunchKernelGGL((gemm_f16_kernel<BM, BN, NSTAGE, CONV, WGM, BK, PP, WGN>), dim3(tiles * (a.splitk > 1 ? a.splitk : 1) + extra), dim3(WGM * WGN * 64), smem, s,

@@ -60,7 +60,7 @@ hipError_t ia2p_launch_qproj_xattn(const GemmArgs& a, const AttnArgs& x, hipStre
   y.xcd_map = (((ia2p_wt_mask() & 8) && (size_t)x.B * x.Nq * x.ldo * 2 < (size_t)0x7ffffff0) ? 2 : 0) | (ia2p_attn_fold_enabled() ? 0 : 4);      // bit 1: write-through O; bit 2: image-token keys NOT folded into the last text tile
   const int extra = (a.pf && a.pf_bytes >= 4096) ? a.pf_blocks : 0;
   int slots_gw;
-  if (!ia2p_pack_skgw(b.ln_stats ? b.ln_slots : 0, b.group_w, b.m_fastest, b.ln_stats != nullptr, &slots_gw)) return hipErrorInvalidValue;
+  if (tiles + extra >= (1 << 21) || !ia2p_pack_skgw(b.ln_stats ? b.ln_slots : 0, b.group_w, b.m_fastest, b.ln_stats != nullptr, &slots_gw)) return hipErrorInvalidValue;      // (udiv_small in the tile decode: counts below 2^21)
   const int mode = y.nseg == 1 ? 0 : (y.seg[1].nkeys <= 64 && y.seg[0].weight != 0.f) ? 1 : 2;     // as ia2p_launch_attention
 #define IA2P_QX_LAUNCH(MODE)                                                                                                                   \
   hipLaunchKernelGGL(qproj_xattn_kernel<MODE>, dim3(tiles + extra), dim3(256), SMEM, s, b.A, b.W, b.zero, b.ln_stats, b.M, b.N, b.K, b.lda, b.ldw, slots_gw, b, y)
@@ -118,7 +118,7 @@ hipError_t ia2p_launch_qkv_sattn(const GemmArgs& a, const AttnArgs& x, hipStream
   y.xcd_map = ((ia2p_wt_mask() & 8) && (size_t)x.B * x.Nq * x.ldo * 2 < (size_t)0x7ffffff0) ? 2 : 0;      // bit 1: write-through O
   const int extra = (a.pf && a.pf_bytes >= 4096) ? a.pf_blocks : 0;
   int slots_gw;
-  if (!ia2p_pack_skgw(b.ln_stats ? b.ln_slots : 0, b.group_w, b.m_fastest, b.ln_stats != nullptr, &slots_gw)) return hipErrorInvalidValue;
+  if (tiles + extra >= (1 << 21) || !ia2p_pack_skgw(b.ln_stats ? b.ln_slots : 0, b.group_w, b.m_fastest, b.ln_stats != nullptr, &slots_gw)) return hipErrorInvalidValue;      // (udiv_small in the tile decode: counts below 2^21)
   hipLaunchKernelGGL(qkv_sattn_kernel, dim3(tiles + extra), dim3(512), SMEM, s, b.A, b.W, b.zero, b.ln_stats, b.M, b.N, b.K, b.lda, b.ldw, slots_gw, b, y);
   return hipGetLastError();
 }

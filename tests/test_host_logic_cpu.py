@@ -370,3 +370,21 @@ def test_the_reference_import_name_resolves_to_the_native_pipeline():
             "import inspect; sig = inspect.signature(InstructAny2PixPipeline.__call__); "
             "assert [k for k in sig.parameters][:3] == ['self', 'inst', 'mm_data'] and sig.parameters['num_inference_steps'].default == 25 and sig.parameters['cfg'].default == 10")
     subprocess.run([sys.executable, "-c", code], check=True, cwd=root)
+
+
+def test_tile_decode_division_is_exact_on_its_domain():
+    """`udiv_small` of the kernels' tile decode (csrc/gemm_tile.h): q = int(float(a) * rcp(float(b))), one correction either way. Replayed here in float32 with the
+    reciprocal pushed one ulp up and one ulp down (v_rcp_f32 is good to 1 ulp): exact for 0 <= a < 2^21, 0 < b < 2^21 -- the launchers refuse larger grids."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    b = np.concatenate([rng.integers(1, 1 << 21, 200_000), rng.integers(1, 4096, 200_000), np.array([1, 2, 3, 5, 7, 255, 256, 257, (1 << 21) - 1])]).astype(np.int64)
+    k = rng.integers(0, 1 << 21, b.shape[0]).astype(np.int64)
+    for delta in (-1, 0, 1):                       # a around a multiple of b, where a wrong reciprocal would flip the floor
+        a = np.clip((k // np.maximum(b, 1)) * b + delta, 0, (1 << 21) - 1)
+        for ulp in (-1, 0, 1):
+            r = (np.float32(1.0) / b.astype(np.float32)).astype(np.float32)
+            r = np.nextafter(r, np.float32(np.inf if ulp > 0 else -np.inf)).astype(np.float32) if ulp else r
+            q = (a.astype(np.float32) * r).astype(np.float32).astype(np.int64)      # (float -> int conversion truncates, as v_cvt_i32_f32 does)
+            rem = a - q * b
+            q = q + (rem >= b) - (rem < 0)
+            assert np.array_equal(q, a // b), (delta, ulp)
